@@ -1,0 +1,265 @@
+// oracle/ref_driver.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// A thin C-ABI wrapper that DRIVES the reference's own, unmodified x86 Saber
+// classes (compiled from the sources where they lie under /root/reference by
+// oracle/Makefile into oracle/_ref/libanakin_x86_ref.so). It exists to
+//   (1) validate oracle/saber_oracle.c (the CPU restatement) bit-for-bit, and
+//   (2) generate the golden vectors under tests/golden/ (tests/golden/make_golden.py),
+//   (3) optionally serve as bench.py's cpu_baseline ("kind": "reference").
+// Nothing in the product path (anakin_amd/, include/) may include or link this.
+//
+// Reference entry points driven here:
+//   GemmX8S8S32XConv::init/dispatch      saber/funcs/impl/x86/gemm_x8s8s32x_conv.cpp:12-308
+//   ScaleUtils::scale_conv_weights_to_nchw_host   saber/funcs/impl/x86/x86_utils.h:293-322
+//   reorder_nhwc_nchw                    saber/funcs/saber_util.h:637-803
+//   SaberEltwise<X86,AK_INT8/AK_FLOAT>   saber/funcs/impl/x86/saber_eltwise.cpp:71-113
+//   SaberConv1X1<AK_FLOAT>               saber/funcs/impl/x86/saber_conv_1x1.cpp:28-108
+//   conv_basic_check / conv_basic_check_int8 / pool_basic_check_int8
+//                                        test/saber/conv_func_helper.h:29-264
+#include "anakin_config.h"
+#include "saber/core/tensor.h"
+#include "saber/core/context.h"
+#include "saber/saber_funcs_param.h"
+#include "saber/funcs/saber_util.h"
+#include "saber/funcs/impl/x86/gemm_x8s8s32x_conv.h"
+#include "saber/funcs/impl/x86/saber_conv_1x1.h"
+#include "saber/funcs/impl/x86/saber_eltwise.h"
+#include "saber/funcs/impl/x86/x86_utils.h"
+#include "test/saber/conv_func_helper.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace anakin::saber;
+
+namespace {
+
+DataType to_dtype(int code) {  // 0 f32, 1 s8, 2 u8  (same codes as include/saber_hip.h)
+    switch (code) {
+    case 0: return AK_FLOAT;
+    case 1: return AK_INT8;
+    case 2: return AK_UINT8;
+    default: return AK_INVALID;
+    }
+}
+size_t dsize(int code) { return code == 0 ? 4 : 1; }
+
+struct EnvOnce {
+    EnvOnce() { Env<X86>::env_init(); }
+};
+Context<X86>& ctx() {
+    static EnvOnce once;
+    static Context<X86> c(0, 0, 0);
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Reference INT8 conv through the GEMM path. x is NHWC [N,H,W,C] s8/u8; weights OIHW either
+// f32 (w_dtype 0; the reference quantises them itself, w_scale ignored) or s8 (w_dtype 1, w_scale[K]).
+// out is NHWC [N,OH,OW,K] of out_dtype. Returns 0 on success.
+int ref_conv_i8(int N, int H, int W, int C, int K, int kh, int kw, int pad_h, int pad_w,
+                int stride_h, int stride_w, int dil_h, int dil_w, int group,
+                int in_dtype, int out_dtype, int w_dtype, int with_relu,
+                const void* x, const void* w, const float* w_scale, const float* bias,
+                float in_scale, float out_scale, void* out) {
+    int OH = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+    int OW = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+    Tensor<X86> tin(Shape({N, H, W, C}, Layout_NHWC), to_dtype(in_dtype));
+    Tensor<X86> tout(Shape({N, OH, OW, K}, Layout_NHWC), to_dtype(out_dtype));
+    Tensor<X86> tw(Shape({K, C / group, kh, kw}, Layout_NCHW), to_dtype(w_dtype));
+    Tensor<X86> tb;
+    memcpy(tin.mutable_data(), x, (size_t)N * H * W * C * dsize(in_dtype));
+    memcpy(tw.mutable_data(), w, (size_t)K * (C / group) * kh * kw * dsize(w_dtype));
+    tin.set_scale({in_scale});
+    tout.set_scale({out_scale});
+    if (w_dtype == 1) {
+        tw.set_scale(std::vector<float>(w_scale, w_scale + K));
+    }
+    if (bias) {
+        tb.re_alloc(Shape({1, K, 1, 1}, Layout_NCHW), AK_FLOAT);
+        memcpy(tb.mutable_data(), bias, sizeof(float) * K);
+    }
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    ConvParam<X86> cp(group, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, &tw, bias ? &tb : nullptr,
+                      act);
+    EltwiseParam<X86> ep(Eltwise_sum);
+    ep.has_eltwise = false;
+    ConvEltwiseParam<X86> cep(cp, ep);
+    std::vector<Tensor<X86>*> ins{&tin}, outs{&tout};
+    GemmX8S8S32XConv impl;
+    if (impl.init(ins, outs, cep, ctx()) != SaberSuccess) {
+        return 1;
+    }
+    if (impl.dispatch(ins, outs, cep) != SaberSuccess) {
+        return 2;
+    }
+    memcpy(out, tout.data(), (size_t)N * OH * OW * K * dsize(out_dtype));
+    return 0;
+}
+
+// Reference weight quantisation (per-out-channel max|w|/127, truncating cast).
+int ref_quant_conv_weights(int K, int C, int kh, int kw, const float* w, int8_t* wq, float* w_scale) {
+    Tensor<X86> tw(Shape({K, C, kh, kw}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tq(Shape({K, C, kh, kw}, Layout_NCHW), AK_INT8);
+    memcpy(tw.mutable_data(), w, sizeof(float) * K * C * kh * kw);
+    utils::ScaleUtils::scale_conv_weights_to_nchw_host(tq, tw);
+    memcpy(wq, tq.data(), (size_t)K * C * kh * kw);
+    auto s = tq.get_scale();
+    for (int i = 0; i < K; ++i) {
+        w_scale[i] = s[i];
+    }
+    return 0;
+}
+
+// reorder_nhwc_nchw in both directions. dir 0: NCHW(src) -> NHWC(dst); dir 1: NHWC(src) -> NCHW(dst).
+// scale is the 8-bit side's tensor scale.
+int ref_reorder(int dir, int N, int C, int H, int W, int src_dtype, int dst_dtype, float scale,
+                const void* src, void* dst) {
+    Shape s_nchw({N, C, H, W}, Layout_NCHW);
+    Shape s_nhwc({N, H, W, C}, Layout_NHWC);
+    Tensor<X86> ts(dir == 0 ? s_nchw : s_nhwc, to_dtype(src_dtype));
+    Tensor<X86> td(dir == 0 ? s_nhwc : s_nchw, to_dtype(dst_dtype));
+    size_t n = (size_t)N * C * H * W;
+    memcpy(ts.mutable_data(), src, n * dsize(src_dtype));
+    ts.set_scale({scale});
+    td.set_scale({scale});
+    reorder_nhwc_nchw(ts, td);
+    memcpy(dst, td.data(), n * dsize(dst_dtype));
+    return 0;
+}
+
+// SaberEltwise<X86, AK_INT8> sum of two s8 NHWC tensors (+relu).
+int ref_eltwise_i8(int N, int H, int W, int C, const int8_t* a, const int8_t* b, float scale_a,
+                   float scale_b, float coeff_a, float coeff_b, int with_relu, float out_scale,
+                   int8_t* out) {
+    Shape sh({N, H, W, C}, Layout_NHWC);
+    Tensor<X86> ta(sh, AK_INT8), tb(sh, AK_INT8), to(sh, AK_INT8);
+    size_t n = (size_t)N * H * W * C;
+    memcpy(ta.mutable_data(), a, n);
+    memcpy(tb.mutable_data(), b, n);
+    ta.set_scale({scale_a});
+    tb.set_scale({scale_b});
+    to.set_scale({out_scale});
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    EltwiseParam<X86> ep(Eltwise_sum, {coeff_a, coeff_b}, act);
+    std::vector<Tensor<X86>*> ins{&ta, &tb}, outs{&to};
+    SaberEltwise<X86, AK_INT8> impl;
+    if (impl.init(ins, outs, ep, ctx()) != SaberSuccess) {
+        return 1;
+    }
+    if (impl.dispatch(ins, outs, ep) != SaberSuccess) {
+        return 2;
+    }
+    memcpy(out, to.data(), n);
+    return 0;
+}
+
+// SaberEltwise<X86, AK_FLOAT> sum (+relu) on flat buffers.
+int ref_eltwise_f32(int N, int C, int H, int W, const float* a, const float* b, float coeff_a,
+                    float coeff_b, int with_relu, float* out) {
+    Shape sh({N, C, H, W}, Layout_NCHW);
+    Tensor<X86> ta(sh, AK_FLOAT), tb(sh, AK_FLOAT), to(sh, AK_FLOAT);
+    size_t n = (size_t)N * H * W * C;
+    memcpy(ta.mutable_data(), a, n * 4);
+    memcpy(tb.mutable_data(), b, n * 4);
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    EltwiseParam<X86> ep(Eltwise_sum, {coeff_a, coeff_b}, act);
+    std::vector<Tensor<X86>*> ins{&ta, &tb}, outs{&to};
+    SaberEltwise<X86, AK_FLOAT> impl;
+    if (impl.init(ins, outs, ep, ctx()) != SaberSuccess) {
+        return 1;
+    }
+    if (impl.dispatch(ins, outs, ep) != SaberSuccess) {
+        return 2;
+    }
+    memcpy(out, to.data(), n * 4);
+    return 0;
+}
+
+// SaberConv1X1<AK_FLOAT>: NCHW f32 1x1 s1 p0 conv (+bias)(+relu), optional fused residual
+// (out += conv; the ConvEltwise path, saber_conv_eltwise.cpp:40-151). out must hold the
+// residual on entry when with_residual.
+int ref_conv1x1_f32(int N, int C, int H, int W, int K, const float* x, const float* w,
+                    const float* bias, int with_relu, int with_residual, float* out) {
+    Tensor<X86> tin(Shape({N, C, H, W}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tout(Shape({N, K, H, W}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tw(Shape({K, C, 1, 1}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tb;
+    memcpy(tin.mutable_data(), x, sizeof(float) * N * C * H * W);
+    memcpy(tw.mutable_data(), w, sizeof(float) * K * C);
+    memcpy(tout.mutable_data(), out, sizeof(float) * N * K * H * W);
+    if (bias) {
+        tb.re_alloc(Shape({1, K, 1, 1}, Layout_NCHW), AK_FLOAT);
+        memcpy(tb.mutable_data(), bias, sizeof(float) * K);
+    }
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    ConvParam<X86> cp(1, 0, 0, 1, 1, 1, 1, &tw, bias ? &tb : nullptr,
+                      with_residual ? ActivationParam<X86>() : act);
+    EltwiseParam<X86> ep(Eltwise_sum, {1.f, 1.f}, with_residual ? act : ActivationParam<X86>());
+    ep.has_eltwise = with_residual != 0;
+    ConvEltwiseParam<X86> cep(cp, ep);
+    std::vector<Tensor<X86>*> ins{&tin}, outs{&tout};
+    SaberConv1X1<AK_FLOAT> impl;
+    if (impl.init(ins, outs, cep, ctx()) != SaberSuccess) {
+        return 1;
+    }
+    if (impl.dispatch(ins, outs, cep) != SaberSuccess) {
+        return 2;
+    }
+    memcpy(out, tout.data(), sizeof(float) * N * K * H * W);
+    return 0;
+}
+
+// The reference's own naive test oracles (test/saber/conv_func_helper.h).
+int ref_conv_basic_check_f32(int N, int C, int H, int W, int K, int kh, int kw, int pad_h, int pad_w,
+                             int stride_h, int stride_w, int dil_h, int dil_w, int group,
+                             const float* x, const float* w, const float* bias, int with_relu,
+                             float* out) {
+    int OH = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+    int OW = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+    Tensor<X86> tin(Shape({N, C, H, W}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tout(Shape({N, K, OH, OW}, Layout_NCHW), AK_FLOAT);
+    memcpy(tin.mutable_data(), x, sizeof(float) * N * C * H * W);
+    memset(tout.mutable_data(), 0, sizeof(float) * N * K * OH * OW);
+    conv_basic_check<X86, float, float>(tin, tout, w, bias, group, kw, kh, stride_w, stride_h, dil_w,
+                                        dil_h, pad_w, pad_h, bias != nullptr, with_relu != 0);
+    memcpy(out, tout.data(), sizeof(float) * N * K * OH * OW);
+    return 0;
+}
+
+int ref_conv_basic_check_int8(int N, int H, int W, int C, int K, int kh, int kw, int pad_h, int pad_w,
+                              int stride_h, int stride_w, int dil_h, int dil_w, int group,
+                              int in_dtype, const void* x, const int8_t* w, const int* bias,
+                              int with_relu, const float* scale, int8_t* out) {
+    int OH = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+    int OW = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+    Tensor<X86> tin(Shape({N, H, W, C}, Layout_NHWC), to_dtype(in_dtype));
+    Tensor<X86> tout(Shape({N, OH, OW, K}, Layout_NHWC), AK_INT8);
+    memcpy(tin.mutable_data(), x, (size_t)N * H * W * C);
+    memset(tout.mutable_data(), 0, (size_t)N * OH * OW * K);
+    std::vector<float> sc(scale, scale + K);
+    conv_basic_check_int8<X86>(tin, tout, (const char*)w, bias, group, kw, kh, stride_w, stride_h,
+                               dil_w, dil_h, pad_w, pad_h, bias != nullptr, with_relu != 0, sc);
+    memcpy(out, tout.data(), (size_t)N * OH * OW * K);
+    return 0;
+}
+
+// pooling_type: 0 max, 1 avg include padding, 2 avg exclude padding
+int ref_pool_basic_check_int8(int N, int H, int W, int C, int OH, int OW, int kh, int kw, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int pooling_type, int dtype,
+                              const void* x, void* out) {
+    Tensor<X86> tin(Shape({N, H, W, C}, Layout_NHWC), to_dtype(dtype));
+    Tensor<X86> tout(Shape({N, OH, OW, C}, Layout_NHWC), to_dtype(dtype));
+    memcpy(tin.mutable_data(), x, (size_t)N * H * W * C);
+    PoolingType pt = pooling_type == 0 ? Pooling_max
+                     : pooling_type == 1 ? Pooling_average_include_padding
+                     : Pooling_average_exclude_padding;
+    pool_basic_check_int8<X86>(tin, tout, kw, kh, stride_w, stride_h, pad_w, pad_h, pt);
+    memcpy(out, tout.data(), (size_t)N * OH * OW * C);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,29 @@
+/* Prototype-only shim for the MKL CBLAS entry points the reference's x86 Saber
+ * GEMM-path sources call (gemm_x8s8s32x_conv.cpp:244-252, saber_conv_1x1.cpp).
+ * The symbols come from the container's /opt/conda/lib/libmkl_rt.so at link time.
+ * TEST INFRASTRUCTURE ONLY (oracle/_ref). */
+#ifndef ORACLE_SHIM_MKL_CBLAS_H
+#define ORACLE_SHIM_MKL_CBLAS_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef int MKL_INT;
+typedef enum { CblasRowMajor = 101, CblasColMajor = 102 } CBLAS_LAYOUT;
+typedef enum { CblasNoTrans = 111, CblasTrans = 112, CblasConjTrans = 113 } CBLAS_TRANSPOSE;
+typedef enum { CblasRowOffset = 171, CblasColOffset = 172, CblasFixOffset = 173 } CBLAS_OFFSET;
+void cblas_gemm_s8u8s32(const CBLAS_LAYOUT Layout, const CBLAS_TRANSPOSE TransA,
+                        const CBLAS_TRANSPOSE TransB, const CBLAS_OFFSET OffsetC,
+                        const MKL_INT M, const MKL_INT N, const MKL_INT K, const float alpha,
+                        const void* A, const MKL_INT lda, const int8_t ao,
+                        const void* B, const MKL_INT ldb, const int8_t bo, const float beta,
+                        int32_t* C, const MKL_INT ldc, const int32_t* cb);
+void cblas_sgemm(const CBLAS_LAYOUT Layout, const CBLAS_TRANSPOSE TransA,
+                 const CBLAS_TRANSPOSE TransB, const MKL_INT M, const MKL_INT N, const MKL_INT K,
+                 const float alpha, const float* A, const MKL_INT lda, const float* B,
+                 const MKL_INT ldb, const float beta, float* C, const MKL_INT ldc);
+#ifdef __cplusplus
+}
+#endif
+#endif

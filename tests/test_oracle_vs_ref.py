@@ -1,0 +1,156 @@
+"""Pin the CPU restatement (oracle/saber_oracle.c) to the reference's own x86 Saber objects
+(oracle/_ref, compiled unmodified from /root/reference by oracle/Makefile). Bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
+
+CONV_CASES = [
+    # N, H, W, C, K, k, pad, stride, dil, group
+    (2, 14, 14, 64, 64, 3, 1, 1, 1, 1),
+    (1, 14, 14, 64, 128, 1, 0, 1, 1, 1),
+    (2, 15, 13, 32, 48, 1, 0, 2, 1, 1),
+    (1, 17, 17, 16, 32, 3, 1, 2, 1, 1),
+    (1, 12, 12, 16, 16, 3, 2, 1, 2, 1),
+    (1, 20, 20, 3, 16, 7, 3, 2, 1, 1),
+    (2, 9, 9, 32, 32, 3, 1, 1, 1, 4),
+    (1, 7, 7, 20, 24, 5, 2, 1, 1, 1),
+]
+
+
+def _mk(case, in_dtype, seed):
+    N, H, W, C, K, k, pad, stride, dil, group = case
+    rng = np.random.default_rng(seed)
+    if in_dtype == O.U8:
+        x = rng.integers(0, 256, (N, H, W, C)).astype(np.uint8)
+    else:
+        x = rng.integers(-128, 128, (N, H, W, C)).astype(np.int8)
+    w = (rng.standard_normal((K, C // group, k, k)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    return x, w, b
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("in_dtype", [O.S8, O.U8])
+@pytest.mark.parametrize("out_dtype", [O.S8, O.U8, O.F32])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_conv_i8_matches_reference(case, in_dtype, out_dtype, relu):
+    if out_dtype == O.U8 and not relu:
+        pytest.skip("u8 output without relu is undefined in the reference GEMM path")
+    if in_dtype == O.U8 and out_dtype == O.S8:
+        pytest.skip("u8->s8: create() computes the scale (gemm_x8s8s32x_conv.cpp:163-166) but "
+                    "dispatch() LOG(FATAL)s 'not support' (:304-306); only the JIT path runs it")
+    N, H, W, C, K, k, pad, stride, dil, group = case
+    x, w, b = _mk(case, in_dtype, seed=hash((case, in_dtype)) % 2**31)
+    in_scale = 0.02
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    # in-range output scale: calibrate from the f32-output run of the oracle itself
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, 1.0, in_dtype, O.F32)
+    real = O.conv_i8(x, wq, bp, sc, O.F32, relu, (pad, pad), (stride, stride), (dil, dil), group)
+    out_scale = float(np.abs(real).max()) / (120.0 if out_dtype == O.S8 else 240.0 * 127 / 255)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, in_dtype, out_dtype)
+    got = O.conv_i8(x, wq, bp, sc, out_dtype, relu, (pad, pad), (stride, stride), (dil, dil), group)
+    # reference, fed the f32 weights (it quantises them itself) ...
+    want = O.ref_conv_i8(x, w, None, b, in_scale, out_scale, out_dtype, relu, (pad, pad),
+                         (stride, stride), (dil, dil), group)
+    assert np.array_equal(got, want)
+    # ... and fed pre-quantised s8 weights + scales
+    want2 = O.ref_conv_i8(x, wq, ws, b, in_scale, out_scale, out_dtype, relu, (pad, pad),
+                          (stride, stride), (dil, dil), group)
+    assert np.array_equal(got, want2)
+
+
+def test_weight_quant_matches_reference():
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((64, 32, 3, 3)) * 0.2).astype(np.float32)
+    q_ref, s_ref = O.ref_quant_conv_weights(w)
+    s = O.weight_scales(w)
+    assert np.array_equal(s, s_ref)
+    assert np.array_equal(O.quant_weights(w, s), q_ref)
+
+
+@pytest.mark.parametrize("dt", [O.S8, O.U8])
+def test_quant_dequant_reorder_matches_reference(dt):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((2, 5, 7, 9)) * 3).astype(np.float32)
+    x[0, 0, 0, :4] = [0.5 * 0.05, 1.5 * 0.05, -0.5 * 0.05, 1e6]  # ties + saturation
+    q = O.quant_nchw_to_nhwc(x, 0.05, dt)
+    assert np.array_equal(q, O.ref_reorder(x, 0, dt, 0.05))
+    f = O.dequant_nhwc_to_nchw(q, 0.05)
+    assert np.array_equal(f, O.ref_reorder(q, 1, O.F32, 0.05))
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+def test_eltwise_i8_matches_reference(relu):
+    rng = np.random.default_rng(5)
+    a = rng.integers(-128, 128, (2, 7, 7, 32)).astype(np.int8)
+    b = rng.integers(-128, 128, (2, 7, 7, 32)).astype(np.int8)
+    for (sa, sb, c0, c1) in [(0.031, 0.047, 1.0, 1.0), (0.5, 0.25, 1.0, 1.0), (0.02, 0.03, 20.0, 20.0)]:
+        got = O.eltwise_i8(a, b, sa, sb, c0, c1, relu)
+        assert np.array_equal(got, O.ref_eltwise_i8(a, b, sa, sb, c0, c1, relu))
+
+
+def test_eltwise_f32_matches_reference():
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((2, 8, 5, 5)).astype(np.float32)
+    b = rng.standard_normal((2, 8, 5, 5)).astype(np.float32)
+    assert np.array_equal(O.eltwise_f32(a, b, 1.0, 1.0, True), O.ref_eltwise_f32(a, b, 1.0, 1.0, True))
+    assert np.array_equal(O.eltwise_f32(a, b, 0.5, 2.0, False), O.ref_eltwise_f32(a, b, 0.5, 2.0, False))
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:6])
+def test_conv_f32_matches_reference_naive(case):
+    N, H, W, C, K, k, pad, stride, dil, group = case
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C // group, k, k)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    got = O.conv_f32_nchw(x, w, b, True, (pad, pad), (stride, stride), (dil, dil), group)
+    want = O.ref_conv_basic_check_f32(x, w, b, True, (pad, pad), (stride, stride), (dil, dil), group)
+    assert np.array_equal(got, want)
+
+
+def test_conv1x1_f32_production_path_within_tolerance():
+    """SaberConv1X1 (MKL sgemm) vs the naive order: FP32 parity is tolerance-only (1e-4 rel)."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 64, 14, 14)).astype(np.float32)
+    w = (rng.standard_normal((128, 64, 1, 1)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    res = rng.standard_normal((2, 128, 14, 14)).astype(np.float32)
+    got = O.conv_f32_nchw(x, w, b, True)
+    want = O.ref_conv1x1_f32(x, w, b, True)
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    got = O.conv_f32_nchw(x, w, b, True, beta=1.0, out_init=res)
+    want = O.ref_conv1x1_f32(x, w, b, True, residual=res)
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_conv_i8_matches_reference_integer_test_oracle():
+    """conv_basic_check_int8 (the only integer oracle in the reference's tests) accumulates in float
+    and has no pre-scaled float bias; with bias=None and |acc| < 2^24 it must agree exactly."""
+    rng = np.random.default_rng(9)
+    x = rng.integers(-128, 128, (1, 9, 9, 32)).astype(np.int8)
+    wq = rng.integers(-127, 128, (16, 32, 3, 3)).astype(np.int8)
+    scale = (rng.random(16) * 1e-3 + 1e-4).astype(np.float32)
+    got = O.conv_i8(x, wq, None, scale, O.S8, True, (1, 1))
+    want = O.ref_conv_basic_check_int8(x, wq, None, scale, True, (1, 1))
+    assert np.array_equal(got, want)
+
+
+def test_pool_matches_reference_test_oracle():
+    rng = np.random.default_rng(10)
+    # 13x13: every 3x3/s2 window is fully in bounds (the helper does not clip when pad == 0)
+    x = rng.integers(0, 128, (2, 13, 13, 16)).astype(np.int8)
+    oh = O.pool_out_dim(13, 0, 3, 2)
+    got = O.pool_i8_nhwc(x, (3, 3), (2, 2), (0, 0), 0)
+    want = O.ref_pool_basic_check_int8(x, oh, oh, (3, 3), (2, 2), (0, 0), 0)
+    assert np.array_equal(got, want)
+    got = O.pool_i8_nhwc(x[:, :12, :12], (2, 2), (2, 2), (0, 0), 1)
+    want = O.ref_pool_basic_check_int8(x[:, :12, :12], 6, 6, (2, 2), (2, 2), (0, 0), 1)
+    assert np.array_equal(got, want)  # /4 is exact both ways
+    got = O.pool_i8_nhwc(x, (3, 3), (2, 2), (0, 0), 1).astype(np.int32)
+    want = O.ref_pool_basic_check_int8(x, oh, oh, (3, 3), (2, 2), (0, 0), 1).astype(np.int32)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
