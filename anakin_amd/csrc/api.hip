@@ -1,0 +1,909 @@
+// anakin_amd/csrc/api.hip — implementation of the C ABI declared in include/saber_hip.h.
+//
+// Host side of the MI355X Saber target: what SaberConv2D<X86,*>::init/create/dispatch
+// (saber/funcs/impl/x86/saber_conv.cpp:21-324) and GemmX8S8S32XConv::create
+// (gemm_x8s8s32x_conv.cpp:40-185) do on the host — quantise + repack weights, pre-scale the bias,
+// derive the per-channel requantisation scales, pick an algorithm — is done here once per operator;
+// `*_run` only fills a POD argument block and enqueues kernels on the caller's stream.
+#include "../../include/saber_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace saber_mi355x;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return SABER_HIP_RUNTIME_ERROR;
+}
+#define HIP_TRY(expr)                                    \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int conv_out(int in, int pad, int k, int dil, int stride) {
+    return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1;  // funcs_utils.h:29-53
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        release();
+        if (h.empty()) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, h.size() * sizeof(T));
+        if (e != hipSuccess) return e;
+        n = h.size();
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+enum Algo { ALGO_IGEMM_I8 = 0, ALGO_IGEMM_I8_C4 = 1, ALGO_IGEMM_F32 = 2, ALGO_DIRECT_I8 = 3, ALGO_DIRECT_F32 = 4 };
+
+}  // namespace
+
+struct saber_hip_conv {
+    saber_hip_conv_desc d;
+    int oh = 0, ow = 0;
+    int algo = ALGO_DIRECT_I8;
+    int tile = TILE_64x64;
+    int epi = EPI_I8_CONV;
+    bool is_i8 = false;
+    int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
+    int c_eff = 0;           // channel count the conv kernel sees (after padding)
+    bool pre_quant = false;  // f32 NCHW input quantised into the workspace first
+    bool pre_pad = false;    // 8-bit C<4 input padded to NHWC4 into the workspace
+    bool pre_transpose = false;  // f32 NCHW input transposed to NHWC(c_eff) into the workspace
+    size_t ws_bytes = 0;
+    int Kg = 0, Kg_pad = 0, kw_pad = 0;
+    float in_scale = 1.f, out_scale = 1.f;
+    bool weights_set = false;
+    std::vector<int8_t> wq_oihw;
+    std::vector<float> w_scale;
+    DevBuf<uint8_t> d_w;
+    DevBuf<float> d_bias, d_scale;
+    DevBuf<int> d_comp;
+    bool has_bias = false, has_comp = false;
+    std::string algo_name;
+};
+
+struct saber_hip_fc {
+    saber_hip_fc_desc d;
+    saber_hip_conv* conv = nullptr;
+    bool pre_quant = false;
+    float in_scale = 1.f;
+};
+
+extern "C" {
+
+const char* saber_hip_last_error(void) { return g_err.c_str(); }
+
+int saber_hip_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+    return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ================================================================================================
+// convolution
+// ================================================================================================
+static void choose_tile(saber_hip_conv* op) {
+    // Largest tile that still yields >= ~1.5 workgroups per CU (256 CUs); otherwise the smallest.
+    const long M = (long)op->d.n * op->oh * op->ow;
+    const int order[] = {TILE_128x128, TILE_128x64, TILE_64x128, TILE_64x64, TILE_64x32, TILE_32x32};
+    op->tile = TILE_32x32;
+    for (int t : order) {
+        int bmk, bnp;
+        tile_dims(t, &bmk, &bnp);
+        if (bmk > round_up(op->d.k, 32) && t != TILE_32x32) continue;
+        const long blocks = ((M + bnp - 1) / bnp) * ((op->d.k + bmk - 1) / bmk);
+        if (blocks >= 384) {
+            op->tile = t;
+            break;
+        }
+    }
+}
+
+static void name_algo(saber_hip_conv* op) {
+    static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
+    int bmk = 0, bnp = 0;
+    tile_dims(op->tile, &bmk, &bnp);
+    char buf[64];
+    if (op->algo <= ALGO_IGEMM_F32) snprintf(buf, sizeof buf, "%s_%dx%d", an[op->algo], bmk, bnp);
+    else snprintf(buf, sizeof buf, "%s", an[op->algo]);
+    op->algo_name = buf;
+}
+
+int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** out) {
+    if (!desc || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv_desc& d = *desc;
+    if (d.n <= 0 || d.h <= 0 || d.w <= 0 || d.c <= 0 || d.k <= 0 || d.kh <= 0 || d.kw <= 0 || d.group <= 0 ||
+        d.stride_h <= 0 || d.stride_w <= 0 || d.dil_h <= 0 || d.dil_w <= 0 || d.pad_h < 0 || d.pad_w < 0)
+        return fail(SABER_HIP_INVALID_VALUE, "bad conv geometry");
+    if (d.c % d.group || d.k % d.group) return fail(SABER_HIP_INVALID_VALUE, "invalid input_channel or output_channel");
+    const int oh = conv_out(d.h, d.pad_h, d.kh, d.dil_h, d.stride_h);
+    const int ow = conv_out(d.w, d.pad_w, d.kw, d.dil_w, d.stride_w);
+    if (oh <= 0 || ow <= 0) return fail(SABER_HIP_INVALID_VALUE, "empty output");
+    auto* op = new saber_hip_conv();
+    op->d = d;
+    op->oh = oh;
+    op->ow = ow;
+    op->is_i8 = d.int8_weights != 0;
+    op->c_eff = d.c;
+    const size_t in_pixels = (size_t)d.n * d.h * d.w;
+    if (op->is_i8) {
+        if (d.out_dtype != SABER_HIP_F32 && d.out_layout != SABER_HIP_NHWC) {
+            delete op;
+            return fail(SABER_HIP_UNIMPL, "8-bit outputs are NHWC (calibrator_parse.cpp:194-244)");
+        }
+        if (d.out_dtype == SABER_HIP_F32 && d.out_layout != SABER_HIP_NHWC) {
+            delete op;
+            return fail(SABER_HIP_UNIMPL, "INT8 conv with f32 output: NHWC only");
+        }
+        op->x_dtype = d.in_dtype;
+        if (d.in_dtype == SABER_HIP_F32) {
+            // quantise on entry: SaberConv2D<X86,AK_INT8>::dispatch -> reorder_nhwc_nchw (saber_conv.cpp:308)
+            if (d.in_layout != SABER_HIP_NCHW) {
+                delete op;
+                return fail(SABER_HIP_UNIMPL, "f32 input of an INT8 conv must be NCHW");
+            }
+            op->pre_quant = true;
+            op->x_dtype = DT_S8;
+            op->c_eff = (d.c < 4 && d.group == 1) ? 4 : d.c;
+            op->ws_bytes = in_pixels * op->c_eff;
+        } else {
+            if (d.in_layout != SABER_HIP_NHWC) {
+                delete op;
+                return fail(SABER_HIP_UNIMPL, "8-bit inputs are NHWC");
+            }
+            if (d.c < 4 && d.group == 1) {
+                op->pre_pad = true;
+                op->c_eff = 4;
+                op->ws_bytes = in_pixels * 4;
+            }
+        }
+        if (d.group == 1 && op->c_eff % 16 == 0) op->algo = ALGO_IGEMM_I8;
+        else if (d.group == 1 && op->c_eff == 4) op->algo = ALGO_IGEMM_I8_C4;
+        else op->algo = ALGO_DIRECT_I8;
+        if (op->algo == ALGO_DIRECT_I8 && d.res_mode == SABER_HIP_RES_NONE) { /* fine */ }
+        op->epi = EPI_I8_CONV;
+        if (d.res_mode == SABER_HIP_RES_ELTWISE && d.out_dtype != SABER_HIP_S8) {
+            delete op;
+            return fail(SABER_HIP_INVALID_VALUE, "RES_ELTWISE produces s8 (SaberEltwise<X86,AK_INT8>)");
+        }
+    } else {
+        if (d.in_dtype != SABER_HIP_F32 || d.out_dtype != SABER_HIP_F32) {
+            delete op;
+            return fail(SABER_HIP_INVALID_VALUE, "FP32 conv needs f32 tensors");
+        }
+        if (d.res_mode == SABER_HIP_RES_ELTWISE) {
+            delete op;
+            return fail(SABER_HIP_UNIMPL, "RES_ELTWISE is INT8 only");
+        }
+        op->x_dtype = DT_F32;
+        op->epi = EPI_F32;
+        if (d.in_layout == SABER_HIP_NCHW) {
+            op->pre_transpose = true;
+            op->c_eff = d.group == 1 ? round_up(d.c, 4) : d.c;
+            op->ws_bytes = in_pixels * op->c_eff * sizeof(float);
+        }
+        if (d.group == 1 && op->c_eff % 4 == 0) op->algo = ALGO_IGEMM_F32;
+        else op->algo = ALGO_DIRECT_F32;
+    }
+    if (op->algo == ALGO_IGEMM_I8_C4) {
+        op->kw_pad = round_up(d.kw, 4);
+        op->Kg = d.kh * op->kw_pad * 4;
+        op->Kg_pad = round_up(op->Kg, 64);
+    } else if (op->algo == ALGO_IGEMM_I8) {
+        op->Kg = d.kh * d.kw * op->c_eff;
+        op->Kg_pad = round_up(op->Kg, 64);
+    } else if (op->algo == ALGO_IGEMM_F32) {
+        op->Kg = d.kh * d.kw * op->c_eff;
+        op->Kg_pad = round_up(op->Kg, 16);
+    }
+    choose_tile(op);
+    name_algo(op);
+    *out = op;
+    return SABER_HIP_OK;
+}
+
+void saber_hip_conv2d_out_shape(const saber_hip_conv_t* op, int* oh, int* ow) {
+    if (oh) *oh = op->oh;
+    if (ow) *ow = op->ow;
+}
+size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op) { return op->ws_bytes; }
+const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_name.c_str(); }
+
+int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
+    if (tile < 0 || tile >= TILE_COUNT) return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
+    op->tile = tile;
+    name_algo(op);
+    return SABER_HIP_OK;
+}
+int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) { return op->tile; }
+
+int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtype, const float* w_scale,
+                                 const float* bias, float in_scale, float out_scale) {
+    if (!op || !w) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv_desc& d = op->d;
+    const int K = d.k, Cg = d.c / d.group, kh = d.kh, kw = d.kw;
+    const size_t inner = (size_t)Cg * kh * kw;
+    op->in_scale = in_scale;
+    op->out_scale = out_scale;
+    op->has_bias = bias != nullptr;
+    const int K_pad = round_up(K, 128);
+    if (op->is_i8) {
+        // ---- weights: quantise (if f32) exactly as scale_conv_weights_to_nchw_host -------------
+        op->wq_oihw.assign((size_t)K * inner, 0);
+        op->w_scale.assign(K, 0.f);
+        if (w_dtype == SABER_HIP_F32) {
+            const float* wf = (const float*)w;
+            for (int k = 0; k < K; ++k) {
+                float max_val = -1e20f;  // get_tensor_scale, x86_utils.h:141-166
+                for (size_t i = 0; i < inner; ++i) {
+                    const float a = fabsf(wf[k * inner + i]);
+                    max_val = a > max_val ? a : max_val;
+                }
+                const float sc = max_val / 127.f;
+                op->w_scale[k] = sc;
+                for (size_t i = 0; i < inner; ++i)  // static_cast<char>(w / scale): truncation, x86_utils.h:316
+                    op->wq_oihw[k * inner + i] = (int8_t)(wf[k * inner + i] / sc);
+            }
+        } else if (w_dtype == SABER_HIP_S8) {
+            if (!w_scale) return fail(SABER_HIP_INVALID_VALUE, "s8 weights need w_scale[k]");
+            std::memcpy(op->wq_oihw.data(), w, (size_t)K * inner);
+            std::memcpy(op->w_scale.data(), w_scale, sizeof(float) * K);
+        } else {
+            return fail(SABER_HIP_INVALID_VALUE, "weights must be f32 or s8");
+        }
+        // ---- per-channel bias' and scale: GemmX8S8S32XConv::create :90-105, :145-182 -----------
+        const int in_dt = d.in_dtype == SABER_HIP_F32 ? DT_S8 : d.in_dtype;  // f32 input is quantised to s8
+        std::vector<float> bias_p(K, 0.f), scale(K, 0.f);
+        for (int k = 0; k < K; ++k) {
+            float s_in;
+            if (in_dt == DT_U8) s_in = op->w_scale[k] * in_scale * (127.f / 255.f);
+            else s_in = op->w_scale[k] * in_scale;
+            if (bias) bias_p[k] = bias[k] * (1.f / s_in);
+            if (d.out_dtype == SABER_HIP_F32) scale[k] = s_in;
+            else if (d.out_dtype == SABER_HIP_U8) scale[k] = s_in / (out_scale * (127.f / 255.f));
+            else scale[k] = s_in / out_scale;
+        }
+        // ---- repack -----------------------------------------------------------------------------
+        std::vector<uint8_t> wr;
+        std::vector<int> comp;
+        const int8_t* q = op->wq_oihw.data();
+        if (op->algo == ALGO_IGEMM_I8 || op->algo == ALGO_IGEMM_I8_C4) {
+            wr.assign((size_t)K_pad * op->Kg_pad, 0);
+            const int Ce = op->c_eff;
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < Cg; ++c)
+                    for (int i = 0; i < kh; ++i)
+                        for (int j = 0; j < kw; ++j) {
+                            const int8_t v = q[(((size_t)k * Cg + c) * kh + i) * kw + j];
+                            size_t kk = op->algo == ALGO_IGEMM_I8 ? ((size_t)(i * kw + j) * Ce + c)
+                                                                   : ((size_t)(i * op->kw_pad + j) * 4 + c);
+                            wr[(size_t)k * op->Kg_pad + kk] = (uint8_t)v;
+                        }
+            if (in_dt == DT_U8) {  // +128 * sum(w): compensation of the u8 -> s8 shift
+                comp.assign(K_pad, 0);
+                for (int k = 0; k < K; ++k) {
+                    int s = 0;
+                    for (size_t i = 0; i < inner; ++i) s += (int)q[k * inner + i];
+                    comp[k] = 128 * s;
+                }
+            }
+        } else {  // direct: [K][kh][kw][Cg]
+            wr.assign((size_t)K * inner, 0);
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < Cg; ++c)
+                    for (int i = 0; i < kh; ++i)
+                        for (int j = 0; j < kw; ++j)
+                            wr[(((size_t)k * kh + i) * kw + j) * Cg + c] =
+                                (uint8_t)q[(((size_t)k * Cg + c) * kh + i) * kw + j];
+        }
+        bias_p.resize(K_pad, 0.f);
+        scale.resize(K_pad, 0.f);
+        HIP_TRY(op->d_w.upload(wr));
+        HIP_TRY(op->d_bias.upload(bias_p));
+        HIP_TRY(op->d_scale.upload(scale));
+        op->has_comp = !comp.empty();
+        if (op->has_comp) HIP_TRY(op->d_comp.upload(comp));
+    } else {
+        if (w_dtype != SABER_HIP_F32) return fail(SABER_HIP_INVALID_VALUE, "FP32 conv needs f32 weights");
+        const float* wf = (const float*)w;
+        std::vector<float> wr;
+        if (op->algo == ALGO_IGEMM_F32) {
+            wr.assign((size_t)K_pad * op->Kg_pad, 0.f);
+            const int Ce = op->c_eff;
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < Cg; ++c)
+                    for (int i = 0; i < kh; ++i)
+                        for (int j = 0; j < kw; ++j)
+                            wr[(size_t)k * op->Kg_pad + (size_t)(i * kw + j) * Ce + c] =
+                                wf[(((size_t)k * Cg + c) * kh + i) * kw + j];
+        } else {
+            wr.assign((size_t)K * inner, 0.f);
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < Cg; ++c)
+                    for (int i = 0; i < kh; ++i)
+                        for (int j = 0; j < kw; ++j)
+                            wr[(((size_t)k * kh + i) * kw + j) * Cg + c] = wf[(((size_t)k * Cg + c) * kh + i) * kw + j];
+        }
+        std::vector<uint8_t> raw((const uint8_t*)wr.data(), (const uint8_t*)wr.data() + wr.size() * sizeof(float));
+        HIP_TRY(op->d_w.upload(raw));
+        std::vector<float> b(K_pad, 0.f);
+        if (bias) std::memcpy(b.data(), bias, sizeof(float) * K);
+        HIP_TRY(op->d_bias.upload(b));
+    }
+    op->weights_set = true;
+    return SABER_HIP_OK;
+}
+
+int saber_hip_conv2d_get_quantized_weights(const saber_hip_conv_t* op, int8_t* wq, float* ws) {
+    if (!op->is_i8 || !op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "no quantised weights");
+    if (wq) std::memcpy(wq, op->wq_oihw.data(), op->wq_oihw.size());
+    if (ws) std::memcpy(ws, op->w_scale.data(), sizeof(float) * op->w_scale.size());
+    return SABER_HIP_OK;
+}
+
+static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, void* y, const void* res) {
+    const saber_hip_conv_desc& d = op->d;
+    std::memset(&a, 0, sizeof a);
+    a.x = x;
+    a.w = op->d_w.p;
+    a.y = y;
+    a.res = res;
+    a.bias = (op->has_bias || !op->is_i8) ? op->d_bias.p : nullptr;
+    if (!op->is_i8 && !op->has_bias) a.bias = nullptr;
+    a.scale = op->d_scale.p;
+    a.comp = op->has_comp ? op->d_comp.p : nullptr;
+    a.N = d.n; a.H = d.h; a.W = d.w; a.C = op->c_eff; a.K = d.k; a.OH = op->oh; a.OW = op->ow;
+    a.kh = d.kh; a.kw = d.kw; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
+    a.stride_h = d.stride_h; a.stride_w = d.stride_w; a.dil_h = d.dil_h; a.dil_w = d.dil_w;
+    a.M = d.n * op->oh * op->ow;
+    a.Kg = op->Kg; a.Kg_pad = op->Kg_pad; a.kw_pad = op->kw_pad;
+    const int estep = op->algo == ALGO_IGEMM_F32 ? 16 : 64;
+    a.steps = op->Kg_pad / estep;
+    a.in_u8 = op->x_dtype == DT_U8;
+    a.out_dtype = d.out_dtype;
+    a.out_nchw = (!op->is_i8 && d.out_layout == SABER_HIP_NCHW) ? 1 : 0;
+    a.relu = d.act == SABER_HIP_ACT_RELU;
+    a.epi = op->epi;
+    a.res_mode = d.res_mode;
+    a.res_relu = d.res_act == SABER_HIP_ACT_RELU;
+    a.res_dtype = d.out_dtype;
+    a.sum_scale = d.sum_scale;
+    a.coeff_conv = d.coeff_conv; a.coeff_res = d.coeff_res;
+    a.scale_conv = op->out_scale; a.scale_res = d.scale_res;
+    if (!op->is_i8 && d.res_mode == SABER_HIP_RES_SUM_INPLACE) {
+        // out = act(conv + bias + y): the activation belongs to the eltwise when fused
+        a.relu = (d.res_act == SABER_HIP_ACT_RELU) || (d.act == SABER_HIP_ACT_RELU);
+    }
+}
+
+int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
+                         saber_hip_stream_t stream) {
+    if (!op || !x || !y) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "set_weights not called");
+    if (op->ws_bytes && !workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
+    if (op->d.res_mode == SABER_HIP_RES_ELTWISE && !res) return fail(SABER_HIP_INVALID_VALUE, "residual tensor required");
+    hipStream_t s = (hipStream_t)stream;
+    const saber_hip_conv_desc& d = op->d;
+    const void* xin = x;
+    if (op->pre_quant) {
+        HIP_TRY(launch_quantize_nchw_to_nhwc(d.n, d.c, d.h, d.w, op->c_eff, DT_S8, op->in_scale, (const float*)x,
+                                             workspace, s));
+        xin = workspace;
+    } else if (op->pre_pad) {
+        HIP_TRY(launch_pad_channels_i8((size_t)d.n * d.h * d.w, d.c, 4, x, workspace, s));
+        xin = workspace;
+    } else if (op->pre_transpose) {
+        HIP_TRY(launch_transpose_nchw_to_nhwc_f32(d.n, d.c, d.h, d.w, op->c_eff, (const float*)x, (float*)workspace, s));
+        xin = workspace;
+    }
+    ConvKArgs a;
+    fill_args(op, a, xin, y, res);
+    switch (op->algo) {
+    case ALGO_IGEMM_I8: HIP_TRY(launch_conv_igemm(0, op->tile, a, s)); break;
+    case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, a, s)); break;
+    case ALGO_IGEMM_F32: HIP_TRY(launch_conv_igemm(2, op->tile, a, s)); break;
+    case ALGO_DIRECT_I8:
+        a.comp = nullptr;
+        HIP_TRY(launch_conv_direct(0, a, d.group, s));
+        break;
+    case ALGO_DIRECT_F32: HIP_TRY(launch_conv_direct(1, a, d.group, s)); break;
+    default: return fail(SABER_HIP_UNIMPL, "no algorithm");
+    }
+    return SABER_HIP_OK;
+}
+
+// RUNTIME strategy (BaseFunc::pick_best_runtime, saber/funcs/base.h:194,205-247): time every tile
+// of the implicit-GEMM kernel on the real tensors and keep the fastest. Leaves y with valid output.
+int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
+                              saber_hip_stream_t stream, int iters) {
+    if (op->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 1e30f;
+    int best_tile = op->tile;
+    for (int t = 0; t < TILE_COUNT; ++t) {
+        op->tile = t;
+        int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) {
+            best = ms;
+            best_tile = t;
+        }
+    }
+    op->tile = best_tile;
+    name_algo(op);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SABER_HIP_OK;
+}
+
+void saber_hip_conv2d_destroy(saber_hip_conv_t* op) { delete op; }
+
+// ================================================================================================
+// fully connected: a 1x1 convolution over a [m,1,1,k] tensor with the FC epilogues
+// ================================================================================================
+int saber_hip_fc_create(const saber_hip_fc_desc* desc, saber_hip_fc_t** out) {
+    if (!desc || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    saber_hip_conv_desc c;
+    std::memset(&c, 0, sizeof c);
+    c.n = desc->m; c.h = 1; c.w = 1; c.c = desc->k; c.k = desc->n; c.kh = c.kw = 1;
+    c.stride_h = c.stride_w = c.dil_h = c.dil_w = c.group = 1;
+    c.in_layout = c.out_layout = SABER_HIP_NHWC;
+    c.out_dtype = SABER_HIP_F32;
+    c.int8_weights = desc->int8_weights;
+    auto* fc = new saber_hip_fc();
+    fc->d = *desc;
+    if (desc->int8_weights) {
+        if (desc->in_dtype == SABER_HIP_F32) {
+            fc->pre_quant = true;  // PackedMKLInt8Gemm::dispatch: scale_fp32_int8 (mkl_packed_int8_gemm.cpp:52-57)
+            c.in_dtype = SABER_HIP_S8;
+        } else {
+            c.in_dtype = desc->in_dtype;
+        }
+    } else {
+        c.in_dtype = SABER_HIP_F32;
+    }
+    int rc = saber_hip_conv2d_create(&c, &fc->conv);
+    if (rc) {
+        delete fc;
+        return rc;
+    }
+    if (desc->int8_weights) {
+        if (fc->conv->algo != ALGO_IGEMM_I8) {
+            saber_hip_conv2d_destroy(fc->conv);
+            delete fc;
+            return fail(SABER_HIP_UNIMPL, "INT8 fc needs k % 16 == 0");
+        }
+        fc->conv->epi = c.in_dtype == SABER_HIP_U8 ? EPI_I8_FC_U8 : EPI_I8_FC_S8;
+    }
+    *out = fc;
+    return SABER_HIP_OK;
+}
+
+int saber_hip_fc_set_weights(saber_hip_fc_t* fc, const void* w, int w_dtype, const float* w_scale,
+                             const float* bias, float in_scale, float out_scale) {
+    const int N = fc->d.n, K = fc->d.k;
+    fc->in_scale = in_scale;
+    // bring the weights to [n,k]
+    std::vector<uint8_t> wt;
+    const void* wnk = w;
+    const size_t es = w_dtype == SABER_HIP_F32 ? 4 : 1;
+    if (fc->d.w_is_kn) {
+        wt.resize((size_t)N * K * es);
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k)
+                std::memcpy(&wt[((size_t)n * K + k) * es], (const uint8_t*)w + ((size_t)k * N + n) * es, es);
+        wnk = wt.data();
+    }
+    saber_hip_conv* op = fc->conv;
+    if (!fc->d.int8_weights) return saber_hip_conv2d_set_weights(op, wnk, w_dtype, w_scale, bias, 1.f, 1.f);
+    // INT8: the conv-style set_weights gives us quantised weights + comp; then override scale/bias
+    int rc = saber_hip_conv2d_set_weights(op, wnk, w_dtype, w_scale, nullptr, in_scale, out_scale);
+    if (rc) return rc;
+    const int K_pad = round_up(N, 128);
+    std::vector<float> scale(K_pad, 0.f), b(K_pad, 0.f);
+    if (op->epi == EPI_I8_FC_S8) {
+        // _scale[n] = w_scale[n] * scale_a; out = acc*scale + bias   (mkl_packed_int8_gemm.cpp:36-38,78-81)
+        for (int n = 0; n < N; ++n) {
+            scale[n] = op->w_scale[n] * in_scale;
+            if (bias) b[n] = bias[n];
+        }
+        op->has_bias = bias != nullptr;
+        HIP_TRY(op->d_bias.upload(b));
+        HIP_TRY(op->d_scale.upload(scale));
+    } else {
+        // u8 input (vender_fc.cpp:284-300): scale = (in_scale*w_scale)/out_scale; bias_i = (int)(bias/scale)
+        std::vector<int> comp(K_pad, 0);
+        const int8_t* q = op->wq_oihw.data();
+        for (int n = 0; n < N; ++n) {
+            scale[n] = (in_scale * op->w_scale[n]) / out_scale;
+            int s = 0;
+            for (int k = 0; k < K; ++k) s += (int)q[(size_t)n * K + k];
+            comp[n] = 128 * s + (bias ? (int)(bias[n] / scale[n]) : 0);
+        }
+        op->has_bias = false;
+        op->has_comp = true;
+        HIP_TRY(op->d_comp.upload(comp));
+        HIP_TRY(op->d_scale.upload(scale));
+    }
+    return SABER_HIP_OK;
+}
+
+size_t saber_hip_fc_workspace_bytes(const saber_hip_fc_t* fc) {
+    return fc->pre_quant ? (size_t)fc->d.m * fc->d.k : 0;
+}
+
+int saber_hip_fc_run(saber_hip_fc_t* fc, const void* x, float* y, void* workspace, saber_hip_stream_t stream) {
+    const void* xin = x;
+    if (fc->pre_quant) {
+        if (!workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
+        HIP_TRY(launch_quantize_flat_s8((size_t)fc->d.m * fc->d.k, fc->in_scale, (const float*)x, (int8_t*)workspace,
+                                        (hipStream_t)stream));
+        xin = workspace;
+    }
+    return saber_hip_conv2d_run(fc->conv, xin, y, nullptr, nullptr, stream);
+}
+
+void saber_hip_fc_destroy(saber_hip_fc_t* fc) {
+    if (fc) saber_hip_conv2d_destroy(fc->conv);
+    delete fc;
+}
+
+// ================================================================================================
+// thin wrappers
+// ================================================================================================
+int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b, float beta,
+                       float* c, saber_hip_stream_t s) {
+    if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
+    HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                                    const float* x, void* y, saber_hip_stream_t s) {
+    if (c_pad < c || (out_dtype != SABER_HIP_S8 && out_dtype != SABER_HIP_U8))
+        return fail(SABER_HIP_INVALID_VALUE, "bad quantize arguments");
+    if ((size_t)n * c * h * w == 0) return SABER_HIP_OK;
+    HIP_TRY(launch_quantize_nchw_to_nhwc(n, c, h, w, c_pad, out_dtype, scale, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_dequantize_nhwc_to_nchw(int n, int c, int h, int w, int in_dtype, float scale, const void* x,
+                                      float* y, saber_hip_stream_t s) {
+    if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
+    if ((size_t)n * c * h * w == 0) return SABER_HIP_OK;
+    HIP_TRY(launch_dequantize_nhwc_to_nchw(n, c, h, w, in_dtype, scale, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                         saber_hip_stream_t s) {
+    HIP_TRY(launch_transpose_nchw_to_nhwc_f32(n, c, h, w, c_pad, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                         saber_hip_stream_t s) {
+    HIP_TRY(launch_transpose_nhwc_to_nchw_f32(n, c, h, w, c_pad, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_quantize_flat_s8(count, scale, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float sa, float sb, float c0, float c1,
+                             int relu, int8_t* y, saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_eltwise_sum_i8(count, a, b, sa, sb, c0, c1, relu, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, float c0, float c1, int relu, float* y,
+                              saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_eltwise_sum_f32(count, a, b, c0, c1, relu, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode) {
+    int o;  // Pooling<>::compute_output_shape, saber/funcs/pooling.h:92-121
+    if (floor_mode) {
+        o = (int)((float)(in + 2 * pad - window) / stride) + 1;
+        if (o <= 0) o = 1;
+    } else {
+        o = (int)ceilf((float)(in + 2 * pad - window) / stride) + 1;
+    }
+    if (pad > 0 && (o - 1) * stride >= in + pad) --o;
+    return o;
+}
+int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                             int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
+                             saber_hip_stream_t s) {
+    if (type == SABER_HIP_POOL_MAX && out_dtype == SABER_HIP_F32)
+        return fail(SABER_HIP_UNIMPL, "dst format (AK_FLOAT) and pooling type (Pooling_max): NOT supported");
+    HIP_TRY(launch_pool2d_i8_nhwc(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, out_dtype, x, y,
+                                  (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int type, int layout, const float* x, float* y, saber_hip_stream_t s) {
+    HIP_TRY(launch_pool2d_f32(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout == SABER_HIP_NCHW, x, y,
+                              (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t s) {
+    if (rows <= 0 || cols <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad softmax shape");
+    HIP_TRY(launch_softmax_f32(rows, cols, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// op-list executor
+// ================================================================================================
+namespace {
+enum OpKind { OP_CONV, OP_FC, OP_QUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_SOFTMAX };
+struct NetOp {
+    OpKind kind;
+    std::string name;
+    saber_hip_conv* conv = nullptr;
+    saber_hip_fc* fc = nullptr;
+    int in = -1, in2 = -1, out = -1;
+    int p[16] = {0};
+    float f[6] = {0};
+    size_t count = 0;
+};
+}  // namespace
+
+struct saber_hip_net {
+    std::vector<size_t> tensor_bytes;
+    std::vector<size_t> tensor_off;
+    std::vector<NetOp> ops;
+    char* arena = nullptr;
+    size_t arena_bytes = 0, ws_off = 0, ws_bytes = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool finalized = false;
+};
+
+static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
+    auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
+    void* ws = net->arena + net->ws_off;
+    switch (o.kind) {
+    case OP_CONV: return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
+    case OP_FC: return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
+    case OP_QUANT:
+        return saber_hip_quantize_nchw_to_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.f[0],
+                                               (const float*)T(o.in), T(o.out), s);
+    case OP_TRANSPOSE_IN:
+        return saber_hip_transpose_nchw_to_nhwc_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], (const float*)T(o.in),
+                                                    (float*)T(o.out), s);
+    case OP_ELT_I8:
+        return saber_hip_eltwise_sum_i8(o.count, (const int8_t*)T(o.in), (const int8_t*)T(o.in2), o.f[0], o.f[1],
+                                        o.f[2], o.f[3], o.p[0], (int8_t*)T(o.out), s);
+    case OP_ELT_F32:
+        return saber_hip_eltwise_sum_f32(o.count, (const float*)T(o.in), (const float*)T(o.in2), o.f[0], o.f[1],
+                                         o.p[0], (float*)T(o.out), s);
+    case OP_POOL_I8:
+        return saber_hip_pool2d_i8_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
+                                        o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.p[14], T(o.in), T(o.out), s);
+    case OP_POOL_F32:
+        return saber_hip_pool2d_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.p[9],
+                                    o.p[10], o.p[11], o.p[12], o.p[13], (const float*)T(o.in), (float*)T(o.out), s);
+    case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
+    }
+    return SABER_HIP_UNIMPL;
+}
+
+extern "C" {
+
+int saber_hip_net_create(saber_hip_net_t** out) {
+    *out = new saber_hip_net();
+    return SABER_HIP_OK;
+}
+int saber_hip_net_add_tensor(saber_hip_net_t* net, size_t bytes) {
+    net->tensor_bytes.push_back(bytes);
+    return (int)net->tensor_bytes.size() - 1;
+}
+static int push(saber_hip_net* net, NetOp&& o) {
+    const int nt = (int)net->tensor_bytes.size();
+    if (o.in >= nt || o.in2 >= nt || o.out >= nt || o.in < 0 || o.out < 0) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    net->ops.push_back(std::move(o));
+    return (int)net->ops.size() - 1;
+}
+int saber_hip_net_add_conv(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id, int out_id, int res_id) {
+    NetOp o;
+    o.kind = OP_CONV; o.conv = op; o.in = in_id; o.out = out_id; o.in2 = res_id;
+    o.name = std::string("conv:") + op->algo_name;
+    if (op->ws_bytes > net->ws_bytes) net->ws_bytes = op->ws_bytes;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_fc(saber_hip_net_t* net, saber_hip_fc_t* op, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_FC; o.fc = op; o.in = in_id; o.out = out_id;
+    o.name = std::string("fc:") + op->conv->algo_name;
+    const size_t w = saber_hip_fc_workspace_bytes(op);
+    if (w > net->ws_bytes) net->ws_bytes = w;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_quantize(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                               int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_QUANT; o.in = in_id; o.out = out_id; o.name = "quantize_nchw_to_nhwc";
+    o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = c_pad; o.p[5] = out_dtype; o.f[0] = scale;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_transpose_in_f32(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int in_id,
+                                       int out_id) {
+    NetOp o;
+    o.kind = OP_TRANSPOSE_IN; o.in = in_id; o.out = out_id; o.name = "transpose_nchw_to_nhwc_f32";
+    o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = c_pad;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_eltwise_i8(saber_hip_net_t* net, size_t count, float sa, float sb, float c0, float c1, int relu,
+                                 int a_id, int b_id, int out_id) {
+    NetOp o;
+    o.kind = OP_ELT_I8; o.in = a_id; o.in2 = b_id; o.out = out_id; o.count = count; o.name = "eltwise_sum_i8";
+    o.f[0] = sa; o.f[1] = sb; o.f[2] = c0; o.f[3] = c1; o.p[0] = relu;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_eltwise_f32(saber_hip_net_t* net, size_t count, float c0, float c1, int relu, int a_id, int b_id,
+                                  int out_id) {
+    NetOp o;
+    o.kind = OP_ELT_F32; o.in = a_id; o.in2 = b_id; o.out = out_id; o.count = count; o.name = "eltwise_sum_f32";
+    o.f[0] = c0; o.f[1] = c1; o.p[0] = relu;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh,
+                              int sw, int ph, int pw, int type, int in_dtype, int out_dtype, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_POOL_I8; o.in = in_id; o.out = out_id; o.name = "pool2d_i8_nhwc";
+    const int v[15] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, out_dtype};
+    std::memcpy(o.p, v, sizeof v);
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_f32(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh,
+                               int sw, int ph, int pw, int type, int layout, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_POOL_F32; o.in = in_id; o.out = out_id; o.name = "pool2d_f32";
+    const int v[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout};
+    std::memcpy(o.p, v, sizeof v);
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_SOFTMAX; o.in = in_id; o.out = out_id; o.name = "softmax_f32";
+    o.p[0] = rows; o.p[1] = cols;
+    return push(net, std::move(o));
+}
+
+int saber_hip_net_finalize(saber_hip_net_t* net) {
+    if (net->finalized) return SABER_HIP_OK;
+    size_t off = 0;
+    net->tensor_off.resize(net->tensor_bytes.size());
+    for (size_t i = 0; i < net->tensor_bytes.size(); ++i) {
+        net->tensor_off[i] = off;
+        off += (net->tensor_bytes[i] + 255) / 256 * 256;
+    }
+    net->ws_off = off;
+    off += (net->ws_bytes + 255) / 256 * 256;
+    net->arena_bytes = off ? off : 256;
+    HIP_TRY(hipMalloc((void**)&net->arena, net->arena_bytes));
+    HIP_TRY(hipMemset(net->arena, 0, net->arena_bytes));
+    net->finalized = true;
+    return SABER_HIP_OK;
+}
+void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id) {
+    if (!net->finalized || id < 0 || id >= (int)net->tensor_off.size()) return nullptr;
+    return net->arena + net->tensor_off[id];
+}
+size_t saber_hip_net_arena_bytes(const saber_hip_net_t* net) { return net->arena_bytes; }
+int saber_hip_net_num_ops(const saber_hip_net_t* net) { return (int)net->ops.size(); }
+const char* saber_hip_net_op_name(const saber_hip_net_t* net, int i) {
+    return (i >= 0 && i < (int)net->ops.size()) ? net->ops[i].name.c_str() : "";
+}
+int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
+    if (!net->finalized) return fail(SABER_HIP_INVALID_VALUE, "net not finalized");
+    for (const NetOp& o : net->ops) {
+        int rc = net_launch(net, o, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SABER_HIP_OK;
+}
+int saber_hip_net_run_op(saber_hip_net_t* net, int index, saber_hip_stream_t stream) {
+    if (!net->finalized || index < 0 || index >= (int)net->ops.size()) return fail(SABER_HIP_INVALID_VALUE, "bad op index");
+    return net_launch(net, net->ops[index], (hipStream_t)stream);
+}
+int saber_hip_net_capture(saber_hip_net_t* net, saber_hip_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (net->exec) {
+        (void)hipGraphExecDestroy(net->exec);
+        (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = saber_hip_net_run(net, stream);
+    hipError_t e = hipStreamEndCapture(s, &net->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+    HIP_TRY(hipGraphInstantiate(&net->exec, net->graph, nullptr, nullptr, 0));
+    return SABER_HIP_OK;
+}
+int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream) {
+    if (!net->exec) return fail(SABER_HIP_INVALID_VALUE, "net not captured");
+    HIP_TRY(hipGraphLaunch(net->exec, (hipStream_t)stream));
+    return SABER_HIP_OK;
+}
+int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        int rc = net_launch(net, net->ops[i], s);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e0, s));
+        for (int it = 0; it < iters; ++it) net_launch(net, net->ops[i], s);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        out_us[i] = ms * 1000.f / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SABER_HIP_OK;
+}
+int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters) {
+    auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
+    for (NetOp& o : net->ops) {
+        saber_hip_conv* c = o.kind == OP_CONV ? o.conv : (o.kind == OP_FC ? o.fc->conv : nullptr);
+        if (!c) continue;
+        if (o.kind == OP_FC && o.fc->pre_quant) continue;
+        int rc = saber_hip_conv2d_autotune(c, T(o.in), T(o.out), T(o.in2), net->arena + net->ws_off, stream, iters);
+        if (rc) return rc;
+        o.name = std::string(o.kind == OP_CONV ? "conv:" : "fc:") + c->algo_name;
+    }
+    return SABER_HIP_OK;
+}
+void saber_hip_net_destroy(saber_hip_net_t* net) {
+    if (!net) return;
+    if (net->exec) (void)hipGraphExecDestroy(net->exec);
+    if (net->graph) (void)hipGraphDestroy(net->graph);
+    if (net->arena) (void)hipFree(net->arena);
+    delete net;
+}
+
+}  // extern "C"

@@ -1,0 +1,505 @@
+// anakin_amd/csrc/elementwise.hip — HBM-bound kernels around the conv/GEMM hot path (gfx950):
+// quantise / dequantise + NCHW<->NHWC (reorder_nhwc_nchw, saber/funcs/saber_util.h:637-803),
+// INT8 / FP32 eltwise sum(+relu) (impl/x86/saber_eltwise.cpp:40-113), 8-bit / FP32 pooling
+// (impl/x86/saber_pooling.cpp:385-654 + kernel/jit_avx512_core_8bit_pooling_kernel.cpp:166-287),
+// softmax (impl/x86/saber_softmax.cpp), and a plain FP32 GEMM (saber/funcs/gemm.h:27-66).
+// All are streaming kernels: coalesced 4..16-byte accesses per lane, no LDS reuse to exploit.
+#include "kernels.h"
+
+namespace saber_mi355x {
+
+__device__ __forceinline__ int q_sat_s8(float v) {
+    v = v < -128.f ? -128.f : v;
+    v = v > 127.f ? 127.f : v;
+    return (int)v;
+}
+__device__ __forceinline__ int q_sat_u8(float v) {
+    v = v < 0.f ? 0.f : v;
+    v = v > 255.f ? 255.f : v;
+    return (int)v;
+}
+
+// ---- f32 NCHW -> s8/u8 NHWC(c_pad) : saturate(roundf(x * inv)) -------------------------------
+__global__ __launch_bounds__(256) void quantize_nchw_to_nhwc_kernel(int n, int c, int hw, int c_pad, int u8,
+                                                                    float inv, const float* __restrict__ x,
+                                                                    unsigned* __restrict__ y) {
+    const int groups = c_pad >> 2;  // dwords per pixel
+    const size_t total = (size_t)n * hw * groups;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        // pixel fastest within a channel group -> coalesced plane reads
+        const size_t per_img = (size_t)hw * groups;
+        const int img = (int)(gid / per_img);
+        const size_t r = gid - (size_t)img * per_img;
+        const int g = (int)(r / hw);
+        const int p = (int)(r - (size_t)g * hw);
+        unsigned pk = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ch = g * 4 + t;
+            int q = 0;
+            if (ch < c) {
+                const float v = roundf(__fmul_rn(x[((size_t)img * c + ch) * hw + p], inv));
+                q = u8 ? q_sat_u8(v) : q_sat_s8(v);
+            }
+            pk |= (unsigned)(q & 0xff) << (8 * t);
+        }
+        y[((size_t)img * hw + p) * groups + g] = pk;
+    }
+}
+
+__global__ void quantize_nchw_to_nhwc_bytes_kernel(int n, int c, int hw, int c_pad, int u8, float inv,
+                                                   const float* __restrict__ x, uint8_t* __restrict__ y);
+
+hipError_t launch_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                                        const float* x, void* y, hipStream_t s) {
+    const float inv = out_dtype == DT_U8 ? 1.f / (scale * (127.f / 255.f)) : 1.f / scale;
+    if (c_pad & 3) {
+        const size_t tb = (size_t)n * h * w * c_pad;
+        const unsigned nb = (unsigned)((tb + 255) / 256 > 8192 ? 8192 : (tb + 255) / 256);
+        hipLaunchKernelGGL(quantize_nchw_to_nhwc_bytes_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, n, c, h * w,
+                           c_pad, out_dtype == DT_U8, inv, x, (uint8_t*)y);
+        return hipGetLastError();
+    }
+    const size_t total = (size_t)n * h * w * (c_pad >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(quantize_nchw_to_nhwc_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n, c, h * w,
+                       c_pad, out_dtype == DT_U8, inv, x, (unsigned*)y);
+    return hipGetLastError();
+}
+
+// channel count not a multiple of 4 on the NHWC side: byte-granular variant
+__global__ __launch_bounds__(256) void quantize_nchw_to_nhwc_bytes_kernel(int n, int c, int hw, int c_pad, int u8,
+                                                                          float inv, const float* __restrict__ x,
+                                                                          uint8_t* __restrict__ y) {
+    const size_t total = (size_t)n * hw * c_pad;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        const int ch = (int)(gid % c_pad);
+        const size_t pp = gid / c_pad;
+        const int img = (int)(pp / hw);
+        const int p = (int)(pp - (size_t)img * hw);
+        int q = 0;
+        if (ch < c) {
+            const float v = roundf(__fmul_rn(x[((size_t)img * c + ch) * hw + p], inv));
+            q = u8 ? q_sat_u8(v) : q_sat_s8(v);
+        }
+        y[gid] = (uint8_t)q;
+    }
+}
+
+// ---- s8/u8 NHWC -> f32 NCHW : q * s ----------------------------------------------------------
+__global__ __launch_bounds__(256) void dequantize_nhwc_to_nchw_kernel(int n, int c, int hw, int u8, float s,
+                                                                      const uint8_t* __restrict__ x,
+                                                                      float* __restrict__ y) {
+    const size_t total = (size_t)n * c * hw;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        const int p = (int)(gid % hw);
+        const size_t r = gid / hw;
+        const int ch = (int)(r % c);
+        const int img = (int)(r / c);
+        const uint8_t b = x[((size_t)img * hw + p) * c + ch];
+        const float q = u8 ? (float)b : (float)(int8_t)b;
+        y[gid] = __fmul_rn(q, s);
+    }
+}
+
+hipError_t launch_dequantize_nhwc_to_nchw(int n, int c, int h, int w, int in_dtype, float scale, const void* x,
+                                          float* y, hipStream_t s) {
+    const float sc = in_dtype == DT_U8 ? scale * (127.f / 255.f) : scale;
+    const size_t total = (size_t)n * c * h * w;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(dequantize_nhwc_to_nchw_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n, c, h * w,
+                       in_dtype == DT_U8, sc, (const uint8_t*)x, y);
+    return hipGetLastError();
+}
+
+// ---- f32 layout transforms -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f32_kernel(int n, int c, int hw, int c_pad,
+                                                               const float* __restrict__ x, float* __restrict__ y) {
+    const size_t total = (size_t)n * hw * c_pad;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        // thread order: pixel fastest within channel (coalesced reads)
+        const size_t per_img = (size_t)hw * c_pad;
+        const int img = (int)(gid / per_img);
+        const size_t r = gid - (size_t)img * per_img;
+        const int ch = (int)(r / hw);
+        const int p = (int)(r - (size_t)ch * hw);
+        y[((size_t)img * hw + p) * c_pad + ch] = ch < c ? x[((size_t)img * c + ch) * hw + p] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(int n, int c, int hw, int c_pad,
+                                                               const float* __restrict__ x, float* __restrict__ y) {
+    const size_t total = (size_t)n * c * hw;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        const int p = (int)(gid % hw);
+        const size_t r = gid / hw;
+        const int ch = (int)(r % c);
+        const int img = (int)(r / c);
+        y[gid] = x[((size_t)img * hw + p) * c_pad + ch];
+    }
+}
+static unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+hipError_t launch_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                             hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(grid_for((size_t)n * h * w * c_pad)), dim3(256), 0, s, n, c,
+                       h * w, c_pad, x, y);
+    return hipGetLastError();
+}
+hipError_t launch_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                             hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((size_t)n * c * h * w)), dim3(256), 0, s, n, c,
+                       h * w, c_pad, x, y);
+    return hipGetLastError();
+}
+
+// ---- 8-bit NHWC channel padding (first-layer path: C=3 -> 4) ---------------------------------
+__global__ __launch_bounds__(256) void pad_channels_i8_kernel(size_t pixels, int c, int c_pad,
+                                                              const uint8_t* __restrict__ x, uint8_t* __restrict__ y) {
+    const size_t total = pixels * c_pad;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        const int ch = (int)(gid % c_pad);
+        const size_t p = gid / c_pad;
+        y[gid] = ch < c ? x[p * c + ch] : 0;
+    }
+}
+hipError_t launch_pad_channels_i8(size_t pixels, int c, int c_pad, const void* x, void* y, hipStream_t s) {
+    hipLaunchKernelGGL(pad_channels_i8_kernel, dim3(grid_for(pixels * c_pad)), dim3(256), 0, s, pixels, c, c_pad,
+                       (const uint8_t*)x, (uint8_t*)y);
+    return hipGetLastError();
+}
+
+// ---- flat f32 -> s8, ScaleUtils::scale_fp32_int8 (x86_utils.h:325-346) ------------------------
+__global__ __launch_bounds__(256) void quantize_flat_s8_kernel(size_t count, float inv, const float* __restrict__ x,
+                                                               int8_t* __restrict__ y) {
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < count; gid += (size_t)gridDim.x * 256) {
+        int t = (int)roundf(__fmul_rn(x[gid], inv));
+        t = t > 127 ? 127 : t;
+        t = t < -128 ? -128 : t;
+        y[gid] = (int8_t)t;
+    }
+}
+hipError_t launch_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_flat_s8_kernel, dim3(grid_for(count)), dim3(256), 0, s, count, 1.f / scale, x, y);
+    return hipGetLastError();
+}
+
+// ---- eltwise sum ------------------------------------------------------------------------------
+__device__ __forceinline__ int elt_i8_one(int a, int b, float sa, float sb, float c0, float c1, int relu) {
+    float t = __fmul_rn(__fmul_rn(c0, (float)a), sa);
+    t = __fadd_rn(t, __fmul_rn(__fmul_rn(c1, (float)b), sb));
+    if (relu) t = t > 0.f ? t : 0.f;
+    return q_sat_s8(roundf(t));
+}
+__global__ __launch_bounds__(256) void eltwise_sum_i8_kernel(size_t count, const int8_t* __restrict__ a,
+                                                             const int8_t* __restrict__ b, float sa, float sb,
+                                                             float c0, float c1, int relu, int8_t* __restrict__ y) {
+    const size_t vec = count >> 4;  // 16 bytes per lane
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < vec; gid += (size_t)gridDim.x * 256) {
+        const uint4 va = ((const uint4*)a)[gid];
+        const uint4 vb = ((const uint4*)b)[gid];
+        const unsigned wa[4] = {va.x, va.y, va.z, va.w};
+        const unsigned wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        unsigned wo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned o = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ai = (int)(int8_t)(wa[d] >> (8 * t));
+                const int bi = (int)(int8_t)(wb[d] >> (8 * t));
+                o |= (unsigned)(elt_i8_one(ai, bi, sa, sb, c0, c1, relu) & 0xff) << (8 * t);
+            }
+            wo[d] = o;
+        }
+        ((uint4*)y)[gid] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+    }
+    // tail
+    const size_t base = vec << 4;
+    for (size_t i = base + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        y[i] = (int8_t)elt_i8_one(a[i], b[i], sa, sb, c0, c1, relu);
+    }
+}
+hipError_t launch_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float sa, float sb, float c0,
+                                 float c1, int relu, int8_t* y, hipStream_t s) {
+    hipLaunchKernelGGL(eltwise_sum_i8_kernel, dim3(grid_for((count + 15) / 16)), dim3(256), 0, s, count, a, b, sa,
+                       sb, c0, c1, relu, y);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void eltwise_sum_f32_kernel(size_t count, const float* __restrict__ a,
+                                                              const float* __restrict__ b, float c0, float c1,
+                                                              int relu, float* __restrict__ y) {
+    const size_t vec = count >> 2;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < vec; gid += (size_t)gridDim.x * 256) {
+        const float4 va = ((const float4*)a)[gid];
+        const float4 vb = ((const float4*)b)[gid];
+        float o[4] = {__fadd_rn(__fmul_rn(c0, va.x), __fmul_rn(c1, vb.x)),
+                      __fadd_rn(__fmul_rn(c0, va.y), __fmul_rn(c1, vb.y)),
+                      __fadd_rn(__fmul_rn(c0, va.z), __fmul_rn(c1, vb.z)),
+                      __fadd_rn(__fmul_rn(c0, va.w), __fmul_rn(c1, vb.w))};
+        if (relu) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = o[t] > 0.f ? o[t] : 0.f;
+        }
+        ((float4*)y)[gid] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    const size_t base = vec << 2;
+    for (size_t i = base + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float t = __fadd_rn(__fmul_rn(c0, a[i]), __fmul_rn(c1, b[i]));
+        y[i] = relu ? (t > 0.f ? t : 0.f) : t;
+    }
+}
+hipError_t launch_eltwise_sum_f32(size_t count, const float* a, const float* b, float c0, float c1, int relu,
+                                  float* y, hipStream_t s) {
+    hipLaunchKernelGGL(eltwise_sum_f32_kernel, dim3(grid_for((count + 3) / 4)), dim3(256), 0, s, count, a, b, c0,
+                       c1, relu, y);
+    return hipGetLastError();
+}
+
+// ---- 8-bit NHWC pooling -----------------------------------------------------------------------
+// One lane per (output pixel, 4-channel dword). JIT semantics: int32 window sum, (float)sum * idivider,
+// round-to-nearest-even, saturate; max by signed/unsigned compare.
+__global__ __launch_bounds__(256) void pool2d_i8_nhwc_kernel(int n, int h, int w, int c, int oh, int ow, int kh,
+                                                             int kw, int sh, int sw, int ph, int pw, int type,
+                                                             int in_u8, int out_dtype,
+                                                             const uint8_t* __restrict__ x, void* __restrict__ y) {
+    const int cg = (c + 3) >> 2;
+    const size_t total = (size_t)n * oh * ow * cg;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        const int g = (int)(gid % cg);
+        size_t r = gid / cg;
+        const int ox = (int)(r % ow);
+        r /= ow;
+        const int oy = (int)(r % oh);
+        const int img = (int)(r / oh);
+        int hs = oy * sh - ph, ws = ox * sw - pw;
+        int he = hs + kh, we = ws + kw;
+        hs = hs < 0 ? 0 : hs;
+        ws = ws < 0 ? 0 : ws;
+        he = he > h ? h : he;
+        we = we > w ? w : we;
+        const int nch = (c - g * 4) < 4 ? (c - g * 4) : 4;
+        int sum[4] = {0, 0, 0, 0};
+        int mx[4];
+        for (int t = 0; t < 4; ++t) mx[t] = in_u8 ? 0 : -128;
+        for (int iy = hs; iy < he; ++iy) {
+            for (int ix = ws; ix < we; ++ix) {
+                const uint8_t* px = x + (((size_t)img * h + iy) * w + ix) * c + g * 4;
+                unsigned v = 0;
+                if (nch == 4 && (c & 3) == 0) {
+                    v = *(const unsigned*)px;
+                } else {
+                    for (int t = 0; t < nch; ++t) v |= (unsigned)px[t] << (8 * t);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int b = (v >> (8 * t)) & 0xff;
+                    const int val = in_u8 ? b : (int)(int8_t)b;
+                    sum[t] += val;
+                    mx[t] = val > mx[t] ? val : mx[t];
+                }
+            }
+        }
+        const float idiv = 1.0f / (float)(type == 2 ? (he - hs) * (we - ws) : kh * kw);
+        const size_t o = (((size_t)img * oh + oy) * ow + ox) * c + g * 4;
+        int q[4];
+        float f[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (type == 0) {
+                q[t] = mx[t];
+            } else {
+                f[t] = __fmul_rn((float)sum[t], idiv);
+                q[t] = out_dtype == DT_U8 ? q_sat_u8(rintf(f[t])) : q_sat_s8(rintf(f[t]));
+            }
+        }
+        if (out_dtype == DT_F32) {
+            for (int t = 0; t < nch; ++t) ((float*)y)[o + t] = f[t];
+        } else if (nch == 4 && (c & 3) == 0) {
+            *(unsigned*)((uint8_t*)y + o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) |
+                                            ((unsigned)(q[3] & 0xff) << 24);
+        } else {
+            for (int t = 0; t < nch; ++t) ((uint8_t*)y)[o + t] = (uint8_t)q[t];
+        }
+    }
+}
+hipError_t launch_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw,
+                                 int ph, int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
+                                 hipStream_t s) {
+    if (type == 0 && out_dtype == DT_F32) return hipErrorInvalidValue;  // as the reference (pooling kernel :425)
+    const size_t total = (size_t)n * oh * ow * ((c + 3) >> 2);
+    hipLaunchKernelGGL(pool2d_i8_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, n, h, w, c, oh, ow, kh, kw,
+                       sh, sw, ph, pw, type, in_dtype == DT_U8, out_dtype, (const uint8_t*)x, y);
+    return hipGetLastError();
+}
+
+// ---- FP32 pooling (NHWC or NCHW) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool2d_f32_kernel(int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                                                         int sh, int sw, int ph, int pw, int type, int nchw,
+                                                         const float* __restrict__ x, float* __restrict__ y) {
+    const size_t total = (size_t)n * oh * ow * c;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        int ch, ox, oy, img;
+        size_t r = gid;
+        if (nchw) {
+            ox = (int)(r % ow); r /= ow;
+            oy = (int)(r % oh); r /= oh;
+            ch = (int)(r % c);
+            img = (int)(r / c);
+        } else {
+            ch = (int)(r % c); r /= c;
+            ox = (int)(r % ow); r /= ow;
+            oy = (int)(r % oh);
+            img = (int)(r / oh);
+        }
+        int hs = oy * sh - ph, ws = ox * sw - pw;
+        int he = hs + kh, we = ws + kw;
+        hs = hs < 0 ? 0 : hs;
+        ws = ws < 0 ? 0 : ws;
+        he = he > h ? h : he;
+        we = we > w ? w : we;
+        float acc = 0.f;
+        bool first = true;
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) {
+                const float v = nchw ? x[(((size_t)img * c + ch) * h + iy) * w + ix]
+                                     : x[(((size_t)img * h + iy) * w + ix) * c + ch];
+                if (type == 0) {
+                    acc = first ? v : (acc >= v ? acc : v);
+                    first = false;
+                } else {
+                    acc = __fadd_rn(acc, v);
+                }
+            }
+        if (type == 1) {  // divisor clipped at in+pad on the far edge (saber_pooling.cpp:466-480)
+            int bh = kh, bw = kw;
+            if (we == w) bw = (ws + kw >= w + pw ? w + pw : ws + kw) - ws;
+            if (he == h) bh = (hs + kh >= h + ph ? h + ph : hs + kh) - hs;
+            acc = acc / (float)(bh * bw);
+        }
+        if (type == 2) acc = acc / (float)((he - hs) * (we - ws));
+        y[gid] = acc;
+    }
+}
+hipError_t launch_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                             int pw, int type, int nchw, const float* x, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(pool2d_f32_kernel, dim3(grid_for((size_t)n * oh * ow * c)), dim3(256), 0, s, n, h, w, c, oh,
+                       ow, kh, kw, sh, sw, ph, pw, type, nchw, x, y);
+    return hipGetLastError();
+}
+
+// ---- softmax over the last axis: one 256-thread block per row, wavefront shuffles ---------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void softmax_f32_kernel(int cols, const float* __restrict__ x,
+                                                          float* __restrict__ y) {
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * cols;
+    float* yr = y + (size_t)blockIdx.x * cols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -3.4e38f;
+    for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) sum += expf(xr[i] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = threadIdx.x; i < cols; i += 256) yr[i] = expf(xr[i] - m) / sum;
+}
+hipError_t launch_softmax_f32(int rows, int cols, const float* x, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_f32_kernel, dim3(rows), dim3(256), 0, s, cols, x, y);
+    return hipGetLastError();
+}
+
+// ---- FP32 GEMM on v_mfma_f32_16x16x4_f32: C = alpha*op(A)*op(B) + beta*C (row-major) ------------
+// 64x64 block tile, 2x2 waves of 32x32, K-step 16; operands staged through LDS as [rows][16 f32]
+// with the same chunk swizzle as the conv kernel (each lane's 16-byte chunk feeds 4 MFMA k-groups).
+typedef int g4i __attribute__((ext_vector_type(4)));
+typedef float g4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int gswz(int row, int q) { return ((0x9C >> (2 * q)) & 3) ^ ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int ta, int tb, int M, int N, int K, float alpha,
+                                                       const float* __restrict__ A, const float* __restrict__ B,
+                                                       float beta, float* __restrict__ C) {
+    __shared__ float lds[2][64 * 16];  // [0]=A tile rows m, [1]=B tile rows n ; each row 16 k
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    g4f acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = g4f{0, 0, 0, 0};
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // stage: 64 rows x 16 k per operand = 1024 floats each, 4 per thread
+        for (int e = tid; e < 1024; e += 256) {
+            const int r = e >> 4, kk = e & 15;
+            const int k = k0 + kk;
+            float va = 0.f, vb = 0.f;
+            if (k < K) {
+                if (m0 + r < M) va = ta ? A[(size_t)k * M + m0 + r] : A[(size_t)(m0 + r) * K + k];
+                if (n0 + r < N) vb = tb ? B[(size_t)(n0 + r) * K + k] : B[(size_t)k * N + n0 + r];
+            }
+            const int q = kk >> 2, w = kk & 3;
+            lds[0][r * 16 + gswz(r, q) * 4 + w] = va;
+            lds[1][r * 16 + gswz(r, q) * 4 + w] = vb;
+        }
+        __syncthreads();
+        g4f af[2], bf[2];
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wm * 2 + i) * 16 + frow;
+            af[i] = *(const g4f*)&lds[0][row * 16 + gswz(row, fq) * 4];
+        }
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wn * 2 + j) * 16 + frow;
+            bf[j] = *(const g4f*)&lds[1][row * 16 + gswz(row, fq) * 4];
+        }
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                // rows of D = n (B operand as MFMA "A"), cols = m: lane gets 4 consecutive n for one m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].x, af[i].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].y, af[i].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].z, af[i].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].w, af[i].w, acc[i][j], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + (wm * 2 + i) * 16 + frow;
+            const int nb = n0 + (wn * 2 + j) * 16 + fq * 4;
+            if (m >= M) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int nn = nb + r;
+                if (nn < N) {
+                    const size_t o = (size_t)m * N + nn;
+                    const float v = __fmul_rn(alpha, acc[i][j][r]);
+                    C[o] = beta == 0.f ? v : __fadd_rn(v, __fmul_rn(beta, C[o]));
+                }
+            }
+        }
+}
+hipError_t launch_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b,
+                           float beta, float* c, hipStream_t s) {
+    dim3 grid((n + 63) / 64, (m + 63) / 64);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, ta, tb, m, n, k, alpha, a, b, beta, c);
+    return hipGetLastError();
+}
+
+}  // namespace saber_mi355x

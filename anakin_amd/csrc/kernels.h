@@ -1,0 +1,77 @@
+// anakin_amd/csrc/kernels.h — internal declarations shared by the HIP kernel TUs and the C-ABI TU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace saber_mi355x {
+
+enum { DT_F32 = 0, DT_S8 = 1, DT_U8 = 2 };
+
+// Epilogue arithmetic selectors
+enum {
+    EPI_I8_CONV = 0,   // d=(float)acc; d+=bias; d*=scale; relu; [residual]; rne+saturate | f32
+    EPI_I8_FC_S8 = 1,  // v=(float)acc*scale; v+=bias                (mkl_packed_int8_gemm.cpp:78-81)
+    EPI_I8_FC_U8 = 2,  // acc+=bias_i (folded into comp); v = scale==1 ? (float)acc : scale*(float)acc
+    EPI_F32 = 3        // d=acc [+ prev]; d+=bias; relu
+};
+enum { RES_NONE = 0, RES_SUM_INPLACE = 1, RES_ELTWISE = 2 };
+
+struct ConvKArgs {
+    const void* x;
+    const void* w;      // repacked weights [K_pad][Kg_pad] (s8 or f32), zero padded
+    void* y;
+    const void* res;
+    const float* bias;  // INT8 conv: pre-scaled bias_p; FC/F32: plain bias; may be null
+    const float* scale; // per out-channel scale (INT8 paths)
+    const int* comp;    // per out-channel int32 offset (u8 shift compensation [+ FC int bias]); may be null
+    int N, H, W, C, K, OH, OW;
+    int kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
+    int M;        // N*OH*OW output pixels (GEMM columns)
+    int Kg;       // real reduction length in elements (kh*kw*C, or kh*kw_pad*4 in C4 mode)
+    int Kg_pad;   // padded to a multiple of one K-step
+    int steps;    // Kg_pad / elements-per-step
+    int kw_pad;   // C4 mode: kw rounded up to 4
+    int in_u8;    // activations are u8: shift to s8 by XOR 0x80 (compensated through comp)
+    int out_dtype;
+    int out_nchw; // f32 outputs only
+    int relu;
+    int epi;
+    int res_mode, res_relu, res_dtype;
+    float sum_scale, coeff_conv, coeff_res, scale_conv, scale_res;
+};
+
+// tile ids for launch_conv_igemm
+enum { TILE_32x32 = 0, TILE_64x32 = 1, TILE_64x64 = 2, TILE_128x64 = 3, TILE_64x128 = 4, TILE_128x128 = 5,
+       TILE_COUNT = 6 };
+void tile_dims(int tile, int* bm_k, int* bn_pix);
+
+// mode: 0 = int8 (C % 16 == 0), 1 = int8 C4 (input NHWC4), 2 = f32 (C % 4 == 0)
+hipError_t launch_conv_igemm(int mode, int tile, const ConvKArgs& a, hipStream_t s);
+// Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
+hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
+
+// elementwise / layout / pooling / softmax (elementwise.hip)
+hipError_t launch_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                                        const float* x, void* y, hipStream_t s);
+hipError_t launch_dequantize_nhwc_to_nchw(int n, int c, int h, int w, int in_dtype, float scale, const void* x,
+                                          float* y, hipStream_t s);
+hipError_t launch_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                             hipStream_t s);
+hipError_t launch_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                             hipStream_t s);
+hipError_t launch_pad_channels_i8(size_t pixels, int c, int c_pad, const void* x, void* y, hipStream_t s);
+hipError_t launch_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, hipStream_t s);
+hipError_t launch_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float sa, float sb, float c0,
+                                 float c1, int relu, int8_t* y, hipStream_t s);
+hipError_t launch_eltwise_sum_f32(size_t count, const float* a, const float* b, float c0, float c1, int relu,
+                                  float* y, hipStream_t s);
+hipError_t launch_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw,
+                                 int ph, int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
+                                 hipStream_t s);
+hipError_t launch_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                             int pw, int type, int nchw, const float* x, float* y, hipStream_t s);
+hipError_t launch_softmax_f32(int rows, int cols, const float* x, float* y, hipStream_t s);
+hipError_t launch_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b,
+                           float beta, float* c, hipStream_t s);
+
+}  // namespace saber_mi355x

@@ -1,0 +1,398 @@
+"""Host-side mirror of the Saber operator interface for the MI355X target, over the C ABI.
+
+Names and argument meaning follow the reference (saber/funcs/*.h, saber/saber_funcs_param.h):
+ConvParam / ActivationParam / EltwiseParam, SaberConv2D / SaberConvEltwise (init = create +
+set_weights, dispatch = run), Fc, Gemm, Pooling, Eltwise, Softmax, and an op-list executor that plays
+the role of Net::prediction (framework/core/net/net.cpp:417-509). torch is used only to own device
+memory and streams; every computation is a call into libsaber_mi355x.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+_TORCH_DT = {L.F32: torch.float32, L.S8: torch.int8, L.U8: torch.uint8}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def dtype_code(t):
+    return {torch.float32: L.F32, torch.int8: L.S8, torch.uint8: L.U8}[t.dtype]
+
+
+class ConvParam:
+    """saber_funcs_param.h:470-581 (+ the EltwiseParam half of ConvEltwiseParam :586-615)."""
+
+    def __init__(self, weight, bias=None, group=1, pad=(0, 0), stride=(1, 1), dilation=(1, 1), relu=False,
+                 w_scale=None):
+        self.weight = weight          # numpy OIHW, f32 or s8
+        self.bias = bias              # numpy f32 [K] or None
+        self.w_scale = w_scale        # numpy f32 [K] when weight is s8
+        self.group = group
+        self.pad, self.stride, self.dilation = pad, stride, dilation
+        self.relu = relu
+        # fused eltwise
+        self.res_mode = L.RES_NONE
+        self.res_relu = False
+        self.sum_scale = 1.0
+        self.coeff = (1.0, 1.0)
+        self.scale_res = 1.0
+
+
+class SaberConv2D:
+    """SaberConv2D<MI355X, AK_INT8|AK_FLOAT> / SaberConvEltwise<MI355X, ...>.
+
+    init(...)  = BaseFunc::init (create + weight quantise/repack, cold path)
+    dispatch() = ImplBase::dispatch: enqueue on the current stream, no sync.
+    """
+
+    def __init__(self, int8=True):
+        self.int8 = int8
+        self.h = C.c_void_p()
+        self.ws = None
+
+    def init(self, in_shape_nchw, param, in_dtype, out_dtype, in_scale=1.0, out_scale=1.0, in_layout=None,
+             out_layout=None):
+        lib = L.load()
+        n, c, h, w = in_shape_nchw
+        k, _, kh, kw = param.weight.shape
+        d = L.ConvDesc()
+        d.n, d.h, d.w, d.c, d.k, d.kh, d.kw = n, h, w, c, k, kh, kw
+        d.pad_h, d.pad_w = param.pad
+        d.stride_h, d.stride_w = param.stride
+        d.dil_h, d.dil_w = param.dilation
+        d.group = param.group
+        d.in_dtype, d.out_dtype = in_dtype, out_dtype
+        d.in_layout = in_layout if in_layout is not None else (L.NCHW if in_dtype == L.F32 else L.NHWC)
+        d.out_layout = out_layout if out_layout is not None else \
+            (L.NCHW if (out_dtype == L.F32 and not self.int8) else L.NHWC)
+        d.act = L.ACT_RELU if param.relu else L.ACT_NONE
+        d.res_mode = param.res_mode
+        d.res_act = L.ACT_RELU if param.res_relu else L.ACT_NONE
+        d.sum_scale = param.sum_scale
+        d.coeff_conv, d.coeff_res = param.coeff
+        d.scale_res = param.scale_res
+        d.int8_weights = 1 if self.int8 else 0
+        self.desc = d
+        L.check(lib.saber_hip_conv2d_create(C.byref(d), C.byref(self.h)))
+        w_np = np.ascontiguousarray(param.weight)
+        w_dt = L.F32 if w_np.dtype == np.float32 else L.S8
+        ws = None if param.w_scale is None else np.ascontiguousarray(param.w_scale, np.float32)
+        b = None if param.bias is None else np.ascontiguousarray(param.bias, np.float32)
+        L.check(lib.saber_hip_conv2d_set_weights(self.h, _np_ptr(w_np), w_dt, _np_ptr(ws), _np_ptr(b),
+                                                 float(in_scale), float(out_scale)))
+        oh, ow = C.c_int(), C.c_int()
+        lib.saber_hip_conv2d_out_shape(self.h, C.byref(oh), C.byref(ow))
+        self.out_hw = (oh.value, ow.value)
+        nbytes = lib.saber_hip_conv2d_workspace_bytes(self.h)
+        self.ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda") if nbytes else None
+        return self
+
+    def out_shape(self):
+        """Logical output shape in the op's output layout."""
+        d = self.desc
+        oh, ow = self.out_hw
+        return (d.n, oh, ow, d.k) if d.out_layout == L.NHWC else (d.n, d.k, oh, ow)
+
+    def new_output(self):
+        return torch.empty(self.out_shape(), dtype=_TORCH_DT[self.desc.out_dtype], device="cuda")
+
+    def dispatch(self, x, y, res=None):
+        L.check(L.load().saber_hip_conv2d_run(self.h, _p(x), _p(y), _p(res), _p(self.ws), _stream()))
+        return y
+
+    def algo(self):
+        return L.load().saber_hip_conv2d_algo(self.h).decode()
+
+    def set_tile(self, tile):
+        L.check(L.load().saber_hip_conv2d_set_tile(self.h, tile))
+
+    def autotune(self, x, y, res=None, iters=5):
+        L.check(L.load().saber_hip_conv2d_autotune(self.h, _p(x), _p(y), _p(res), _p(self.ws), _stream(), iters))
+
+    def quantized_weights(self):
+        d = self.desc
+        wq = np.empty((d.k, d.c // d.group, d.kh, d.kw), np.int8)
+        ws = np.empty(d.k, np.float32)
+        L.check(L.load().saber_hip_conv2d_get_quantized_weights(self.h, _np_ptr(wq), _np_ptr(ws)))
+        return wq, ws
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_conv2d_destroy(self.h)
+        except Exception:
+            pass
+
+
+class SaberFc:
+    """Fc<MI355X, AK_FLOAT|AK_INT8> (saber/funcs/fc.h:48-127): out[m,n] = in[m,k] W[n,k]^T + bias."""
+
+    def __init__(self, int8=True):
+        self.int8 = int8
+        self.h = C.c_void_p()
+        self.ws = None
+
+    def init(self, m, n, k, weight, bias, in_dtype, in_scale=1.0, out_scale=1.0, w_scale=None, w_is_kn=False):
+        lib = L.load()
+        d = L.FcDesc(m, n, k, in_dtype, 1 if self.int8 else 0, 1 if w_is_kn else 0)
+        self.desc = d
+        L.check(lib.saber_hip_fc_create(C.byref(d), C.byref(self.h)))
+        w_np = np.ascontiguousarray(weight)
+        w_dt = L.F32 if w_np.dtype == np.float32 else L.S8
+        ws = None if w_scale is None else np.ascontiguousarray(w_scale, np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        L.check(lib.saber_hip_fc_set_weights(self.h, _np_ptr(w_np), w_dt, _np_ptr(ws), _np_ptr(b), float(in_scale),
+                                             float(out_scale)))
+        nbytes = lib.saber_hip_fc_workspace_bytes(self.h)
+        self.ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda") if nbytes else None
+        return self
+
+    def dispatch(self, x, y):
+        L.check(L.load().saber_hip_fc_run(self.h, _p(x), _p(y), _p(self.ws), _stream()))
+        return y
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_fc_destroy(self.h)
+        except Exception:
+            pass
+
+
+def gemm(trans_a, trans_b, m, n, k, alpha, a, b, beta, c):
+    """Gemm<MI355X, SABER_IMPL, float, float>::dispatch (saber/funcs/gemm.h:30-40), raw row-major."""
+    L.check(L.load().saber_hip_gemm_f32(int(trans_a), int(trans_b), m, n, k, float(alpha), _p(a), _p(b),
+                                        float(beta), _p(c), _stream()))
+    return c
+
+
+def quantize_nchw_to_nhwc(x, scale, out_dtype, c_pad=None):
+    n, c, h, w = x.shape
+    c_pad = c if c_pad is None else c_pad
+    y = torch.empty((n, h, w, c_pad), dtype=_TORCH_DT[out_dtype], device="cuda")
+    L.check(L.load().saber_hip_quantize_nchw_to_nhwc(n, c, h, w, c_pad, out_dtype, float(scale), _p(x), _p(y),
+                                                     _stream()))
+    return y
+
+
+def dequantize_nhwc_to_nchw(x, scale):
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device="cuda")
+    L.check(L.load().saber_hip_dequantize_nhwc_to_nchw(n, c, h, w, dtype_code(x), float(scale), _p(x), _p(y),
+                                                       _stream()))
+    return y
+
+
+def transpose_nchw_to_nhwc(x, c_pad=None):
+    n, c, h, w = x.shape
+    c_pad = c if c_pad is None else c_pad
+    y = torch.empty((n, h, w, c_pad), dtype=torch.float32, device="cuda")
+    L.check(L.load().saber_hip_transpose_nchw_to_nhwc_f32(n, c, h, w, c_pad, _p(x), _p(y), _stream()))
+    return y
+
+
+def transpose_nhwc_to_nchw(x, c=None):
+    n, h, w, c_pad = x.shape
+    c = c_pad if c is None else c
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device="cuda")
+    L.check(L.load().saber_hip_transpose_nhwc_to_nchw_f32(n, c, h, w, c_pad, _p(x), _p(y), _stream()))
+    return y
+
+
+def quantize_flat_s8(x, scale):
+    y = torch.empty(x.shape, dtype=torch.int8, device="cuda")
+    L.check(L.load().saber_hip_quantize_flat_s8(x.numel(), float(scale), _p(x), _p(y), _stream()))
+    return y
+
+
+def eltwise_sum(a, b, coeff=(1.0, 1.0), relu=True, scale_a=1.0, scale_b=1.0):
+    """Eltwise<MI355X, AK_INT8|AK_FLOAT> sum (EltwiseParam :1077-1140)."""
+    y = torch.empty_like(a)
+    if a.dtype == torch.int8:
+        L.check(L.load().saber_hip_eltwise_sum_i8(a.numel(), _p(a), _p(b), float(scale_a), float(scale_b),
+                                                  float(coeff[0]), float(coeff[1]), int(relu), _p(y), _stream()))
+    else:
+        L.check(L.load().saber_hip_eltwise_sum_f32(a.numel(), _p(a), _p(b), float(coeff[0]), float(coeff[1]),
+                                                   int(relu), _p(y), _stream()))
+    return y
+
+
+def pool_out_dim(inp, pad, win, stride, floor_mode=False):
+    return L.load().saber_hip_pool_out_dim(inp, pad, win, stride, int(floor_mode))
+
+
+def pooling_i8(x, window, stride, pad, pool_type, out_dtype=None, global_pooling=False, floor_mode=False):
+    """Pooling<MI355X, AK_INT8> on NHWC s8/u8 (PoolingParam :2087)."""
+    n, h, w, c = x.shape
+    if global_pooling:
+        window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
+    else:
+        oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
+        ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
+    od = dtype_code(x) if out_dtype is None else out_dtype
+    y = torch.empty((n, oh, ow, c), dtype=_TORCH_DT[od], device="cuda")
+    L.check(L.load().saber_hip_pool2d_i8_nhwc(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1],
+                                              pad[0], pad[1], pool_type, dtype_code(x), od, _p(x), _p(y), _stream()))
+    return y
+
+
+def pooling_f32(x, window, stride, pad, pool_type, layout=L.NCHW, global_pooling=False, floor_mode=False):
+    if layout == L.NCHW:
+        n, c, h, w = x.shape
+    else:
+        n, h, w, c = x.shape
+    if global_pooling:
+        window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
+    else:
+        oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
+        ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
+    shape = (n, c, oh, ow) if layout == L.NCHW else (n, oh, ow, c)
+    y = torch.empty(shape, dtype=torch.float32, device="cuda")
+    L.check(L.load().saber_hip_pool2d_f32(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1], pad[0],
+                                          pad[1], pool_type, layout, _p(x), _p(y), _stream()))
+    return y
+
+
+def softmax(x):
+    rows, cols = x.shape[0], x.numel() // x.shape[0]
+    y = torch.empty_like(x)
+    L.check(L.load().saber_hip_softmax_f32(rows, cols, _p(x), _p(y), _stream()))
+    return y
+
+
+class Net:
+    """Op-list executor: the device half of Net<T,P,R>::prediction (net.cpp:417-509). Tensors are edge
+    buffers in one arena; ops run in insertion order on one stream; `capture()` turns the launch
+    sequence into a hipGraph."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        L.check(L.load().saber_hip_net_create(C.byref(self.h)))
+        self.keep = []          # conv/fc python objects whose handles the net references
+        self.tensors = {}       # name -> (id, shape, torch dtype)
+        self.finalized = False
+
+    def add_tensor(self, name, shape, dtype_code_):
+        nbytes = int(np.prod(shape)) * (4 if dtype_code_ == L.F32 else 1)
+        tid = L.load().saber_hip_net_add_tensor(self.h, nbytes)
+        self.tensors[name] = (tid, tuple(shape), _TORCH_DT[dtype_code_])
+        return tid
+
+    def tid(self, name):
+        return self.tensors[name][0]
+
+    def add_conv(self, conv, x, y, res=None):
+        self.keep.append(conv)
+        rc = L.load().saber_hip_net_add_conv(self.h, conv.h, self.tid(x), self.tid(y), -1 if res is None else self.tid(res))
+        if rc < 0:
+            L.check(rc)
+        return rc
+
+    def add_fc(self, fc, x, y):
+        self.keep.append(fc)
+        rc = L.load().saber_hip_net_add_fc(self.h, fc.h, self.tid(x), self.tid(y))
+        if rc < 0:
+            L.check(rc)
+        return rc
+
+    def _chk(self, rc):
+        if rc < 0:
+            L.check(rc)
+        return rc
+
+    def add_quantize(self, n, c, h, w, c_pad, out_dtype, scale, x, y):
+        return self._chk(L.load().saber_hip_net_add_quantize(self.h, n, c, h, w, c_pad, out_dtype, float(scale),
+                                                             self.tid(x), self.tid(y)))
+
+    def add_transpose_in(self, n, c, h, w, c_pad, x, y):
+        return self._chk(L.load().saber_hip_net_add_transpose_in_f32(self.h, n, c, h, w, c_pad, self.tid(x), self.tid(y)))
+
+    def add_eltwise_i8(self, count, sa, sb, c0, c1, relu, a, b, y):
+        return self._chk(L.load().saber_hip_net_add_eltwise_i8(self.h, count, float(sa), float(sb), float(c0),
+                                                               float(c1), int(relu), self.tid(a), self.tid(b), self.tid(y)))
+
+    def add_eltwise_f32(self, count, c0, c1, relu, a, b, y):
+        return self._chk(L.load().saber_hip_net_add_eltwise_f32(self.h, count, float(c0), float(c1), int(relu),
+                                                                self.tid(a), self.tid(b), self.tid(y)))
+
+    def add_pool_i8(self, n, h, w, c, oh, ow, win, stride, pad, ptype, in_dtype, out_dtype, x, y):
+        return self._chk(L.load().saber_hip_net_add_pool_i8(self.h, n, h, w, c, oh, ow, win[0], win[1], stride[0],
+                                                            stride[1], pad[0], pad[1], ptype, in_dtype, out_dtype,
+                                                            self.tid(x), self.tid(y)))
+
+    def add_pool_f32(self, n, h, w, c, oh, ow, win, stride, pad, ptype, layout, x, y):
+        return self._chk(L.load().saber_hip_net_add_pool_f32(self.h, n, h, w, c, oh, ow, win[0], win[1], stride[0],
+                                                             stride[1], pad[0], pad[1], ptype, layout, self.tid(x),
+                                                             self.tid(y)))
+
+    def add_softmax(self, rows, cols, x, y):
+        return self._chk(L.load().saber_hip_net_add_softmax(self.h, rows, cols, self.tid(x), self.tid(y)))
+
+    def finalize(self):
+        L.check(L.load().saber_hip_net_finalize(self.h))
+        self.finalized = True
+
+    def tensor(self, name):
+        """A torch view (no copy) of an edge tensor inside the arena."""
+        tid, shape, dt = self.tensors[name]
+        ptr = L.load().saber_hip_net_tensor_ptr(self.h, tid)
+        n = int(np.prod(shape))
+        nbytes = n * (4 if dt == torch.float32 else 1)
+        # wrap raw device memory via the __cuda_array_interface__ protocol
+        holder = _RawCuda(ptr, nbytes)
+        return torch.as_tensor(holder, device="cuda").view(dt).view(shape)
+
+    def num_ops(self):
+        return L.load().saber_hip_net_num_ops(self.h)
+
+    def op_name(self, i):
+        return L.load().saber_hip_net_op_name(self.h, i).decode()
+
+    def run(self):
+        L.check(L.load().saber_hip_net_run(self.h, _stream()))
+
+    def run_op(self, i):
+        L.check(L.load().saber_hip_net_run_op(self.h, i, _stream()))
+
+    def capture(self):
+        L.check(L.load().saber_hip_net_capture(self.h, _stream()))
+
+    def replay(self):
+        L.check(L.load().saber_hip_net_replay(self.h, _stream()))
+
+    def autotune(self, iters=5):
+        L.check(L.load().saber_hip_net_autotune(self.h, _stream(), iters))
+
+    def time_ops(self, iters=20):
+        out = (C.c_float * self.num_ops())()
+        L.check(L.load().saber_hip_net_time_ops(self.h, _stream(), iters, out))
+        return list(out)
+
+    def arena_bytes(self):
+        return L.load().saber_hip_net_arena_bytes(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_net_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _RawCuda:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}

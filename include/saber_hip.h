@@ -1,0 +1,234 @@
+/* include/saber_hip.h — the C-ABI drop-in boundary of the MI355X (gfx950) Saber target.
+ *
+ * This is what a `SaberConv2D<MI355X, ...>` / `SaberConvEltwise<MI355X, ...>` / `SaberFc<MI355X, ...>` /
+ * `Gemm<MI355X, SABER_IMPL, ...>` specialisation under saber/funcs/impl/ would bind to
+ * (INTEGRATION.md shows the adaptor a maintainer adds). The reference has no C ABI today; the
+ * interface each group of functions replaces is its C++ template API:
+ *
+ *   ImplBase<TargetType, OpDtype, Param>::init / create / dispatch
+ *                                              saber/funcs/impl/impl_base.h:33-69
+ *   BaseFunc<...>::init / operator()           saber/funcs/base.h:85-162
+ *   Conv<T,D> / ConvEltwise<T,D>               saber/funcs/conv.h:56-131, conv_eltwise.h:44-110
+ *   ConvParam / ConvEltwiseParam / ActivationParam / EltwiseParam
+ *                                              saber/saber_funcs_param.h:470-581,586-615,48-110,1077-1140
+ *   Fc<T,D>, FcParam                           saber/funcs/fc.h:48-127, saber_funcs_param.h:1236-1279
+ *   Gemm<T,impl,in,out>::init / dispatch       saber/funcs/gemm.h:27-66
+ *   Pooling<T,D>, Eltwise<T,D>, Softmax<T,D>   saber/funcs/pooling.h:69-130, eltwise.h, softmax.h
+ *   reorder_nhwc_nchw (quantise / dequantise)  saber/funcs/saber_util.h:637-803
+ *   Net<T,P,R>::prediction (the caller)        framework/core/net/net.cpp:417-509
+ *
+ * Call protocol (mirrors init-once / dispatch-many):
+ *   *_create           once per operator ("init"/"create": shapes, algorithm choice)
+ *   *_set_weights      once ("init": quantise + repack weights, pre-scale bias — HOST pointers, cold path)
+ *   *_run              every inference ("dispatch"): enqueues on the given hipStream_t, never syncs.
+ * All tensor pointers given to *_run are DEVICE pointers owned by the caller. Returns 0 on success
+ * or a negative saber_hip_status; the adaptor maps 0 -> SaberSuccess(-1, saber_types.h:224) and
+ * the others onto SaberInvalidValue / SaberUnImplError / SaberOutOfMem.
+ *
+ * Plain C: no C++ types, no torch types. `hipStream_t` is passed as void*.
+ */
+#ifndef SABER_HIP_H
+#define SABER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* saber_hip_stream_t; /* a hipStream_t */
+
+typedef enum {
+    SABER_HIP_OK = 0,
+    SABER_HIP_INVALID_VALUE = -2, /* -> SaberInvalidValue */
+    SABER_HIP_UNIMPL = -3,        /* -> SaberUnImplError  */
+    SABER_HIP_OUT_OF_MEM = -4,    /* -> SaberOutOfMem     */
+    SABER_HIP_RUNTIME_ERROR = -5  /* a HIP call failed; see saber_hip_last_error() */
+} saber_hip_status;
+
+/* DataType (saber_types.h:205-222) subset on this path */
+typedef enum { SABER_HIP_F32 = 0, SABER_HIP_S8 = 1, SABER_HIP_U8 = 2, SABER_HIP_S32 = 3 } saber_hip_dtype;
+/* LayoutType (saber_types.h:69-87) subset */
+typedef enum { SABER_HIP_NHWC = 0, SABER_HIP_NCHW = 1 } saber_hip_layout;
+/* ActiveType: only what the x86 path implements on this route */
+typedef enum { SABER_HIP_ACT_NONE = 0, SABER_HIP_ACT_RELU = 1 } saber_hip_act;
+/* PoolingType (saber_types.h) */
+typedef enum { SABER_HIP_POOL_MAX = 0, SABER_HIP_POOL_AVG_INCL = 1, SABER_HIP_POOL_AVG_EXCL = 2 } saber_hip_pool_type;
+
+/* Fused residual modes of the convolution epilogue (ConvEltwiseParam) */
+typedef enum {
+    SABER_HIP_RES_NONE = 0,
+    /* INT8: the x86 JIT `with_sum` post-op (jit_avx512_core_x8s8s32x_conv_kernel.cpp:156-177):
+     *   d = sum_scale==1 ? d + prev : fmaf(prev, sum_scale, d); relu.  prev is read from y (in place).
+     * FP32: out = act(conv + bias + 1*y)  (SaberConvEltwise<X86,AK_FLOAT>, saber_conv_eltwise.cpp:40-151). */
+    SABER_HIP_RES_SUM_INPLACE = 1,
+    /* INT8 only: bit-exact fusion of  conv(->s8)  +  SaberEltwise<X86,AK_INT8> sum(+relu)  (the two
+     * ops of the unfused INT8 graph, graph.cpp:423-436; saber_eltwise.cpp:98-111). res is a separate s8
+     * NHWC tensor; y is s8. */
+    SABER_HIP_RES_ELTWISE = 2
+} saber_hip_res_mode;
+
+const char* saber_hip_last_error(void);
+/* 1 when a gfx950 device is visible to this process. */
+int saber_hip_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Convolution (SaberConv2D / SaberConvEltwise), FP32 and INT8                                  */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, h, w, c;              /* input  [n,c,h,w] logical */
+    int k;                       /* out channels */
+    int kh, kw;
+    int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, group;   /* ConvParam:470-581 */
+    int in_dtype, out_dtype;     /* saber_hip_dtype. f32/f32 = FP32 conv; s8|u8 in = INT8 conv;
+                                    f32 in + 8-bit weights = INT8 conv that quantises on entry
+                                    (SaberConv2D<X86,AK_INT8>::dispatch, saber_conv.cpp:293-324) */
+    int in_layout, out_layout;   /* 8-bit tensors are NHWC (calibrator_parse.cpp:194-244); f32 NCHW or NHWC */
+    int act;                     /* ActivationParam of the conv (relu) */
+    int res_mode;                /* saber_hip_res_mode */
+    int res_act;                 /* activation of the eltwise (RES_ELTWISE / FP32 SUM_INPLACE) */
+    float sum_scale;             /* RES_SUM_INPLACE INT8 */
+    float coeff_conv, coeff_res; /* RES_ELTWISE: EltwiseParam.coeff[0], coeff[1] */
+    float scale_res;             /* RES_ELTWISE: scale of the residual tensor */
+    int int8_weights;            /* 1: INT8 arithmetic (AK_INT8 op), 0: FP32 arithmetic */
+} saber_hip_conv_desc;
+
+typedef struct saber_hip_conv saber_hip_conv_t;
+
+int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** out);
+/* w: HOST pointer, OIHW [k, c/group, kh, kw]; w_dtype f32 or s8.
+ *   INT8 op + f32 weights: quantised here exactly as scale_conv_weights_to_nchw_host does
+ *   (per-out-channel max|w|/127, truncating cast; x86_utils.h:141-166,293-322), w_scale ignored.
+ *   INT8 op + s8 weights : w_scale[k] required.
+ * bias: HOST f32 [k] or NULL. in_scale / out_scale: the edge tensors' scales (Tensor::get_scale()[0]). */
+int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtype, const float* w_scale,
+                                 const float* bias, float in_scale, float out_scale);
+size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op);
+void saber_hip_conv2d_out_shape(const saber_hip_conv_t* op, int* oh, int* ow);
+/* x, y, res, workspace: DEVICE pointers. res may be NULL unless res_mode == RES_ELTWISE. */
+int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
+                         saber_hip_stream_t stream);
+void saber_hip_conv2d_destroy(saber_hip_conv_t* op);
+/* Debug / parity helpers: copy out the quantised weights (OIHW s8) and their scales. */
+int saber_hip_conv2d_get_quantized_weights(const saber_hip_conv_t* op, int8_t* wq_oihw, float* w_scale);
+/* Name of the kernel variant `run` will launch (e.g. "igemm_i8_64x64"), for profiling/tests. */
+const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op);
+/* Implementation selection. `create` picks a tile statically (BaseFunc STATIC strategy,
+ * saber/funcs/base.h:173-192); `autotune` is the RUNTIME strategy (base.h:194,205-247): it times every
+ * tile of the implicit-GEMM kernel on the given device tensors and keeps the fastest. */
+int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile);
+int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op);
+int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
+                              saber_hip_stream_t stream, int iters);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Fully connected (SaberFc / VenderFc), FP32 and INT8                                          */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int m, n, k;          /* out[m,n] = in[m,k] * W[n,k]^T + bias[n] */
+    int in_dtype;         /* f32 (FP32 op, or INT8 op quantising on entry), s8, u8 */
+    int int8_weights;
+    int w_is_kn;          /* FcParam.is_transpose_weights: weights stored [k,n] */
+} saber_hip_fc_desc;
+typedef struct saber_hip_fc saber_hip_fc_t;
+int saber_hip_fc_create(const saber_hip_fc_desc* desc, saber_hip_fc_t** out);
+int saber_hip_fc_set_weights(saber_hip_fc_t* op, const void* w, int w_dtype, const float* w_scale,
+                             const float* bias, float in_scale, float out_scale);
+size_t saber_hip_fc_workspace_bytes(const saber_hip_fc_t* op);
+/* out is f32 [m,n]. */
+int saber_hip_fc_run(saber_hip_fc_t* op, const void* x, float* y, void* workspace, saber_hip_stream_t stream);
+void saber_hip_fc_destroy(saber_hip_fc_t* op);
+
+/* ------------------------------------------------------------------------------------------- */
+/* GEMM (Gemm<T, SABER_IMPL, float, float>): row-major C = alpha*op(A)*op(B) + beta*C, raw pointers */
+/* ------------------------------------------------------------------------------------------- */
+int saber_hip_gemm_f32(int trans_a, int trans_b, int m, int n, int k, float alpha, const float* a,
+                       const float* b, float beta, float* c, saber_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Quantise / dequantise + layout (reorder_nhwc_nchw)                                           */
+/* ------------------------------------------------------------------------------------------- */
+/* f32 NCHW [n,c,h,w] -> s8/u8 NHWC [n,h,w,c_pad] (channels c..c_pad-1 written as 0; c_pad >= c). */
+int saber_hip_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                                    const float* x, void* y, saber_hip_stream_t stream);
+/* s8/u8 NHWC -> f32 NCHW */
+int saber_hip_dequantize_nhwc_to_nchw(int n, int c, int h, int w, int in_dtype, float scale, const void* x,
+                                      float* y, saber_hip_stream_t stream);
+/* f32 layout transforms (c_pad: channel padding of the NHWC side, zero filled) */
+int saber_hip_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                         saber_hip_stream_t stream);
+int saber_hip_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                         saber_hip_stream_t stream);
+/* flat f32 -> s8 with ScaleUtils::scale_fp32_int8 semantics (x86_utils.h:325-346) */
+int saber_hip_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, saber_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Eltwise sum (+relu), pooling, softmax — the "next" rows of SURVEY.md §8(f)                   */
+/* ------------------------------------------------------------------------------------------- */
+int saber_hip_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float scale_a, float scale_b,
+                             float coeff_a, float coeff_b, int relu, int8_t* y, saber_hip_stream_t stream);
+int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, float coeff_a, float coeff_b,
+                              int relu, float* y, saber_hip_stream_t stream);
+/* Pooling<>::compute_output_shape (pooling.h:69-130) */
+int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode);
+/* NHWC s8/u8 -> s8/u8 (max, avg) or f32 (avg) */
+int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
+                             int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype, int out_dtype,
+                             const void* x, void* y, saber_hip_stream_t stream);
+/* f32, NHWC or NCHW (same layout in and out) */
+int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
+                         int stride_w, int pad_h, int pad_w, int pool_type, int layout, const float* x,
+                         float* y, saber_hip_stream_t stream);
+/* softmax over the last axis of [rows, cols] */
+int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Op-list executor: the device-side half of Net<T,P,R>::prediction (net.cpp:417-509)           */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct saber_hip_net saber_hip_net_t;
+int saber_hip_net_create(saber_hip_net_t** out);
+/* Declares an edge tensor of `bytes` bytes; returns its id (>= 0). */
+int saber_hip_net_add_tensor(saber_hip_net_t* net, size_t bytes);
+/* The ops take ownership of nothing; conv/fc handles must outlive the net. */
+int saber_hip_net_add_conv(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id, int out_id, int res_id);
+int saber_hip_net_add_fc(saber_hip_net_t* net, saber_hip_fc_t* op, int in_id, int out_id);
+int saber_hip_net_add_quantize(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int out_dtype,
+                               float scale, int in_id, int out_id);
+int saber_hip_net_add_transpose_in_f32(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int in_id,
+                                       int out_id);
+int saber_hip_net_add_eltwise_i8(saber_hip_net_t* net, size_t count, float scale_a, float scale_b,
+                                 float coeff_a, float coeff_b, int relu, int a_id, int b_id, int out_id);
+int saber_hip_net_add_eltwise_f32(saber_hip_net_t* net, size_t count, float coeff_a, float coeff_b, int relu,
+                                  int a_id, int b_id, int out_id);
+int saber_hip_net_add_pool_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                              int stride_h, int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype,
+                              int out_dtype, int in_id, int out_id);
+int saber_hip_net_add_pool_f32(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                               int stride_h, int stride_w, int pad_h, int pad_w, int pool_type, int layout,
+                               int in_id, int out_id);
+int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
+/* Allocates every edge tensor + the shared workspace (one hipMalloc arena). */
+int saber_hip_net_finalize(saber_hip_net_t* net);
+void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id);
+size_t saber_hip_net_arena_bytes(const saber_hip_net_t* net);
+int saber_hip_net_num_ops(const saber_hip_net_t* net);
+/* Enqueue every op in order on `stream` (eager launches). */
+int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream);
+/* Enqueue only op `index` (per-op timing / parity checks). */
+int saber_hip_net_run_op(saber_hip_net_t* net, int index, saber_hip_stream_t stream);
+/* Capture the op list into a hipGraph once; later runs replay it with one launch. */
+int saber_hip_net_capture(saber_hip_net_t* net, saber_hip_stream_t stream);
+int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream);
+/* Per-op device time in microseconds measured with hipEvents on `stream` (iters launches each,
+ * eager). out_us has saber_hip_net_num_ops() entries. */
+int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us);
+const char* saber_hip_net_op_name(const saber_hip_net_t* net, int index);
+/* RUNTIME strategy over every conv/fc op of the list (on whatever the edge tensors currently hold). */
+int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters);
+void saber_hip_net_destroy(saber_hip_net_t* net);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SABER_HIP_H */

@@ -436,7 +436,8 @@ int orc_pool_i8_nhwc(int N, int H, int W, int C, int OH, int OW, int kh, int kw,
 }
 
 /* [unpinned] SaberPooling<X86, AK_FLOAT> generic NCHW path (saber_pooling.cpp:385-500):
- * max over in-bounds window; avg = sum / (kh*kw) (include) or / valid count (exclude). */
+ * max over in-bounds window; avg = sequential sum / window area (include; clipped at in+pad on the
+ * far edge) or / valid count (exclude). */
 int orc_pool_f32_nchw(int N, int C, int H, int W, int OH, int OW, int kh, int kw, int stride_h,
                       int stride_w, int pad_h, int pad_w, int type, const float* x, float* out) {
 #pragma omp parallel for collapse(2) schedule(static)
@@ -458,7 +459,12 @@ int orc_pool_f32_nchw(int N, int C, int H, int W, int OH, int OW, int kh, int kw
                             if (type == 0) r = r >= v ? r : v;
                             else r += v;
                         }
-                    if (type == 1) r /= (float)(kh * kw);
+                    if (type == 1) { /* divisor clipped at in+pad on the far edge, saber_pooling.cpp:466-480 */
+                        int bh = kh, bw = kw;
+                        if (we == W) bw = (ws + kw >= W + pad_w ? W + pad_w : ws + kw) - ws;
+                        if (he == H) bh = (hs + kh >= H + pad_h ? H + pad_h : hs + kh) - hs;
+                        r /= (float)(bh * bw);
+                    }
                     if (type == 2) r /= (float)((he - hs) * (we - ws));
                     out[(((size_t)n * C + c) * OH + oh) * OW + ow] = r;
                 }

@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every symbol
+include/saber_hip.h declares. No compute (no GPU here)."""
+import os
+import re
+
+import pytest
+
+from anakin_amd import build as B
+from anakin_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(L.LIB_PATH) or os.path.exists("/opt/rocm/bin/hipcc"):
+        B.build()
+    return L.load()
+
+
+def test_header_symbols_are_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "saber_hip.h")).read()
+    declared = set(re.findall(r"\b(saber_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    for name in sorted(declared):
+        assert hasattr(built, name), name
+
+
+def test_create_validates_without_gpu(built):
+    import ctypes as C
+    d = L.ConvDesc()
+    h = C.c_void_p()
+    assert built.saber_hip_conv2d_create(C.byref(d), C.byref(h)) == -2  # SaberInvalidValue: empty geometry
+    assert b"geometry" in built.saber_hip_last_error()
+    d.n, d.h, d.w, d.c, d.k, d.kh, d.kw = 1, 8, 8, 6, 9, 3, 3
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1
+    d.group = 4
+    assert built.saber_hip_conv2d_create(C.byref(d), C.byref(h)) == -2  # c % group != 0
+    assert built.saber_hip_pool_out_dim(112, 0, 3, 2, 0) == 56      # ceil mode, pooling.h:109-115
+    assert built.saber_hip_pool_out_dim(112, 0, 3, 2, 1) == 55
+    assert built.saber_hip_pool_out_dim(224, 1, 3, 2, 0) == 113 - 0
+
+
+def test_algorithm_selection_is_host_side(built):
+    """create() picks the kernel family from shapes alone (no device needed)."""
+    import ctypes as C
+
+    def algo(c, k, kh, int8, in_dt, out_dt, n=8, hw=14, group=1, in_layout=L.NHWC, out_layout=L.NHWC):
+        d = L.ConvDesc()
+        d.n, d.h, d.w, d.c, d.k, d.kh, d.kw = n, hw, hw, c, k, kh, kh
+        d.pad_h = d.pad_w = kh // 2
+        d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1
+        d.group = group
+        d.in_dtype, d.out_dtype, d.in_layout, d.out_layout, d.int8_weights = in_dt, out_dt, in_layout, out_layout, int8
+        h = C.c_void_p()
+        assert built.saber_hip_conv2d_create(C.byref(d), C.byref(h)) == 0, built.saber_hip_last_error()
+        name = built.saber_hip_conv2d_algo(h).decode()
+        built.saber_hip_conv2d_destroy(h)
+        return name
+
+    assert algo(256, 256, 3, 1, L.U8, L.U8).startswith("igemm_i8_")
+    assert algo(3, 64, 7, 1, L.F32, L.U8, hw=224, in_layout=L.NCHW).startswith("igemm_i8_c4_")
+    assert algo(64, 64, 3, 0, L.F32, L.F32, in_layout=L.NCHW, out_layout=L.NCHW).startswith("igemm_f32_")
+    assert algo(32, 32, 3, 1, L.U8, L.U8, group=4) == "direct_i8"
+    assert algo(20, 24, 5, 1, L.S8, L.F32) == "direct_i8"

@@ -1,0 +1,330 @@
+"""Parity of the HIP path (through the C ABI) against the committed golden vectors and the CPU oracle.
+INT8 / byte / index results must be BIT-EXACT; FP32 within 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from anakin_amd import lib as L  # noqa: E402
+from anakin_amd import saber as S  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.golden_util import conv_f32_fixtures, conv_i8_fixtures, load  # noqa: E402
+
+FP32_RTOL = 1e-4  # relative to max|reference| (tensor_cmp_host style, saber/core/tensor_op.cpp:580-600)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    L.require_device()  # fail loudly: no fallback path exists
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def run_conv_i8(x, w, w_scale, bias, in_scale, out_scale, out_dtype, relu, pad, stride, dil, group, tile=None,
+                res_param=None, res=None, y_init=None):
+    N, H, W, Cc = x.shape
+    p = S.ConvParam(w, bias, group, (pad, pad), (stride, stride), (dil, dil), bool(relu), w_scale)
+    if res_param:
+        p.res_mode, p.res_relu, p.sum_scale, p.coeff, p.scale_res = res_param
+    conv = S.SaberConv2D(int8=True).init((N, Cc, H, W), p, O.code_of(x), out_dtype, in_scale, out_scale)
+    if tile is not None and conv.algo().startswith("igemm"):
+        conv.set_tile(tile)
+    y = conv.new_output()
+    if y_init is not None:
+        y.copy_(dev(y_init))
+    conv.dispatch(dev(x), y, None if res is None else dev(res))
+    return host(y), conv
+
+
+@pytest.mark.parametrize("name", conv_i8_fixtures())
+def test_conv_i8_golden(name):
+    g = load(name)
+    N, H, W, C, K, k, pad, stride, dil, group, idt, odt, relu = [int(v) for v in g["spec"]]
+    y, conv = run_conv_i8(g["x"], g["wq"], g["w_scale"], g["bias"], float(g["in_scale"]), float(g["out_scale"]),
+                          odt, relu, pad, stride, dil, group)
+    assert np.array_equal(y, g["y"]), conv.algo()
+    if "w" in g.files:  # f32 weights in: the library quantises them (reference quirk: truncation)
+        y2, conv2 = run_conv_i8(g["x"], g["w"], None, g["bias"], float(g["in_scale"]), float(g["out_scale"]),
+                                odt, relu, pad, stride, dil, group)
+        wq, ws = conv2.quantized_weights()
+        assert np.array_equal(wq, g["wq"]) and np.array_equal(ws, g["w_scale"])
+        assert np.array_equal(y2, g["y"])
+
+
+@pytest.mark.parametrize("tile", range(len(L.TILES)))
+@pytest.mark.parametrize("name", ["conv_i8_res2a_2b_3x3_u8u8", "conv_i8_res3a_2a_1x1s2_s8u8",
+                                  "conv_i8_res4_2c_1x1_u8f32", "conv_i8_conv1_7x7s2_s8u8"])
+def test_conv_i8_golden_every_tile(name, tile):
+    g = load(name)
+    N, H, W, C, K, k, pad, stride, dil, group, idt, odt, relu = [int(v) for v in g["spec"]]
+    y, conv = run_conv_i8(g["x"], g["wq"], g["w_scale"], g["bias"], float(g["in_scale"]), float(g["out_scale"]),
+                          odt, relu, pad, stride, dil, group, tile=tile)
+    assert np.array_equal(y, g["y"]), conv.algo()
+
+
+SWEEP = [
+    # N, H, W, C, K, k, pad, stride, dil
+    (3, 9, 9, 16, 20, 1, 0, 1, 1),     # K not a multiple of the tile / of 4-wide stores? (20 % 4 == 0)
+    (1, 7, 7, 48, 34, 3, 1, 1, 1),     # K % 4 != 0 -> byte stores; C = 48 (K-step straddles taps)
+    (2, 13, 11, 32, 64, 3, 1, 2, 1),   # ragged spatial, stride 2
+    (1, 10, 10, 16, 16, 3, 2, 1, 2),   # dilation 2
+    (1, 5, 5, 64, 32, 5, 2, 1, 1),     # 5x5
+    (2, 1, 1, 128, 10, 1, 0, 1, 1),    # 1x1 spatial (fc-like), tiny M
+    (1, 33, 17, 4, 24, 3, 1, 1, 1),    # C == 4 -> first-layer (C4) path
+    (1, 16, 16, 3, 8, 7, 3, 2, 1),     # C == 3 -> padded to 4
+    (1, 6, 6, 1, 8, 3, 1, 1, 1),       # C == 1
+]
+
+
+@pytest.mark.parametrize("case", SWEEP)
+@pytest.mark.parametrize("combo", [(O.S8, O.S8, 0), (O.S8, O.U8, 1), (O.U8, O.S8, 0), (O.U8, O.U8, 1),
+                                   (O.U8, O.F32, 0), (O.S8, O.F32, 1)])
+def test_conv_i8_sweep_vs_oracle(case, combo):
+    N, H, W, C, K, k, pad, stride, dil = case
+    idt, odt, relu = combo
+    rng = np.random.default_rng(abs(hash((case, combo))) % 2**31)
+    x = (rng.integers(0, 256, (N, H, W, C)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, W, C)).astype(np.int8))
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    in_scale, out_scale = 0.017, 0.041
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, odt)
+    want = O.conv_i8(x, wq, bp, sc, odt, relu, (pad, pad), (stride, stride), (dil, dil))
+    got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, stride, dil, 1)
+    assert got.dtype == want.dtype and np.array_equal(got, want), conv.algo()
+
+
+def test_conv_i8_empty_and_invalid():
+    lib = L.load()
+    import ctypes as C
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.c, d.k, d.kh, d.kw = 1, 2, 2, 16, 16, 3, 3   # 3x3 on 2x2 without padding: empty output
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.group = 1
+    d.in_dtype, d.out_dtype, d.int8_weights = L.S8, L.S8, 1
+    h = C.c_void_p()
+    assert lib.saber_hip_conv2d_create(C.byref(d), C.byref(h)) == -2
+    # run before set_weights must fail loudly, not silently compute
+    d.pad_h = d.pad_w = 1
+    assert lib.saber_hip_conv2d_create(C.byref(d), C.byref(h)) == 0
+    x = torch.zeros(64, dtype=torch.int8, device="cuda")
+    assert lib.saber_hip_conv2d_run(h, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), None, None, None) == -2
+    lib.saber_hip_conv2d_destroy(h)
+
+
+def test_conv_i8_f32_input_quantises_on_entry():
+    """SaberConv2D<X86,AK_INT8> handed an f32 NCHW tensor (first layer): reorder_nhwc_nchw then conv."""
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (2, 3, 32, 32)).astype(np.float32)
+    w = (rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    in_scale, out_scale = 1.0 / 127, 0.02
+    p = S.ConvParam(w, b, 1, (3, 3), (2, 2), (1, 1), True)
+    conv = S.SaberConv2D(True).init(x.shape, p, L.F32, L.U8, in_scale, out_scale, in_layout=L.NCHW)
+    y = conv.new_output()
+    conv.dispatch(dev(x), y)
+    xq = O.quant_nchw_to_nhwc(x, in_scale, O.S8)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, O.S8, O.U8)
+    want = O.conv_i8(xq, O.quant_weights(w, ws), bp, sc, O.U8, 1, (3, 3), (2, 2))
+    assert np.array_equal(host(y), want), conv.algo()
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+def test_conv_i8_fused_eltwise_equals_two_ops(relu):
+    """RES_ELTWISE == conv(->s8) followed by SaberEltwise<AK_INT8> sum(+relu), bit for bit."""
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 256, (2, 14, 14, 64)).astype(np.uint8)
+    w = (rng.standard_normal((256, 64, 1, 1)) * 0.15).astype(np.float32)
+    b = (rng.standard_normal(256) * 0.5).astype(np.float32)
+    res = rng.integers(-128, 128, (2, 14, 14, 256)).astype(np.int8)
+    in_scale, out_scale, s_res, s_out = 0.02, 0.05, 0.043, 0.06
+    c = 1.0 / s_out
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, O.U8, O.S8)
+    y1 = O.conv_i8(x, wq, bp, sc, O.S8, 0)
+    want = O.eltwise_i8(y1, res, out_scale, s_res, c, c, relu)
+    got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, O.S8, 0, 0, 1, 1, 1,
+                            res_param=(L.RES_ELTWISE, bool(relu), 1.0, (c, c), s_res), res=res)
+    assert np.array_equal(got, want), conv.algo()
+    # and the unfused device ops agree too
+    y1d, _ = run_conv_i8(x, w, None, b, in_scale, out_scale, O.S8, 0, 0, 1, 1, 1)
+    assert np.array_equal(y1d, y1)
+    e = S.eltwise_sum(dev(y1d), dev(res), (c, c), bool(relu), out_scale, s_res)
+    assert np.array_equal(host(e), want)
+
+
+def test_conv_i8_jit_sum_inplace():
+    rng = np.random.default_rng(13)
+    x = rng.integers(-128, 128, (1, 7, 7, 32)).astype(np.int8)
+    w = (rng.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32)
+    prev = rng.integers(0, 200, (1, 7, 7, 32)).astype(np.uint8)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, None, 0.03, 0.04, O.S8, O.U8)
+    for sum_scale in (1.0, 0.37):
+        rp = O.Residual(O.RES_JIT_SUM, 0, sum_scale, O.U8, 0, 0, 0, 0)
+        want = O.conv_i8(x, O.quant_weights(w, ws), None, sc, O.U8, 1, (1, 1), residual=rp, out_init=prev)
+        got, conv = run_conv_i8(x, w, None, None, 0.03, 0.04, O.U8, 1, 1, 1, 1, 1,
+                                res_param=(L.RES_SUM_INPLACE, False, sum_scale, (1.0, 1.0), 1.0), y_init=prev)
+        assert np.array_equal(got, want), conv.algo()
+
+
+def test_quant_dequant_golden():
+    g = load("quant_dequant")
+    s = float(g["scale"])
+    x = dev(g["x"])
+    assert np.array_equal(host(S.quantize_nchw_to_nhwc(x, s, L.S8)), g["q_s8"])
+    assert np.array_equal(host(S.quantize_nchw_to_nhwc(x, s, L.U8)), g["q_u8"])
+    assert np.array_equal(host(S.dequantize_nhwc_to_nchw(dev(g["q_s8"]), s)), g["deq_s8"])
+    assert np.array_equal(host(S.dequantize_nhwc_to_nchw(dev(g["q_u8"]), s)), g["deq_u8"])
+    # channel padding (first layer: C=3 -> 4) writes zeros in the pad lane
+    xp = np.random.default_rng(1).uniform(-1, 1, (2, 3, 5, 6)).astype(np.float32)
+    q = host(S.quantize_nchw_to_nhwc(dev(xp), 0.01, L.S8, c_pad=4))
+    assert np.array_equal(q[..., :3], O.quant_nchw_to_nhwc(xp, 0.01, O.S8)) and not q[..., 3].any()
+
+
+def test_eltwise_golden_and_ragged():
+    g = load("eltwise")
+    sa, sb, c = float(g["sa"]), float(g["sb"]), float(g["c"])
+    assert np.array_equal(host(S.eltwise_sum(dev(g["a"]), dev(g["b"]), (c, c), True, sa, sb)), g["y_relu"])
+    assert np.array_equal(host(S.eltwise_sum(dev(g["a"]), dev(g["b"]), (1, 1), False, sa, sb)), g["y_lin"])
+    assert np.array_equal(host(S.eltwise_sum(dev(g["fa"]), dev(g["fb"]), (1, 1), True)), g["yf"])
+    rng = np.random.default_rng(2)
+    a = rng.integers(-128, 128, 1003).astype(np.int8)   # not a multiple of the 16-byte vector
+    b = rng.integers(-128, 128, 1003).astype(np.int8)
+    assert np.array_equal(host(S.eltwise_sum(dev(a), dev(b), (7.5, 3.25), True, 0.1, 0.2)),
+                          O.eltwise_i8(a, b, 0.1, 0.2, 7.5, 3.25, True))
+
+
+@pytest.mark.parametrize("name", conv_f32_fixtures())
+def test_conv_f32_golden(name):
+    g = load(name)
+    N, C, H, W, K, k, pad, stride = [int(v) for v in g["spec"]]
+    p = S.ConvParam(g["w"], g["bias"], 1, (pad, pad), (stride, stride), (1, 1), True)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32)
+    y = conv.new_output()
+    conv.dispatch(dev(g["x"]), y)
+    err = np.abs(host(y) - g["y"]).max() / np.abs(g["y"]).max()
+    assert err <= FP32_RTOL, (conv.algo(), err)
+
+
+def test_conv_f32_residual_golden():
+    g = load("conv_f32_1x1_residual_mkl")   # produced by SaberConv1X1 (MKL sgemm, beta = 1)
+    p = S.ConvParam(g["w"], g["bias"], 1, (0, 0), (1, 1), (1, 1), False)
+    p.res_mode, p.res_relu = L.RES_SUM_INPLACE, True
+    conv = S.SaberConv2D(int8=False).init(g["x"].shape, p, L.F32, L.F32)
+    y = dev(g["res"])
+    conv.dispatch(dev(g["x"]), y)
+    err = np.abs(host(y) - g["y"]).max() / np.abs(g["y"]).max()
+    assert err <= FP32_RTOL, (conv.algo(), err)
+
+
+@pytest.mark.parametrize("case", [(2, 20, 9, 9, 24, 3, 1, 1, 1), (1, 8, 12, 12, 8, 3, 1, 1, 2),
+                                  (1, 64, 14, 14, 256, 1, 0, 1, 1), (2, 16, 15, 15, 32, 3, 1, 2, 1)])
+def test_conv_f32_sweep_vs_oracle(case):
+    N, C, H, W, K, k, pad, stride, group = case
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C // group, k, k)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, True, (pad, pad), (stride, stride), (1, 1), group)
+    p = S.ConvParam(w, b, group, (pad, pad), (stride, stride), (1, 1), True)
+    conv = S.SaberConv2D(False).init(x.shape, p, L.F32, L.F32)
+    y = conv.new_output()
+    conv.dispatch(dev(x), y)
+    err = np.abs(host(y) - want).max() / np.abs(want).max()
+    assert err <= FP32_RTOL, (conv.algo(), err)
+
+
+@pytest.mark.parametrize("dt", [O.S8, O.U8])
+def test_pooling_i8_vs_oracle(dt):
+    rng = np.random.default_rng(31)
+    mk = (lambda s: rng.integers(0, 256, s).astype(np.uint8)) if dt == O.U8 else \
+        (lambda s: rng.integers(-128, 128, s).astype(np.int8))
+    x = mk((2, 112, 112, 64)[:1] + (30, 30, 64))
+    for (win, st, pad, pt) in [((3, 3), (2, 2), (0, 0), 0), ((3, 3), (2, 2), (1, 1), 0), ((2, 2), (2, 2), (0, 0), 1),
+                               ((3, 3), (2, 2), (1, 1), 2), ((3, 3), (1, 1), (1, 1), 1)]:
+        want = O.pool_i8_nhwc(x, win, st, pad, pt)
+        got = host(S.pooling_i8(dev(x), win, st, pad, pt))
+        assert np.array_equal(got, want), (win, st, pad, pt)
+    x7 = mk((3, 7, 7, 2048))
+    assert np.array_equal(host(S.pooling_i8(dev(x7), None, None, None, 1, global_pooling=True)),
+                          O.pool_i8_nhwc(x7, None, None, None, 1, global_pool=True))
+    assert np.array_equal(host(S.pooling_i8(dev(x7), None, None, None, 1, out_dtype=L.F32, global_pooling=True)),
+                          O.pool_i8_nhwc(x7, None, None, None, 1, out_dtype=O.F32, global_pool=True))
+    xo = mk((1, 9, 9, 10))  # channel count not a multiple of 4
+    assert np.array_equal(host(S.pooling_i8(dev(xo), (3, 3), (2, 2), (0, 0), 0)),
+                          O.pool_i8_nhwc(xo, (3, 3), (2, 2), (0, 0), 0))
+
+
+def test_pooling_f32_vs_oracle():
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal((2, 16, 13, 13)).astype(np.float32)
+    for (win, st, pad, pt) in [((3, 3), (2, 2), (0, 0), 0), ((3, 3), (2, 2), (1, 1), 1), ((2, 2), (2, 2), (0, 0), 2)]:
+        want = O.pool_f32_nchw(x, win, st, pad, pt)
+        got = host(S.pooling_f32(dev(x), win, st, pad, pt))
+        assert np.array_equal(got, want), (win, st, pad, pt)
+    want = O.pool_f32_nchw(x, None, None, None, 1, global_pool=True)
+    assert np.array_equal(host(S.pooling_f32(dev(x), None, None, None, 1, global_pooling=True)), want)
+
+
+def test_fc_vs_oracle():
+    rng = np.random.default_rng(41)
+    M, N, K = 8, 1000, 2048
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    # INT8 fc, f32 input: quantise on entry (PackedMKLInt8Gemm), f32 out — bit exact
+    xf = rng.standard_normal((M, K)).astype(np.float32)
+    in_scale = float(np.abs(xf).max() / 127)
+    want = O.fc_i8(O.quant_flat_s8(xf, in_scale), wq, ws, in_scale, b)
+    fc = S.SaberFc(True).init(M, N, K, w, b, L.F32, in_scale)
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    assert np.array_equal(host(fc.dispatch(dev(xf), y)), want)
+    # s8 input
+    xs = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    fc = S.SaberFc(True).init(M, N, K, wq, b, L.S8, 0.031, w_scale=ws)
+    assert np.array_equal(host(fc.dispatch(dev(xs), y)), O.fc_i8(xs, wq, ws, 0.031, b))
+    # u8 input (VenderFc<X86,AK_INT8> u8 path: int bias, scale*(acc+bias))
+    xu = rng.integers(0, 256, (M, K)).astype(np.uint8)
+    fc = S.SaberFc(True).init(M, N, K, wq, b, L.U8, 0.031, 0.5, w_scale=ws)
+    assert np.array_equal(host(fc.dispatch(dev(xu), y)), O.fc_i8(xu, wq, ws, 0.031, b, 0.5))
+    # FP32 fc, both weight layouts
+    want = O.fc_f32(xf, w, b)
+    fc = S.SaberFc(False).init(M, N, K, w, b, L.F32)
+    assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * np.abs(want).max()
+    fc = S.SaberFc(False).init(M, N, K, np.ascontiguousarray(w.T), b, L.F32, w_is_kn=True)
+    assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * np.abs(want).max()
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_vs_oracle(ta, tb):
+    rng = np.random.default_rng(51)
+    M, N, K = 70, 130, 45   # ragged on purpose
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    want = O.gemm_f32(A, B, M, N, K, ta, tb, 0.7, 0.3, C0)
+    c = dev(C0)
+    S.gemm(ta, tb, M, N, K, 0.7, dev(A), dev(B), 0.3, c)
+    assert np.abs(host(c) - want).max() <= FP32_RTOL * np.abs(want).max()
+
+
+def test_softmax_vs_oracle():
+    rng = np.random.default_rng(61)
+    x = (rng.standard_normal((8, 1000)) * 4).astype(np.float32)
+    got = host(S.softmax(dev(x)))
+    want = O.softmax_f32(x)
+    assert np.abs(got - want).max() <= 1e-6 and np.allclose(got.sum(1), 1.0, atol=1e-5)
