@@ -55,10 +55,14 @@ __device__ __forceinline__ v4i mma_step(v4i a, v4i b, v4i c) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ v4f mma_step(v4i a, v4i b, v4f c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    // whole-vector bit casts: __builtin_bit_cast on a single ext-vector ELEMENT (a.y ...) was observed to
+    // read element 0 for every component with hipcc 7.2
+    const v4f af = __builtin_bit_cast(v4f, a);
+    const v4f bf = __builtin_bit_cast(v4f, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
     return c;
 }
 

@@ -64,6 +64,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64 with the same SONAME as /opt/rocm's: whichever loads first
+        # serves the whole process. Import torch first so one HIP runtime owns the device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise SaberHipError(
             "anakin_amd/libsaber_mi355x.so is missing - build it with `python anakin_amd/build.py` "

@@ -327,4 +327,4 @@ def test_softmax_vs_oracle():
     x = (rng.standard_normal((8, 1000)) * 4).astype(np.float32)
     got = host(S.softmax(dev(x)))
     want = O.softmax_f32(x)
-    assert np.abs(got - want).max() <= 1e-6 and np.allclose(got.sum(1), 1.0, atol=1e-5)
+    assert np.abs(got - want).max() <= FP32_RTOL * want.max() and np.allclose(got.sum(1), 1.0, atol=1e-5)
