@@ -673,7 +673,7 @@ int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hi
 // op-list executor
 // ================================================================================================
 namespace {
-enum OpKind { OP_CONV, OP_FC, OP_QUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_SOFTMAX };
+enum OpKind { OP_CONV, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_SOFTMAX };
 struct NetOp {
     OpKind kind;
     std::string name;
@@ -706,6 +706,9 @@ static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     case OP_QUANT:
         return saber_hip_quantize_nchw_to_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.f[0],
                                                (const float*)T(o.in), T(o.out), s);
+    case OP_DEQUANT:
+        return saber_hip_dequantize_nhwc_to_nchw(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.f[0], T(o.in),
+                                                 (float*)T(o.out), s);
     case OP_TRANSPOSE_IN:
         return saber_hip_transpose_nchw_to_nhwc_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], (const float*)T(o.in),
                                                     (float*)T(o.out), s);
@@ -762,6 +765,13 @@ int saber_hip_net_add_quantize(saber_hip_net_t* net, int n, int c, int h, int w,
     NetOp o;
     o.kind = OP_QUANT; o.in = in_id; o.out = out_id; o.name = "quantize_nchw_to_nhwc";
     o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = c_pad; o.p[5] = out_dtype; o.f[0] = scale;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_dequantize(saber_hip_net_t* net, int n, int c, int h, int w, int in_dtype, float scale,
+                                 int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_DEQUANT; o.in = in_id; o.out = out_id; o.name = "dequantize_nhwc_to_nchw";
+    o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = in_dtype; o.f[0] = scale;
     return push(net, std::move(o));
 }
 int saber_hip_net_add_transpose_in_f32(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int in_id,

@@ -31,7 +31,7 @@ SYMBOLS = [
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_softmax_f32",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
-    "saber_hip_net_add_quantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
+    "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
     "saber_hip_net_add_softmax", "saber_hip_net_finalize", "saber_hip_net_tensor_ptr",
     "saber_hip_net_arena_bytes", "saber_hip_net_num_ops", "saber_hip_net_run", "saber_hip_net_run_op",
@@ -116,6 +116,7 @@ def load():
     lib.saber_hip_net_add_conv.argtypes = [P, P, I, I, I]
     lib.saber_hip_net_add_fc.argtypes = [P, P, I, I]
     lib.saber_hip_net_add_quantize.argtypes = [P, I, I, I, I, I, I, F, I, I]
+    lib.saber_hip_net_add_dequantize.argtypes = [P, I, I, I, I, I, F, I, I]
     lib.saber_hip_net_add_transpose_in_f32.argtypes = [P, I, I, I, I, I, I, I]
     lib.saber_hip_net_add_eltwise_i8.argtypes = [P, Z, F, F, F, F, I, I, I, I]
     lib.saber_hip_net_add_eltwise_f32.argtypes = [P, Z, F, F, I, I, I, I]

@@ -317,6 +317,10 @@ class Net:
         return self._chk(L.load().saber_hip_net_add_quantize(self.h, n, c, h, w, c_pad, out_dtype, float(scale),
                                                              self.tid(x), self.tid(y)))
 
+    def add_dequantize(self, n, c, h, w, in_dtype, scale, x, y):
+        return self._chk(L.load().saber_hip_net_add_dequantize(self.h, n, c, h, w, in_dtype, float(scale),
+                                                               self.tid(x), self.tid(y)))
+
     def add_transpose_in(self, n, c, h, w, c_pad, x, y):
         return self._chk(L.load().saber_hip_net_add_transpose_in_f32(self.h, n, c, h, w, c_pad, self.tid(x), self.tid(y)))
 

@@ -1,0 +1,339 @@
+"""Synthetic post-fusion op lists for the benchmark configurations of BASELINE.json.
+
+The reference loads a `.anakin.bin` (protobuf) and runs its graph fusion; neither the model files
+nor protobuf exist here, so the SAME post-fusion structure is generated directly:
+Caffe-topology ResNet50 / ResNet101 (stride 2 on the 1x1 branch2a/branch1 of the first block of
+stages 3-5) and VGG16, seeded weights, BatchNorm+Scale folded into the convolutions with the float
+sequence of WeightsFusion::update_weights (framework/utils/parameter_fusion.cpp:88-131), and — for
+INT8 — per-edge MAXABS activation scales (saber_types.h:357-360) from one FP32 pass.
+
+Edge dtype / layout rules for the INT8 graph follow the x86 calibrator
+(framework/core/net/calibrator_parse.cpp:82-128,194-244): 8-bit edges are NHWC; conv+relu outputs are
+u8, conv without relu and eltwise outputs are s8; the first conv takes the f32 NCHW image and
+quantises on entry (saber_conv.cpp:223-242,308); conv+eltwise fusion is OFF for INT8 (graph.cpp:423-436)
+so `fuse_eltwise=False` reproduces the reference op list one to one, while `fuse_eltwise=True` uses the
+bit-identical fused epilogue (include/saber_hip.h RES_ELTWISE).
+"""
+import numpy as np
+
+F32, S8, U8 = 0, 1, 2
+
+
+# --------------------------------------------------------------------------------------------- topology
+def resnet_spec(depth=50):
+    """Returns the layer list: dicts with kind in {conv, pool, eltwise, gpool, fc, softmax}."""
+    blocks = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}[depth]
+    L = []
+    L.append(dict(kind="conv", name="conv1", src="data", cin=3, cout=64, k=7, stride=2, pad=3, relu=True))
+    L.append(dict(kind="pool", name="pool1", src="conv1", win=3, stride=2, pad=0, type=0))
+    prev, cin, hw = "pool1", 64, 56
+    for si, nb in enumerate(blocks):
+        mid = 64 << si
+        cout = mid * 4
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and si > 0) else 1
+            tag = "res%d%s" % (si + 2, chr(ord("a") + bi) if nb <= 26 else "b%d" % bi)
+            if bi == 0:
+                L.append(dict(kind="conv", name=tag + "_branch1", src=prev, cin=cin, cout=cout, k=1, stride=stride,
+                              pad=0, relu=False))
+                shortcut = tag + "_branch1"
+            else:
+                shortcut = prev
+            L.append(dict(kind="conv", name=tag + "_branch2a", src=prev, cin=cin, cout=mid, k=1, stride=stride, pad=0,
+                          relu=True))
+            L.append(dict(kind="conv", name=tag + "_branch2b", src=tag + "_branch2a", cin=mid, cout=mid, k=3, stride=1,
+                          pad=1, relu=True))
+            L.append(dict(kind="conv", name=tag + "_branch2c", src=tag + "_branch2b", cin=mid, cout=cout, k=1,
+                          stride=1, pad=0, relu=False, eltwise=tag))
+            L.append(dict(kind="eltwise", name=tag, a=tag + "_branch2c", b=shortcut, relu=True))
+            prev, cin = tag, cout
+    L.append(dict(kind="gpool", name="pool5", src=prev))
+    L.append(dict(kind="fc", name="fc1000", src="pool5", cin=cin, cout=1000))
+    L.append(dict(kind="softmax", name="prob", src="fc1000"))
+    return L
+
+
+def vgg16_spec():
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+    L, prev, cin, i, p = [], "data", 3, 0, 0
+    for v in cfg:
+        if v == "M":
+            p += 1
+            L.append(dict(kind="pool", name="pool%d" % p, src=prev, win=2, stride=2, pad=0, type=0))
+            prev = "pool%d" % p
+        else:
+            i += 1
+            L.append(dict(kind="conv", name="conv%d" % i, src=prev, cin=cin, cout=v, k=3, stride=1, pad=1, relu=True))
+            prev, cin = "conv%d" % i, v
+    L.append(dict(kind="fc", name="fc6", src=prev, cin=512 * 7 * 7, cout=4096, relu=True, flatten_chw=(512, 7, 7)))
+    L.append(dict(kind="fc", name="fc7", src="fc6", cin=4096, cout=4096, relu=True))
+    L.append(dict(kind="fc", name="fc8", src="fc7", cin=4096, cout=1000))
+    L.append(dict(kind="softmax", name="prob", src="fc8"))
+    return L
+
+
+def conv_macs(spec, hw=224):
+    """Algorithmic MACs per image of the conv + fc layers."""
+    sizes, total = {"data": hw}, 0
+    for l in spec:
+        if l["kind"] == "conv":
+            o = (sizes[l["src"]] + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+            sizes[l["name"]] = o
+            total += l["cin"] * l["cout"] * l["k"] ** 2 * o * o
+        elif l["kind"] == "pool":
+            s = sizes[l["src"]]
+            sizes[l["name"]] = int(np.ceil((s + 2 * l["pad"] - l["win"]) / l["stride"])) + 1
+        elif l["kind"] == "eltwise":
+            sizes[l["name"]] = sizes[l["a"]]
+        elif l["kind"] == "fc":
+            total += l["cin"] * l["cout"]
+    return total
+
+
+# --------------------------------------------------------------------------------------------- weights
+def fold_bn(w, bias, bn_scale, eps, mean, var, scale_w, scale_b):
+    """WeightsFusion<float,T>::update_weights (parameter_fusion.cpp:88-131) in numpy float32, same order."""
+    f = np.float32
+    s = f(1.0) if bn_scale == 0 else f(1.0) / f(bn_scale)
+    alpha = f(1.0) / np.sqrt(var.astype(f) * s + f(eps), dtype=f)
+    beta = f(-1.0) * (mean.astype(f) * s) * alpha
+    alpha = scale_w.astype(f) * alpha
+    beta = beta * scale_w.astype(f)
+    if scale_b is not None:
+        beta = beta + scale_b.astype(f)
+    w2 = (w.astype(f) * alpha.reshape(-1, 1, 1, 1)).astype(f)
+    b0 = bias.astype(f) if bias is not None else np.zeros(w.shape[0], f)
+    return w2, (b0 * alpha + beta).astype(f)
+
+
+def build_model(name="resnet50", seed=42):
+    """Seeded weights: conv ~ N(0, sqrt(2/(C*k*k))), BN gamma U(.5,1.5), beta/mean U(-.1,.1), var U(.5,1.5)."""
+    spec = {"resnet50": lambda: resnet_spec(50), "resnet101": lambda: resnet_spec(101), "vgg16": vgg16_spec}[name]()
+    params = {}
+    for idx, l in enumerate(spec):
+        rng = np.random.default_rng(seed + idx)
+        if l["kind"] == "conv":
+            c, k, ks = l["cin"], l["cout"], l["k"]
+            w = (rng.standard_normal((k, c, ks, ks)) * np.sqrt(2.0 / (c * ks * ks))).astype(np.float32)
+            if name == "vgg16":
+                b = (rng.uniform(-0.1, 0.1, k)).astype(np.float32)
+                params[l["name"]] = (w, b)
+            else:
+                gamma = rng.uniform(0.5, 1.5, k).astype(np.float32)
+                beta = rng.uniform(-0.1, 0.1, k).astype(np.float32)
+                mean = rng.uniform(-0.1, 0.1, k).astype(np.float32)
+                var = rng.uniform(0.5, 1.5, k).astype(np.float32)
+                params[l["name"]] = fold_bn(w, None, 1.0, 1e-5, mean, var, gamma, beta)
+        elif l["kind"] == "fc":
+            w = (rng.standard_normal((l["cout"], l["cin"])) * np.sqrt(1.0 / l["cin"])).astype(np.float32)
+            b = rng.uniform(-0.1, 0.1, l["cout"]).astype(np.float32)
+            params[l["name"]] = (w, b)
+    return dict(name=name, spec=spec, params=params)
+
+
+def make_input(batch, seed=1234, hw=224):
+    rng = np.random.default_rng(seed + batch)
+    return rng.uniform(-1.0, 1.0, (batch, 3, hw, hw)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------- calibration
+def calibrate(model, x):
+    """MAXABS per-edge scales from one FP32 pass (torch CPU conv: model preparation, not the hot path)."""
+    import torch
+    import torch.nn.functional as Fn
+    t = {"data": torch.from_numpy(x)}
+    scales = {"data": float(np.abs(x).max()) / 127.0}
+    with torch.no_grad():
+        for l in model["spec"]:
+            kd = l["kind"]
+            if kd == "conv":
+                w, b = model["params"][l["name"]]
+                y = Fn.conv2d(t[l["src"]], torch.from_numpy(w), torch.from_numpy(b), l["stride"], l["pad"])
+                if l["relu"]:
+                    y = torch.relu(y)
+            elif kd == "pool":
+                y = Fn.max_pool2d(t[l["src"]], l["win"], l["stride"], l["pad"], ceil_mode=True)
+            elif kd == "eltwise":
+                y = torch.relu(t[l["a"]] + t[l["b"]])
+            elif kd == "gpool":
+                y = t[l["src"]].mean((2, 3), keepdim=True)
+            elif kd == "fc":
+                w, b = model["params"][l["name"]]
+                y = Fn.linear(t[l["src"]].flatten(1), torch.from_numpy(w), torch.from_numpy(b))
+                if l.get("relu"):
+                    y = torch.relu(y)
+            elif kd == "softmax":
+                y = torch.softmax(t[l["src"]], 1)
+            t[l["name"]] = y
+            scales[l["name"]] = max(float(y.abs().max()), 1e-6) / 127.0
+    return scales
+
+
+# --------------------------------------------------------------------------------------------- device nets
+def _out_hw(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224):
+    """ResNet INT8 op list on the device (see module docstring for the dtype rules)."""
+    from . import lib as L
+    from . import saber as S
+    net = S.Net()
+    B = batch
+    net.add_tensor("data", (B, 3, hw, hw), F32)
+    shape = {"data": (hw, 3)}        # name -> (spatial, channels)
+    dtype = {"data": F32}
+    pending = {}                     # branch2c convs waiting for their eltwise when fusing
+    for l in model["spec"]:
+        kd, nm = l["kind"], l["name"]
+        if kd == "conv":
+            hin, cin = shape[l["src"]]
+            ho = _out_hw(hin, l["k"], l["stride"], l["pad"])
+            w, b = model["params"][nm]
+            odt = U8 if l["relu"] else S8
+            p = S.ConvParam(w, b, 1, (l["pad"],) * 2, (l["stride"],) * 2, (1, 1), l["relu"])
+            shape[nm], dtype[nm] = (ho, l["cout"]), odt
+            if fuse_eltwise and "eltwise" in l:
+                pending[l["eltwise"]] = (l, p, hin, cin, ho)
+                continue
+            conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[l["src"]], odt, scales[l["src"]], scales[nm],
+                                            in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
+            net.add_tensor(nm, (B, ho, ho, l["cout"]), odt)
+            net.add_conv(conv, l["src"], nm)
+        elif kd == "pool":
+            hin, c = shape[l["src"]]
+            ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
+            shape[nm], dtype[nm] = (ho, c), dtype[l["src"]]
+            scales[nm] = scales[l["src"]]   # SaberPooling<X86,AK_INT8>::init: output scale := input scale
+            net.add_tensor(nm, (B, ho, ho, c), dtype[nm])
+            net.add_pool_i8(B, hin, hin, c, ho, ho, (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"],
+                            dtype[l["src"]], dtype[nm], l["src"], nm)
+        elif kd == "eltwise":
+            ho, c = shape[l["a"]]
+            shape[nm], dtype[nm] = (ho, c), S8
+            net.add_tensor(nm, (B, ho, ho, c), S8)
+            coeff = 1.0 / scales[nm]
+            if nm in pending:
+                cl, p, hin, cin, _ = pending.pop(nm)
+                p.res_mode, p.res_relu = L.RES_ELTWISE, l["relu"]
+                p.coeff, p.scale_res = (coeff, coeff), scales[l["b"]]
+                conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[cl["src"]], S8, scales[cl["src"]],
+                                                scales[cl["name"]])
+                net.add_conv(conv, cl["src"], nm, res=l["b"])
+            else:
+                net.add_eltwise_i8(B * ho * ho * c, scales[l["a"]], scales[l["b"]], coeff, coeff, l["relu"], l["a"],
+                                   l["b"], nm)
+        elif kd == "gpool":
+            # FP32 pooling op fed an s8 NHWC edge: dequantise on entry (saber_pooling.cpp:399-402), then avg
+            hin, c = shape[l["src"]]
+            net.add_tensor(nm + "_deq", (B, c, hin, hin), F32)
+            net.add_tensor(nm, (B, c, 1, 1), F32)
+            net.add_dequantize(B, c, hin, hin, dtype[l["src"]], scales[l["src"]], l["src"], nm + "_deq")
+            net.add_pool_f32(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, L.NCHW, nm + "_deq", nm)
+            shape[nm], dtype[nm] = (1, c), F32
+        elif kd == "fc":
+            w, b = model["params"][nm]
+            fc = S.SaberFc(True).init(B, l["cout"], l["cin"], w, b, F32, scales[l["src"]])
+            net.add_tensor(nm, (B, l["cout"]), F32)
+            net.add_fc(fc, l["src"], nm)
+        elif kd == "softmax":
+            net.add_tensor(nm, (B, 1000), F32)
+            net.add_softmax(B, 1000, l["src"], nm)
+    net.finalize()
+    return net
+
+
+def build_fp32_net(model, batch, hw=224):
+    """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
+    does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132)."""
+    from . import lib as L
+    from . import saber as S
+    net = S.Net()
+    B = batch
+    net.add_tensor("data", (B, 3, hw, hw), F32)
+    net.add_tensor("data_nhwc", (B, hw, hw, 4), F32)
+    net.add_transpose_in(B, 3, hw, hw, 4, "data", "data_nhwc")
+    shape = {"data_nhwc": (hw, 4)}
+    alias = {"data": "data_nhwc"}
+
+    def T(n):
+        return alias.get(n, n)
+    for l in model["spec"]:
+        kd, nm = l["kind"], l["name"]
+        if kd == "conv":
+            hin, cin = shape[T(l["src"])]
+            ho = _out_hw(hin, l["k"], l["stride"], l["pad"])
+            w, b = model["params"][nm]
+            if cin != w.shape[1]:   # first layer: channels padded 3 -> 4
+                w = np.concatenate([w, np.zeros((w.shape[0], cin - w.shape[1]) + w.shape[2:], np.float32)], 1)
+            p = S.ConvParam(w, b, 1, (l["pad"],) * 2, (l["stride"],) * 2, (1, 1), l["relu"])
+            if "eltwise" in l:
+                # fused: accumulate onto the shortcut tensor, relu of the eltwise
+                el = next(e for e in model["spec"] if e["kind"] == "eltwise" and e["name"] == l["eltwise"])
+                p.res_mode, p.res_relu = L.RES_SUM_INPLACE, el["relu"]
+                conv = S.SaberConv2D(False).init((B, cin, hin, hin), p, F32, F32, in_layout=L.NHWC, out_layout=L.NHWC)
+                # identity blocks: the shortcut is the block input, still needed? no - branch2a already consumed it
+                net.add_conv(conv, T(l["src"]), T(el["b"]))
+                alias[el["name"]] = T(el["b"])
+                shape[T(el["b"])] = (ho, l["cout"])
+                continue
+            conv = S.SaberConv2D(False).init((B, cin, hin, hin), p, F32, F32, in_layout=L.NHWC, out_layout=L.NHWC)
+            net.add_tensor(nm, (B, ho, ho, l["cout"]), F32)
+            shape[nm] = (ho, l["cout"])
+            net.add_conv(conv, T(l["src"]), nm)
+        elif kd == "pool":
+            hin, c = shape[T(l["src"])]
+            ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
+            net.add_tensor(nm, (B, ho, ho, c), F32)
+            shape[nm] = (ho, c)
+            net.add_pool_f32(B, hin, hin, c, ho, ho, (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"],
+                             L.NHWC, T(l["src"]), nm)
+        elif kd == "eltwise":
+            pass  # fused into branch2c above
+        elif kd == "gpool":
+            hin, c = shape[T(l["src"])]
+            net.add_tensor(nm, (B, c), F32)
+            shape[nm] = (1, c)
+            net.add_pool_f32(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, L.NHWC, T(l["src"]), nm)
+        elif kd == "fc":
+            w, b = model["params"][nm]
+            if "flatten_chw" in l:   # NCHW-flattened weights -> our NHWC flatten order
+                c, h, ww = l["flatten_chw"]
+                w = np.ascontiguousarray(w.reshape(-1, c, h, ww).transpose(0, 2, 3, 1).reshape(w.shape[0], -1))
+            fc = S.SaberFc(False).init(B, l["cout"], l["cin"], w, b, F32)
+            net.add_tensor(nm, (B, l["cout"]), F32)
+            net.add_fc(fc, T(l["src"]), nm)
+            if l.get("relu"):
+                net.keep.append("relu-after-fc: applied by eltwise(x, x, 0.5, 0.5, relu)")
+                net.add_eltwise_f32(B * l["cout"], 0.5, 0.5, True, nm, nm, nm)
+        elif kd == "softmax":
+            net.add_tensor(nm, (B, 1000), F32)
+            net.add_softmax(B, 1000, T(l["src"]), nm)
+    net.alias = alias
+    net.finalize()
+    return net
+
+
+# --------------------------------------------------------------------------------------------- algorithmic counts
+def algorithmic_bytes_int8(model, batch, hw=224):
+    """Compulsory HBM bytes of the conv/fc kernels of one batch (each tensor touched once; weights once
+    per batch), per SURVEY.md §8(d): INT8 conv in + out (+ residual re-read) elements x 1 byte + weights."""
+    sizes = {"data": (hw, 3)}
+    act, wts = 0, 0
+    for l in model["spec"]:
+        if l["kind"] == "conv":
+            hin, cin = sizes[l["src"]]
+            ho = _out_hw(hin, l["k"], l["stride"], l["pad"])
+            sizes[l["name"]] = (ho, l["cout"])
+            act += cin * hin * hin + l["cout"] * ho * ho
+            if "eltwise" in l:
+                act += l["cout"] * ho * ho
+            wts += cin * l["cout"] * l["k"] ** 2
+        elif l["kind"] == "pool":
+            hin, c = sizes[l["src"]]
+            sizes[l["name"]] = (int(np.ceil((hin + 2 * l["pad"] - l["win"]) / l["stride"])) + 1, c)
+        elif l["kind"] == "eltwise":
+            sizes[l["name"]] = sizes[l["a"]]
+        elif l["kind"] == "fc":
+            wts += l["cin"] * l["cout"]
+    return act * batch + wts

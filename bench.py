@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — ResNet50 INT8 inference throughput on MI355X through the C-ABI HIP Saber target.
+
+A "step" is ONE forward pass of the post-fusion ResNet50 INT8 op list (53 conv-like ops, 2 pools,
+16 residual adds fused bit-exactly into the branch2c epilogues, global pool, FC, softmax) over one
+batch of synthetic images already resident in HBM. Protocol mirrors the reference's (README.md:44,
+benchmark/CNN/run.sh): warm-up, then K timed iterations; images/s = batch * K / time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; the batch is sharded as independent
+per-GPU sub-batches (weak scaling, no data-path collective) and the per-rank logits are
+all-gathered over RCCL each step (the only exchange the path has).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_I8_PEAK_TOPS = 5000.0   # dense i8 = 2x bf16 dense (~2.5 PF), MI355X_MICROARCH.md MFMA table
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet101", "vgg16"])
+    ap.add_argument("--precision", default="int8", choices=["int8", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-fuse", action="store_true", help="keep the 16 eltwise ops separate (reference op list)")
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    return ap.parse_args()
+
+
+def build_net(W, model, scales, batch, args):
+    if args.precision == "int8":
+        return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse)
+    return W.build_fp32_net(model, batch)
+
+
+def timed_steps(net, steps, use_graph, gather=None):
+    import torch
+    for _ in range(steps):
+        if use_graph:
+            net.replay()
+        else:
+            net.run()
+        if gather is not None:
+            gather()
+    torch.cuda.synchronize()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from anakin_amd import lib as L
+    from anakin_amd import workloads as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    L.require_device()   # no fallback: the HIP library and a gfx950 device are mandatory
+    n_gpus = world
+
+    B = args.batch
+    model = W.build_model(args.model)
+    x = W.make_input(B, seed=1234 + rank)
+    scales = W.calibrate(model, W.make_input(2)) if args.precision == "int8" else {}
+    net = build_net(W, model, scales, B, args)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    torch.cuda.synchronize()
+    if not args.no_autotune:
+        net.autotune(iters=10)   # RUNTIME strategy (BaseFunc::pick_best_runtime), once, outside the timed region
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    use_graph = not args.no_graph
+    if use_graph:
+        net.capture()
+
+    logits = net.tensor("prob")
+    gather = None
+    if world > 1:
+        gathered = torch.empty((world,) + tuple(logits.shape), dtype=logits.dtype, device="cuda")
+
+        def gather():
+            dist.all_gather_into_tensor(gathered, logits)
+
+    # ---------------- warm-up, then the timed region (barrier + synchronize on both sides) ----------
+    timed_steps(net, args.warmup, use_graph, gather)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timed_steps(net, args.steps, use_graph, gather)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt * 1000.0 / args.steps
+    value = n_gpus * B * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---------------- per-step latency distribution (hipEvents around each replay) -------------
+        lat = []
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+        for a, b in ev:
+            a.record()
+            net.replay() if use_graph else net.run()
+            b.record()
+        torch.cuda.synchronize()
+        lat = sorted(a.elapsed_time(b) for a, b in ev)
+        p50, p99 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(len(lat) * 0.99))]
+
+        # ---------------- roofline of the dominant kernel family (implicit-GEMM conv) ---------------
+        op_us = net.time_ops(iters=20)          # hipEvents on the launch stream, per op, eager back-to-back
+        names = [net.op_name(i) for i in range(net.num_ops())]
+        conv_us = sum(t for t, n in zip(op_us, names) if n.startswith("conv:") or n.startswith("fc:"))
+        n_conv = sum(1 for n in names if n.startswith("conv:") or n.startswith("fc:"))
+        es = 1 if args.precision == "int8" else 4
+        alg_bytes = W.algorithmic_bytes_int8(model, B) * es
+        alg_ops = 2.0 * W.conv_macs(model["spec"]) * B
+        achieved_gbs = alg_bytes / (conv_us * 1e-6) / 1e9
+        achieved_tops = alg_ops / (conv_us * 1e-6) / 1e12
+        peak_ops = MFMA_I8_PEAK_TOPS if args.precision == "int8" else MFMA_F32_PEAK_TFLOPS
+        t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), alg_ops / (peak_ops * 1e12)
+        bound = "hbm" if t_hbm >= t_mfma else "mfma"
+        if bound == "hbm":
+            roof = dict(bound="hbm", achieved=round(achieved_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved_gbs / HBM_PEAK_GBS, 4), traffic=None)
+        else:
+            roof = dict(bound="mfma", achieved=round(achieved_tops, 2), peak=peak_ops, unit="TFLOP/s",
+                        frac=round(achieved_tops / peak_ops, 4), traffic=None)
+        roof.update(kernel="conv_igemm_kernel (all %d conv/fc launches of one forward)" % n_conv,
+                    launches=n_conv, avg_launch_us=round(conv_us / n_conv, 3),
+                    algorithmic_bytes_per_forward=int(alg_bytes), algorithmic_ops_per_forward=int(alg_ops),
+                    mfma_frac=round(achieved_tops / peak_ops, 4), hbm_frac=round(achieved_gbs / HBM_PEAK_GBS, 4),
+                    sum_all_op_us=round(sum(op_us), 1))
+        if args.per_op:
+            for n, t in sorted(zip(names, op_us), key=lambda p: -p[1])[:25]:
+                print("%8.2f us  %s" % (t, n), file=sys.stderr)
+
+        # ---------------- batch-1 latency leg (the metric quotes p50 @ batch 1 and 8) ---------------
+        b1 = None
+        if not args.no_b1 and B != 1:
+            net1 = build_net(W, model, scales, 1, args)
+            net1.tensor("data").copy_(torch.from_numpy(W.make_input(1)).cuda())
+            net1.run()
+            if not args.no_autotune:
+                net1.autotune(iters=10)
+            if use_graph:
+                net1.capture()
+            timed_steps(net1, 20, use_graph)
+            ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+            for a, b in ev1:
+                a.record()
+                net1.replay() if use_graph else net1.run()
+                b.record()
+            torch.cuda.synchronize()
+            l1 = sorted(a.elapsed_time(b) for a, b in ev1)
+            b1 = dict(p50_ms=round(l1[len(l1) // 2], 4), mean_ms=round(statistics.mean(l1), 4),
+                      images_per_s=round(1000.0 / statistics.mean(l1), 1))
+
+        # ---------------- CPU baseline: the oracle (a port), bounded sample, rank 0 only --------------
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and args.precision == "int8":
+            from oracle import net_oracle as NO
+            cores = os.cpu_count() or 1
+            xs = W.make_input(1)
+            t1 = time.perf_counter()
+            NO.run_int8(model, dict(scales), xs)
+            one = time.perf_counter() - t1
+            n_img = max(1, min(16, int(args.cpu_seconds / max(one, 1e-3))))
+            t1 = time.perf_counter()
+            for _ in range(n_img):
+                NO.run_int8(model, dict(scales), xs)
+            tot = time.perf_counter() - t1
+            cpu = dict(value=round(n_img / tot, 3), unit="images/s", cores=cores, kind="port",
+                       sample="%d x ResNet50 INT8 forward (batch 1, 224x224) through oracle/saber_oracle.c, "
+                              "OpenMP over %d host threads; the reference's JIT-VNNI x86 path is not buildable "
+                              "here (README.md:92 quotes 3.21 ms on 8 Xeon-6271 threads)" % (n_img, cores))
+
+        out = {
+            "metric": "ResNet50 INT8 images/sec @ batch %d (p50 latency alongside), %dxMI355X" % (B, n_gpus)
+            if args.precision == "int8" and args.model == "resnet50" else
+            "%s %s images/sec @ batch %d" % (args.model, args.precision, B),
+            "value": round(value, 1), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "s8/u8 x s8 -> s32 (MFMA i8), f32 epilogue" if args.precision == "int8" else "f32",
+            "data": "synthetic (seeded uniform images, He-init weights with folded BN, MAXABS scales)",
+            "config": {"workload": "%s %s post-fusion op list, batch %d per GPU, 224x224" %
+                                   (args.model, args.precision, B),
+                       "global_batch": B * n_gpus, "ops": net.num_ops(), "hip_graph": use_graph,
+                       "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus},
+            "latency_ms": {"batch": B, "p50": round(p50, 4), "p99": round(p99, 4)},
+            "batch1": b1,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

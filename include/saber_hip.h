@@ -195,6 +195,8 @@ int saber_hip_net_add_conv(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id
 int saber_hip_net_add_fc(saber_hip_net_t* net, saber_hip_fc_t* op, int in_id, int out_id);
 int saber_hip_net_add_quantize(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int out_dtype,
                                float scale, int in_id, int out_id);
+int saber_hip_net_add_dequantize(saber_hip_net_t* net, int n, int c, int h, int w, int in_dtype, float scale,
+                                 int in_id, int out_id);
 int saber_hip_net_add_transpose_in_f32(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int in_id,
                                        int out_id);
 int saber_hip_net_add_eltwise_i8(saber_hip_net_t* net, size_t count, float scale_a, float scale_b,
