@@ -67,6 +67,7 @@ struct saber_hip_conv {
     int oh = 0, ow = 0;
     int algo = ALGO_DIRECT_I8;
     int tile = TILE_64x64;
+    int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
     int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
@@ -131,7 +132,7 @@ static void name_algo(saber_hip_conv* op) {
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
     char buf[64];
-    if (op->algo <= ALGO_IGEMM_F32) snprintf(buf, sizeof buf, "%s_%dx%d", an[op->algo], bmk, bnp);
+    if (op->algo <= ALGO_IGEMM_F32) snprintf(buf, sizeof buf, "%s_%dx%d_k%d", an[op->algo], bmk, bnp, op->ks);
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
     op->algo_name = buf;
 }
@@ -215,15 +216,19 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
     if (op->algo == ALGO_IGEMM_I8_C4) {
         op->kw_pad = round_up(d.kw, 4);
         op->Kg = d.kh * op->kw_pad * 4;
-        op->Kg_pad = round_up(op->Kg, 64);
+        op->Kg_pad = round_up(op->Kg, 256);
     } else if (op->algo == ALGO_IGEMM_I8) {
         op->Kg = d.kh * d.kw * op->c_eff;
-        op->Kg_pad = round_up(op->Kg, 64);
+        op->Kg_pad = round_up(op->Kg, 256);
     } else if (op->algo == ALGO_IGEMM_F32) {
         op->Kg = d.kh * d.kw * op->c_eff;
-        op->Kg_pad = round_up(op->Kg, 16);
+        op->Kg_pad = round_up(op->Kg, 64);
     }
     choose_tile(op);
+    {   // stage depth: as many 64-byte k-steps per barrier as the reduction has (max 4)
+        const int kbytes = op->Kg * (op->algo == ALGO_IGEMM_F32 ? 4 : 1);
+        op->ks = kbytes >= 256 ? 4 : (kbytes >= 128 ? 2 : 1);
+    }
     name_algo(op);
     *out = op;
     return SABER_HIP_OK;
@@ -237,12 +242,17 @@ size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op) { return op-
 const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_name.c_str(); }
 
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
-    if (tile < 0 || tile >= TILE_COUNT) return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
+    // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15
+    const int ks = (tile >> 8) & 0xff;
+    tile &= 0xff;
+    if (tile < 0 || tile >= TILE_COUNT || !(ks == 0 || ks == 1 || ks == 2 || ks == 4))
+        return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
+    if (ks) op->ks = ks;
     op->tile = tile;
     name_algo(op);
     return SABER_HIP_OK;
 }
-int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) { return op->tile; }
+int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) { return op->tile | (op->ks << 8); }
 
 int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtype, const float* w_scale,
                                  const float* bias, float in_scale, float out_scale) {
@@ -384,8 +394,10 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.stride_h = d.stride_h; a.stride_w = d.stride_w; a.dil_h = d.dil_h; a.dil_w = d.dil_w;
     a.M = d.n * op->oh * op->ow;
     a.Kg = op->Kg; a.Kg_pad = op->Kg_pad; a.kw_pad = op->kw_pad;
-    const int estep = op->algo == ALGO_IGEMM_F32 ? 16 : 64;
-    a.steps = op->Kg_pad / estep;
+    const int estage = (op->algo == ALGO_IGEMM_F32 ? 16 : 64) * op->ks;   // elements per pipeline stage
+    a.steps = (op->Kg + estage - 1) / estage;
+    a.inv_ohw = 1.0f / (float)(op->oh * op->ow);
+    a.inv_ow = 1.0f / (float)op->ow;
     a.in_u8 = op->x_dtype == DT_U8;
     a.out_dtype = d.out_dtype;
     a.out_nchw = (!op->is_i8 && d.out_layout == SABER_HIP_NCHW) ? 1 : 0;
@@ -426,9 +438,9 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     ConvKArgs a;
     fill_args(op, a, xin, y, res);
     switch (op->algo) {
-    case ALGO_IGEMM_I8: HIP_TRY(launch_conv_igemm(0, op->tile, a, s)); break;
-    case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, a, s)); break;
-    case ALGO_IGEMM_F32: HIP_TRY(launch_conv_igemm(2, op->tile, a, s)); break;
+    case ALGO_IGEMM_I8: HIP_TRY(launch_conv_igemm(0, op->tile, op->ks, a, s)); break;
+    case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s)); break;
+    case ALGO_IGEMM_F32: HIP_TRY(launch_conv_igemm(2, op->tile, op->ks, a, s)); break;
     case ALGO_DIRECT_I8:
         a.comp = nullptr;
         HIP_TRY(launch_conv_direct(0, a, d.group, s));
@@ -449,22 +461,28 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     float best = 1e30f;
-    int best_tile = op->tile;
+    int best_tile = op->tile, best_ks = op->ks;
+    const int ks_list[3] = {1, 2, 4};
     for (int t = 0; t < TILE_COUNT; ++t) {
-        op->tile = t;
-        int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
-        HIP_TRY(hipEventRecord(e1, s));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (ms < best) {
-            best = ms;
-            best_tile = t;
+        for (int ki = 0; ki < 3; ++ki) {
+            op->tile = t;
+            op->ks = ks_list[ki];
+            int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(e0, s));
+            for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
+            HIP_TRY(hipEventRecord(e1, s));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) {
+                best = ms;
+                best_tile = t;
+                best_ks = ks_list[ki];
+            }
         }
     }
+    op->ks = best_ks;
     op->tile = best_tile;
     name_algo(op);
     (void)hipEventDestroy(e0);

@@ -67,29 +67,62 @@ __device__ __forceinline__ v4f mma_step(v4i a, v4i b, v4f c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Epilogues. p = output pixel index (n*OH*OW + oh*OW + ow), k0 = first of 4 consecutive out channels.
+// Epilogue of one lane: NV = TM*4 CONSECUTIVE output channels (kb .. kb+NV-1) of one output pixel p.
+// The weight rows of a block tile are permuted so that MFMA tile tm / D-row i holds channel
+// (i>>2)*(TM*4) + tm*4 + (i&3): a lane's TM accumulator quads are therefore adjacent channels and are
+// written with ONE 4/8/16-byte store (int8) or TM float4 stores.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, v4i acc, int p, int k0) {
-    if (p >= a.M || k0 >= a.K) return;
-    const size_t o = (size_t)p * a.K + k0;
-    const bool full = (k0 + 3 < a.K) && ((a.K & 3) == 0);
-    int outq[4];
-    float outf[4];
+template <int NV>
+struct ChanParams {   // per-lane channel constants, loaded once per block (vector loads)
+    float bias[NV], scale[NV];
+    int comp[NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void load_chan_params(const ConvKArgs& a, int kb, ChanParams<NV>& cp) {
+    // arrays are padded to a multiple of 128 channels on the host, so vector loads never run off the end
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k = k0 + r;
-        if (k >= a.K) { outq[r] = 0; outf[r] = 0.f; continue; }
-        int v = acc[r];
-        if (a.comp) v += a.comp[k];
+    for (int v = 0; v < NV; v += 4) {
+        const float4 sc = a.scale ? *(const float4*)(a.scale + kb + v) : make_float4(1, 1, 1, 1);
+        const float4 bi = a.bias ? *(const float4*)(a.bias + kb + v) : make_float4(0, 0, 0, 0);
+        const int4 co = a.comp ? *(const int4*)(a.comp + kb + v) : make_int4(0, 0, 0, 0);
+        cp.scale[v] = sc.x; cp.scale[v + 1] = sc.y; cp.scale[v + 2] = sc.z; cp.scale[v + 3] = sc.w;
+        cp.bias[v] = bi.x; cp.bias[v + 1] = bi.y; cp.bias[v + 2] = bi.z; cp.bias[v + 3] = bi.w;
+        cp.comp[v] = co.x; cp.comp[v + 1] = co.y; cp.comp[v + 2] = co.z; cp.comp[v + 3] = co.w;
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, const int (&acc)[NV], const ChanParams<NV>& cp,
+                                            int p, int kb) {
+    if (p >= a.M || kb >= a.K) return;
+    const size_t o = (size_t)p * a.K + kb;
+    const bool full = (kb + NV <= a.K) && (a.K % NV == 0);
+    const bool f32_out = (a.epi != EPI_I8_CONV) || (a.out_dtype == DT_F32 && a.res_mode != RES_ELTWISE);
+    int outq[NV];
+    float outf[NV];
+    // residual / previous-output bytes for the fused modes (one vector load per lane when aligned)
+    int resv[NV];
+    if (a.epi == EPI_I8_CONV && a.res_mode != RES_NONE) {
+        const void* src = a.res_mode == RES_ELTWISE ? a.res : (const void*)a.y;
+        const int rdt = a.res_mode == RES_ELTWISE ? DT_S8 : a.res_dtype;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            if (kb + r >= a.K) { resv[r] = 0; continue; }
+            if (rdt == DT_F32) resv[r] = __float_as_int(((const float*)src)[o + r]);
+            else if (rdt == DT_U8) resv[r] = (int)((const uint8_t*)src)[o + r];
+            else resv[r] = (int)((const int8_t*)src)[o + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int v = acc[r] + cp.comp[r];
         float d = (float)v;
         if (a.epi == EPI_I8_CONV) {
-            if (a.bias) d = __fadd_rn(d, a.bias[k]);
-            d = __fmul_rn(d, a.scale[k]);
+            d = __fadd_rn(d, cp.bias[r]);          // bias' is 0 when the op has no bias: d + 0 == d exactly
+            d = __fmul_rn(d, cp.scale[r]);
             if (a.res_mode == RES_SUM_INPLACE) {
-                float prev;
-                if (a.res_dtype == DT_F32) prev = ((const float*)a.y)[o + r];
-                else if (a.res_dtype == DT_U8) prev = (float)((const uint8_t*)a.y)[o + r];
-                else prev = (float)((const int8_t*)a.y)[o + r];
+                const float prev = a.res_dtype == DT_F32 ? __int_as_float(resv[r]) : (float)resv[r];
                 d = (a.sum_scale == 1.f) ? __fadd_rn(d, prev) : __fmaf_rn(prev, a.sum_scale, d);
                 if (a.relu || a.out_dtype == DT_U8) d = d > 0.f ? d : 0.f;
             } else if (a.relu) {
@@ -98,8 +131,7 @@ __device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, v4i acc, int p, 
             if (a.res_mode == RES_ELTWISE) {
                 const int q = sat_s8(rintf(d));
                 float t = __fmul_rn(__fmul_rn(a.coeff_conv, (float)q), a.scale_conv);
-                const float rv = (float)((const int8_t*)a.res)[o + r];
-                t = __fadd_rn(t, __fmul_rn(__fmul_rn(a.coeff_res, rv), a.scale_res));
+                t = __fadd_rn(t, __fmul_rn(__fmul_rn(a.coeff_res, (float)resv[r]), a.scale_res));
                 if (a.res_relu) t = t > 0.f ? t : 0.f;
                 outq[r] = sat_s8(roundf(t));
             } else if (a.out_dtype == DT_F32) {
@@ -110,57 +142,64 @@ __device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, v4i acc, int p, 
                 outq[r] = sat_s8(rintf(d));
             }
         } else if (a.epi == EPI_I8_FC_S8) {
-            float t = __fmul_rn(d, a.scale[k]);
-            if (a.bias) t = __fadd_rn(t, a.bias[k]);
-            outf[r] = t;
+            outf[r] = __fadd_rn(__fmul_rn(d, cp.scale[r]), cp.bias[r]);   // v*scale (+ bias; +0 when absent)
         } else {  // EPI_I8_FC_U8 (int bias already folded into comp)
-            const float sc = a.scale[k];
-            outf[r] = (sc == 1.f) ? d : __fmul_rn(sc, d);
+            outf[r] = (cp.scale[r] == 1.f) ? d : __fmul_rn(cp.scale[r], d);
         }
     }
-    const bool f32_out = (a.epi != EPI_I8_CONV) || (a.out_dtype == DT_F32 && a.res_mode != RES_ELTWISE);
     if (f32_out) {
         float* y = (float*)a.y;
         if (full) {
-            *(float4*)(y + o) = make_float4(outf[0], outf[1], outf[2], outf[3]);
+#pragma unroll
+            for (int v = 0; v < NV; v += 4) *(float4*)(y + o + v) = make_float4(outf[v], outf[v + 1], outf[v + 2], outf[v + 3]);
         } else {
-            for (int r = 0; r < 4; ++r) if (k0 + r < a.K) y[o + r] = outf[r];
+            for (int r = 0; r < NV; ++r) if (kb + r < a.K) y[o + r] = outf[r];
         }
     } else {
         uint8_t* y = (uint8_t*)a.y;
         if (full) {
-            const unsigned pk = (outq[0] & 0xff) | ((outq[1] & 0xff) << 8) | ((outq[2] & 0xff) << 16) |
-                                ((unsigned)(outq[3] & 0xff) << 24);
-            *(unsigned*)(y + o) = pk;
+            unsigned pk[NV / 4];
+#pragma unroll
+            for (int v = 0; v < NV / 4; ++v)
+                pk[v] = (outq[4 * v] & 0xff) | ((outq[4 * v + 1] & 0xff) << 8) | ((outq[4 * v + 2] & 0xff) << 16) |
+                        ((unsigned)(outq[4 * v + 3] & 0xff) << 24);
+            if constexpr (NV == 4) *(unsigned*)(y + o) = pk[0];
+            else if constexpr (NV == 8) *(uint2*)(y + o) = make_uint2(pk[0], pk[1]);
+            else *(uint4*)(y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         } else {
-            for (int r = 0; r < 4; ++r) if (k0 + r < a.K) y[o + r] = (uint8_t)outq[r];
+            for (int r = 0; r < NV; ++r) if (kb + r < a.K) y[o + r] = (uint8_t)outq[r];
         }
     }
 }
 
-__device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, v4f acc, int p, int k0) {
-    if (p >= a.M || k0 >= a.K) return;
+template <int NV>
+__device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, const float (&acc)[NV], const ChanParams<NV>& cp,
+                                             int p, int kb, int n, int sp) {
+    if (p >= a.M || kb >= a.K) return;
     float* y = (float*)a.y;
     const int ohw = a.OH * a.OW;
-    const int n = p / ohw;
-    const int sp = p - n * ohw;
-    float outf[4];
+    const bool vec = !a.out_nchw && (kb + NV <= a.K) && ((a.K & 3) == 0);
+    float outf[NV];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k = k0 + r;
+    for (int r = 0; r < NV; ++r) {
+        const int k = kb + r;
         if (k >= a.K) { outf[r] = 0.f; continue; }
-        const size_t o = a.out_nchw ? ((size_t)n * a.K + k) * ohw + sp : (size_t)p * a.K + k;
         float d = acc[r];
-        if (a.res_mode == RES_SUM_INPLACE) d = __fadd_rn(d, y[o]);
-        if (a.bias) d = __fadd_rn(d, a.bias[k]);
+        if (a.res_mode == RES_SUM_INPLACE) {
+            const size_t o = a.out_nchw ? ((size_t)n * a.K + k) * ohw + sp : (size_t)p * a.K + k;
+            d = __fadd_rn(d, y[o]);
+        }
+        d = __fadd_rn(d, cp.bias[r]);
         if (a.relu) d = d > 0.f ? d : 0.f;
         outf[r] = d;
     }
-    if (!a.out_nchw && (k0 + 3 < a.K) && ((a.K & 3) == 0)) {
-        *(float4*)(y + (size_t)p * a.K + k0) = make_float4(outf[0], outf[1], outf[2], outf[3]);
+    if (vec) {
+#pragma unroll
+        for (int v = 0; v < NV; v += 4)
+            *(float4*)(y + (size_t)p * a.K + kb + v) = make_float4(outf[v], outf[v + 1], outf[v + 2], outf[v + 3]);
     } else {
-        for (int r = 0; r < 4; ++r) {
-            const int k = k0 + r;
+        for (int r = 0; r < NV; ++r) {
+            const int k = kb + r;
             if (k < a.K) {
                 const size_t o = a.out_nchw ? ((size_t)n * a.K + k) * ohw + sp : (size_t)p * a.K + k;
                 y[o] = outf[r];
@@ -169,27 +208,46 @@ __device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, v4f acc, int p,
     }
 }
 
+// exact p / d and p % d for 0 <= p < 2^24 using a precomputed float reciprocal (+ one fix-up step)
+__device__ __forceinline__ void fast_divmod(int p, int d, float inv, int& q, int& r) {
+    q = (int)((float)p * inv);
+    r = p - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
+// physical 16-byte chunk of logical chunk c in LDS row `row`; CPR = chunks per row (4, 8, 16).
+template <int CPR>
+__device__ __forceinline__ int phys_chunk(int row, int c) {
+    if constexpr (CPR == 4) return (c & ~3) | (((0x9C >> (2 * (c & 3))) & 3) ^ ((row >> 2) & 3));
+    else if constexpr (CPR == 8) return c ^ ((row >> 1) & 7);
+    else return c ^ (row & 15);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The kernel. MODE 0: int8, C % 16 == 0.  MODE 1: int8, input NHWC4 (C == 4, first-layer path).
 //             MODE 2: f32, C % 4 == 0.
 // Block = 256 threads = 2x2 waves; wave tile = (TM*16 out-channels) x (TN*16 pixels).
+// One pipeline stage = KS MFMA k-steps = KS*64 bytes of the reduction per row, double-buffered in LDS
+// with the next stage's global loads in flight (registers) while the current one is consumed.
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int TM, int TN>
+template <int MODE, int TM, int TN, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr bool F32 = (MODE == 2);
     constexpr bool C4 = (MODE == 1);
     constexpr int ES = F32 ? 4 : 1;      // bytes per element
     constexpr int EC = 16 / ES;          // elements per 16-byte chunk
-    constexpr int ESTEP = 64 / ES;       // elements per K-step
+    constexpr int CPR = 4 * KS;          // chunks per row per stage
+    constexpr int ESTAGE = CPR * EC;     // elements per stage
+    constexpr int RPP = 256 / CPR;       // rows staged per pass of the 256 threads
     constexpr int BMK = 2 * TM * 16;     // out channels per block
     constexpr int BNP = 2 * TN * 16;     // pixels per block
-    constexpr int WCH = BMK * 4;         // 16-byte chunks per weight tile
-    constexpr int XCH = BNP * 4;
-    constexpr int WIT = (WCH + 255) / 256;
-    constexpr int XIT = (XCH + 255) / 256;
+    constexpr int WIT = (BMK + RPP - 1) / RPP;
+    constexpr int XIT = (BNP + RPP - 1) / RPP;
+    constexpr int NV = TM * 4;
     using acc_t = typename std::conditional<F32, v4f, v4i>::type;
 
-    __shared__ v4i lds[2][WCH + XCH];
+    __shared__ v4i lds[2][(BMK + BNP) * CPR];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -197,80 +255,68 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int pix_base = blockIdx.x * BNP;
     const int k_base = blockIdx.y * BMK;
+    const int lq = tid % CPR;            // this thread's chunk column within a stage
+    const int lr = tid / CPR;            // first row it stages
 
-    // ---- per-thread gather state for the activation chunks it stages -------------------------
+    // ---- gather state: one (channel, tap) cursor per thread, XIT pixel rows ---------------------
     int x_base[XIT], x_ih0[XIT], x_iw0[XIT];
-    int x_c[XIT], x_i[XIT], x_j[XIT];
     bool x_ok[XIT];
     const int ohw = a.OH * a.OW;
-    const int cpr = C4 ? (a.kw_pad >> 2) : 1;  // chunks per filter row (C4)
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
-        const int idx = tid + it * 256;
-        const int r = idx >> 2, q = idx & 3;
+        const int r = lr + it * RPP;
         const int p = pix_base + r;
-        x_ok[it] = (idx < XCH) && (p < a.M);
+        x_ok[it] = (r < BNP) && (p < a.M);
         const int pp = x_ok[it] ? p : 0;
-        const int n = pp / ohw;
-        const int rem = pp - n * ohw;
-        const int oh = rem / a.OW;
-        const int ow = rem - oh * a.OW;
+        int n, rem, oh, ow;
+        fast_divmod(pp, ohw, a.inv_ohw, n, rem);
+        fast_divmod(rem, a.OW, a.inv_ow, oh, ow);
         x_base[it] = n * a.H * a.W * a.C;
         x_ih0[it] = oh * a.stride_h - a.pad_h;
         x_iw0[it] = ow * a.stride_w - a.pad_w;
-        if (C4) {
-            x_i[it] = q / cpr;
-            x_j[it] = q - x_i[it] * cpr;  // chunk index within the filter row
-            x_c[it] = 0;
-        } else {
-            const int kk0 = q * EC;
-            const int tap = kk0 / a.C;
-            x_c[it] = kk0 - tap * a.C;
-            x_i[it] = tap / a.kw;
-            x_j[it] = tap - x_i[it] * a.kw;
-        }
+    }
+    int cur_c, cur_i, cur_j;             // normal: channel offset, tap row, tap col; C4: -, tap row, chunk-in-row
+    const int cpr4 = C4 ? (a.kw_pad >> 2) : 1;
+    if (C4) {
+        cur_i = lq / cpr4;
+        cur_j = lq - cur_i * cpr4;
+        cur_c = 0;
+    } else {
+        const int kk0 = lq * EC;
+        const int tap = kk0 / a.C;
+        cur_c = kk0 - tap * a.C;
+        cur_i = tap / a.kw;
+        cur_j = tap - cur_i * a.kw;
     }
 
     v4i xv[XIT], wv[WIT];
     const v4i* w16 = (const v4i*)a.w;
     const int w_row_chunks = a.Kg_pad / EC;
 
-    auto load_step = [&](int s) {
+    auto load_stage = [&](int s) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < WCH) {
-                const int r = idx >> 2, q = idx & 3;
-                wv[it] = w16[(size_t)(k_base + r) * w_row_chunks + s * 4 + q];
-            }
+            const int r = lr + it * RPP;
+            if (r < BMK) wv[it] = w16[(size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
         }
+        const bool tap_ok = cur_i < a.kh;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             v4i v = {0, 0, 0, 0};
-            const int ih = x_ih0[it] + x_i[it] * a.dil_h;
-            const bool row_ok = x_ok[it] && (x_i[it] < a.kh) && (ih >= 0) && (ih < a.H);
+            const int ih = x_ih0[it] + cur_i * a.dil_h;
+            const bool row_ok = x_ok[it] && tap_ok && (ih >= 0) && (ih < a.H);
             if (C4) {
                 const unsigned* xp = (const unsigned*)a.x;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int iw = x_iw0[it] + (x_j[it] * 4 + t) * a.dil_w;
-                    if (row_ok && iw >= 0 && iw < a.W) {
-                        v[t] = (int)xp[(x_base[it] >> 2) + ih * a.W + iw];
-                    }
+                    const int iw = x_iw0[it] + (cur_j * 4 + t) * a.dil_w;
+                    if (row_ok && iw >= 0 && iw < a.W) v[t] = (int)xp[(x_base[it] >> 2) + ih * a.W + iw];
                 }
-                x_j[it] += 4;
-                while (x_j[it] >= cpr) { x_j[it] -= cpr; ++x_i[it]; }
             } else {
-                const int iw = x_iw0[it] + x_j[it] * a.dil_w;
+                const int iw = x_iw0[it] + cur_j * a.dil_w;
                 if (row_ok && iw >= 0 && iw < a.W) {
-                    const char* xp = (const char*)a.x +
-                                     ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + x_c[it]) * ES;
+                    const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES;
                     v = *(const v4i*)xp;
-                }
-                x_c[it] += ESTEP;
-                while (x_c[it] >= a.C) {
-                    x_c[it] -= a.C;
-                    if (++x_j[it] == a.kw) { x_j[it] = 0; ++x_i[it]; }
                 }
             }
             if (!F32 && a.in_u8) {
@@ -278,23 +324,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             }
             xv[it] = v;
         }
+        // advance the cursor by one stage
+        if (C4) {
+            cur_j += CPR;
+            while (cur_j >= cpr4) { cur_j -= cpr4; ++cur_i; }
+        } else {
+            cur_c += ESTAGE;
+            while (cur_c >= a.C) {
+                cur_c -= a.C;
+                if (++cur_j == a.kw) { cur_j = 0; ++cur_i; }
+            }
+        }
     };
-    auto store_step = [&](int buf) {
+    auto store_stage = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < WCH) {
-                const int r = idx >> 2, q = idx & 3;
-                lds[buf][r * 4 + swz(r, q)] = wv[it];
+            const int r = lr + it * RPP;
+            if (r < BMK) {
+                // permuted LDS row so that MFMA tile (wm, tm) reads 16 consecutive rows (conflict-free)
+                const int rr = r % (TM * 16), wmr = r / (TM * 16);
+                const int lrow = (wmr * TM + ((rr >> 2) % TM)) * 16 + (rr / (TM * 4)) * 4 + (rr & 3);
+                lds[buf][lrow * CPR + phys_chunk<CPR>(lrow, lq)] = wv[it];
             }
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < XCH) {
-                const int r = idx >> 2, q = idx & 3;
-                lds[buf][WCH + r * 4 + swz(r, q)] = xv[it];
-            }
+            const int r = lr + it * RPP;
+            if (r < BNP) lds[buf][(BMK + r) * CPR + phys_chunk<CPR>(r, lq)] = xv[it];
         }
     };
 
@@ -304,42 +360,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-    load_step(0);
-    store_step(0);
+    load_stage(0);
+    store_stage(0);
     __syncthreads();
 
     const int frow = lane & 15, fq = lane >> 4;
+    // LDS row of the weight tile feeding MFMA tile i (rows were permuted when staged)
+    int wrow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) wrow[i] = (wm * TM + i) * 16 + frow;
+
     for (int s = 0; s < a.steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < a.steps) load_step(s + 1);
-        v4i af[TM], bf[TN];
+        if (s + 1 < a.steps) load_stage(s + 1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 16 + frow;
-            af[i] = lds[buf][row * 4 + swz(row, fq)];
+        for (int ks = 0; ks < KS; ++ks) {
+            v4i af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds[buf][wrow[i] * CPR + phys_chunk<CPR>(wrow[i], ks * 4 + fq)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + frow;
+                bf[j] = lds[buf][(BMK + row) * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = (wn * TN + j) * 16 + frow;
-            bf[j] = lds[buf][WCH + row * 4 + swz(row, fq)];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
-        if (s + 1 < a.steps) store_step(buf ^ 1);
+        if (s + 1 < a.steps) store_stage(buf ^ 1);
         __syncthreads();
     }
 
+    // ---- epilogue: lane owns channels kb .. kb+NV-1 of pixels p(j) -------------------------------
+    const int kb = k_base + wm * (TM * 16) + fq * NV;
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int p = pix_base + (wn * TN + j) * 16 + frow;
+        if constexpr (F32) {
+            float v[NV];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int k0 = k_base + (wm * TM + i) * 16 + fq * 4;
-            const int p = pix_base + (wn * TN + j) * 16 + frow;
-            if constexpr (F32) epilogue_f32(a, acc[i][j], p, k0);
-            else epilogue_i8(a, acc[i][j], p, k0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            int n = 0, sp = 0;
+            if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
+            epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
+        } else {
+            int v[NV];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            epilogue_i8<NV>(a, v, cp, p, kb);
         }
+    }
 }
 
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
@@ -348,29 +425,39 @@ void tile_dims(int tile, int* bm_k, int* bn_pix) {
     *bn_pix = d[tile][1];
 }
 
-template <int MODE>
+template <int MODE, int KS>
 static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     int bmk, bnp;
     tile_dims(tile, &bmk, &bnp);
     dim3 grid((a.M + bnp - 1) / bnp, (a.K + bmk - 1) / bmk);
     dim3 block(256);
     switch (tile) {
-    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1>), grid, block, 0, s, a); break;
-    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1>), grid, block, 0, s, a); break;
-    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2>), grid, block, 0, s, a); break;
-    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 2>), grid, block, 0, s, a); break;
-    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4>), grid, block, 0, s, a); break;
-    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 4>), grid, block, 0, s, a); break;
+    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, KS>), grid, block, 0, s, a); break;
+    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1, KS>), grid, block, 0, s, a); break;
+    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, KS>), grid, block, 0, s, a); break;
+    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 2, KS>), grid, block, 0, s, a); break;
+    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4, KS>), grid, block, 0, s, a); break;
+    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 4, KS>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_conv_igemm(int mode, int tile, const ConvKArgs& a, hipStream_t s) {
+template <int MODE>
+static hipError_t launch_ks(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+    switch (ks) {
+    case 1: return launch_mode<MODE, 1>(tile, a, s);
+    case 2: return launch_mode<MODE, 2>(tile, a, s);
+    case 4: return launch_mode<MODE, 4>(tile, a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
     switch (mode) {
-    case 0: return launch_mode<0>(tile, a, s);
-    case 1: return launch_mode<1>(tile, a, s);
-    case 2: return launch_mode<2>(tile, a, s);
+    case 0: return launch_ks<0>(tile, ks, a, s);
+    case 1: return launch_ks<1>(tile, ks, a, s);
+    case 2: return launch_ks<2>(tile, ks, a, s);
     default: return hipErrorInvalidValue;
     }
 }

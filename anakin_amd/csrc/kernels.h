@@ -29,7 +29,8 @@ struct ConvKArgs {
     int M;        // N*OH*OW output pixels (GEMM columns)
     int Kg;       // real reduction length in elements (kh*kw*C, or kh*kw_pad*4 in C4 mode)
     int Kg_pad;   // padded to a multiple of one K-step
-    int steps;    // Kg_pad / elements-per-step
+    int steps;    // number of pipeline stages = ceil(Kg / elements-per-stage)
+    float inv_ohw, inv_ow;  // 1/(OH*OW), 1/OW for the exact float-reciprocal div/mod
     int kw_pad;   // C4 mode: kw rounded up to 4
     int in_u8;    // activations are u8: shift to s8 by XOR 0x80 (compensated through comp)
     int out_dtype;
@@ -46,7 +47,8 @@ enum { TILE_32x32 = 0, TILE_64x32 = 1, TILE_64x64 = 2, TILE_128x64 = 3, TILE_64x
 void tile_dims(int tile, int* bm_k, int* bn_pix);
 
 // mode: 0 = int8 (C % 16 == 0), 1 = int8 C4 (input NHWC4), 2 = f32 (C % 4 == 0)
-hipError_t launch_conv_igemm(int mode, int tile, const ConvKArgs& a, hipStream_t s);
+// ks: 64-byte MFMA k-steps per pipeline stage (1, 2 or 4)
+hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

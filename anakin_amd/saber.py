@@ -372,7 +372,17 @@ class Net:
         L.check(L.load().saber_hip_net_run_op(self.h, i, _stream()))
 
     def capture(self):
-        L.check(L.load().saber_hip_net_capture(self.h, _stream()))
+        """Stream capture is not permitted on the legacy default stream: capture on a side stream
+        (ordered after the current stream); the instantiated graph can be replayed on any stream."""
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream == 0:
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                L.check(L.load().saber_hip_net_capture(self.h, _stream()))
+            cur.wait_stream(side)
+        else:
+            L.check(L.load().saber_hip_net_capture(self.h, _stream()))
 
     def replay(self):
         L.check(L.load().saber_hip_net_replay(self.h, _stream()))

@@ -84,6 +84,10 @@ def main():
     L.require_device()   # no fallback: the HIP library and a gfx950 device are mandatory
     n_gpus = world
 
+    # all launches go to one non-default stream (graph capture/replay, event timing)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+
     B = args.batch
     model = W.build_model(args.model)
     x = W.make_input(B, seed=1234 + rank)

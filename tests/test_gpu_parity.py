@@ -60,15 +60,32 @@ def test_conv_i8_golden(name):
         assert np.array_equal(y2, g["y"])
 
 
+@pytest.mark.parametrize("ks", [1, 2, 4])
 @pytest.mark.parametrize("tile", range(len(L.TILES)))
 @pytest.mark.parametrize("name", ["conv_i8_res2a_2b_3x3_u8u8", "conv_i8_res3a_2a_1x1s2_s8u8",
-                                  "conv_i8_res4_2c_1x1_u8f32", "conv_i8_conv1_7x7s2_s8u8"])
-def test_conv_i8_golden_every_tile(name, tile):
+                                  "conv_i8_res4_2c_1x1_u8f32", "conv_i8_conv1_7x7s2_s8u8",
+                                  "conv_i8_branch1_1x1s2_s8s8"])
+def test_conv_i8_golden_every_tile(name, tile, ks):
+    """Every (block tile, stage depth) variant of the implicit-GEMM kernel reproduces the golden bytes."""
     g = load(name)
     N, H, W, C, K, k, pad, stride, dil, group, idt, odt, relu = [int(v) for v in g["spec"]]
     y, conv = run_conv_i8(g["x"], g["wq"], g["w_scale"], g["bias"], float(g["in_scale"]), float(g["out_scale"]),
-                          odt, relu, pad, stride, dil, group, tile=tile)
+                          odt, relu, pad, stride, dil, group, tile=tile | (ks << 8))
     assert np.array_equal(y, g["y"]), conv.algo()
+
+
+@pytest.mark.parametrize("ks", [1, 2, 4])
+@pytest.mark.parametrize("tile", range(len(L.TILES)))
+def test_conv_f32_every_tile(tile, ks):
+    g = load("conv_f32_3x3")
+    N, C, H, W, K, k, pad, stride = [int(v) for v in g["spec"]]
+    p = S.ConvParam(g["w"], g["bias"], 1, (pad, pad), (stride, stride), (1, 1), True)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32)
+    conv.set_tile(tile | (ks << 8))
+    y = conv.new_output()
+    conv.dispatch(dev(g["x"]), y)
+    err = np.abs(host(y) - g["y"]).max() / np.abs(g["y"]).max()
+    assert err <= FP32_RTOL, (conv.algo(), err)
 
 
 SWEEP = [
