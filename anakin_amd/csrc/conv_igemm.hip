@@ -1,45 +1,12 @@
-// anakin_amd/csrc/conv_igemm.hip — implicit-GEMM convolution on CDNA4 matrix cores (gfx950 only).
-//
-// Role: the MI355X counterpart of the kernels behind SaberConv2D / SaberConvEltwise / SaberFc
-// (reference: x86 GemmX8S8S32XConv::sub_dispatch, gemm_x8s8s32x_conv.cpp:187-288 for the INT8
-// arithmetic; conv_basic_check, test/saber/conv_func_helper.h:196-264 for FP32). Not a port: the
-// reference materialises an im2col buffer and calls MKL; here the im2col gather is folded into the
-// global->LDS staging of an MFMA GEMM.
-//
-// GEMM view (per group=1 conv, NHWC activations):
-//     D[kout][pixel] = sum_kk  Wr[kout][kk] * Xcol[pixel][kk],   kk = (i*kw + j)*C + c
-//   rows  (MFMA "A" operand) = output channels  -> each lane ends up with 4 CONSECUTIVE output
-//   channels of one pixel (C/D map: col = lane&15, row = (lane>>4)*4 + reg), i.e. one packed 4-byte
-//   (int8) or 16-byte (f32) NHWC store per accumulator tile.
-//   cols  (MFMA "B" operand) = output pixels n*OH*OW.
-// One K-step = 64 bytes of kk per row for both operands (= one v_mfma_i32_16x16x64_i8, or four
-// v_mfma_f32_16x16x4_f32). Each lane reads ONE 16-byte chunk per 16-row fragment with ds_read_b128;
-// the (lane>>4) chunk index is the MFMA k-group, and because A and B use the same chunk->k-group
-// assignment the reduction pairs the same kk on both sides (integer sums are order independent; the
-// FP32 sum order differs from the reference only within its 1e-4 tolerance).
-//
-// u8 activations: MFMA i8 is signed x signed, so u8 bytes are XORed with 0x80 (= x-128 as s8) on
-// the way into LDS; zero padding becomes -128 the same way, so the correction is the uniform
-// +128*sum(w[kout]) int32 term `comp[kout]` (exact), the mirror image of the reference's own
-// s8 -> u8 shift (gemm_x8s8s32x_conv.cpp:124-133,488-570).
-//
-// LDS: tiles are [rows][64 B]; chunk q of row r lives at physical chunk g(q) ^ ((r>>2)&3),
-// g = {0,3,1,2}, which makes every ds_read_b128 lane group of the fragment read hit 16 distinct
-// 16-byte slots (MI355X_MICROARCH.md §LDS lane groups) and keeps ds_write_b128 conflict free.
+// anakin_amd/csrc/conv_igemm.hip — dispatch of the implicit-GEMM convolution kernels
+// (conv_igemm_impl.h; one TU per (operand mode, epilogue kind) in igemm_m*_e*.hip) and the generic
+// direct-convolution fallback.
 #include "kernels.h"
-
-#include <type_traits>
 
 namespace saber_mi355x {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int swz(int row, int q) { return ((0x9C >> (2 * q)) & 3) ^ ((row >> 2) & 3); }
-
 __device__ __forceinline__ float relu_ref(float d) { return d < 0.f ? 0.f : d; }
-
-__device__ __forceinline__ int sat_s8(float v) {  // saturate<int8_t>(float): clamp, then cast
+__device__ __forceinline__ int sat_s8(float v) {
     v = v < -128.f ? -128.f : v;
     v = v > 127.f ? 127.f : v;
     return (int)v;
@@ -50,414 +17,34 @@ __device__ __forceinline__ int sat_u8(float v) {
     return (int)v;
 }
 
-// One 16-row x 16-col x 64-byte MFMA step.
-__device__ __forceinline__ v4i mma_step(v4i a, v4i b, v4i c) {
-    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ v4f mma_step(v4i a, v4i b, v4f c) {
-    // whole-vector bit casts: __builtin_bit_cast on a single ext-vector ELEMENT (a.y ...) was observed to
-    // read element 0 for every component with hipcc 7.2
-    const v4f af = __builtin_bit_cast(v4f, a);
-    const v4f bf = __builtin_bit_cast(v4f, b);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
-    return c;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Epilogue of one lane: NV = TM*4 CONSECUTIVE output channels (kb .. kb+NV-1) of one output pixel p.
-// The weight rows of a block tile are permuted so that MFMA tile tm / D-row i holds channel
-// (i>>2)*(TM*4) + tm*4 + (i&3): a lane's TM accumulator quads are therefore adjacent channels and are
-// written with ONE 4/8/16-byte store (int8) or TM float4 stores.
-// ---------------------------------------------------------------------------------------------
-template <int NV>
-struct ChanParams {   // per-lane channel constants, loaded once per block (vector loads)
-    float bias[NV], scale[NV];
-    int comp[NV];
-};
-
-template <int NV>
-__device__ __forceinline__ void load_chan_params(const ConvKArgs& a, int kb, ChanParams<NV>& cp) {
-    // arrays are padded to a multiple of 128 channels on the host, so vector loads never run off the end
-#pragma unroll
-    for (int v = 0; v < NV; v += 4) {
-        const float4 sc = a.scale ? *(const float4*)(a.scale + kb + v) : make_float4(1, 1, 1, 1);
-        const float4 bi = a.bias ? *(const float4*)(a.bias + kb + v) : make_float4(0, 0, 0, 0);
-        const int4 co = a.comp ? *(const int4*)(a.comp + kb + v) : make_int4(0, 0, 0, 0);
-        cp.scale[v] = sc.x; cp.scale[v + 1] = sc.y; cp.scale[v + 2] = sc.z; cp.scale[v + 3] = sc.w;
-        cp.bias[v] = bi.x; cp.bias[v + 1] = bi.y; cp.bias[v + 2] = bi.z; cp.bias[v + 3] = bi.w;
-        cp.comp[v] = co.x; cp.comp[v + 1] = co.y; cp.comp[v + 2] = co.z; cp.comp[v + 3] = co.w;
-    }
-}
-
-template <int NV>
-__device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, const int (&acc)[NV], const ChanParams<NV>& cp,
-                                            int p, int kb) {
-    if (p >= a.M || kb >= a.K) return;
-    const size_t o = (size_t)p * a.K + kb;
-    const bool full = (kb + NV <= a.K) && (a.K % NV == 0);
-    const bool f32_out = (a.epi != EPI_I8_CONV) || (a.out_dtype == DT_F32 && a.res_mode != RES_ELTWISE);
-    int outq[NV];
-    float outf[NV];
-    // residual / previous-output bytes for the fused modes (one vector load per lane when aligned)
-    int resv[NV];
-    if (a.epi == EPI_I8_CONV && a.res_mode != RES_NONE) {
-        const void* src = a.res_mode == RES_ELTWISE ? a.res : (const void*)a.y;
-        const int rdt = a.res_mode == RES_ELTWISE ? DT_S8 : a.res_dtype;
-#pragma unroll
-        for (int r = 0; r < NV; ++r) {
-            if (kb + r >= a.K) { resv[r] = 0; continue; }
-            if (rdt == DT_F32) resv[r] = __float_as_int(((const float*)src)[o + r]);
-            else if (rdt == DT_U8) resv[r] = (int)((const uint8_t*)src)[o + r];
-            else resv[r] = (int)((const int8_t*)src)[o + r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < NV; ++r) {
-        const int v = acc[r] + cp.comp[r];
-        float d = (float)v;
-        if (a.epi == EPI_I8_CONV) {
-            d = __fadd_rn(d, cp.bias[r]);          // bias' is 0 when the op has no bias: d + 0 == d exactly
-            d = __fmul_rn(d, cp.scale[r]);
-            if (a.res_mode == RES_SUM_INPLACE) {
-                const float prev = a.res_dtype == DT_F32 ? __int_as_float(resv[r]) : (float)resv[r];
-                d = (a.sum_scale == 1.f) ? __fadd_rn(d, prev) : __fmaf_rn(prev, a.sum_scale, d);
-                if (a.relu || a.out_dtype == DT_U8) d = d > 0.f ? d : 0.f;
-            } else if (a.relu) {
-                d = relu_ref(d);
-            }
-            if (a.res_mode == RES_ELTWISE) {
-                const int q = sat_s8(rintf(d));
-                float t = __fmul_rn(__fmul_rn(a.coeff_conv, (float)q), a.scale_conv);
-                t = __fadd_rn(t, __fmul_rn(__fmul_rn(a.coeff_res, (float)resv[r]), a.scale_res));
-                if (a.res_relu) t = t > 0.f ? t : 0.f;
-                outq[r] = sat_s8(roundf(t));
-            } else if (a.out_dtype == DT_F32) {
-                outf[r] = d;
-            } else if (a.out_dtype == DT_U8) {
-                outq[r] = sat_u8(rintf(d));
-            } else {
-                outq[r] = sat_s8(rintf(d));
-            }
-        } else if (a.epi == EPI_I8_FC_S8) {
-            outf[r] = __fadd_rn(__fmul_rn(d, cp.scale[r]), cp.bias[r]);   // v*scale (+ bias; +0 when absent)
-        } else {  // EPI_I8_FC_U8 (int bias already folded into comp)
-            outf[r] = (cp.scale[r] == 1.f) ? d : __fmul_rn(cp.scale[r], d);
-        }
-    }
-    if (f32_out) {
-        float* y = (float*)a.y;
-        if (full) {
-#pragma unroll
-            for (int v = 0; v < NV; v += 4) *(float4*)(y + o + v) = make_float4(outf[v], outf[v + 1], outf[v + 2], outf[v + 3]);
-        } else {
-            for (int r = 0; r < NV; ++r) if (kb + r < a.K) y[o + r] = outf[r];
-        }
-    } else {
-        uint8_t* y = (uint8_t*)a.y;
-        if (full) {
-            unsigned pk[NV / 4];
-#pragma unroll
-            for (int v = 0; v < NV / 4; ++v)
-                pk[v] = (outq[4 * v] & 0xff) | ((outq[4 * v + 1] & 0xff) << 8) | ((outq[4 * v + 2] & 0xff) << 16) |
-                        ((unsigned)(outq[4 * v + 3] & 0xff) << 24);
-            if constexpr (NV == 4) *(unsigned*)(y + o) = pk[0];
-            else if constexpr (NV == 8) *(uint2*)(y + o) = make_uint2(pk[0], pk[1]);
-            else *(uint4*)(y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        } else {
-            for (int r = 0; r < NV; ++r) if (kb + r < a.K) y[o + r] = (uint8_t)outq[r];
-        }
-    }
-}
-
-template <int NV>
-__device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, const float (&acc)[NV], const ChanParams<NV>& cp,
-                                             int p, int kb, int n, int sp) {
-    if (p >= a.M || kb >= a.K) return;
-    float* y = (float*)a.y;
-    const int ohw = a.OH * a.OW;
-    const bool vec = !a.out_nchw && (kb + NV <= a.K) && ((a.K & 3) == 0);
-    float outf[NV];
-#pragma unroll
-    for (int r = 0; r < NV; ++r) {
-        const int k = kb + r;
-        if (k >= a.K) { outf[r] = 0.f; continue; }
-        float d = acc[r];
-        if (a.res_mode == RES_SUM_INPLACE) {
-            const size_t o = a.out_nchw ? ((size_t)n * a.K + k) * ohw + sp : (size_t)p * a.K + k;
-            d = __fadd_rn(d, y[o]);
-        }
-        d = __fadd_rn(d, cp.bias[r]);
-        if (a.relu) d = d > 0.f ? d : 0.f;
-        outf[r] = d;
-    }
-    if (vec) {
-#pragma unroll
-        for (int v = 0; v < NV; v += 4)
-            *(float4*)(y + (size_t)p * a.K + kb + v) = make_float4(outf[v], outf[v + 1], outf[v + 2], outf[v + 3]);
-    } else {
-        for (int r = 0; r < NV; ++r) {
-            const int k = kb + r;
-            if (k < a.K) {
-                const size_t o = a.out_nchw ? ((size_t)n * a.K + k) * ohw + sp : (size_t)p * a.K + k;
-                y[o] = outf[r];
-            }
-        }
-    }
-}
-
-// exact p / d and p % d for 0 <= p < 2^24 using a precomputed float reciprocal (+ one fix-up step)
-__device__ __forceinline__ void fast_divmod(int p, int d, float inv, int& q, int& r) {
-    q = (int)((float)p * inv);
-    r = p - q * d;
-    if (r < 0) { --q; r += d; }
-    if (r >= d) { ++q; r -= d; }
-}
-
-// physical 16-byte chunk of logical chunk c in LDS row `row`; CPR = chunks per row (4, 8, 16).
-template <int CPR>
-__device__ __forceinline__ int phys_chunk(int row, int c) {
-    if constexpr (CPR == 4) return (c & ~3) | (((0x9C >> (2 * (c & 3))) & 3) ^ ((row >> 2) & 3));
-    else if constexpr (CPR == 8) return c ^ ((row >> 1) & 7);
-    else return c ^ (row & 15);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The kernel. MODE 0: int8, C % 16 == 0.  MODE 1: int8, input NHWC4 (C == 4, first-layer path).
-//             MODE 2: f32, C % 4 == 0.
-// Block = 256 threads = 2x2 waves; wave tile = (TM*16 out-channels) x (TN*16 pixels).
-// One pipeline stage = KS MFMA k-steps = KS*64 bytes of the reduction per row, double-buffered in LDS
-// with the next stage's global loads in flight (registers) while the current one is consumed.
-// ---------------------------------------------------------------------------------------------
-template <int MODE, int TM, int TN, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
-    constexpr bool F32 = (MODE == 2);
-    constexpr bool C4 = (MODE == 1);
-    constexpr int ES = F32 ? 4 : 1;      // bytes per element
-    constexpr int EC = 16 / ES;          // elements per 16-byte chunk
-    constexpr int CPR = 4 * KS;          // chunks per row per stage
-    constexpr int ESTAGE = CPR * EC;     // elements per stage
-    constexpr int RPP = 256 / CPR;       // rows staged per pass of the 256 threads
-    constexpr int BMK = 2 * TM * 16;     // out channels per block
-    constexpr int BNP = 2 * TN * 16;     // pixels per block
-    constexpr int WIT = (BMK + RPP - 1) / RPP;
-    constexpr int XIT = (BNP + RPP - 1) / RPP;
-    constexpr int NV = TM * 4;
-    using acc_t = typename std::conditional<F32, v4f, v4i>::type;
-
-    __shared__ v4i lds[2][(BMK + BNP) * CPR];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int pix_base = blockIdx.x * BNP;
-    const int k_base = blockIdx.y * BMK;
-    const int lq = tid % CPR;            // this thread's chunk column within a stage
-    const int lr = tid / CPR;            // first row it stages
-
-    // ---- gather state: one (channel, tap) cursor per thread, XIT pixel rows ---------------------
-    int x_base[XIT], x_ih0[XIT], x_iw0[XIT];
-    bool x_ok[XIT];
-    const int ohw = a.OH * a.OW;
-#pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int r = lr + it * RPP;
-        const int p = pix_base + r;
-        x_ok[it] = (r < BNP) && (p < a.M);
-        const int pp = x_ok[it] ? p : 0;
-        int n, rem, oh, ow;
-        fast_divmod(pp, ohw, a.inv_ohw, n, rem);
-        fast_divmod(rem, a.OW, a.inv_ow, oh, ow);
-        x_base[it] = n * a.H * a.W * a.C;
-        x_ih0[it] = oh * a.stride_h - a.pad_h;
-        x_iw0[it] = ow * a.stride_w - a.pad_w;
-    }
-    int cur_c, cur_i, cur_j;             // normal: channel offset, tap row, tap col; C4: -, tap row, chunk-in-row
-    const int cpr4 = C4 ? (a.kw_pad >> 2) : 1;
-    if (C4) {
-        cur_i = lq / cpr4;
-        cur_j = lq - cur_i * cpr4;
-        cur_c = 0;
-    } else {
-        const int kk0 = lq * EC;
-        const int tap = kk0 / a.C;
-        cur_c = kk0 - tap * a.C;
-        cur_i = tap / a.kw;
-        cur_j = tap - cur_i * a.kw;
-    }
-
-    v4i xv[XIT], wv[WIT];
-    const v4i* w16 = (const v4i*)a.w;
-    const int w_row_chunks = a.Kg_pad / EC;
-
-    auto load_stage = [&](int s) {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int r = lr + it * RPP;
-            if (r < BMK) wv[it] = w16[(size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
-        }
-        const bool tap_ok = cur_i < a.kh;
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            v4i v = {0, 0, 0, 0};
-            const int ih = x_ih0[it] + cur_i * a.dil_h;
-            const bool row_ok = x_ok[it] && tap_ok && (ih >= 0) && (ih < a.H);
-            if (C4) {
-                const unsigned* xp = (const unsigned*)a.x;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int iw = x_iw0[it] + (cur_j * 4 + t) * a.dil_w;
-                    if (row_ok && iw >= 0 && iw < a.W) v[t] = (int)xp[(x_base[it] >> 2) + ih * a.W + iw];
-                }
-            } else {
-                const int iw = x_iw0[it] + cur_j * a.dil_w;
-                if (row_ok && iw >= 0 && iw < a.W) {
-                    const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES;
-                    v = *(const v4i*)xp;
-                }
-            }
-            if (!F32 && a.in_u8) {
-                v.x ^= 0x80808080; v.y ^= 0x80808080; v.z ^= 0x80808080; v.w ^= 0x80808080;
-            }
-            xv[it] = v;
-        }
-        // advance the cursor by one stage
-        if (C4) {
-            cur_j += CPR;
-            while (cur_j >= cpr4) { cur_j -= cpr4; ++cur_i; }
-        } else {
-            cur_c += ESTAGE;
-            while (cur_c >= a.C) {
-                cur_c -= a.C;
-                if (++cur_j == a.kw) { cur_j = 0; ++cur_i; }
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int r = lr + it * RPP;
-            if (r < BMK) {
-                // permuted LDS row so that MFMA tile (wm, tm) reads 16 consecutive rows (conflict-free)
-                const int rr = r % (TM * 16), wmr = r / (TM * 16);
-                const int lrow = (wmr * TM + ((rr >> 2) % TM)) * 16 + (rr / (TM * 4)) * 4 + (rr & 3);
-                lds[buf][lrow * CPR + phys_chunk<CPR>(lrow, lq)] = wv[it];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int r = lr + it * RPP;
-            if (r < BNP) lds[buf][(BMK + r) * CPR + phys_chunk<CPR>(r, lq)] = xv[it];
-        }
-    };
-
-    acc_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-
-    const int frow = lane & 15, fq = lane >> 4;
-    // LDS row of the weight tile feeding MFMA tile i (rows were permuted when staged)
-    int wrow[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) wrow[i] = (wm * TM + i) * 16 + frow;
-
-    for (int s = 0; s < a.steps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < a.steps) load_stage(s + 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            v4i af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = lds[buf][wrow[i] * CPR + phys_chunk<CPR>(wrow[i], ks * 4 + fq)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + frow;
-                bf[j] = lds[buf][(BMK + row) * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
-        }
-        if (s + 1 < a.steps) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane owns channels kb .. kb+NV-1 of pixels p(j) -------------------------------
-    const int kb = k_base + wm * (TM * 16) + fq * NV;
-    ChanParams<NV> cp;
-    load_chan_params<NV>(a, kb, cp);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int p = pix_base + (wn * TN + j) * 16 + frow;
-        if constexpr (F32) {
-            float v[NV];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
-            int n = 0, sp = 0;
-            if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
-            epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
-        } else {
-            int v[NV];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
-            epilogue_i8<NV>(a, v, cp, p, kb);
-        }
-    }
-}
-
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
     static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
     *bm_k = d[tile][0];
     *bn_pix = d[tile][1];
 }
 
-template <int MODE, int KS>
-static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
-    int bmk, bnp;
-    tile_dims(tile, &bmk, &bnp);
-    dim3 grid((a.M + bnp - 1) / bnp, (a.K + bmk - 1) / bmk);
-    dim3 block(256);
-    switch (tile) {
-    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, KS>), grid, block, 0, s, a); break;
-    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1, KS>), grid, block, 0, s, a); break;
-    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, KS>), grid, block, 0, s, a); break;
-    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 2, KS>), grid, block, 0, s, a); break;
-    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4, KS>), grid, block, 0, s, a); break;
-    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 4, KS>), grid, block, 0, s, a); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-template <int MODE>
-static hipError_t launch_ks(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
-    switch (ks) {
-    case 1: return launch_mode<MODE, 1>(tile, a, s);
-    case 2: return launch_mode<MODE, 2>(tile, a, s);
-    case 4: return launch_mode<MODE, 4>(tile, a, s);
-    default: return hipErrorInvalidValue;
-    }
-}
+#define DECL(m, e) hipError_t launch_igemm_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
+DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3)
+#undef DECL
 
 hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
-    switch (mode) {
-    case 0: return launch_ks<0>(tile, ks, a, s);
-    case 1: return launch_ks<1>(tile, ks, a, s);
-    case 2: return launch_ks<2>(tile, ks, a, s);
+    // epilogue kind from the argument block (host side, once per launch)
+    int ek = 3;
+    if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE) {
+        if (a.res_mode == RES_ELTWISE) ek = 2;
+        else if (a.out_dtype == DT_U8) ek = 1;
+        else if (a.out_dtype == DT_S8) ek = 0;
+    }
+    switch (mode * 4 + ek) {
+    case 0: return launch_igemm_m0_e0(tile, ks, a, s);
+    case 1: return launch_igemm_m0_e1(tile, ks, a, s);
+    case 2: return launch_igemm_m0_e2(tile, ks, a, s);
+    case 3: return launch_igemm_m0_e3(tile, ks, a, s);
+    case 4: return launch_igemm_m1_e0(tile, ks, a, s);
+    case 5: return launch_igemm_m1_e1(tile, ks, a, s);
+    case 6: return launch_igemm_m1_e2(tile, ks, a, s);
+    case 7: return launch_igemm_m1_e3(tile, ks, a, s);
+    case 11: return launch_igemm_m2_e3(tile, ks, a, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -122,6 +122,24 @@ def test_conv_i8_sweep_vs_oracle(case, combo):
     assert got.dtype == want.dtype and np.array_equal(got, want), conv.algo()
 
 
+@pytest.mark.parametrize("combo", [(O.U8, O.U8, 1), (O.U8, O.S8, 0), (O.S8, O.S8, 1), (O.S8, O.U8, 0)])
+def test_conv_i8_saturation_both_ends(combo):
+    """Tiny out_scale: most outputs saturate at -128/127 or 0/255 (vpmovsdb/vpmovusdb semantics);
+    exact .5 ties in the requantised value exercise round-to-nearest-even."""
+    idt, odt, relu = combo
+    rng = np.random.default_rng(77)
+    x = (rng.integers(0, 256, (2, 9, 9, 32)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (2, 9, 9, 32)).astype(np.int8))
+    wq = rng.integers(-127, 128, (64, 32, 3, 3)).astype(np.int8)
+    ws = np.full(64, 0.5, np.float32)          # scale = 0.5*1/1 -> d = acc/2: half of the values are exact ties
+    for out_scale in (1.0, 400.0):
+        bp, sc = O.conv_i8_prepare(ws, None, 1.0, out_scale, idt, odt)
+        want = O.conv_i8(x, wq, None, sc, odt, relu, (1, 1))
+        got, conv = run_conv_i8(x, wq, ws, None, 1.0, out_scale, odt, relu, 1, 1, 1, 1)
+        assert np.array_equal(got, want), (conv.algo(), out_scale)
+        assert (want == (255 if odt == O.U8 else 127)).any() or out_scale > 1
+
+
 def test_conv_i8_empty_and_invalid():
     lib = L.load()
     import ctypes as C
