@@ -58,6 +58,16 @@ struct DevBuf {
     }
 };
 
+// 256 zero bytes in device memory, shared by every op (padded taps of the LDS-DMA kernels)
+void* zero_page() {
+    static void* p = nullptr;
+    if (!p) {
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, 256);
+    }
+    return p;
+}
+
 enum Algo { ALGO_IGEMM_I8 = 0, ALGO_IGEMM_I8_C4 = 1, ALGO_IGEMM_F32 = 2, ALGO_DIRECT_I8 = 3, ALGO_DIRECT_F32 = 4 };
 
 }  // namespace
@@ -68,6 +78,7 @@ struct saber_hip_conv {
     int algo = ALGO_DIRECT_I8;
     int tile = TILE_64x64;
     int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
+    int dma = 0;             // 1: LDS-DMA ring kernel (conv_igemm_dma.h), 0: register-staged kernel
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
     int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
@@ -132,7 +143,8 @@ static void name_algo(saber_hip_conv* op) {
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
     char buf[64];
-    if (op->algo <= ALGO_IGEMM_F32) snprintf(buf, sizeof buf, "%s_%dx%d_k%d", an[op->algo], bmk, bnp, op->ks);
+    if (op->algo <= ALGO_IGEMM_F32)
+        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks, op->dma ? "_dma" : "");
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
     op->algo_name = buf;
 }
@@ -147,6 +159,7 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
     const int oh = conv_out(d.h, d.pad_h, d.kh, d.dil_h, d.stride_h);
     const int ow = conv_out(d.w, d.pad_w, d.kw, d.dil_w, d.stride_w);
     if (oh <= 0 || ow <= 0) return fail(SABER_HIP_INVALID_VALUE, "empty output");
+    if (saber_hip_device_ok()) (void)zero_page();   // allocate outside any stream capture
     auto* op = new saber_hip_conv();
     op->d = d;
     op->oh = oh;
@@ -242,9 +255,13 @@ size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op) { return op-
 const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_name.c_str(); }
 
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
-    // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15
+    // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15,
+    // optional staging variant in bits 16..23 (1 = register-staged, 2 = LDS-DMA ring)
     const int ks = (tile >> 8) & 0xff;
+    const int var = (tile >> 16) & 0xff;
     tile &= 0xff;
+    if (var > 2 || (var == 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
+    if (var) op->dma = var - 1;
     if (tile < 0 || tile >= TILE_COUNT || !(ks == 0 || ks == 1 || ks == 2 || ks == 4))
         return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
     if (ks) op->ks = ks;
@@ -252,7 +269,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     name_algo(op);
     return SABER_HIP_OK;
 }
-int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) { return op->tile | (op->ks << 8); }
+int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) { return op->tile | (op->ks << 8) | ((op->dma + 1) << 16); }
 
 int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtype, const float* w_scale,
                                  const float* bias, float in_scale, float out_scale) {
@@ -389,6 +406,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     if (!op->is_i8 && !op->has_bias) a.bias = nullptr;
     a.scale = op->d_scale.p;
     a.comp = op->has_comp ? op->d_comp.p : nullptr;
+    a.zero = zero_page();
     a.N = d.n; a.H = d.h; a.W = d.w; a.C = op->c_eff; a.K = d.k; a.OH = op->oh; a.OW = op->ow;
     a.kh = d.kh; a.kw = d.kw; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
     a.stride_h = d.stride_h; a.stride_w = d.stride_w; a.dil_h = d.dil_h; a.dil_w = d.dil_w;
@@ -438,9 +456,13 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     ConvKArgs a;
     fill_args(op, a, xin, y, res);
     switch (op->algo) {
-    case ALGO_IGEMM_I8: HIP_TRY(launch_conv_igemm(0, op->tile, op->ks, a, s)); break;
+    case ALGO_IGEMM_I8:
+        HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
+        break;
     case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s)); break;
-    case ALGO_IGEMM_F32: HIP_TRY(launch_conv_igemm(2, op->tile, op->ks, a, s)); break;
+    case ALGO_IGEMM_F32:
+        HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
+        break;
     case ALGO_DIRECT_I8:
         a.comp = nullptr;
         HIP_TRY(launch_conv_direct(0, a, d.group, s));
@@ -461,27 +483,33 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     float best = 1e30f;
-    int best_tile = op->tile, best_ks = op->ks;
+    int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
     const int ks_list[3] = {1, 2, 4};
-    for (int t = 0; t < TILE_COUNT; ++t) {
-        for (int ki = 0; ki < 3; ++ki) {
-            op->tile = t;
-            op->ks = ks_list[ki];
-            int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(e0, s));
-            for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
-            HIP_TRY(hipEventRecord(e1, s));
-            HIP_TRY(hipEventSynchronize(e1));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best) {
-                best = ms;
-                best_tile = t;
-                best_ks = ks_list[ki];
+    const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 2;
+    for (int var = 0; var < nvar; ++var) {
+        for (int t = 0; t < TILE_COUNT; ++t) {
+            for (int ki = 0; ki < 3; ++ki) {
+                op->tile = t;
+                op->ks = ks_list[ki];
+                op->dma = var;
+                int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(e0, s));
+                for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
+                HIP_TRY(hipEventRecord(e1, s));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) {
+                    best = ms;
+                    best_tile = t;
+                    best_ks = ks_list[ki];
+                    best_dma = var;
+                }
             }
         }
     }
+    op->dma = best_dma;
     op->ks = best_ks;
     op->tile = best_tile;
     name_algo(op);

@@ -26,16 +26,34 @@ void tile_dims(int tile, int* bm_k, int* bn_pix) {
 #define DECL(m, e) hipError_t launch_igemm_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
 DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3)
 #undef DECL
+#define DECL(m, e) hipError_t launch_igemm_dma_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
+DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(2, 3)
+#undef DECL
 
-hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
-    // epilogue kind from the argument block (host side, once per launch)
+static int epilogue_kind(int mode, const ConvKArgs& a) {
     int ek = 3;
     if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE) {
         if (a.res_mode == RES_ELTWISE) ek = 2;
         else if (a.out_dtype == DT_U8) ek = 1;
         else if (a.out_dtype == DT_S8) ek = 0;
     }
-    switch (mode * 4 + ek) {
+    return ek;
+}
+
+hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+    switch (mode * 4 + epilogue_kind(mode, a)) {
+    case 0: return launch_igemm_dma_m0_e0(tile, ks, a, s);
+    case 1: return launch_igemm_dma_m0_e1(tile, ks, a, s);
+    case 2: return launch_igemm_dma_m0_e2(tile, ks, a, s);
+    case 3: return launch_igemm_dma_m0_e3(tile, ks, a, s);
+    case 11: return launch_igemm_dma_m2_e3(tile, ks, a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+    // epilogue kind from the argument block (host side, once per launch)
+    switch (mode * 4 + epilogue_kind(mode, a)) {
     case 0: return launch_igemm_m0_e0(tile, ks, a, s);
     case 1: return launch_igemm_m0_e1(tile, ks, a, s);
     case 2: return launch_igemm_m0_e2(tile, ks, a, s);

@@ -1,0 +1,253 @@
+// anakin_amd/csrc/conv_igemm_dma.h — implicit-GEMM convolution with LDS-DMA staging (gfx950).
+//
+// Same GEMM view, fragment layout, LDS swizzle and epilogues as conv_igemm_impl.h, but both operands
+// are staged with `global_load_lds_dwordx4` (16 B per lane written straight into LDS, no VGPR round
+// trip) into a RING of NS stages, so NS-1 stages of global loads are in flight while one stage is
+// consumed. The deep-K layers of ResNet (stage 4/5: few output tiles, 4..18 stages of reduction) are
+// latency-bound with one stage in flight; with the ring the K loop costs ~one memory latency.
+//
+//  * LDS-DMA writes lane L's 16 bytes at  wave-uniform base + L*16, so the LDS image is lane-linear:
+//    the swizzle is applied on the SOURCE side (each lane fetches the logical chunk whose physical slot
+//    it owns) — cdna_hip_programming.md §5.4 rule 21.
+//  * Out-of-image taps / rows beyond the tile cannot be predicated off (an inactive lane would leave
+//    stale LDS bytes): they fetch from a 16-byte zero page instead.
+//  * u8 activations: the XOR 0x80 (u8 -> s8 shift) is applied to the pixel fragments after ds_read.
+//  * Ordering: counted `s_waitcnt vmcnt(N)` (this wave's DMA for the stage has landed) -> raw
+//    `s_barrier` (every wave's has) -> ds_read. Never __syncthreads() inside the loop (it would drain
+//    the DMA queue), never an ordinary global load inside the loop (hipcc would wait vmcnt(0) for it).
+#pragma once
+#include "conv_igemm_impl.h"
+
+namespace saber_mi355x {
+
+template <int BYTES>
+constexpr int ring_stages() {   // ring depth from a ~96 KiB LDS budget, 2..8
+    constexpr int n = (96 * 1024) / BYTES;
+    return n > 8 ? 8 : (n < 2 ? 2 : n);
+}
+
+#define SABER_WAIT_VMCNT_CASE(n) \
+    case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+
+// waits until at most `cnt` LDS-DMA instructions of this wave are outstanding (cnt is wave-uniform)
+__device__ __forceinline__ void wait_vmcnt(int cnt) {
+    switch (cnt) {
+        SABER_WAIT_VMCNT_CASE(0) SABER_WAIT_VMCNT_CASE(1) SABER_WAIT_VMCNT_CASE(2) SABER_WAIT_VMCNT_CASE(3)
+        SABER_WAIT_VMCNT_CASE(4) SABER_WAIT_VMCNT_CASE(5) SABER_WAIT_VMCNT_CASE(6) SABER_WAIT_VMCNT_CASE(7)
+        SABER_WAIT_VMCNT_CASE(8) SABER_WAIT_VMCNT_CASE(9) SABER_WAIT_VMCNT_CASE(10) SABER_WAIT_VMCNT_CASE(11)
+        SABER_WAIT_VMCNT_CASE(12) SABER_WAIT_VMCNT_CASE(13) SABER_WAIT_VMCNT_CASE(14) SABER_WAIT_VMCNT_CASE(15)
+        SABER_WAIT_VMCNT_CASE(16) SABER_WAIT_VMCNT_CASE(17) SABER_WAIT_VMCNT_CASE(18) SABER_WAIT_VMCNT_CASE(19)
+        SABER_WAIT_VMCNT_CASE(20) SABER_WAIT_VMCNT_CASE(21) SABER_WAIT_VMCNT_CASE(22) SABER_WAIT_VMCNT_CASE(23)
+        SABER_WAIT_VMCNT_CASE(24) SABER_WAIT_VMCNT_CASE(25) SABER_WAIT_VMCNT_CASE(26) SABER_WAIT_VMCNT_CASE(27)
+        SABER_WAIT_VMCNT_CASE(28) SABER_WAIT_VMCNT_CASE(29) SABER_WAIT_VMCNT_CASE(30) SABER_WAIT_VMCNT_CASE(31)
+        SABER_WAIT_VMCNT_CASE(32) SABER_WAIT_VMCNT_CASE(36) SABER_WAIT_VMCNT_CASE(40) SABER_WAIT_VMCNT_CASE(42)
+        SABER_WAIT_VMCNT_CASE(48) SABER_WAIT_VMCNT_CASE(56)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// MODE 0: int8 (C % 16 == 0); MODE 2: f32 (C % 4 == 0).
+template <int MODE, int TM, int TN, int KS, int EK>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) {
+    constexpr bool F32 = (MODE == 2);
+    constexpr int ES = F32 ? 4 : 1;
+    constexpr int EC = 16 / ES;
+    constexpr int CPR = 4 * KS;
+    constexpr int ESTAGE = CPR * EC;
+    constexpr int RPP = 256 / CPR;       // rows covered by one DMA pass of the 256 threads
+    constexpr int BMK = 2 * TM * 16;
+    constexpr int BNP = 2 * TN * 16;
+    constexpr int WIT = (BMK + RPP - 1) / RPP;
+    constexpr int XIT = (BNP + RPP - 1) / RPP;
+    constexpr int WROWS = WIT * RPP;     // tile rows rounded up to whole DMA passes (pad rows fetch zeros)
+    constexpr int XROWS = XIT * RPP;
+    constexpr int STAGE = (WROWS + XROWS) * CPR;        // 16-byte chunks per stage
+    constexpr int NS = ring_stages<STAGE * 16>();
+    constexpr int LPS = WIT + XIT;       // DMA instructions per wave per stage
+    constexpr int NV = TM * 4;
+    using acc_t = typename std::conditional<F32, v4f, v4i>::type;
+
+    __shared__ v4i lds[NS][STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int pix_base = blockIdx.x * BNP;
+    const int k_base = blockIdx.y * BMK;
+    const int pc = tid % CPR;            // physical chunk column this thread's DMA lands in
+    const int lr = tid / CPR;            // first LDS row it fills
+    // logical chunk column whose physical home (in row lr + it*RPP, any it) is pc: inverse of phys_chunk
+    int lq;
+    if constexpr (CPR == 4) lq = (0x78 >> (2 * (pc ^ ((lr >> 2) & 3)))) & 3;
+    else if constexpr (CPR == 8) lq = pc ^ ((lr >> 1) & 7);
+    else lq = pc ^ (lr & 15);
+
+    // ---- per-row gather state ---------------------------------------------------------------------
+    int x_base[XIT], x_ih0[XIT], x_iw0[XIT];
+    bool x_ok[XIT];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int r = lr + it * RPP;
+        const int p = pix_base + r;
+        x_ok[it] = (r < BNP) && (p < a.M);
+        const int pp = x_ok[it] ? p : 0;
+        int n, rem, oh, ow;
+        fast_divmod(pp, ohw, a.inv_ohw, n, rem);
+        fast_divmod(rem, a.OW, a.inv_ow, oh, ow);
+        x_base[it] = n * a.H * a.W * a.C;
+        x_ih0[it] = oh * a.stride_h - a.pad_h;
+        x_iw0[it] = ow * a.stride_w - a.pad_w;
+    }
+    const char* w_src[WIT];              // weight row base pointers (nullptr -> zero page)
+    const int w_row_bytes = a.Kg_pad * ES;
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int rho = lr + it * RPP;   // LDS row -> weight row of the block tile (inverse of the store permutation)
+        const int tile16 = rho >> 4;
+        const int r = (tile16 / TM) * (TM * 16) + ((rho >> 2) & 3) * (TM * 4) + (tile16 % TM) * 4 + (rho & 3);
+        w_src[it] = (rho < BMK) ? (const char*)a.w + (size_t)(k_base + r) * w_row_bytes + (size_t)lq * 16 : nullptr;
+    }
+    int cur_c, cur_i, cur_j;
+    {
+        const int kk0 = lq * EC;
+        const int tap = kk0 / a.C;
+        cur_c = kk0 - tap * a.C;
+        cur_i = tap / a.kw;
+        cur_j = tap - cur_i * a.kw;
+    }
+    const char* zero = (const char*)a.zero;
+
+    auto issue_stage = [&](int s) {
+        v4i* stage = lds[s % NS];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const char* src = w_src[it] ? w_src[it] + (size_t)s * (CPR * 16) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + it * 256 + wave * 64),
+                                             16, 0, 0);
+        }
+        const bool tap_ok = cur_i < a.kh;
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int ih = x_ih0[it] + cur_i * a.dil_h;
+            const int iw = x_iw0[it] + cur_j * a.dil_w;
+            const bool ok = x_ok[it] && tap_ok && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
+            const char* src = ok ? (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES
+                                 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + WROWS * CPR + it * 256 + wave * 64),
+                                             16, 0, 0);
+        }
+        cur_c += ESTAGE;
+        while (cur_c >= a.C) {
+            cur_c -= a.C;
+            if (++cur_j == a.kw) { cur_j = 0; ++cur_i; }
+        }
+    };
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+    const int steps = a.steps;
+    const int pre = steps < NS - 1 ? steps : NS - 1;
+    for (int s = 0; s < pre; ++s) issue_stage(s);
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned xmask = (!F32 && a.in_u8) ? 0x80808080u : 0u;
+    for (int s = 0; s < steps; ++s) {
+        // stages s+1 .. min(s+NS-2, steps-1) may stay in flight
+        const int ahead = (steps - 1 - s) < (NS - 2) ? (steps - 1 - s) : (NS - 2);
+        wait_vmcnt(ahead * LPS);
+        __builtin_amdgcn_s_barrier();    // stage s landed for every wave; everyone finished reading stage s-1
+        if (s + NS - 1 < steps) issue_stage(s + NS - 1);   // refills the buffer consumed in iteration s-1
+        const v4i* stage = lds[s % NS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            v4i af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + frow;
+                af[i] = stage[row * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + frow;
+                v4i v = stage[(WROWS + row) * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
+                if (!F32) { v.x ^= xmask; v.y ^= xmask; v.z ^= xmask; v.w ^= xmask; }
+                bf[j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue (identical to the register-staged kernel) ---------------------------------------
+    const int kb = k_base + wm * (TM * 16) + fq * NV;
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int p = pix_base + (wn * TN + j) * 16 + frow;
+        if constexpr (F32) {
+            float v[NV];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            int n = 0, sp = 0;
+            if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
+            epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
+        } else {
+            int v[NV];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            if constexpr (EK == EK_GEN) {
+                epilogue_i8<NV>(a, v, cp, p, kb);
+            } else {
+                if (p < a.M && kb < a.K) {
+                    if ((kb + NV <= a.K) && (a.K % NV == 0)) epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);
+                    else epilogue_i8<NV>(a, v, cp, p, kb);
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int KS, int EK>
+static hipError_t launch_dma_mode(int tile, const ConvKArgs& a, hipStream_t s) {
+    int bmk, bnp;
+    tile_dims(tile, &bmk, &bnp);
+    dim3 grid((a.M + bnp - 1) / bnp, (a.K + bmk - 1) / bmk);
+    dim3 block(256);
+    switch (tile) {
+    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 1, 1, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 1, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 2, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 4, 2, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 4, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 4, 4, KS, EK>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int MODE, int EK>
+static hipError_t launch_igemm_dma_inst(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+    switch (ks) {
+    case 1: return launch_dma_mode<MODE, 1, EK>(tile, a, s);
+    case 2: return launch_dma_mode<MODE, 2, EK>(tile, a, s);
+    case 4: return launch_dma_mode<MODE, 4, EK>(tile, a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace saber_mi355x

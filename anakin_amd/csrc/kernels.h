@@ -24,6 +24,7 @@ struct ConvKArgs {
     const float* bias;  // INT8 conv: pre-scaled bias_p; FC/F32: plain bias; may be null
     const float* scale; // per out-channel scale (INT8 paths)
     const int* comp;    // per out-channel int32 offset (u8 shift compensation [+ FC int bias]); may be null
+    const void* zero;   // >= 16 zero bytes in device memory (source of padded taps for the LDS-DMA kernels)
     int N, H, W, C, K, OH, OW;
     int kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
     int M;        // N*OH*OW output pixels (GEMM columns)
@@ -49,6 +50,8 @@ void tile_dims(int tile, int* bm_k, int* bn_pix);
 // mode: 0 = int8 (C % 16 == 0), 1 = int8 C4 (input NHWC4), 2 = f32 (C % 4 == 0)
 // ks: 64-byte MFMA k-steps per pipeline stage (1, 2 or 4)
 hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s);
+// LDS-DMA ring variant (modes 0 and 2 only)
+hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

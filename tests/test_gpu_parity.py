@@ -60,28 +60,34 @@ def test_conv_i8_golden(name):
         assert np.array_equal(y2, g["y"])
 
 
+@pytest.mark.parametrize("var", [1, 2])   # 1 = register-staged, 2 = LDS-DMA ring
 @pytest.mark.parametrize("ks", [1, 2, 4])
 @pytest.mark.parametrize("tile", range(len(L.TILES)))
 @pytest.mark.parametrize("name", ["conv_i8_res2a_2b_3x3_u8u8", "conv_i8_res3a_2a_1x1s2_s8u8",
                                   "conv_i8_res4_2c_1x1_u8f32", "conv_i8_conv1_7x7s2_s8u8",
-                                  "conv_i8_branch1_1x1s2_s8s8"])
-def test_conv_i8_golden_every_tile(name, tile, ks):
-    """Every (block tile, stage depth) variant of the implicit-GEMM kernel reproduces the golden bytes."""
+                                  "conv_i8_branch1_1x1s2_s8s8", "conv_i8_res5_2a_1x1_s8u8",
+                                  "conv_i8_res5_2b_3x3_u8u8"])
+def test_conv_i8_golden_every_tile(name, tile, ks, var):
+    """Every (block tile, stage depth, staging) variant of the implicit-GEMM kernel reproduces the golden bytes."""
     g = load(name)
     N, H, W, C, K, k, pad, stride, dil, group, idt, odt, relu = [int(v) for v in g["spec"]]
+    if C < 16 and var == 2:
+        pytest.skip("first-layer (NHWC4) path is register-staged only")
     y, conv = run_conv_i8(g["x"], g["wq"], g["w_scale"], g["bias"], float(g["in_scale"]), float(g["out_scale"]),
-                          odt, relu, pad, stride, dil, group, tile=tile | (ks << 8))
+                          odt, relu, pad, stride, dil, group, tile=tile | (ks << 8) | (var << 16))
     assert np.array_equal(y, g["y"]), conv.algo()
+    assert conv.algo().endswith("_dma") == (var == 2)
 
 
+@pytest.mark.parametrize("var", [1, 2])
 @pytest.mark.parametrize("ks", [1, 2, 4])
 @pytest.mark.parametrize("tile", range(len(L.TILES)))
-def test_conv_f32_every_tile(tile, ks):
+def test_conv_f32_every_tile(tile, ks, var):
     g = load("conv_f32_3x3")
     N, C, H, W, K, k, pad, stride = [int(v) for v in g["spec"]]
     p = S.ConvParam(g["w"], g["bias"], 1, (pad, pad), (stride, stride), (1, 1), True)
     conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32)
-    conv.set_tile(tile | (ks << 8))
+    conv.set_tile(tile | (ks << 8) | (var << 16))
     y = conv.new_output()
     conv.dispatch(dev(g["x"]), y)
     err = np.abs(host(y) - g["y"]).max() / np.abs(g["y"]).max()
@@ -120,6 +126,11 @@ def test_conv_i8_sweep_vs_oracle(case, combo):
     want = O.conv_i8(x, wq, bp, sc, odt, relu, (pad, pad), (stride, stride), (dil, dil))
     got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, stride, dil, 1)
     assert got.dtype == want.dtype and np.array_equal(got, want), conv.algo()
+    if conv.algo().startswith("igemm_i8_") and "_c4_" not in conv.algo():
+        for tile in (0, 2):
+            got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, stride, dil, 1,
+                                    tile=tile | (4 << 8) | (2 << 16))
+            assert np.array_equal(got, want), conv.algo()
 
 
 @pytest.mark.parametrize("combo", [(O.U8, O.U8, 1), (O.U8, O.S8, 0), (O.S8, O.S8, 1), (O.S8, O.U8, 0)])
