@@ -78,7 +78,7 @@ struct saber_hip_conv {
     int algo = ALGO_DIRECT_I8;
     int tile = TILE_64x64;
     int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
-    int dma = 0;             // 1: LDS-DMA ring kernel (conv_igemm_dma.h), 0: register-staged kernel
+    int dma = 0;             // 0: register-staged kernel; 1/2/4: LDS-DMA ring kernel with that many wave groups
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
     int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
@@ -144,7 +144,8 @@ static void name_algo(saber_hip_conv* op) {
     tile_dims(op->tile, &bmk, &bnp);
     char buf[64];
     if (op->algo <= ALGO_IGEMM_F32)
-        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks, op->dma ? "_dma" : "");
+        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
+                 op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")));
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
     op->algo_name = buf;
 }
@@ -229,13 +230,14 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
     if (op->algo == ALGO_IGEMM_I8_C4) {
         op->kw_pad = round_up(d.kw, 4);
         op->Kg = d.kh * op->kw_pad * 4;
-        op->Kg_pad = round_up(op->Kg, 256);
+        op->Kg_pad = round_up(op->Kg, 256);    // register-staged only: widest stage is 256 B
     } else if (op->algo == ALGO_IGEMM_I8) {
         op->Kg = d.kh * d.kw * op->c_eff;
-        op->Kg_pad = round_up(op->Kg, 256);
+        op->Kg_pad = round_up(op->Kg, 1024);   // widest stage: 4 k-steps x 4 wave groups x 64 B; the zero tail
+                                               // keeps out-of-range k-steps inert (also for XOR-shifted u8 pads)
     } else if (op->algo == ALGO_IGEMM_F32) {
         op->Kg = d.kh * d.kw * op->c_eff;
-        op->Kg_pad = round_up(op->Kg, 64);
+        op->Kg_pad = round_up(op->Kg, 256);    // f32 elements: 1024 B
     }
     choose_tile(op);
     {   // stage depth: as many 64-byte k-steps per barrier as the reduction has (max 4)
@@ -256,12 +258,15 @@ const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_
 
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15,
-    // optional staging variant in bits 16..23 (1 = register-staged, 2 = LDS-DMA ring)
+    // optional staging variant in bits 16..23 (1 = register-staged, 2 = LDS-DMA ring, 3 / 4 = LDS-DMA ring
+    // with 2 / 4 wave groups: needs stage depth 4 and a 32x32, 64x32 or 64x64 tile)
     const int ks = (tile >> 8) & 0xff;
     const int var = (tile >> 16) & 0xff;
     tile &= 0xff;
-    if (var > 2 || (var == 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
-    if (var) op->dma = var - 1;
+    if (var > 4 || (var >= 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
+    if ((var >= 3 && ((ks ? ks : op->ks) != 4 || tile > TILE_64x64)) || (var == 4 && tile != TILE_32x32))
+        return fail(SABER_HIP_INVALID_VALUE, "wave groups need stage depth 4 and a tile <= 64x64 (32x32 for 4 groups)");
+    if (var) op->dma = var == 1 ? 0 : (var == 2 ? 1 : (var == 3 ? 2 : 4));
     if (tile < 0 || tile >= TILE_COUNT || !(ks == 0 || ks == 1 || ks == 2 || ks == 4))
         return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
     if (ks) op->ks = ks;
@@ -269,7 +274,10 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     name_algo(op);
     return SABER_HIP_OK;
 }
-int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) { return op->tile | (op->ks << 8) | ((op->dma + 1) << 16); }
+int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
+    const int var = op->dma == 0 ? 1 : (op->dma == 1 ? 2 : (op->dma == 2 ? 3 : 4));
+    return op->tile | (op->ks << 8) | (var << 16);
+}
 
 int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtype, const float* w_scale,
                                  const float* bias, float in_scale, float out_scale) {
@@ -412,7 +420,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.stride_h = d.stride_h; a.stride_w = d.stride_w; a.dil_h = d.dil_h; a.dil_w = d.dil_w;
     a.M = d.n * op->oh * op->ow;
     a.Kg = op->Kg; a.Kg_pad = op->Kg_pad; a.kw_pad = op->kw_pad;
-    const int estage = (op->algo == ALGO_IGEMM_F32 ? 16 : 64) * op->ks;   // elements per pipeline stage
+    const int estage = (op->algo == ALGO_IGEMM_F32 ? 16 : 64) * op->ks * (op->dma > 1 ? op->dma : 1);   // elements per stage
     a.steps = (op->Kg + estage - 1) / estage;
     a.inv_ohw = 1.0f / (float)(op->oh * op->ow);
     a.inv_ow = 1.0f / (float)op->ow;
@@ -457,11 +465,11 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     fill_args(op, a, xin, y, res);
     switch (op->algo) {
     case ALGO_IGEMM_I8:
-        HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
+        HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
         break;
     case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s)); break;
     case ALGO_IGEMM_F32:
-        HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
+        HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
         break;
     case ALGO_DIRECT_I8:
         a.comp = nullptr;
@@ -485,13 +493,16 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     float best = 1e30f;
     int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
     const int ks_list[3] = {1, 2, 4};
-    const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 2;
-    for (int var = 0; var < nvar; ++var) {
+    const int dma_list[4] = {0, 1, 2, 4};
+    const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 4;
+    for (int vi = 0; vi < nvar; ++vi) {
         for (int t = 0; t < TILE_COUNT; ++t) {
             for (int ki = 0; ki < 3; ++ki) {
+                if (dma_list[vi] > 1 && (ks_list[ki] != 4 || t > TILE_64x64)) continue;
+                if (dma_list[vi] == 4 && t != TILE_32x32) continue;
                 op->tile = t;
                 op->ks = ks_list[ki];
-                op->dma = var;
+                op->dma = dma_list[vi];
                 int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
                 if (rc) return rc;
                 HIP_TRY(hipEventRecord(e0, s));
@@ -504,7 +515,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
                     best = ms;
                     best_tile = t;
                     best_ks = ks_list[ki];
-                    best_dma = var;
+                    best_dma = dma_list[vi];
                 }
             }
         }

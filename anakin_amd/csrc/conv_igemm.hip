@@ -26,7 +26,7 @@ void tile_dims(int tile, int* bm_k, int* bn_pix) {
 #define DECL(m, e) hipError_t launch_igemm_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
 DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3)
 #undef DECL
-#define DECL(m, e) hipError_t launch_igemm_dma_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
+#define DECL(m, e) hipError_t launch_igemm_dma_m##m##_e##e(int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
 DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(2, 3)
 #undef DECL
 
@@ -40,13 +40,13 @@ static int epilogue_kind(int mode, const ConvKArgs& a) {
     return ek;
 }
 
-hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s) {
     switch (mode * 4 + epilogue_kind(mode, a)) {
-    case 0: return launch_igemm_dma_m0_e0(tile, ks, a, s);
-    case 1: return launch_igemm_dma_m0_e1(tile, ks, a, s);
-    case 2: return launch_igemm_dma_m0_e2(tile, ks, a, s);
-    case 3: return launch_igemm_dma_m0_e3(tile, ks, a, s);
-    case 11: return launch_igemm_dma_m2_e3(tile, ks, a, s);
+    case 0: return launch_igemm_dma_m0_e0(tile, ks, wg, a, s);
+    case 1: return launch_igemm_dma_m0_e1(tile, ks, wg, a, s);
+    case 2: return launch_igemm_dma_m0_e2(tile, ks, wg, a, s);
+    case 3: return launch_igemm_dma_m0_e3(tile, ks, wg, a, s);
+    case 11: return launch_igemm_dma_m2_e3(tile, ks, wg, a, s);
     default: return hipErrorInvalidValue;
     }
 }

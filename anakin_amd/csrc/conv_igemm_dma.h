@@ -47,14 +47,18 @@ __device__ __forceinline__ void wait_vmcnt(int cnt) {
 }
 
 // MODE 0: int8 (C % 16 == 0); MODE 2: f32 (C % 4 == 0).
-template <int MODE, int TM, int TN, int KS, int EK>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) {
+// WG wave groups of 4 waves (256 threads) each: every group multiplies the same output tile against its
+// own KS k-steps of a stage (intra-block split-K) so that each SIMD hosts WG waves whose wait / issue
+// phases overlap; the partial accumulators are summed through LDS before the epilogue.
+template <int MODE, int TM, int TN, int KS, int EK, int WG>
+__global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArgs a) {
     constexpr bool F32 = (MODE == 2);
     constexpr int ES = F32 ? 4 : 1;
     constexpr int EC = 16 / ES;
-    constexpr int CPR = 4 * KS;
+    constexpr int NT = 256 * WG;         // threads per block
+    constexpr int CPR = 4 * KS * WG;     // 16-byte chunks per row per stage
     constexpr int ESTAGE = CPR * EC;
-    constexpr int RPP = 256 / CPR;       // rows covered by one DMA pass of the 256 threads
+    constexpr int RPP = NT / CPR;        // rows covered by one DMA pass of the block
     constexpr int BMK = 2 * TM * 16;
     constexpr int BNP = 2 * TN * 16;
     constexpr int WIT = (BMK + RPP - 1) / RPP;
@@ -71,17 +75,20 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int pix_base = blockIdx.x * BNP;
-    const int k_base = blockIdx.y * BMK;
+    const int wave = tid >> 6;           // 0 .. 4*WG-1
+    const int grp = wave >> 2;           // wave group = which k-steps of a stage
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    int tile_px, tile_ky;
+    xcd_tile(a, tile_px, tile_ky);
+    const int pix_base = tile_px * BNP;
+    const int k_base = tile_ky * BMK;
     const int pc = tid % CPR;            // physical chunk column this thread's DMA lands in
     const int lr = tid / CPR;            // first LDS row it fills
     // logical chunk column whose physical home (in row lr + it*RPP, any it) is pc: inverse of phys_chunk
     int lq;
     if constexpr (CPR == 4) lq = (0x78 >> (2 * (pc ^ ((lr >> 2) & 3)))) & 3;
     else if constexpr (CPR == 8) lq = pc ^ ((lr >> 1) & 7);
-    else lq = pc ^ (lr & 15);
+    else lq = pc ^ (lr & 15);            // CPR >= 16 (phys_chunk XORs the low 4 bits of the chunk index)
 
     // ---- per-row gather state ---------------------------------------------------------------------
     int x_base[XIT], x_ih0[XIT], x_iw0[XIT];
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) 
         for (int it = 0; it < WIT; ++it) {
             const char* src = w_src[it] ? w_src[it] + (size_t)s * (CPR * 16) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(stage + it * 256 + wave * 64),
+                                             (__attribute__((address_space(3))) void*)(stage + it * NT + wave * 64),
                                              16, 0, 0);
         }
         const bool tap_ok = cur_i < a.kh;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) 
             const char* src = ok ? (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES
                                  : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(stage + WROWS * CPR + it * 256 + wave * 64),
+                                             (__attribute__((address_space(3))) void*)(stage + WROWS * CPR + it * NT + wave * 64),
                                              16, 0, 0);
         }
         cur_c += ESTAGE;
@@ -172,12 +179,12 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 16 + frow;
-                af[i] = stage[row * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
+                af[i] = stage[row * CPR + phys_chunk<CPR>(row, (grp * KS + ks) * 4 + fq)];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = (wn * TN + j) * 16 + frow;
-                v4i v = stage[(WROWS + row) * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
+                v4i v = stage[(WROWS + row) * CPR + phys_chunk<CPR>(row, (grp * KS + ks) * 4 + fq)];
                 if (!F32) { v.x ^= xmask; v.y ^= xmask; v.z ^= xmask; v.w ^= xmask; }
                 bf[j] = v;
             }
@@ -186,6 +193,27 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
         }
+    }
+
+    // ---- intra-block split-K: groups 1..WG-1 hand their partial accumulators to group 0 via LDS ------
+    if constexpr (WG > 1) {
+        __syncthreads();                 // all DMA consumed (every wait above ended at vmcnt(0)), ring is free
+        acc_t* red = (acc_t*)&lds[0][0];
+        constexpr int PER_GRP = 256 * TM * TN;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) red[(grp - 1) * PER_GRP + (i * TN + j) * 256 + (tid & 255)] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < WG; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += red[(g - 1) * PER_GRP + (i * TN + j) * 256 + tid];
     }
 
     // ---- epilogue (identical to the register-staged kernel) ---------------------------------------
@@ -222,30 +250,46 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvKArgs a) 
     }
 }
 
-template <int MODE, int KS, int EK>
+template <int MODE, int KS, int EK, int WG>
 static hipError_t launch_dma_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     int bmk, bnp;
     tile_dims(tile, &bmk, &bnp);
-    dim3 grid((a.M + bnp - 1) / bnp, (a.K + bmk - 1) / bmk);
-    dim3 block(256);
+    ConvKArgs b = a;
+    b.npx = (a.M + bnp - 1) / bnp;
+    b.nky = (a.K + bmk - 1) / bmk;
+    dim3 grid(b.npx * b.nky);
+    dim3 block(256 * WG);
     switch (tile) {
-    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 1, 1, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 1, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 2, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 4, 2, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 4, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 4, 4, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 1, 1, KS, EK, WG>), grid, block, 0, s, b); break;
+    case TILE_64x32:   // 4 wave groups would need > 160 KiB of LDS
+        if constexpr (WG <= 2) { hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 1, KS, EK, WG>), grid, block, 0, s, b); break; }
+        return hipErrorInvalidValue;
+    case TILE_64x64:
+        if constexpr (WG <= 2) { hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 2, KS, EK, WG>), grid, block, 0, s, b); break; }
+        return hipErrorInvalidValue;
+    case TILE_128x64:
+        if constexpr (WG == 1) { hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 4, 2, KS, EK, 1>), grid, block, 0, s, b); break; }
+        return hipErrorInvalidValue;
+    case TILE_64x128:
+        if constexpr (WG == 1) { hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 2, 4, KS, EK, 1>), grid, block, 0, s, b); break; }
+        return hipErrorInvalidValue;
+    case TILE_128x128:
+        if constexpr (WG == 1) { hipLaunchKernelGGL((conv_igemm_dma_kernel<MODE, 4, 4, KS, EK, 1>), grid, block, 0, s, b); break; }
+        return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
+// wg: wave groups (1, 2 or 4). wg > 1 exists for stage depth 4 on the 32x32 / 64x32 / 64x64 tiles.
 template <int MODE, int EK>
-static hipError_t launch_igemm_dma_inst(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+static hipError_t launch_igemm_dma_inst(int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s) {
+    if (wg == 2) return ks == 4 ? launch_dma_mode<MODE, 4, EK, 2>(tile, a, s) : hipErrorInvalidValue;
+    if (wg == 4) return ks == 4 ? launch_dma_mode<MODE, 4, EK, 4>(tile, a, s) : hipErrorInvalidValue;
     switch (ks) {
-    case 1: return launch_dma_mode<MODE, 1, EK>(tile, a, s);
-    case 2: return launch_dma_mode<MODE, 2, EK>(tile, a, s);
-    case 4: return launch_dma_mode<MODE, 4, EK>(tile, a, s);
+    case 1: return launch_dma_mode<MODE, 1, EK, 1>(tile, a, s);
+    case 2: return launch_dma_mode<MODE, 2, EK, 1>(tile, a, s);
+    case 4: return launch_dma_mode<MODE, 4, EK, 1>(tile, a, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -271,6 +271,20 @@ __device__ __forceinline__ void epilogue_i8_fast(const ConvKArgs& a, const int (
     else *(uint4*)(y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
+
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroup b runs on XCD b % 8; give every XCD a
+// CONTIGUOUS range of the ky-major tile list so the workgroups of one XCD share weight tiles in that
+// XCD's private L2 (the deep-K, small-M layers are weight-traffic bound). Bijective for any tile count.
+__device__ __forceinline__ void xcd_tile(const ConvKArgs& a, int& px, int& ky) {
+    const int T = a.npx * a.nky;
+    const int b = blockIdx.x;
+    const int q = T >> 3, r = T & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    ky = L / a.npx;
+    px = L - ky * a.npx;
+}
+
 // exact p / d and p % d for 0 <= p < 2^24 using a precomputed float reciprocal (+ one fix-up step)
 __device__ __forceinline__ void fast_divmod(int p, int d, float inv, int& q, int& r) {
     q = (int)((float)p * inv);
@@ -316,8 +330,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int pix_base = blockIdx.x * BNP;
-    const int k_base = blockIdx.y * BMK;
+    int tile_px, tile_ky;
+    xcd_tile(a, tile_px, tile_ky);
+    const int pix_base = tile_px * BNP;
+    const int k_base = tile_ky * BMK;
     const int lq = tid % CPR;            // this thread's chunk column within a stage
     const int lr = tid / CPR;            // first row it stages
 
@@ -493,15 +509,18 @@ template <int MODE, int KS, int EK>
 static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     int bmk, bnp;
     tile_dims(tile, &bmk, &bnp);
-    dim3 grid((a.M + bnp - 1) / bnp, (a.K + bmk - 1) / bmk);
+    ConvKArgs b = a;
+    b.npx = (a.M + bnp - 1) / bnp;
+    b.nky = (a.K + bmk - 1) / bmk;
+    dim3 grid(b.npx * b.nky);
     dim3 block(256);
     switch (tile) {
-    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 2, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4, KS, EK>), grid, block, 0, s, a); break;
-    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 4, KS, EK>), grid, block, 0, s, a); break;
+    case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, KS, EK>), grid, block, 0, s, b); break;
+    case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1, KS, EK>), grid, block, 0, s, b); break;
+    case TILE_64x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, KS, EK>), grid, block, 0, s, b); break;
+    case TILE_128x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 2, KS, EK>), grid, block, 0, s, b); break;
+    case TILE_64x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4, KS, EK>), grid, block, 0, s, b); break;
+    case TILE_128x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 4, KS, EK>), grid, block, 0, s, b); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

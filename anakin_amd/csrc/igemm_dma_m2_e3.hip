@@ -1,7 +1,7 @@
 // Instantiates the LDS-DMA implicit-GEMM kernels for operand mode 2 / epilogue kind 3 (conv_igemm_dma.h).
 #include "conv_igemm_dma.h"
 namespace saber_mi355x {
-hipError_t launch_igemm_dma_m2_e3(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
-    return launch_igemm_dma_inst<2, 3>(tile, ks, a, s);
+hipError_t launch_igemm_dma_m2_e3(int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s) {
+    return launch_igemm_dma_inst<2, 3>(tile, ks, wg, a, s);
 }
 }  // namespace saber_mi355x

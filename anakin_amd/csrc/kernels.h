@@ -31,6 +31,7 @@ struct ConvKArgs {
     int Kg;       // real reduction length in elements (kh*kw*C, or kh*kw_pad*4 in C4 mode)
     int Kg_pad;   // padded to a multiple of one K-step
     int steps;    // number of pipeline stages = ceil(Kg / elements-per-stage)
+    int npx, nky;   // pixel tiles / out-channel tiles of the launch (1-D grid, XCD-aware tile order)
     float inv_ohw, inv_ow;  // 1/(OH*OW), 1/OW for the exact float-reciprocal div/mod
     int kw_pad;   // C4 mode: kw rounded up to 4
     int in_u8;    // activations are u8: shift to s8 by XOR 0x80 (compensated through comp)
@@ -51,7 +52,7 @@ void tile_dims(int tile, int* bm_k, int* bn_pix);
 // ks: 64-byte MFMA k-steps per pipeline stage (1, 2 or 4)
 hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s);
 // LDS-DMA ring variant (modes 0 and 2 only)
-hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

@@ -60,9 +60,11 @@ for (name, cin, hin, cout, k, stride, pad, in_dt, relu, elt) in LAYERS:
     gmac = M * cout * cin * k * k / 1e9
     mbytes = (B * hin * hin * cin + M * cout * (2 if elt else 1) + cin * cout * k * k) / 1e6
     res = {}
-    for var in ((1,) if cin < 16 else (1, 2)):
+    for var in ((1,) if cin < 16 else (1, 2, 3, 4)):
       for tile in range(6):
         for ks in (1, 2, 4):
+            if var >= 3 and (ks != 4 or tile > 2 or (var == 4 and tile != 0)):
+                continue
             conv.set_tile(tile | (ks << 8) | (var << 16))
             net.capture()
             net.replay()
@@ -73,7 +75,7 @@ for (name, cin, hin, cout, k, stride, pad, in_dt, relu, elt) in LAYERS:
                 net.replay()
             e1.record()
             torch.cuda.synchronize()
-            res[(L.TILES[tile] + ("d" if var == 2 else "r"), ks)] = e0.elapsed_time(e1) * 1000 / (3 * REP)
+            res[(L.TILES[tile] + ("r", "d", "d2", "d4")[var - 1], ks)] = e0.elapsed_time(e1) * 1000 / (3 * REP)
     best = min(res, key=res.get)
     print("%-24s M=%6d K=%4d Kg=%5d  %.3f GMAC %.2f MB | best %s k%d %.2f us (%.0f GB/s, %.1f TOPS)" % (
         name, M, cout, cin * k * k, gmac, mbytes, best[0], best[1], res[best], mbytes / res[best] * 1e3,

@@ -77,6 +77,12 @@ def test_conv_i8_golden_every_tile(name, tile, ks, var):
                           odt, relu, pad, stride, dil, group, tile=tile | (ks << 8) | (var << 16))
     assert np.array_equal(y, g["y"]), conv.algo()
     assert conv.algo().endswith("_dma") == (var == 2)
+    if var == 2 and ks == 4 and tile <= 2:   # intra-block split-K variants (2 / 4 wave groups)
+        for v in ((3, 4) if tile == 0 else (3,)):
+            y, conv = run_conv_i8(g["x"], g["wq"], g["w_scale"], g["bias"], float(g["in_scale"]),
+                                  float(g["out_scale"]), odt, relu, pad, stride, dil, group,
+                                  tile=tile | (ks << 8) | (v << 16))
+            assert np.array_equal(y, g["y"]), conv.algo()
 
 
 @pytest.mark.parametrize("var", [1, 2])
@@ -127,9 +133,9 @@ def test_conv_i8_sweep_vs_oracle(case, combo):
     got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, stride, dil, 1)
     assert got.dtype == want.dtype and np.array_equal(got, want), conv.algo()
     if conv.algo().startswith("igemm_i8_") and "_c4_" not in conv.algo():
-        for tile in (0, 2):
+        for tile, var in ((0, 2), (2, 2), (0, 3), (1, 3), (2, 3), (0, 4)):   # dma, dma + 2 / 4 wave groups
             got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, stride, dil, 1,
-                                    tile=tile | (4 << 8) | (2 << 16))
+                                    tile=tile | (4 << 8) | (var << 16))
             assert np.array_equal(got, want), conv.algo()
 
 
