@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling aid: only warm-up + timed region (no latency / per-op / cpu legs), so the last "
+                         "dispatches of a rocprofv3 trace are exactly one forward pass")
     return ap.parse_args()
 
 
@@ -130,6 +133,12 @@ def main():
     value = n_gpus * B * args.steps / dt
 
     out = None
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"value": round(value, 1), "unit": "images/s", "ms_per_step": round(ms_per_step, 4)}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if rank == 0:
         # ---------------- per-step latency distribution (hipEvents around each replay) -------------
         lat = []
@@ -161,8 +170,20 @@ def main():
         else:
             roof = dict(bound="mfma", achieved=round(achieved_tops, 2), peak=peak_ops, unit="TFLOP/s",
                         frac=round(achieved_tops / peak_ops, 4), traffic=None)
+        # HBM traffic from the committed PMC passes (profiles/r01_traffic.json; same workload, same batch):
+        # per launch, FETCH_SIZE doubled per the gfx950 correction. Null when no matching profile exists.
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tr.get("batch") == B and args.precision == "int8" and args.model == "resnet50":
+                roof["traffic"] = round(tr["hbm_bytes_per_launch"] / 1e9 / (conv_us / n_conv * 1e-6), 1) \
+                    if bound == "hbm" else tr["hbm_bytes_per_launch"]
+                roof["traffic_bytes_per_launch"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_note"] = "traffic = PMC HBM bytes per launch / avg launch time, GB/s (same unit as achieved)"
+        except (OSError, ValueError, KeyError):
+            pass
         roof.update(kernel="conv_igemm_kernel (all %d conv/fc launches of one forward)" % n_conv,
                     launches=n_conv, avg_launch_us=round(conv_us / n_conv, 3),
+                    algorithmic_bytes_per_launch=int(alg_bytes / n_conv),
                     algorithmic_bytes_per_forward=int(alg_bytes), algorithmic_ops_per_forward=int(alg_ops),
                     mfma_frac=round(achieved_tops / peak_ops, 4), hbm_frac=round(achieved_gbs / HBM_PEAK_GBS, 4),
                     sum_all_op_us=round(sum(op_us), 1))

@@ -1,0 +1,192 @@
+// integration/saber_mi355x_adaptor.h — the reference-side binding of the MI355X Saber target.
+//
+// This is the code a maintainer drops into the reference as
+//   saber/funcs/impl/mi355x/saber_conv.h, saber_conv_eltwise.h, saber_fc.h, saber_gemm.h
+// (one `SaberXxx<MI355X, OpDtype>` partial specialisation per operator, the pattern of
+// saber/funcs/impl/x86/saber_conv.h:24-69) and includes from the facade headers' target ladder
+// (saber/funcs/conv.h:23-50). It only marshals Tensor / Param objects into the POD descriptors of
+// include/saber_hip.h; all arithmetic lives behind the C ABI.
+//
+// It is written against the reference's own headers and is templated on the target type so that it can be
+// COMPILE-CHECKED in this repository with TargetType = X86 (`make -C oracle adaptor_check`, run by
+// __graft_entry__.build() when /root/reference is present). With the real MI355X target
+// (docs/Manual/addCustomDevice.md: TargetTypeEnum, TargetWrapper<MI355X> on hipMalloc/hipMemcpyAsync/
+// hipStream_t, Env/Device/Context), `TargetType` is MI355X, Tensor::data() returns device pointers and
+// Context::get_compute_stream() a hipStream_t.
+#ifndef SABER_MI355X_ADAPTOR_H
+#define SABER_MI355X_ADAPTOR_H
+
+#include "saber/funcs/impl/impl_base.h"
+#include "saber/saber_funcs_param.h"
+#include "saber_hip.h"
+
+namespace anakin {
+namespace saber {
+
+inline SaberStatus mi355x_status(int rc) {   // saber_types.h:223-233
+    switch (rc) {
+    case SABER_HIP_OK: return SaberSuccess;
+    case SABER_HIP_INVALID_VALUE: return SaberInvalidValue;
+    case SABER_HIP_UNIMPL: return SaberUnImplError;
+    case SABER_HIP_OUT_OF_MEM: return SaberOutOfMem;
+    default: return SaberUnKownError;
+    }
+}
+inline int mi355x_dtype(DataType t) {
+    return t == AK_FLOAT ? SABER_HIP_F32 : (t == AK_INT8 ? SABER_HIP_S8 : (t == AK_UINT8 ? SABER_HIP_U8 : -1));
+}
+inline int mi355x_layout(LayoutType l) { return l == Layout_NHWC ? SABER_HIP_NHWC : SABER_HIP_NCHW; }
+
+// SaberConv2D<MI355X, OpDtype> and SaberConvEltwise<MI355X, OpDtype> share this body
+// (ConvEltwiseParam = ConvParam + EltwiseParam, saber_funcs_param.h:586-615).
+template <typename TargetType, DataType OpDtype>
+class SaberConvEltwiseMI355X : public ImplBase<TargetType, OpDtype, ConvEltwiseParam<TargetType> > {
+public:
+    SaberConvEltwiseMI355X() : _op(nullptr), _ws(nullptr), _ws_bytes(0) {}
+    ~SaberConvEltwiseMI355X() {
+        if (_op) saber_hip_conv2d_destroy(_op);
+        // workspace is released through the target's TargetWrapper<...>::mem_free in the real target
+    }
+
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs,
+                             std::vector<Tensor<TargetType>*>& outputs,
+                             ConvEltwiseParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        return create(inputs, outputs, param, ctx);
+    }
+
+    // init/create: geometry + algorithm choice + weight quantise/repack (cold path, host pointers)
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs,
+                               std::vector<Tensor<TargetType>*>& outputs,
+                               ConvEltwiseParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        ConvParam<TargetType>& cp = param.conv_param;
+        EltwiseParam<TargetType>& ep = param.eltwise_param;
+        Tensor<TargetType>* in = inputs[0];
+        Tensor<TargetType>* out = outputs[0];
+        saber_hip_conv_desc d;
+        memset(&d, 0, sizeof d);
+        d.n = in->num(); d.c = in->channel(); d.h = in->height(); d.w = in->width();
+        d.k = cp.weight()->num(); d.kh = cp.weight()->height(); d.kw = cp.weight()->width();
+        d.pad_h = cp.pad_h; d.pad_w = cp.pad_w; d.stride_h = cp.stride_h; d.stride_w = cp.stride_w;
+        d.dil_h = cp.dilation_h; d.dil_w = cp.dilation_w; d.group = cp.group;
+        d.in_dtype = mi355x_dtype(in->get_dtype());
+        d.out_dtype = mi355x_dtype(out->get_dtype());
+        d.in_layout = mi355x_layout(in->get_layout());
+        d.out_layout = mi355x_layout(out->get_layout());
+        d.int8_weights = (OpDtype == AK_INT8) ? 1 : 0;
+        d.act = (cp.activation_param.has_active && cp.activation_param.active == Active_relu) ? SABER_HIP_ACT_RELU
+                                                                                              : SABER_HIP_ACT_NONE;
+        if (ep.has_eltwise && ep.operation == Eltwise_sum) {
+            // x86 semantics: in-place sum onto the output tensor (saber_conv_eltwise.cpp:40-151; JIT with_sum)
+            d.res_mode = SABER_HIP_RES_SUM_INPLACE;
+            d.res_act = (ep.activation_param.has_active && ep.activation_param.active == Active_relu)
+                            ? SABER_HIP_ACT_RELU : SABER_HIP_ACT_NONE;
+            d.sum_scale = cp.beta;   // the INT8 caller pre-divides by the output scale as jit_..._conv.cpp:175-189 does
+        }
+        if (_op) { saber_hip_conv2d_destroy(_op); _op = nullptr; }
+        int rc = saber_hip_conv2d_create(&d, &_op);
+        if (rc) return mi355x_status(rc);
+        const Tensor<TargetType>* w = cp.weight();
+        const Tensor<TargetType>* b = cp.bias();
+        const float in_scale = in->get_scale().size() ? in->get_scale()[0] : 1.f;
+        const float out_scale = out->get_scale().size() ? out->get_scale()[0] : 1.f;
+        // weights/bias: the PBlock's HOST copy in the real target (PBlock::h_tensor(), parameter.h:192+)
+        rc = saber_hip_conv2d_set_weights(_op, w->data(), mi355x_dtype(w->get_dtype()),
+                                          w->get_scale().size() ? w->get_scale().data() : nullptr,
+                                          (b && b->valid_size() > 0) ? (const float*)b->data() : nullptr,
+                                          in_scale, out_scale);
+        _ws_bytes = saber_hip_conv2d_workspace_bytes(_op);   // allocate _ws with the target's mem_alloc
+        return mi355x_status(rc);
+    }
+
+    // dispatch: enqueue on the context's compute stream, never sync (net.cpp:456-458 records the event)
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs,
+                                 std::vector<Tensor<TargetType>*>& outputs,
+                                 ConvEltwiseParam<TargetType>& param) {
+        saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
+        return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), nullptr, _ws,
+                                                  stream));
+    }
+
+    // Conv<>::trans_weights static_casts to this (conv.h:103-119): the repack already happened in create()
+    SaberStatus trans_weights(Tensor<TargetType>&, Tensor<TargetType>&, int, int, int, int, int, int, int) {
+        return SaberSuccess;
+    }
+
+private:
+    saber_hip_conv_t* _op;
+    void* _ws;
+    size_t _ws_bytes;
+};
+
+// Fc<MI355X, OpDtype> (saber/funcs/fc.h:48-127)
+template <typename TargetType, DataType OpDtype>
+class SaberFcMI355X : public ImplBase<TargetType, OpDtype, FcParam<TargetType> > {
+public:
+    SaberFcMI355X() : _op(nullptr), _ws(nullptr) {}
+    ~SaberFcMI355X() { if (_op) saber_hip_fc_destroy(_op); }
+
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs,
+                             std::vector<Tensor<TargetType>*>& outputs, FcParam<TargetType>& param,
+                             Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        return create(inputs, outputs, param, ctx);
+    }
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs,
+                               std::vector<Tensor<TargetType>*>& outputs, FcParam<TargetType>& param,
+                               Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        saber_hip_fc_desc d;
+        d.m = inputs[0]->count_valid(0, param.axis);
+        d.k = inputs[0]->count_valid(param.axis, inputs[0]->dims());
+        d.n = param.num_output;
+        d.in_dtype = mi355x_dtype(inputs[0]->get_dtype());
+        d.int8_weights = (OpDtype == AK_INT8) ? 1 : 0;
+        d.w_is_kn = param.is_transpose_weights ? 1 : 0;
+        if (_op) { saber_hip_fc_destroy(_op); _op = nullptr; }
+        int rc = saber_hip_fc_create(&d, &_op);
+        if (rc) return mi355x_status(rc);
+        const Tensor<TargetType>* w = param.weights;
+        const Tensor<TargetType>* b = param.bias;
+        rc = saber_hip_fc_set_weights(_op, w->data(), mi355x_dtype(w->get_dtype()),
+                                      w->get_scale().size() ? w->get_scale().data() : nullptr,
+                                      (b && b->valid_size() > 0) ? (const float*)b->data() : nullptr,
+                                      inputs[0]->get_scale().size() ? inputs[0]->get_scale()[0] : 1.f,
+                                      outputs[0]->get_scale().size() ? outputs[0]->get_scale()[0] : 1.f);
+        return mi355x_status(rc);
+    }
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs,
+                                 std::vector<Tensor<TargetType>*>& outputs, FcParam<TargetType>& param) {
+        saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
+        return mi355x_status(saber_hip_fc_run(_op, inputs[0]->data(), (float*)outputs[0]->mutable_data(), _ws, stream));
+    }
+
+private:
+    saber_hip_fc_t* _op;
+    void* _ws;
+};
+
+// Gemm<MI355X, SABER_IMPL, float, float> (saber/funcs/gemm.h:27-66): raw row-major pointers
+template <typename TargetType>
+class SaberGemmMI355X {
+public:
+    SaberStatus init(const bool trans_a, const bool trans_b, const int m, const int n, const int k,
+                     Context<TargetType> ctx) {
+        _ta = trans_a; _tb = trans_b; _m = m; _n = n; _k = k; _ctx = ctx;
+        return SaberSuccess;
+    }
+    SaberStatus dispatch(const float alpha, const float beta, const float* a, const float* b, float* c) {
+        return mi355x_status(saber_hip_gemm_f32(_ta, _tb, _m, _n, _k, alpha, a, b, beta, c,
+                                                (saber_hip_stream_t)_ctx.get_compute_stream()));
+    }
+
+private:
+    bool _ta, _tb;
+    int _m, _n, _k;
+    Context<TargetType> _ctx;
+};
+
+}  // namespace saber
+}  // namespace anakin
+#endif

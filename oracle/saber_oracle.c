@@ -159,7 +159,7 @@ int orc_conv_i8(int N, int H, int W, int C, int K, int kh, int kw, int pad_h, in
     const int8_t* xs = (const int8_t*)x;
     const uint8_t* xu = (const uint8_t*)x;
     const int mode = rp ? rp->mode : ORC_RES_NONE;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int n = 0; n < N; ++n) {
         for (int oh = 0; oh < OH; ++oh) {
             for (int ow = 0; ow < OW; ++ow) {
