@@ -73,6 +73,7 @@ def main():
     import torch
     import torch.distributed as dist
     from anakin_amd import lib as L
+    from anakin_amd import shard
     from anakin_amd import workloads as W
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,10 +110,10 @@ def main():
     logits = net.tensor("prob")
     gather = None
     if world > 1:
-        gathered = torch.empty((world,) + tuple(logits.shape), dtype=logits.dtype, device="cuda")
+        gathered = torch.empty((world * logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device="cuda")
 
-        def gather():
-            dist.all_gather_into_tensor(gathered, logits)
+        def gather():   # the path's only exchange: per-rank logits over RCCL (anakin_amd/shard.py)
+            shard.gather_logits(logits, world, gathered)
 
     # ---------------- warm-up, then the timed region (barrier + synchronize on both sides) ----------
     timed_steps(net, args.warmup, use_graph, gather)
@@ -125,10 +126,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(dt, "cuda")
     ms_per_step = dt * 1000.0 / args.steps
     value = n_gpus * B * args.steps / dt
 

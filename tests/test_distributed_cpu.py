@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, each runs its images through the (oracle) op list,
+the logits are all-gathered, and the result equals the single-process run bit for bit."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from anakin_amd import shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tiny_forward(x):
+    """A per-image INT8 pipeline out of oracle ops: quantise -> conv -> pool -> fc (no cross-image math)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((16, 3, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(16).astype(np.float32)
+    fw = (rng.standard_normal((10, 16)) * 0.3).astype(np.float32)
+    xq = O.quant_nchw_to_nhwc(x, 1 / 127.0, O.S8)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, 1 / 127.0, 0.05, O.S8, O.U8)
+    y = O.conv_i8(xq, O.quant_weights(w, ws), bp, sc, O.U8, 1, (1, 1))
+    p = O.pool_i8_nhwc(y, None, None, None, 1, global_pool=True).reshape(x.shape[0], 16)
+    fws = O.weight_scales(fw)
+    return O.fc_i8(p, O.quant_weights(fw, fws), fws, 0.05, None, 1.0)
+
+
+def _worker(rank, world, port, global_batch, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = np.random.default_rng(0).uniform(-1, 1, (global_batch, 3, 8, 8)).astype(np.float32)
+    start, count = shard.shard_range(global_batch, world, rank)
+    local = torch.from_numpy(_tiny_forward(x[start:start + count]))
+    full = shard.gather_logits(local, world)
+    t = shard.max_over_ranks(0.5 + rank)
+    if rank == 0:
+        ret["logits"] = full.numpy().copy()
+        ret["t"] = t
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_batch():
+    for gb, w in [(64, 8), (8, 2), (10, 4), (3, 4)]:
+        spans = [shard.shard_range(gb, w, r) for r in range(w)]
+        assert sum(c for _, c in spans) == gb
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_two_rank_gloo_matches_single_process():
+    world, gb = 2, 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), gb, ret), nprocs=world, join=True)
+    x = np.random.default_rng(0).uniform(-1, 1, (gb, 3, 8, 8)).astype(np.float32)
+    want = _tiny_forward(x)
+    assert np.array_equal(ret["logits"], want)     # batch sharding changes nothing, bit for bit
+    assert ret["t"] == 1.5                          # max over ranks
