@@ -718,6 +718,14 @@ int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int
                               (hipStream_t)s));
     return SABER_HIP_OK;
 }
+int saber_hip_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                                 int pw, int type, int in_dtype, float scale, const void* x, float* y,
+                                 saber_hip_stream_t s) {
+    if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
+    HIP_TRY(launch_pool2d_f32_from_i8(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y,
+                                      (hipStream_t)s));
+    return SABER_HIP_OK;
+}
 int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t s) {
     if (rows <= 0 || cols <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad softmax shape");
     HIP_TRY(launch_softmax_f32(rows, cols, x, y, (hipStream_t)s));
@@ -730,7 +738,7 @@ int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hi
 // op-list executor
 // ================================================================================================
 namespace {
-enum OpKind { OP_CONV, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_SOFTMAX };
+enum OpKind { OP_CONV, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_SOFTMAX };
 struct NetOp {
     OpKind kind;
     std::string name;
@@ -781,6 +789,10 @@ static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     case OP_POOL_F32:
         return saber_hip_pool2d_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.p[9],
                                     o.p[10], o.p[11], o.p[12], o.p[13], (const float*)T(o.in), (float*)T(o.out), s);
+    case OP_POOL_F32_I8:
+        return saber_hip_pool2d_f32_from_i8(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
+                                            o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.f[0], T(o.in),
+                                            (float*)T(o.out), s);
     case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
     }
     return SABER_HIP_UNIMPL;
@@ -866,6 +878,16 @@ int saber_hip_net_add_pool_f32(saber_hip_net_t* net, int n, int h, int w, int c,
     o.kind = OP_POOL_F32; o.in = in_id; o.out = out_id; o.name = "pool2d_f32";
     const int v[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout};
     std::memcpy(o.p, v, sizeof v);
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_f32_from_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                                       int sh, int sw, int ph, int pw, int type, int in_dtype, float scale, int in_id,
+                                       int out_id) {
+    NetOp o;
+    o.kind = OP_POOL_F32_I8; o.in = in_id; o.out = out_id; o.name = "pool2d_f32_from_i8";
+    const int v[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype};
+    std::memcpy(o.p, v, sizeof v);
+    o.f[0] = scale;
     return push(net, std::move(o));
 }
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id) {
@@ -958,8 +980,13 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     for (NetOp& o : net->ops) {
         saber_hip_conv* c = o.kind == OP_CONV ? o.conv : (o.kind == OP_FC ? o.fc->conv : nullptr);
         if (!c) continue;
-        if (o.kind == OP_FC && o.fc->pre_quant) continue;
-        int rc = saber_hip_conv2d_autotune(c, T(o.in), T(o.out), T(o.in2), net->arena + net->ws_off, stream, iters);
+        const void* xin = T(o.in);
+        if (o.kind == OP_FC && o.fc->pre_quant) {   // the GEMM reads the quantised copy in the workspace
+            int rq = net_launch(net, o, (hipStream_t)stream);
+            if (rq) return rq;
+            xin = net->arena + net->ws_off;
+        }
+        int rc = saber_hip_conv2d_autotune(c, xin, T(o.out), T(o.in2), net->arena + net->ws_off, stream, iters);
         if (rc) return rc;
         o.name = std::string(o.kind == OP_CONV ? "conv:" : "fc:") + c->algo_name;
     }

@@ -216,10 +216,11 @@ enum { EK_S8 = 0,   // INT8 conv -> s8 (relu optional)
        EK_ELT = 2,  // INT8 conv -> s8 -> fused SaberEltwise sum(+relu) -> s8
        EK_GEN = 3 };// everything else (f32 outputs, FC epilogues, in-place JIT sum, FP32 conv)
 
-// roundf (half away from zero) from v_rndne: only exact ties differ
+// roundf (round half away from zero) == trunc(t + copysign(0.49999997f, t)) for every float with
+// |t| < 2^23 (exhaustively verified: oracle/saber_oracle.c orc_check_round_identity, tests/test_oracle_golden.py);
+// larger magnitudes are already integers and saturate afterwards.
 __device__ __forceinline__ float round_half_away(float t) {
-    const float r = rintf(t);
-    return (fabsf(t - r) == 0.5f) ? t + copysignf(0.5f, t) : r;
+    return truncf(t + copysignf(0x1.fffffep-2f, t));
 }
 
 // Fast INT8 epilogues (full NV-wide, aligned stores). Bit-identical to epilogue_i8:

@@ -18,6 +18,9 @@ __device__ __forceinline__ int q_sat_u8(float v) {
     v = v > 255.f ? 255.f : v;
     return (int)v;
 }
+// roundf() as three VALU ops; identical to roundf for |t| < 2^23 (exhaustively verified on the CPU,
+// oracle orc_check_round_identity), and larger magnitudes are integers already.
+__device__ __forceinline__ float round_away(float t) { return truncf(t + copysignf(0x1.fffffep-2f, t)); }
 
 // ---- f32 NCHW -> s8/u8 NHWC(c_pad) : saturate(roundf(x * inv)) -------------------------------
 __global__ __launch_bounds__(256) void quantize_nchw_to_nhwc_kernel(int n, int c, int hw, int c_pad, int u8,
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void quantize_nchw_to_nhwc_kernel(int n, int c
             const int ch = g * 4 + t;
             int q = 0;
             if (ch < c) {
-                const float v = roundf(__fmul_rn(x[((size_t)img * c + ch) * hw + p], inv));
+                const float v = round_away(__fmul_rn(x[((size_t)img * c + ch) * hw + p], inv));
                 q = u8 ? q_sat_u8(v) : q_sat_s8(v);
             }
             pk |= (unsigned)(q & 0xff) << (8 * t);
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void quantize_nchw_to_nhwc_bytes_kernel(int n,
         const int p = (int)(pp - (size_t)img * hw);
         int q = 0;
         if (ch < c) {
-            const float v = roundf(__fmul_rn(x[((size_t)img * c + ch) * hw + p], inv));
+            const float v = round_away(__fmul_rn(x[((size_t)img * c + ch) * hw + p], inv));
             q = u8 ? q_sat_u8(v) : q_sat_s8(v);
         }
         y[gid] = (uint8_t)q;
@@ -176,7 +179,7 @@ hipError_t launch_pad_channels_i8(size_t pixels, int c, int c_pad, const void* x
 __global__ __launch_bounds__(256) void quantize_flat_s8_kernel(size_t count, float inv, const float* __restrict__ x,
                                                                int8_t* __restrict__ y) {
     for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < count; gid += (size_t)gridDim.x * 256) {
-        int t = (int)roundf(__fmul_rn(x[gid], inv));
+        int t = (int)round_away(__fmul_rn(x[gid], inv));
         t = t > 127 ? 127 : t;
         t = t < -128 ? -128 : t;
         y[gid] = (int8_t)t;
@@ -192,7 +195,7 @@ __device__ __forceinline__ int elt_i8_one(int a, int b, float sa, float sb, floa
     float t = __fmul_rn(__fmul_rn(c0, (float)a), sa);
     t = __fadd_rn(t, __fmul_rn(__fmul_rn(c1, (float)b), sb));
     if (relu) t = t > 0.f ? t : 0.f;
-    return q_sat_s8(roundf(t));
+    return q_sat_s8(round_away(t));
 }
 __global__ __launch_bounds__(256) void eltwise_sum_i8_kernel(size_t count, const int8_t* __restrict__ a,
                                                              const int8_t* __restrict__ b, float sa, float sb,
@@ -389,6 +392,98 @@ hipError_t launch_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh,
                              int pw, int type, int nchw, const float* x, float* y, hipStream_t s) {
     hipLaunchKernelGGL(pool2d_f32_kernel, dim3(grid_for((size_t)n * oh * ow * c)), dim3(256), 0, s, n, h, w, c, oh,
                        ow, kh, kw, sh, sw, ph, pw, type, nchw, x, y);
+    return hipGetLastError();
+}
+
+
+// ---- FP32 pooling fed an 8-bit NHWC tensor: SaberPooling<X86,AK_FLOAT>::dispatch dequantises on entry
+// (reorder_nhwc_nchw, saber_pooling.cpp:399-402) and pools in NCHW; fused here, same float sequence:
+// v = (float)q * s ; window accumulated in (h, w) order ; / area. Output NCHW f32.
+__global__ __launch_bounds__(256) void pool2d_f32_from_i8_kernel(int n, int h, int w, int c, int oh, int ow, int kh,
+                                                                 int kw, int sh, int sw, int ph, int pw, int type,
+                                                                 int in_u8, float s, const uint8_t* __restrict__ x,
+                                                                 float* __restrict__ y) {
+    const size_t total = (size_t)n * oh * ow * c;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        size_t r = gid;
+        const int ch = (int)(r % c); r /= c;      // channel fastest: coalesced NHWC reads
+        const int ox = (int)(r % ow); r /= ow;
+        const int oy = (int)(r % oh);
+        const int img = (int)(r / oh);
+        int hs = oy * sh - ph, ws = ox * sw - pw;
+        int he = hs + kh, we = ws + kw;
+        hs = hs < 0 ? 0 : hs;
+        ws = ws < 0 ? 0 : ws;
+        he = he > h ? h : he;
+        we = we > w ? w : we;
+        float acc = 0.f;
+        bool first = true;
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) {
+                const uint8_t b = x[(((size_t)img * h + iy) * w + ix) * c + ch];
+                const float v = __fmul_rn(in_u8 ? (float)b : (float)(int8_t)b, s);
+                if (type == 0) {
+                    acc = first ? v : (acc >= v ? acc : v);
+                    first = false;
+                } else {
+                    acc = __fadd_rn(acc, v);
+                }
+            }
+        if (type == 1) {
+            int bh = kh, bw = kw;
+            if (we == w) bw = (ws + kw >= w + pw ? w + pw : ws + kw) - ws;
+            if (he == h) bh = (hs + kh >= h + ph ? h + ph : hs + kh) - hs;
+            acc = acc / (float)(bh * bw);
+        }
+        if (type == 2) acc = acc / (float)((he - hs) * (we - ws));
+        y[(((size_t)img * c + ch) * oh + oy) * ow + ox] = acc;
+    }
+}
+
+// Global average pool specialisation of the kernel above (window = whole image, no padding): one lane
+// per (image, 4 channels); pixels are fetched 25 at a time (independent dword loads in flight) and then
+// accumulated in (h, w) order, so the float sequence is unchanged.
+__global__ __launch_bounds__(256) void gpool_f32_from_i8_kernel(int n, int hw, int c, int type, int in_u8, float s,
+                                                                const uint8_t* __restrict__ x, float* __restrict__ y) {
+    const int cg = c >> 2;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * cg) return;
+    const int img = gid / cg, g = gid - img * cg;
+    const unsigned* px = (const unsigned*)(x + (size_t)img * hw * c) + g;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    bool first = true;
+    for (int p0 = 0; p0 < hw; p0 += 25) {
+        unsigned v[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) v[t] = (p0 + t < hw) ? px[(size_t)(p0 + t) * cg] : 0u;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            if (p0 + t < hw) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int q = (v[t] >> (8 * b)) & 0xff;
+                    const float f = __fmul_rn(in_u8 ? (float)q : (float)(int8_t)q, s);
+                    if (type == 0) acc[b] = first ? f : (acc[b] >= f ? acc[b] : f);
+                    else acc[b] = __fadd_rn(acc[b], f);
+                }
+                first = false;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) y[(size_t)img * c + g * 4 + b] = type == 0 ? acc[b] : acc[b] / (float)hw;
+}
+hipError_t launch_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                                     int pw, int type, int in_dtype, float scale, const void* x, float* y,
+                                     hipStream_t s) {
+    const float sc = in_dtype == DT_U8 ? scale * (127.f / 255.f) : scale;
+    if (oh == 1 && ow == 1 && kh == h && kw == w && ph == 0 && pw == 0 && (c & 3) == 0) {
+        hipLaunchKernelGGL(gpool_f32_from_i8_kernel, dim3((n * (c >> 2) + 255) / 256), dim3(256), 0, s, n, h * w, c, type,
+                           in_dtype == DT_U8, sc, (const uint8_t*)x, y);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(pool2d_f32_from_i8_kernel, dim3(grid_for((size_t)n * oh * ow * c)), dim3(256), 0, s, n, h, w, c,
+                       oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype == DT_U8, sc, (const uint8_t*)x, y);
     return hipGetLastError();
 }
 

@@ -29,11 +29,11 @@ SYMBOLS = [
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
-    "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_softmax_f32",
+    "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_softmax_f32",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
-    "saber_hip_net_add_softmax", "saber_hip_net_finalize", "saber_hip_net_tensor_ptr",
+    "saber_hip_net_add_pool_f32_from_i8", "saber_hip_net_add_softmax", "saber_hip_net_finalize", "saber_hip_net_tensor_ptr",
     "saber_hip_net_arena_bytes", "saber_hip_net_num_ops", "saber_hip_net_run", "saber_hip_net_run_op",
     "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_op_name",
     "saber_hip_net_autotune", "saber_hip_net_destroy",
@@ -110,6 +110,7 @@ def load():
     lib.saber_hip_pool_out_dim.argtypes = [I, I, I, I, I]
     lib.saber_hip_pool2d_i8_nhwc.argtypes = [I] * 15 + [P, P, P]
     lib.saber_hip_pool2d_f32.argtypes = [I] * 14 + [P, P, P]
+    lib.saber_hip_pool2d_f32_from_i8.argtypes = [I] * 14 + [F, P, P, P]
     lib.saber_hip_softmax_f32.argtypes = [I, I, P, P, P]
     lib.saber_hip_net_create.argtypes = [C.POINTER(P)]
     lib.saber_hip_net_add_tensor.argtypes = [P, Z]
@@ -122,6 +123,7 @@ def load():
     lib.saber_hip_net_add_eltwise_f32.argtypes = [P, Z, F, F, I, I, I, I]
     lib.saber_hip_net_add_pool_i8.argtypes = [P] + [I] * 17
     lib.saber_hip_net_add_pool_f32.argtypes = [P] + [I] * 16
+    lib.saber_hip_net_add_pool_f32_from_i8.argtypes = [P] + [I] * 14 + [F, I, I]
     lib.saber_hip_net_add_softmax.argtypes = [P, I, I, I, I]
     lib.saber_hip_net_finalize.argtypes = [P]
     lib.saber_hip_net_tensor_ptr.argtypes = [P, I]

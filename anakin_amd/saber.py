@@ -266,6 +266,21 @@ def pooling_f32(x, window, stride, pad, pool_type, layout=L.NCHW, global_pooling
     return y
 
 
+def pooling_f32_from_i8(x, scale, window, stride, pad, pool_type, global_pooling=False, floor_mode=False):
+    """Pooling<MI355X, AK_FLOAT> fed an s8/u8 NHWC tensor: dequantise on entry, pool, f32 NCHW out."""
+    n, h, w, c = x.shape
+    if global_pooling:
+        window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
+    else:
+        oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
+        ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device="cuda")
+    L.check(L.load().saber_hip_pool2d_f32_from_i8(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1],
+                                                  pad[0], pad[1], pool_type, dtype_code(x), float(scale), _p(x), _p(y),
+                                                  _stream()))
+    return y
+
+
 def softmax(x):
     rows, cols = x.shape[0], x.numel() // x.shape[0]
     y = torch.empty_like(x)
@@ -341,6 +356,11 @@ class Net:
         return self._chk(L.load().saber_hip_net_add_pool_f32(self.h, n, h, w, c, oh, ow, win[0], win[1], stride[0],
                                                              stride[1], pad[0], pad[1], ptype, layout, self.tid(x),
                                                              self.tid(y)))
+
+    def add_pool_f32_from_i8(self, n, h, w, c, oh, ow, win, stride, pad, ptype, in_dtype, scale, x, y):
+        return self._chk(L.load().saber_hip_net_add_pool_f32_from_i8(self.h, n, h, w, c, oh, ow, win[0], win[1],
+                                                                     stride[0], stride[1], pad[0], pad[1], ptype,
+                                                                     in_dtype, float(scale), self.tid(x), self.tid(y)))
 
     def add_softmax(self, rows, cols, x, y):
         return self._chk(L.load().saber_hip_net_add_softmax(self.h, rows, cols, self.tid(x), self.tid(y)))

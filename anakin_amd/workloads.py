@@ -226,10 +226,9 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224):
         elif kd == "gpool":
             # FP32 pooling op fed an s8 NHWC edge: dequantise on entry (saber_pooling.cpp:399-402), then avg
             hin, c = shape[l["src"]]
-            net.add_tensor(nm + "_deq", (B, c, hin, hin), F32)
             net.add_tensor(nm, (B, c, 1, 1), F32)
-            net.add_dequantize(B, c, hin, hin, dtype[l["src"]], scales[l["src"]], l["src"], nm + "_deq")
-            net.add_pool_f32(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, L.NCHW, nm + "_deq", nm)
+            net.add_pool_f32_from_i8(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
+                                     scales[l["src"]], l["src"], nm)
             shape[nm], dtype[nm] = (1, c), F32
         elif kd == "fc":
             w, b = model["params"][nm]

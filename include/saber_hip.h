@@ -180,6 +180,11 @@ int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh,
 int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
                          int stride_w, int pad_h, int pad_w, int pool_type, int layout, const float* x,
                          float* y, saber_hip_stream_t stream);
+/* FP32 pooling op fed an 8-bit NHWC tensor (SaberPooling<X86,AK_FLOAT> dequantises on entry,
+ * saber_pooling.cpp:399-402): s8/u8 NHWC in, f32 NCHW out; same float sequence as dequantize + pool2d_f32. */
+int saber_hip_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
+                                 int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype, float scale,
+                                 const void* x, float* y, saber_hip_stream_t stream);
 /* softmax over the last axis of [rows, cols] */
 int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t stream);
 
@@ -209,6 +214,9 @@ int saber_hip_net_add_pool_i8(saber_hip_net_t* net, int n, int h, int w, int c, 
 int saber_hip_net_add_pool_f32(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
                                int stride_h, int stride_w, int pad_h, int pad_w, int pool_type, int layout,
                                int in_id, int out_id);
+int saber_hip_net_add_pool_f32_from_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh,
+                                       int kw, int stride_h, int stride_w, int pad_h, int pad_w, int pool_type,
+                                       int in_dtype, float scale, int in_id, int out_id);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
 /* Allocates every edge tensor + the shared workspace (one hipMalloc arena). */
 int saber_hip_net_finalize(saber_hip_net_t* net);

@@ -585,3 +585,22 @@ void orc_softmax_f32(int outer, int Cn, int inner, const float* x, float* out) {
             for (int c = 0; c < Cn; ++c) op[(size_t)c * inner] /= s;
         }
 }
+
+/* ---- identities the HIP kernels rely on ----------------------------------------------------- */
+
+/* roundf(x) == truncf(x + copysignf(0x1.fffffep-2f, x)) for every float with |x| < 2^23; returns the
+ * number of mismatches over ALL such floats (both signs). Used to justify the 3-instruction roundf of the
+ * device epilogues. */
+long orc_check_round_identity(void) {
+    long bad = 0;
+    const float h = 0x1.fffffep-2f;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (uint32_t b = 0; b < 0x4B000000u; ++b) {
+        float x;
+        memcpy(&x, &b, 4);
+        if (truncf(x + copysignf(h, x)) != roundf(x)) ++bad;
+        x = -x;
+        if (truncf(x + copysignf(h, x)) != roundf(x)) ++bad;
+    }
+    return bad;
+}

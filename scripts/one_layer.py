@@ -19,7 +19,7 @@ p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (1, 1), relu)
 odt = L.U8 if relu else L.S8
 if elt:
     p.res_mode, p.res_relu, p.coeff, p.scale_res = L.RES_ELTWISE, True, (20.0, 20.0), 0.04
-conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, in_dt, odt, 0.02, 0.05)
+conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, in_dt, odt, 0.02, 0.05)  # in_dt s8/u8: NHWC input
 conv.set_tile(tile | (ks << 8))
 x = torch.randint(0, 127, (B, hin, hin, cin), device="cuda").to(torch.uint8 if in_dt == L.U8 else torch.int8)
 y = conv.new_output()

@@ -331,6 +331,19 @@ def test_pooling_f32_vs_oracle():
     assert np.array_equal(host(S.pooling_f32(dev(x), None, None, None, 1, global_pooling=True)), want)
 
 
+def test_pooling_f32_from_i8_equals_dequant_then_pool():
+    rng = np.random.default_rng(33)
+    for dt, mk in ((O.S8, lambda s: rng.integers(-128, 128, s).astype(np.int8)),
+                   (O.U8, lambda s: rng.integers(0, 256, s).astype(np.uint8))):
+        x = mk((3, 7, 7, 2048))
+        want = O.pool_f32_nchw(O.dequant_nhwc_to_nchw(x, 0.37), None, None, None, 1, global_pool=True)
+        got = host(S.pooling_f32_from_i8(dev(x), 0.37, None, None, None, 1, global_pooling=True))
+        assert np.array_equal(got, want)
+        x = mk((2, 13, 13, 24))
+        want = O.pool_f32_nchw(O.dequant_nhwc_to_nchw(x, 0.05), (3, 3), (2, 2), (1, 1), 0)
+        assert np.array_equal(host(S.pooling_f32_from_i8(dev(x), 0.05, (3, 3), (2, 2), (1, 1), 0)), want)
+
+
 def test_fc_vs_oracle():
     rng = np.random.default_rng(41)
     M, N, K = 8, 1000, 2048

@@ -69,3 +69,11 @@ def test_conv_i8_properties():
     rp = O.Residual(O.RES_ELTWISE, 1, 0.0, O.S8, 20.0, 20.0, 0.05, 0.07)
     fused = O.conv_i8(x1, wq, None, scale, O.S8, 0, (1, 1), residual=rp, res=res)
     assert np.array_equal(two_op, fused)
+
+
+def test_round_identity_exhaustive():
+    """The device epilogues compute roundf as trunc(x + copysign(0.49999997, x)); exact for all |x| < 2^23."""
+    import ctypes
+    lib = O.lib()
+    lib.orc_check_round_identity.restype = ctypes.c_long
+    assert lib.orc_check_round_identity() == 0
