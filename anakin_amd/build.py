@@ -51,5 +51,27 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_cpp_tests(verbose=False):
+    """tests/cpp/*.cpp -> tests/cpp/*.bin, linked against the HIP library and the oracle library (the test's checker)."""
+    import glob
+    root = os.path.dirname(HERE)
+    build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "oracle"])
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    outs = []
+    for src in sorted(glob.glob(os.path.join(root, "tests", "cpp", "*.cpp"))):
+        out = src[:-4] + ".bin"
+        deps = [src, os.path.join(root, "include", "saber_mi355x.hpp"), os.path.join(root, "include", "saber_hip.h"), LIB]
+        if _stale(out, deps):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-o", out,
+                   "-L" + HERE, "-lsaber_mi355x", "-L" + os.path.join(root, "oracle"), "-lsaber_oracle",
+                   "-Wl,-rpath,$ORIGIN/../../anakin_amd", "-Wl,-rpath,$ORIGIN/../../oracle", "-Wno-unused-result"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -330,10 +330,61 @@ __global__ __launch_bounds__(256) void pool2d_i8_nhwc_kernel(int n, int h, int w
         }
     }
 }
+
+// Max pooling, channel count a multiple of 16: one lane per (output pixel, 16 channels), 16-byte loads,
+// byte-wise max as packed 16-bit maxima of the even / odd bytes (s8 is mapped to u8 order by XOR 0x80).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    const us2 r = __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+    return __builtin_bit_cast(unsigned, r);
+}
+__global__ __launch_bounds__(256) void maxpool_i8_nhwc_vec16_kernel(int n, int h, int w, int c, int oh, int ow, int kh,
+                                                                    int kw, int sh, int sw, int ph, int pw, int in_u8,
+                                                                    const uint4* __restrict__ x, uint4* __restrict__ y) {
+    const int cg = c >> 4;
+    const size_t total = (size_t)n * oh * ow * cg;
+    const unsigned flip = in_u8 ? 0u : 0x80808080u;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        const int g = (int)(gid % cg);
+        size_t r = gid / cg;
+        const int ox = (int)(r % ow);
+        r /= ow;
+        const int oy = (int)(r % oh);
+        const int img = (int)(r / oh);
+        int hs = oy * sh - ph, ws = ox * sw - pw;
+        int he = hs + kh, we = ws + kw;
+        hs = hs < 0 ? 0 : hs;
+        ws = ws < 0 ? 0 : ws;
+        he = he > h ? h : he;
+        we = we > w ? w : we;
+        unsigned ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};   // running maxima of even / odd bytes (u8 order)
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) {
+                const uint4 v = x[(((size_t)img * h + iy) * w + ix) * cg + g];
+                const unsigned d[4] = {v.x ^ flip, v.y ^ flip, v.z ^ flip, v.w ^ flip};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ev[t] = pk_max_u16(ev[t], d[t] & 0x00ff00ffu);
+                    od[t] = pk_max_u16(od[t], (d[t] >> 8) & 0x00ff00ffu);
+                }
+            }
+        uint4 o;
+        o.x = (ev[0] | (od[0] << 8)) ^ flip;
+        o.y = (ev[1] | (od[1] << 8)) ^ flip;
+        o.z = (ev[2] | (od[2] << 8)) ^ flip;
+        o.w = (ev[3] | (od[3] << 8)) ^ flip;
+        y[(((size_t)img * oh + oy) * ow + ox) * cg + g] = o;
+    }
+}
 hipError_t launch_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw,
                                  int ph, int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
                                  hipStream_t s) {
     if (type == 0 && out_dtype == DT_F32) return hipErrorInvalidValue;  // as the reference (pooling kernel :425)
+    if (type == 0 && (c & 15) == 0 && in_dtype == out_dtype) {
+        hipLaunchKernelGGL(maxpool_i8_nhwc_vec16_kernel, dim3(grid_for((size_t)n * oh * ow * (c >> 4))), dim3(256), 0, s,
+                           n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, in_dtype == DT_U8, (const uint4*)x, (uint4*)y);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)n * oh * ow * ((c + 3) >> 2);
     hipLaunchKernelGGL(pool2d_i8_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, n, h, w, c, oh, ow, kh, kw,
                        sh, sw, ph, pw, type, in_dtype == DT_U8, out_dtype, (const uint8_t*)x, y);
