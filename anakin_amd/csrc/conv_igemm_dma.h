@@ -154,6 +154,12 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
         }
     };
 
+    // per-channel epilogue constants: requested BEFORE the reduction loop so their latency is hidden behind it
+    const int frow = lane & 15, fq = lane >> 4;
+    const int kb = k_base + wm * (TM * 16) + fq * NV;
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
+
     acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -164,7 +170,6 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
     const int pre = steps < NS - 1 ? steps : NS - 1;
     for (int s = 0; s < pre; ++s) issue_stage(s);
 
-    const int frow = lane & 15, fq = lane >> 4;
     const unsigned xmask = (!F32 && a.in_u8) ? 0x80808080u : 0u;
     for (int s = 0; s < steps; ++s) {
         // stages s+1 .. min(s+NS-2, steps-1) may stay in flight
@@ -217,9 +222,6 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
     }
 
     // ---- epilogue (identical to the register-staged kernel) ---------------------------------------
-    const int kb = k_base + wm * (TM * 16) + fq * NV;
-    ChanParams<NV> cp;
-    load_chan_params<NV>(a, kb, cp);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int p = pix_base + (wn * TN + j) * 16 + frow;

@@ -434,6 +434,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         }
     };
 
+    // per-channel epilogue constants: requested BEFORE the reduction loop so their latency is hidden behind it
+    const int frow = lane & 15, fq = lane >> 4;
+    const int kb = k_base + wm * (TM * 16) + fq * NV;
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
+
     acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -444,7 +450,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     store_stage(0);
     __syncthreads();
 
-    const int frow = lane & 15, fq = lane >> 4;
     // LDS row of the weight tile feeding MFMA tile i (rows were permuted when staged)
     int wrow[TM];
 #pragma unroll
@@ -473,9 +478,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
 
     // ---- epilogue: lane owns channels kb .. kb+NV-1 of pixels p(j) -------------------------------
-    const int kb = k_base + wm * (TM * 16) + fq * NV;
-    ChanParams<NV> cp;
-    load_chan_params<NV>(a, kb, cp);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int p = pix_base + (wn * TN + j) * 16 + frow;

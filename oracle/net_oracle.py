@@ -7,10 +7,28 @@ from . import oracle as O
 F32, S8, U8 = O.F32, O.S8, O.U8
 
 
-def run_int8(model, scales, x, keep=True):
+def prepare_int8(model):
+    """Cold path, once per model: per-layer weight scales + quantised weights (the `init` work of the ops)."""
+    prep = {}
+    for l in model["spec"]:
+        if l["kind"] in ("conv", "fc"):
+            w, _ = model["params"][l["name"]]
+            ws = O.weight_scales(w)
+            prep[l["name"]] = (ws, O.quant_weights(w, ws))
+    return prep
+
+
+def set_threads(n):
+    """OpenMP thread count of the oracle library (bench.py cpu_baseline states the number it used)."""
+    import ctypes
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+def run_int8(model, scales, x, keep=True, prep=None):
     """x: f32 NCHW batch. Returns {edge name: numpy tensor} (8-bit edges NHWC) following exactly the
     unfused reference op list (graph.cpp:423-436: conv+eltwise fusion is off for INT8)."""
     scales = dict(scales)
+    prep = prep if prep is not None else prepare_int8(model)
     t = {"data": x}
     dt = {"data": F32}
     for l in model["spec"]:
@@ -24,8 +42,7 @@ def run_int8(model, scales, x, keep=True):
             else:
                 in_dt = dt[l["src"]]
             odt = U8 if l["relu"] else S8
-            ws = O.weight_scales(w)
-            wq = O.quant_weights(w, ws)
+            ws, wq = prep[nm]
             bp, sc = O.conv_i8_prepare(ws, b, scales[l["src"]], scales[nm], in_dt, odt)
             t[nm] = O.conv_i8(src, wq, bp, sc, odt, l["relu"], (l["pad"],) * 2, (l["stride"],) * 2)
             dt[nm] = odt
@@ -43,8 +60,7 @@ def run_int8(model, scales, x, keep=True):
             dt[nm] = F32
         elif kd == "fc":
             w, b = model["params"][nm]
-            ws = O.weight_scales(w)
-            wq = O.quant_weights(w, ws)
+            ws, wq = prep[nm]
             xin = t[l["src"]].reshape(t[l["src"]].shape[0], -1)
             xq = O.quant_flat_s8(xin, scales[l["src"]])
             t[nm] = O.fc_i8(xq, wq, ws, scales[l["src"]], b)
