@@ -32,7 +32,8 @@ def resnet_spec(depth=50):
         cout = mid * 4
         for bi in range(nb):
             stride = 2 if (bi == 0 and si > 0) else 1
-            tag = "res%d%s" % (si + 2, chr(ord("a") + bi) if nb <= 26 else "b%d" % bi)
+            # Caffe naming: res4a, res4b, ... for short stages; res4a, res4b1 .. res4b22 for ResNet101's long stage
+            tag = "res%d%s" % (si + 2, chr(ord("a") + bi) if nb <= 6 else ("a" if bi == 0 else "b%d" % bi))
             if bi == 0:
                 L.append(dict(kind="conv", name=tag + "_branch1", src=prev, cin=cin, cout=cout, k=1, stride=stride,
                               pad=0, relu=False))

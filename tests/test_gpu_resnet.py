@@ -71,3 +71,36 @@ def test_resnet50_fp32_within_tolerance():
     assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
     mid = _h(net.tensor("res2a_branch2b")).transpose(0, 3, 1, 2)
     assert np.abs(mid - ref["res2a_branch2b"]).max() <= 1e-4 * np.abs(ref["res2a_branch2b"]).max()
+
+
+def test_resnet101_int8_logits_bit_exact():
+    """BASELINE.json config 4 (ResNet101 INT8): 104 convs, same op kinds; logits must match the oracle exactly."""
+    model = W.build_model("resnet101")
+    x = W.make_input(1, hw=96)
+    scales = W.calibrate(model, x)
+    ref = NO.run_int8(model, scales, x)
+    net = W.build_int8_net(model, dict(scales), 1, fuse_eltwise=True, hw=96)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    assert np.array_equal(_h(net.tensor("fc1000")), ref["fc1000"])
+    assert np.array_equal(_h(net.tensor("res4b22")), ref["res4b22"])
+
+
+def test_vgg16_fp32_within_tolerance():
+    """BASELINE.json config 4 (VGG16 FP32): 13 3x3 convs + 5 max pools + 3 FC, FP32 NHWC on the device."""
+    model = W.build_model("vgg16")
+    x = W.make_input(1, hw=224)
+    net = W.build_fp32_net(model, 1, hw=224)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    # oracle for the first two conv layers + pool (the full 15.5 GMAC naive pass is too slow for a unit test)
+    from oracle import oracle as O
+    w1, b1 = model["params"]["conv1"]
+    w2, b2 = model["params"]["conv2"]
+    y1 = O.conv_f32_nchw(x, w1, b1, True, (1, 1))
+    y2 = O.conv_f32_nchw(y1, w2, b2, True, (1, 1))
+    p1 = O.pool_f32_nchw(y2, (2, 2), (2, 2), (0, 0), 0)
+    got = _h(net.tensor("pool1")).transpose(0, 3, 1, 2)
+    assert np.abs(got - p1).max() <= 1e-4 * np.abs(p1).max()
+    prob = _h(net.tensor("prob"))
+    assert prob.shape == (1, 1000) and abs(float(prob.sum()) - 1.0) < 1e-4 and np.isfinite(prob).all()
