@@ -745,6 +745,8 @@ struct NetOp {
     saber_hip_conv* conv = nullptr;
     saber_hip_fc* fc = nullptr;
     int in = -1, in2 = -1, out = -1;
+    int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
+    bool record = false;     // an op on the other lane consumes this op's output: record an event after it
     int p[16] = {0};
     float f[6] = {0};
     size_t count = 0;
@@ -760,6 +762,12 @@ struct saber_hip_net {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool finalized = false;
+    // two-lane execution: independent branches (ResNet branch1 vs branch2a/2b) run on a side stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_op;     // one per op that needs to publish its output to the other lane
+    std::vector<int> writer;           // tensor id -> index of the op that last wrote it (-1: external)
+    bool lanes_ready = false, has_side = false;
 };
 
 static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
@@ -922,12 +930,74 @@ int saber_hip_net_num_ops(const saber_hip_net_t* net) { return (int)net->ops.siz
 const char* saber_hip_net_op_name(const saber_hip_net_t* net, int i) {
     return (i >= 0 && i < (int)net->ops.size()) ? net->ops[i].name.c_str() : "";
 }
+static int net_prepare_lanes(saber_hip_net* net) {
+    if (net->lanes_ready) return SABER_HIP_OK;
+    const int nops = (int)net->ops.size();
+    net->writer.assign(net->tensor_bytes.size(), -1);
+    net->ev_op.assign(nops, nullptr);
+    net->has_side = false;
+    std::vector<int> w(net->tensor_bytes.size(), -1);
+    for (int i = 0; i < nops; ++i) {
+        NetOp& o = net->ops[i];
+        if (o.lane) net->has_side = true;
+        const int ins[3] = {o.in, o.in2, o.out};   // `out` counts as an input: in-place epilogues read it
+        for (int t : ins)
+            if (t >= 0 && w[t] >= 0 && net->ops[w[t]].lane != o.lane) net->ops[w[t]].record = true;
+        w[o.out] = i;
+    }
+    if (net->has_side) {
+        HIP_TRY(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&net->ev_start, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+        for (int i = 0; i < nops; ++i)
+            if (net->ops[i].record) HIP_TRY(hipEventCreateWithFlags(&net->ev_op[i], hipEventDisableTiming));
+    }
+    net->lanes_ready = true;
+    return SABER_HIP_OK;
+}
+
 int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
     if (!net->finalized) return fail(SABER_HIP_INVALID_VALUE, "net not finalized");
-    for (const NetOp& o : net->ops) {
-        int rc = net_launch(net, o, (hipStream_t)stream);
-        if (rc) return rc;
+    int rc = net_prepare_lanes(net);
+    if (rc) return rc;
+    hipStream_t main_s = (hipStream_t)stream;
+    if (!net->has_side) {
+        for (const NetOp& o : net->ops) {
+            rc = net_launch(net, o, main_s);
+            if (rc) return rc;
+        }
+        return SABER_HIP_OK;
     }
+    // fork: the side lane starts after everything already queued on the caller's stream
+    HIP_TRY(hipEventRecord(net->ev_start, main_s));
+    HIP_TRY(hipStreamWaitEvent(net->side, net->ev_start, 0));
+    std::fill(net->writer.begin(), net->writer.end(), -1);
+    bool side_dirty = false;
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        const NetOp& o = net->ops[i];
+        hipStream_t s = o.lane ? net->side : main_s;
+        const int ins[3] = {o.in, o.in2, o.out};
+        for (int t : ins) {
+            if (t < 0) continue;
+            const int wi = net->writer[t];
+            if (wi >= 0 && net->ops[wi].lane != o.lane) HIP_TRY(hipStreamWaitEvent(s, net->ev_op[wi], 0));
+        }
+        rc = net_launch(net, o, s);
+        if (rc) return rc;
+        if (o.record) HIP_TRY(hipEventRecord(net->ev_op[i], s));
+        if (o.lane) side_dirty = true;
+        net->writer[o.out] = (int)i;
+    }
+    if (side_dirty) {   // join: required before a capture ends, and so that the caller sees one ordered stream
+        HIP_TRY(hipEventRecord(net->ev_join, net->side));
+        HIP_TRY(hipStreamWaitEvent(main_s, net->ev_join, 0));
+    }
+    return SABER_HIP_OK;
+}
+int saber_hip_net_set_lane(saber_hip_net_t* net, int index, int lane) {
+    if (index < 0 || index >= (int)net->ops.size() || lane < 0 || lane > 1) return fail(SABER_HIP_INVALID_VALUE, "bad op index / lane");
+    if (net->lanes_ready) return fail(SABER_HIP_INVALID_VALUE, "lanes are fixed after the first run");
+    net->ops[index].lane = lane;
     return SABER_HIP_OK;
 }
 int saber_hip_net_run_op(saber_hip_net_t* net, int index, saber_hip_stream_t stream) {
@@ -997,6 +1067,11 @@ void saber_hip_net_destroy(saber_hip_net_t* net) {
     if (net->exec) (void)hipGraphExecDestroy(net->exec);
     if (net->graph) (void)hipGraphDestroy(net->graph);
     if (net->arena) (void)hipFree(net->arena);
+    for (hipEvent_t e : net->ev_op)
+        if (e) (void)hipEventDestroy(e);
+    if (net->ev_start) (void)hipEventDestroy(net->ev_start);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->side) (void)hipStreamDestroy(net->side);
     delete net;
 }
 

@@ -33,7 +33,7 @@ SYMBOLS = [
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
-    "saber_hip_net_add_pool_f32_from_i8", "saber_hip_net_add_softmax", "saber_hip_net_finalize", "saber_hip_net_tensor_ptr",
+    "saber_hip_net_add_pool_f32_from_i8", "saber_hip_net_add_softmax", "saber_hip_net_set_lane", "saber_hip_net_finalize", "saber_hip_net_tensor_ptr",
     "saber_hip_net_arena_bytes", "saber_hip_net_num_ops", "saber_hip_net_run", "saber_hip_net_run_op",
     "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_op_name",
     "saber_hip_net_autotune", "saber_hip_net_destroy",
@@ -125,6 +125,7 @@ def load():
     lib.saber_hip_net_add_pool_f32.argtypes = [P] + [I] * 16
     lib.saber_hip_net_add_pool_f32_from_i8.argtypes = [P] + [I] * 14 + [F, I, I]
     lib.saber_hip_net_add_softmax.argtypes = [P, I, I, I, I]
+    lib.saber_hip_net_set_lane.argtypes = [P, I, I]
     lib.saber_hip_net_finalize.argtypes = [P]
     lib.saber_hip_net_tensor_ptr.argtypes = [P, I]
     lib.saber_hip_net_tensor_ptr.restype = P

@@ -365,6 +365,9 @@ class Net:
     def add_softmax(self, rows, cols, x, y):
         return self._chk(L.load().saber_hip_net_add_softmax(self.h, rows, cols, self.tid(x), self.tid(y)))
 
+    def set_lane(self, op_index, lane):
+        L.check(L.load().saber_hip_net_set_lane(self.h, op_index, lane))
+
     def finalize(self):
         L.check(L.load().saber_hip_net_finalize(self.h))
         self.finalized = True

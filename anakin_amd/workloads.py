@@ -175,7 +175,7 @@ def _out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224):
+def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules)."""
     from . import lib as L
     from . import saber as S
@@ -200,7 +200,9 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224):
             conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[l["src"]], odt, scales[l["src"]], scales[nm],
                                             in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
             net.add_tensor(nm, (B, ho, ho, l["cout"]), odt)
-            net.add_conv(conv, l["src"], nm)
+            idx = net.add_conv(conv, l["src"], nm)
+            if lanes and nm.endswith("_branch1"):
+                net.set_lane(idx, 1)   # the shortcut projection is independent of branch2a/2b: side lane
         elif kd == "pool":
             hin, c = shape[l["src"]]
             ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"])

@@ -218,6 +218,10 @@ int saber_hip_net_add_pool_f32_from_i8(saber_hip_net_t* net, int n, int h, int w
                                        int kw, int stride_h, int stride_w, int pad_h, int pad_w, int pool_type,
                                        int in_dtype, float scale, int in_id, int out_id);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
+/* Lane of an op (graph::Lane, framework/core/net/operator_func.h:103-114; ParallScheduler): 0 = the caller's
+ * stream, 1 = the net's side stream. Cross-lane tensor dependencies are ordered with events automatically and
+ * become parallel branches of the captured hipGraph. Must be set before the first run. */
+int saber_hip_net_set_lane(saber_hip_net_t* net, int op_index, int lane);
 /* Allocates every edge tensor + the shared workspace (one hipMalloc arena). */
 int saber_hip_net_finalize(saber_hip_net_t* net);
 void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id);

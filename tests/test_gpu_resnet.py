@@ -30,7 +30,7 @@ def _h(t):
 @pytest.mark.parametrize("fuse", [False, True])
 def test_resnet50_int8_every_edge_bit_exact(setup, fuse):
     model, x, scales, ref = setup
-    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=fuse)
+    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=fuse, lanes=fuse)   # the fused case also exercises two-lane execution
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     checked = 0
