@@ -79,6 +79,7 @@ struct saber_hip_conv {
     int tile = TILE_64x64;
     int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
     int dma = 0;             // 0: register-staged kernel; 1/2/4: LDS-DMA ring kernel with that many wave groups
+    int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
     int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
@@ -138,12 +139,20 @@ static void choose_tile(saber_hip_conv* op) {
     }
 }
 
+static bool halo_ok(const saber_hip_conv* op) {
+    const saber_hip_conv_desc& d = op->d;
+    return op->algo == ALGO_IGEMM_I8 && op->epi == EPI_I8_CONV && d.kh == 3 && d.kw == 3 && d.stride_h == 1 &&
+           d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 && d.group == 1 && op->c_eff % 64 == 0 && d.pad_h <= 1 &&
+           d.pad_w <= 1;
+}
+
 static void name_algo(saber_hip_conv* op) {
     static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
     char buf[64];
-    if (op->algo <= ALGO_IGEMM_F32)
+    if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
+    else if (op->algo <= ALGO_IGEMM_F32)
         snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
                  op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")));
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
@@ -263,6 +272,13 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     const int ks = (tile >> 8) & 0xff;
     const int var = (tile >> 16) & 0xff;
     tile &= 0xff;
+    if (var == 5 || var == 6) {   // LDS-halo 3x3 kernel, 4 / 8 tile rows
+        if (!halo_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "halo kernel needs an INT8 3x3 stride-1 conv with C % 64 == 0");
+        op->halo = var == 5 ? 4 : 8;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
+    if (var) op->halo = 0;
     if (var > 4 || (var >= 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
     if ((var >= 3 && ((ks ? ks : op->ks) != 4 || tile > TILE_64x64)) || (var == 4 && tile != TILE_32x32))
         return fail(SABER_HIP_INVALID_VALUE, "wave groups need stage depth 4 and a tile <= 64x64 (32x32 for 4 groups)");
@@ -275,6 +291,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
+    if (op->halo) return op->tile | (op->ks << 8) | ((op->halo == 4 ? 5 : 6) << 16);
     const int var = op->dma == 0 ? 1 : (op->dma == 1 ? 2 : (op->dma == 2 ? 3 : 4));
     return op->tile | (op->ks << 8) | (var << 16);
 }
@@ -465,6 +482,10 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     fill_args(op, a, xin, y, res);
     switch (op->algo) {
     case ALGO_IGEMM_I8:
+        if (op->halo) {
+            HIP_TRY(launch_conv3x3_halo(op->halo, a, s));
+            break;
+        }
         HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
         break;
     case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s)); break;
@@ -492,6 +513,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     HIP_TRY(hipEventCreate(&e1));
     float best = 1e30f;
     int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
+    op->halo = 0;
     const int ks_list[3] = {1, 2, 4};
     const int dma_list[4] = {0, 1, 2, 4};
     const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 4;
@@ -520,6 +542,25 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
             }
         }
     }
+    int best_halo = 0;
+    if (halo_ok(op)) {
+        for (int th = 4; th <= 8; th += 4) {
+            op->halo = th;
+            int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(e0, s));
+            for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
+            HIP_TRY(hipEventRecord(e1, s));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) {
+                best = ms;
+                best_halo = th;
+            }
+        }
+    }
+    op->halo = best_halo;
     op->dma = best_dma;
     op->ks = best_ks;
     op->tile = best_tile;

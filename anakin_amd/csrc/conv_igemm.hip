@@ -30,6 +30,11 @@ DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(1, 0) DECL(1, 1) DECL(1, 2) DEC
 DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(2, 3)
 #undef DECL
 
+hipError_t launch_halo_e0(int th, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_halo_e1(int th, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_halo_e2(int th, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_halo_e3(int th, const ConvKArgs& a, hipStream_t s);
+
 static int epilogue_kind(int mode, const ConvKArgs& a) {
     int ek = 3;
     if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE) {
@@ -38,6 +43,15 @@ static int epilogue_kind(int mode, const ConvKArgs& a) {
         else if (a.out_dtype == DT_S8) ek = 0;
     }
     return ek;
+}
+
+hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s) {
+    switch (epilogue_kind(0, a)) {
+    case 0: return launch_halo_e0(th, a, s);
+    case 1: return launch_halo_e1(th, a, s);
+    case 2: return launch_halo_e2(th, a, s);
+    default: return launch_halo_e3(th, a, s);
+    }
 }
 
 hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s) {

@@ -53,6 +53,8 @@ void tile_dims(int tile, int* bm_k, int* bn_pix);
 hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s);
 // LDS-DMA ring variant (modes 0 and 2 only)
 hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
+// INT8 3x3 / stride 1 / dilation 1 / C % 64 == 0 with an LDS-resident input halo; th = 4 or 8 tile rows
+hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

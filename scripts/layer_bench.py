@@ -76,6 +76,19 @@ for (name, cin, hin, cout, k, stride, pad, in_dt, relu, elt) in LAYERS:
             e1.record()
             torch.cuda.synchronize()
             res[(L.TILES[tile] + ("r", "d", "d2", "d4")[var - 1], ks)] = e0.elapsed_time(e1) * 1000 / (3 * REP)
+    if k == 3 and stride == 1 and cin % 64 == 0:
+        for var, nm in ((5, "halo4"), (6, "halo8")):
+            conv.set_tile(var << 16)
+            net.capture()
+            net.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                net.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            res[(nm, 0)] = e0.elapsed_time(e1) * 1000 / (3 * REP)
     best = min(res, key=res.get)
     print("%-24s M=%6d K=%4d Kg=%5d  %.3f GMAC %.2f MB | best %s k%d %.2f us (%.0f GB/s, %.1f TOPS)" % (
         name, M, cout, cin * k * k, gmac, mbytes, best[0], best[1], res[best], mbytes / res[best] * 1e3,

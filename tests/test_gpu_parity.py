@@ -85,6 +85,43 @@ def test_conv_i8_golden_every_tile(name, tile, ks, var):
             assert np.array_equal(y, g["y"]), conv.algo()
 
 
+@pytest.mark.parametrize("var", [5, 6])   # LDS-halo 3x3 kernel, 4 / 8 tile rows
+@pytest.mark.parametrize("combo", [(O.U8, O.U8, 1), (O.S8, O.S8, 0), (O.U8, O.F32, 0), (O.U8, O.S8, 1)])
+@pytest.mark.parametrize("case", [(2, 56, 56, 64, 64, 1), (1, 28, 28, 128, 128, 1), (3, 14, 14, 256, 64, 1),
+                                  (2, 7, 7, 512, 128, 1), (1, 19, 21, 64, 72, 1), (1, 10, 9, 128, 64, 0)])
+def test_conv3x3_halo_vs_oracle(case, combo, var):
+    N, H, W, C, K, pad = case
+    idt, odt, relu = combo
+    rng = np.random.default_rng(abs(hash((case, combo))) % 2**31)
+    x = (rng.integers(0, 256, (N, H, W, C)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, W, C)).astype(np.int8))
+    w = (rng.standard_normal((K, C, 3, 3)) * np.sqrt(2.0 / (C * 9))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    in_scale, out_scale = 0.017, 0.041
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, odt)
+    want = O.conv_i8(x, wq, bp, sc, odt, relu, (pad, pad))
+    got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, 1, 1, 1, tile=var << 16)
+    assert conv.algo().startswith("halo3x3"), conv.algo()
+    assert got.dtype == want.dtype and np.array_equal(got, want), conv.algo()
+
+
+def test_conv3x3_halo_fused_eltwise():
+    rng = np.random.default_rng(14)
+    x = rng.integers(0, 256, (2, 28, 28, 128)).astype(np.uint8)
+    w = (rng.standard_normal((128, 128, 3, 3)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(128) * 0.5).astype(np.float32)
+    res = rng.integers(-128, 128, (2, 28, 28, 128)).astype(np.int8)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, 0.02, 0.05, O.U8, O.S8)
+    y1 = O.conv_i8(x, O.quant_weights(w, ws), bp, sc, O.S8, 0, (1, 1))
+    want = O.eltwise_i8(y1, res, 0.05, 0.043, 20.0, 20.0, True)
+    got, conv = run_conv_i8(x, w, None, b, 0.02, 0.05, O.S8, 0, 1, 1, 1, 1, tile=6 << 16,
+                            res_param=(L.RES_ELTWISE, True, 1.0, (20.0, 20.0), 0.043), res=res)
+    assert conv.algo().startswith("halo3x3") and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("var", [1, 2])
 @pytest.mark.parametrize("ks", [1, 2, 4])
 @pytest.mark.parametrize("tile", range(len(L.TILES)))
