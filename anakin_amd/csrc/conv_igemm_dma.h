@@ -171,6 +171,19 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
     for (int s = 0; s < pre; ++s) issue_stage(s);
 
     const unsigned xmask = (!F32 && a.in_u8) ? 0x80808080u : 0u;
+    // fragment chunk indices for this wave group's k-step 0; phys_chunk(row, c ^ (ks*4)) == phys_chunk(row, c) ^ (ks*4)
+    // because the group base (grp*KS*4, a multiple of 16 when WG > 1) and fq do not touch chunk bits 2..3
+    int a_idx[TM], b_idx[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 16 + frow;
+        a_idx[i] = row * CPR + phys_chunk<CPR>(row, grp * KS * 4 + fq);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 16 + frow;
+        b_idx[j] = (WROWS + row) * CPR + phys_chunk<CPR>(row, grp * KS * 4 + fq);
+    }
     for (int s = 0; s < steps; ++s) {
         // stages s+1 .. min(s+NS-2, steps-1) may stay in flight
         const int ahead = (steps - 1 - s) < (NS - 2) ? (steps - 1 - s) : (NS - 2);
@@ -182,14 +195,10 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
         for (int ks = 0; ks < KS; ++ks) {
             v4i af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 16 + frow;
-                af[i] = stage[row * CPR + phys_chunk<CPR>(row, (grp * KS + ks) * 4 + fq)];
-            }
+            for (int i = 0; i < TM; ++i) af[i] = stage[a_idx[i] ^ (ks << 2)];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + frow;
-                v4i v = stage[(WROWS + row) * CPR + phys_chunk<CPR>(row, (grp * KS + ks) * 4 + fq)];
+                v4i v = stage[b_idx[j] ^ (ks << 2)];
                 if (!F32) { v.x ^= xmask; v.y ^= xmask; v.z ^= xmask; v.w ^= xmask; }
                 bf[j] = v;
             }

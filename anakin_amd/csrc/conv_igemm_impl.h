@@ -455,19 +455,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) wrow[i] = (wm * TM + i) * 16 + frow;
 
+    // fragment chunk indices for k-step 0 (hoisted out of the loop; CPR >= 8 rows are multiples of 8 chunks,
+    // so XORing (ks << 2) into the index selects the k-step)
+    int a_idx[TM], b_idx[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_idx[i] = wrow[i] * CPR + phys_chunk<CPR>(wrow[i], fq);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 16 + frow;
+        b_idx[j] = (BMK + row) * CPR + phys_chunk<CPR>(row, fq);
+    }
     for (int s = 0; s < a.steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < a.steps) load_stage(s + 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             v4i af[TM], bf[TN];
+            // phys_chunk(row, ks*4 + fq) == phys_chunk(row, fq) ^ (ks*4): the k-step only touches chunk bits 2..3
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = lds[buf][wrow[i] * CPR + phys_chunk<CPR>(wrow[i], ks * 4 + fq)];
+            for (int i = 0; i < TM; ++i) af[i] = lds[buf][a_idx[i] ^ (ks << 2)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + frow;
-                bf[j] = lds[buf][(BMK + row) * CPR + phys_chunk<CPR>(row, ks * 4 + fq)];
-            }
+            for (int j = 0; j < TN; ++j) bf[j] = lds[buf][b_idx[j] ^ (ks << 2)];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
