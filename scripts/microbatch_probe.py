@@ -1,0 +1,31 @@
+"""Probe: batch 8 as k concurrent micro-batch op lists on k streams (each its own hipGraph)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from anakin_amd import workloads as W
+
+model = W.build_model("resnet50")
+scales = W.calibrate(model, W.make_input(2))
+for k in (1, 2, 4):
+    b = 8 // k
+    nets, streams = [], []
+    for i in range(k):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            net = W.build_int8_net(model, dict(scales), b)
+            net.tensor("data").copy_(torch.from_numpy(W.make_input(b, seed=i)).cuda())
+            net.run(); net.autotune(iters=10); net.capture()
+        nets.append(net); streams.append(s)
+    torch.cuda.synchronize()
+    def step():
+        for net, s in zip(nets, streams):
+            with torch.cuda.stream(s):
+                net.replay()
+    for _ in range(20): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 300
+    for _ in range(n): step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("micro-batches=%d x batch %d: %.4f ms per 8 images -> %.0f images/s" % (k, b, dt * 1e3, 8 / dt))

@@ -104,3 +104,25 @@ def test_vgg16_fp32_within_tolerance():
     assert np.abs(got - p1).max() <= 1e-4 * np.abs(p1).max()
     prob = _h(net.tensor("prob"))
     assert prob.shape == (1, 1000) and abs(float(prob.sum()) - 1.0) < 1e-4 and np.isfinite(prob).all()
+
+
+def test_resnet50_int8_batch_invariance_full_size(setup):
+    """Size-independent property at BASELINE's full batch-8 size: every op on the path is per-image, so
+    image i of a batch-8 run (autotuned tiles, hipGraph) must equal the batch-1 run of the same image bit
+    for bit, and both must equal the oracle's logits for the images it was run on."""
+    model, x2, scales, ref = setup
+    x8 = np.concatenate([x2, W.make_input(6, seed=99)], 0)
+    net8 = W.build_int8_net(model, dict(scales), 8)
+    net8.tensor("data").copy_(torch.from_numpy(x8).cuda())
+    net8.run()
+    net8.autotune(iters=3)
+    net8.tensor("data").copy_(torch.from_numpy(x8).cuda())
+    net8.capture()
+    net8.replay()
+    l8 = _h(net8.tensor("fc1000")).copy()
+    assert np.array_equal(l8[:2], ref["fc1000"])          # the two images the oracle ran
+    net1 = W.build_int8_net(model, dict(scales), 1)
+    for i in (0, 5, 7):
+        net1.tensor("data").copy_(torch.from_numpy(x8[i:i + 1]).cuda())
+        net1.run()
+        assert np.array_equal(_h(net1.tensor("fc1000"))[0], l8[i]), i
