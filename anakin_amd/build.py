@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libsaber_mi355x.so")
 SOURCES = ["conv_igemm.hip", "elementwise.hip", "api.hip"] + \
     ["igemm_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (1, 3), (2, 3)]] + \
     ["igemm_dma_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (2, 3)]] + \
-    ["halo_e%d.hip" % e for e in range(4)]
+    ["halo_e%d.hip" % e for e in range(4)] + ["stem_e%d.hip" % e for e in range(4)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-result"]
 
@@ -28,7 +28,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv_igemm_impl.h"), os.path.join(CSRC, "conv_igemm_dma.h"), os.path.join(CSRC, "conv3x3_halo.h"),
+    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv_igemm_impl.h"), os.path.join(CSRC, "conv_igemm_dma.h"), os.path.join(CSRC, "conv3x3_halo.h"), os.path.join(CSRC, "conv_stem.h"),
                os.path.join(HERE, "..", "include", "saber_hip.h")]
     objs = []
     procs = []

@@ -79,6 +79,7 @@ struct saber_hip_conv {
     int tile = TILE_64x64;
     int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
     int dma = 0;             // 0: register-staged kernel; 1/2/4: LDS-DMA ring kernel with that many wave groups
+    int stem = 0;            // 1: LDS-patch stem kernel (conv_stem.h) instead of the NHWC4 implicit GEMM
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
@@ -146,12 +147,19 @@ static bool halo_ok(const saber_hip_conv* op) {
            d.pad_w <= 1;
 }
 
+static bool stem_ok(const saber_hip_conv* op) {
+    const saber_hip_conv_desc& d = op->d;
+    return op->algo == ALGO_IGEMM_I8_C4 && op->epi == EPI_I8_CONV && d.kh == 7 && d.kw == 7 && d.stride_h == 2 &&
+           d.stride_w == 2 && d.dil_h == 1 && d.dil_w == 1 && d.group == 1;
+}
+
 static void name_algo(saber_hip_conv* op) {
     static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
     char buf[64];
-    if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
+    if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
+    else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
         snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
                  op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")));
@@ -248,6 +256,7 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
         op->Kg = d.kh * d.kw * op->c_eff;
         op->Kg_pad = round_up(op->Kg, 256);    // f32 elements: 1024 B
     }
+    op->stem = stem_ok(op) ? 1 : 0;
     choose_tile(op);
     {   // stage depth: as many 64-byte k-steps per barrier as the reduction has (max 4)
         const int kbytes = op->Kg * (op->algo == ALGO_IGEMM_F32 ? 4 : 1);
@@ -265,6 +274,8 @@ void saber_hip_conv2d_out_shape(const saber_hip_conv_t* op, int* oh, int* ow) {
 size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op) { return op->ws_bytes; }
 const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_name.c_str(); }
 
+static inline bool tile_arg_ks(int ks) { return ks == 1 || ks == 2 || ks == 4; }
+
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15,
     // optional staging variant in bits 16..23 (1 = register-staged, 2 = LDS-DMA ring, 3 / 4 = LDS-DMA ring
@@ -272,13 +283,25 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     const int ks = (tile >> 8) & 0xff;
     const int var = (tile >> 16) & 0xff;
     tile &= 0xff;
+    if (var == 7 || var == 8) {   // stem kernel on / off (first-layer path)
+        if (var == 7 && !stem_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "stem kernel needs an INT8 7x7 stride-2 conv with <= 4 channels");
+        op->stem = var == 7;
+        tile &= 0xff;
+        if (var == 8 && tile < TILE_COUNT) op->tile = tile;
+        if (var == 8 && ((tile_arg_ks(ks)))) op->ks = ks;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
     if (var == 5 || var == 6) {   // LDS-halo 3x3 kernel, 4 / 8 tile rows
         if (!halo_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "halo kernel needs an INT8 3x3 stride-1 conv with C % 64 == 0");
         op->halo = var == 5 ? 4 : 8;
         name_algo(op);
         return SABER_HIP_OK;
     }
-    if (var) op->halo = 0;
+    if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
+        op->halo = 0;
+        op->stem = 0;
+    }
     if (var > 4 || (var >= 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
     if ((var >= 3 && ((ks ? ks : op->ks) != 4 || tile > TILE_64x64)) || (var == 4 && tile != TILE_32x32))
         return fail(SABER_HIP_INVALID_VALUE, "wave groups need stage depth 4 and a tile <= 64x64 (32x32 for 4 groups)");
@@ -467,6 +490,15 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     hipStream_t s = (hipStream_t)stream;
     const saber_hip_conv_desc& d = op->d;
     const void* xin = x;
+    if (op->stem && op->pre_quant) {
+        // fused: the stem kernel reads the f32 NCHW image and quantises while staging its LDS patch
+        ConvKArgs a;
+        fill_args(op, a, x, y, res);
+        a.Cin = d.c;
+        a.qinv = 1.f / op->in_scale;
+        HIP_TRY(launch_conv_stem(1, a, s));
+        return SABER_HIP_OK;
+    }
     if (op->pre_quant) {
         HIP_TRY(launch_quantize_nchw_to_nhwc(d.n, d.c, d.h, d.w, op->c_eff, DT_S8, op->in_scale, (const float*)x,
                                              workspace, s));
@@ -488,7 +520,10 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
         }
         HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
         break;
-    case ALGO_IGEMM_I8_C4: HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s)); break;
+    case ALGO_IGEMM_I8_C4:
+        if (op->stem) HIP_TRY(launch_conv_stem(0, a, s));
+        else HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s));
+        break;
     case ALGO_IGEMM_F32:
         HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
         break;
@@ -514,6 +549,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     float best = 1e30f;
     int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
     op->halo = 0;
+    op->stem = 0;   // the tile sweep below times the implicit-GEMM path; the stem kernel is timed after it
     const int ks_list[3] = {1, 2, 4};
     const int dma_list[4] = {0, 1, 2, 4};
     const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 4;
@@ -542,6 +578,24 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
             }
         }
     }
+    int best_stem = 0;
+    op->stem = 0;
+    if (stem_ok(op)) {
+        op->stem = 1;
+        int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) {
+            best = ms;
+            best_stem = 1;
+        }
+        op->stem = 0;
+    }
     int best_halo = 0;
     if (halo_ok(op)) {
         for (int th = 4; th <= 8; th += 4) {
@@ -561,6 +615,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         }
     }
     op->halo = best_halo;
+    op->stem = best_stem;
     op->dma = best_dma;
     op->ks = best_ks;
     op->tile = best_tile;

@@ -35,6 +35,11 @@ hipError_t launch_halo_e1(int th, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_halo_e2(int th, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_halo_e3(int th, const ConvKArgs& a, hipStream_t s);
 
+hipError_t launch_stem_e0(int f32_in, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_stem_e1(int f32_in, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_stem_e2(int f32_in, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_stem_e3(int f32_in, const ConvKArgs& a, hipStream_t s);
+
 static int epilogue_kind(int mode, const ConvKArgs& a) {
     int ek = 3;
     if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE) {
@@ -43,6 +48,15 @@ static int epilogue_kind(int mode, const ConvKArgs& a) {
         else if (a.out_dtype == DT_S8) ek = 0;
     }
     return ek;
+}
+
+hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s) {
+    switch (epilogue_kind(1, a)) {
+    case 0: return launch_stem_e0(f32_in, a, s);
+    case 1: return launch_stem_e1(f32_in, a, s);
+    case 2: return launch_stem_e2(f32_in, a, s);
+    default: return launch_stem_e3(f32_in, a, s);
+    }
 }
 
 hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s) {

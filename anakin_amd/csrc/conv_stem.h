@@ -1,0 +1,160 @@
+// anakin_amd/csrc/conv_stem.h — the ResNet stem: INT8 7x7 / stride-2 convolution over a <=4-channel image
+// with the input tile resident in LDS and the f32 -> s8 quantisation of the reference's
+// "quantise on entry" (SaberConv2D<X86,AK_INT8>::dispatch -> reorder_nhwc_nchw, saber_conv.cpp:308,
+// saber_util.h:759-781) fused into the staging (gfx950).
+//
+// The implicit-GEMM first-layer path gathers every input pixel ~12 times (49 taps / stride^2) from global
+// memory, after a separate quantise kernel wrote the NHWC4 copy. Here a workgroup owns an 8 x 16 tile of
+// output pixels of one image and 64 output channels: it reads the 21 x 38 input patch once (f32 NCHW
+// planes, quantised on the fly: saturate(roundf(x * 1/scale)), packed as 4 bytes per pixel) into LDS
+// together with the 16 KiB of weights, then runs 4 MFMA k-steps (two filter rows of 8x4 bytes each) whose
+// B fragments are 16 contiguous LDS bytes at (2*py + i, 2*px + j). Same arithmetic and epilogues as
+// conv_igemm_impl.h; weights use the first-layer repack [K][kh][8][4].
+#pragma once
+#include "conv_igemm_impl.h"
+
+namespace saber_mi355x {
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <int EK, bool F32IN>
+__global__ __launch_bounds__(256) void conv_stem7x7s2_kernel(const ConvKArgs a) {
+    constexpr int TH = 8, TW = 16;
+    constexpr int IR = (TH - 1) * 2 + 7 + 1;        // 22 input rows (one spare: the zero-weight 8th filter row)
+    constexpr int ICP = 40;                         // input cols per LDS row ((TW-1)*2 + 8 = 38, padded to 40 -> 160 B)
+    constexpr int TM = 2, TN = 4, NV = 8;
+    constexpr int WCH = 64 * 16;                    // weight tile: 64 rows x 256 B
+
+    __shared__ v4i lds_w[WCH];
+    __shared__ unsigned lds_x[IR * ICP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    int ptile, tile_ky;
+    xcd_tile(a, ptile, tile_ky);
+    const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
+    const int per_img = tiles_x * tiles_y;
+    const int n = ptile / per_img;
+    const int trem = ptile - n * per_img;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+    const int k_base = tile_ky * 64;
+
+    const int kb = k_base + wm * 32 + fq * NV;
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
+
+    // ---- weights -> LDS (rows permuted for 8-byte stores, chunks swizzled: CPR = 16 layout) ------------
+    const v4i* w16 = (const v4i*)a.w;
+    const int w_row_chunks = a.Kg_pad >> 4;
+    v4i wv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 256;
+        wv[it] = w16[(size_t)(k_base + (idx >> 4)) * w_row_chunks + (idx & 15)];
+    }
+    // ---- input patch -> LDS, quantising on the way ---------------------------------------------------
+    const int iy0 = ty0 * 2 - a.pad_h, ix0 = tx0 * 2 - a.pad_w;
+    const unsigned xmask = a.in_u8 ? 0x80808080u : 0u;
+    for (int idx = tid; idx < IR * ICP; idx += 256) {
+        const int r = idx / ICP, c = idx - r * ICP;
+        const int iy = iy0 + r, ix = ix0 + c;
+        unsigned pk = 0;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+            if constexpr (F32IN) {
+                const float* xp = (const float*)a.x + ((size_t)n * a.Cin * a.H + iy) * a.W + ix;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    if (ch < a.Cin) {
+                        float v = __fmul_rn(xp[(size_t)ch * a.H * a.W], a.qinv);
+                        v = truncf(v + copysignf(0x1.fffffep-2f, v));          // roundf (conv_igemm_impl.h)
+                        v = v < -128.f ? -128.f : (v > 127.f ? 127.f : v);      // saturate<int8_t>
+                        pk |= ((unsigned)((int)v) & 0xffu) << (8 * ch);
+                    }
+                }
+            } else {
+                pk = ((const unsigned*)a.x)[((size_t)n * a.H + iy) * a.W + ix];
+            }
+        }
+        lds_x[idx] = pk ^ xmask;   // padding becomes -128 for u8 inputs (compensated through comp)
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 4, q = idx & 15;
+        const int rr = r & 31, wmr = r >> 5;
+        const int lrow = (wmr * 2 + ((rr >> 2) & 1)) * 16 + (rr >> 3) * 4 + (rr & 3);
+        lds_w[lrow * 16 + (q ^ (lrow & 15))] = wv[it];
+    }
+    __syncthreads();
+
+    v4i acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    int a_idx[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 16 + frow;
+        a_idx[i] = row * 16 + (fq ^ (row & 15));
+    }
+    // B fragment of k-step ks: filter row 2*ks + (fq>>1), taps 4*(fq&1) .. +3 -> 16 contiguous bytes
+    int b_off[TN];   // dword index of (row 2*py + (fq>>1), col 2*px + 4*(fq&1)) at ks = 0
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int py = wn * TN + j;
+        b_off[j] = (2 * py + (fq >> 1)) * ICP + 2 * frow + 4 * (fq & 1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        v4i af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = lds_w[a_idx[i] ^ (ks << 2)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const v2i* p = (const v2i*)&lds_x[b_off[j] + ks * 2 * ICP];   // 8-byte aligned (even dword index)
+            const v2i lo = p[0], hi = p[1];
+            bf[j] = v4i{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int oy = ty0 + wn * TN + j, ox = tx0 + frow;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const int p = (n * a.OH + oy) * a.OW + ox;
+        int v[NV];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+        if constexpr (EK == EK_GEN) {
+            epilogue_i8<NV>(a, v, cp, p, kb);
+        } else {
+            if (kb < a.K) {
+                if ((kb + NV <= a.K) && (a.K % NV == 0)) epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);
+                else epilogue_i8<NV>(a, v, cp, p, kb);
+            }
+        }
+    }
+}
+
+template <int EK>
+static hipError_t launch_conv_stem_inst(int f32_in, const ConvKArgs& a, hipStream_t s) {
+    ConvKArgs b = a;
+    b.npx = a.N * ((a.OW + 15) / 16) * ((a.OH + 7) / 8);
+    b.nky = (a.K + 63) / 64;
+    dim3 grid(b.npx * b.nky), block(256);
+    if (f32_in) hipLaunchKernelGGL((conv_stem7x7s2_kernel<EK, true>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((conv_stem7x7s2_kernel<EK, false>), grid, block, 0, s, b);
+    return hipGetLastError();
+}
+
+}  // namespace saber_mi355x

@@ -31,6 +31,8 @@ struct ConvKArgs {
     int Kg;       // real reduction length in elements (kh*kw*C, or kh*kw_pad*4 in C4 mode)
     int Kg_pad;   // padded to a multiple of one K-step
     int steps;    // number of pipeline stages = ceil(Kg / elements-per-stage)
+    int Cin;        // stem kernel with fused quantisation: channels of the f32 NCHW image (<= 4)
+    float qinv;     // ... and 1/in_scale
     int npx, nky;   // pixel tiles / out-channel tiles of the launch (1-D grid, XCD-aware tile order)
     float inv_ohw, inv_ow;  // 1/(OH*OW), 1/OW for the exact float-reciprocal div/mod
     int kw_pad;   // C4 mode: kw rounded up to 4
@@ -55,6 +57,8 @@ hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hip
 hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
 // INT8 3x3 / stride 1 / dilation 1 / C % 64 == 0 with an LDS-resident input halo; th = 4 or 8 tile rows
 hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s);
+// ResNet stem (7x7 stride 2, <= 4 channels) with the input patch in LDS; f32_in: fuse the quantise-on-entry
+hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

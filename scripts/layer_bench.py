@@ -76,6 +76,18 @@ for (name, cin, hin, cout, k, stride, pad, in_dt, relu, elt) in LAYERS:
             e1.record()
             torch.cuda.synchronize()
             res[(L.TILES[tile] + ("r", "d", "d2", "d4")[var - 1], ks)] = e0.elapsed_time(e1) * 1000 / (3 * REP)
+    if k == 7 and stride == 2 and cin <= 4:
+        conv.set_tile(7 << 16)
+        net.capture()
+        net.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            net.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        res[("stem", 0)] = e0.elapsed_time(e1) * 1000 / (3 * REP)
     if k == 3 and stride == 1 and cin % 64 == 0:
         for var, nm in ((5, "halo4"), (6, "halo8")):
             conv.set_tile(var << 16)

@@ -36,7 +36,7 @@ def run_conv_i8(x, w, w_scale, bias, in_scale, out_scale, out_dtype, relu, pad, 
     if res_param:
         p.res_mode, p.res_relu, p.sum_scale, p.coeff, p.scale_res = res_param
     conv = S.SaberConv2D(int8=True).init((N, Cc, H, W), p, O.code_of(x), out_dtype, in_scale, out_scale)
-    if tile is not None and conv.algo().startswith("igemm"):
+    if tile is not None and conv.algo().startswith(("igemm", "stem", "halo")):
         conv.set_tile(tile)
     y = conv.new_output()
     if y_init is not None:
@@ -211,6 +211,29 @@ def test_conv_i8_empty_and_invalid():
     lib.saber_hip_conv2d_destroy(h)
 
 
+@pytest.mark.parametrize("combo", [(O.S8, O.U8, 1), (O.U8, O.U8, 1), (O.S8, O.S8, 0), (O.U8, O.F32, 0)])
+@pytest.mark.parametrize("case", [(2, 64, 64, 3, 64, 3), (1, 37, 45, 4, 64, 3), (1, 30, 30, 1, 24, 2), (2, 224, 224, 3, 64, 3)])
+def test_conv_stem_vs_oracle(case, combo):
+    """The LDS-patch stem kernel (7x7 stride 2, <= 4 channels) against the oracle, and against the
+    implicit-GEMM first-layer path it replaces."""
+    N, H, W, C, K, pad = case
+    idt, odt, relu = combo
+    rng = np.random.default_rng(abs(hash((case, combo))) % 2**31)
+    x = (rng.integers(0, 256, (N, H, W, C)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, W, C)).astype(np.int8))
+    w = (rng.standard_normal((K, C, 7, 7)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, 0.017, 0.08, idt, odt)
+    want = O.conv_i8(x, O.quant_weights(w, ws), bp, sc, odt, relu, (pad, pad), (2, 2))
+    got, conv = run_conv_i8(x, w, None, b, 0.017, 0.08, odt, relu, pad, 2, 1, 1, tile=7 << 16)
+    assert conv.algo().startswith("stem7x7s2"), conv.algo()
+    assert np.array_equal(got, want)
+    got, conv = run_conv_i8(x, w, None, b, 0.017, 0.08, odt, relu, pad, 2, 1, 1, tile=8 << 16)
+    assert conv.algo().startswith("igemm_i8_c4"), conv.algo()
+    assert np.array_equal(got, want)
+
+
 def test_conv_i8_f32_input_quantises_on_entry():
     """SaberConv2D<X86,AK_INT8> handed an f32 NCHW tensor (first layer): reorder_nhwc_nchw then conv."""
     rng = np.random.default_rng(11)
@@ -226,7 +249,19 @@ def test_conv_i8_f32_input_quantises_on_entry():
     ws = O.weight_scales(w)
     bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, O.S8, O.U8)
     want = O.conv_i8(xq, O.quant_weights(w, ws), bp, sc, O.U8, 1, (3, 3), (2, 2))
+    assert conv.algo() == "stem7x7s2_i8_8x16_fusedquant"
     assert np.array_equal(host(y), want), conv.algo()
+    conv.set_tile(8 << 16)   # the unfused path: quantise kernel + NHWC4 implicit GEMM
+    y.zero_()
+    conv.dispatch(dev(x), y)
+    assert conv.algo().startswith("igemm_i8_c4") and np.array_equal(host(y), want)
+    # values exactly on .5 ties and beyond the int8 range quantise like reorder_nhwc_nchw
+    x2 = x.copy()
+    x2[0, :, 0, :6] = np.array([0.5, 1.5, -0.5, -2.5, 300.0, -300.0], np.float32) * np.float32(in_scale)
+    conv.set_tile(7 << 16)
+    conv.dispatch(dev(x2), y)
+    want2 = O.conv_i8(O.quant_nchw_to_nhwc(x2, in_scale, O.S8), O.quant_weights(w, ws), bp, sc, O.U8, 1, (3, 3), (2, 2))
+    assert np.array_equal(host(y), want2)
 
 
 @pytest.mark.parametrize("relu", [0, 1])
