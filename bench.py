@@ -238,9 +238,11 @@ def main():
                               "Xeon-6271 threads)" % (n_img, cores))
 
         out = {
-            "metric": "ResNet50 INT8 images/sec @ batch %d (p50 latency alongside), %dxMI355X" % (B, n_gpus)
-            if args.precision == "int8" and args.model == "resnet50" else
-            "%s %s images/sec @ batch %d" % (args.model, args.precision, B),
+            # BASELINE.json's metric: value = images/s at batch 8 per GPU; the p50 latencies at batch 8 and batch 1 are
+            # in latency_ms / batch1
+            "metric": "ResNet50 INT8 images/sec + p50 latency @ batch 1/8, %d\u00d7MI355X" % n_gpus
+            if args.precision == "int8" and args.model == "resnet50" and B == 8 else
+            "%s %s images/sec @ batch %d, %d\u00d7MI355X" % (args.model, args.precision, B, n_gpus),
             "value": round(value, 1), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,

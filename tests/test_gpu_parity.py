@@ -194,6 +194,23 @@ def test_conv_i8_saturation_both_ends(combo):
         assert (want == (255 if odt == O.U8 else 127)).any() or out_scale > 1
 
 
+def test_conv_i8_accumulators_beyond_2_pow_24():
+    """|acc| far above 2^24: (float)acc must round like the CPU's int->float conversion (RNE), for every kernel
+    family (implicit GEMM, LDS-DMA + wave groups, LDS-halo)."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(200, 256, (1, 7, 7, 512)).astype(np.uint8)
+    wq = rng.integers(100, 128, (64, 512, 3, 3)).astype(np.int8)
+    ws = np.full(64, 1e-3, np.float32)
+    acc = O.conv_i8_acc(x, wq, (1, 1))
+    assert np.abs(acc).max() > 5 * 2**24
+    for odt, out_scale in ((O.F32, 1.0), (O.S8, 900.0)):
+        bp, sc = O.conv_i8_prepare(ws, None, 1.0, out_scale, O.U8, odt)
+        want = O.conv_i8(x, wq, None, sc, odt, 0, (1, 1))
+        for tile in (None, 2 | (4 << 8) | (1 << 16), 0 | (4 << 8) | (4 << 16), 6 << 16):
+            got, conv = run_conv_i8(x, wq, ws, None, 1.0, out_scale, odt, 0, 1, 1, 1, 1, tile=tile)
+            assert np.array_equal(got, want), conv.algo()
+
+
 def test_conv_i8_empty_and_invalid():
     lib = L.load()
     import ctypes as C
