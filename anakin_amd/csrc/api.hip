@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace saber_mi355x;
@@ -56,6 +57,13 @@ struct DevBuf {
         n = h.size();
         return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
+    hipError_t alloc_zero(size_t count) {
+        release();
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) return e;
+        n = count;
+        return hipMemset(p, 0, count * sizeof(T));
+    }
 };
 
 // 256 zero bytes in device memory, shared by every op (padded taps of the LDS-DMA kernels)
@@ -99,6 +107,8 @@ struct saber_hip_conv {
     DevBuf<int> d_comp;
     bool has_bias = false, has_comp = false;
     std::string algo_name;
+    // sibling pair (saber_hip_conv2d_create_pair): d.k = k1 + k2, rows >= k1 belong to the second conv
+    int pair_k1 = 0, pair_k2 = 0, pair_relu2 = 0, pair_dtype2 = 0;
 };
 
 struct saber_hip_fc {
@@ -164,7 +174,7 @@ static void name_algo(saber_hip_conv* op) {
         snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
                  op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")));
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
-    op->algo_name = buf;
+    op->algo_name = std::string(op->pair_k2 ? "pair_" : "") + buf;
 }
 
 int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** out) {
@@ -293,7 +303,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         return SABER_HIP_OK;
     }
     if (var == 5 || var == 6) {   // LDS-halo 3x3 kernel, 4 / 8 tile rows
-        if (!halo_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "halo kernel needs an INT8 3x3 stride-1 conv with C % 64 == 0");
+        if (!halo_ok(op) || op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "halo kernel needs an INT8 3x3 stride-1 conv with C % 64 == 0");
         op->halo = var == 5 ? 4 : 8;
         name_algo(op);
         return SABER_HIP_OK;
@@ -443,7 +453,8 @@ int saber_hip_conv2d_get_quantized_weights(const saber_hip_conv_t* op, int8_t* w
     return SABER_HIP_OK;
 }
 
-static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, void* y, const void* res) {
+static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, void* y, const void* res,
+                      void* y2 = nullptr) {
     const saber_hip_conv_desc& d = op->d;
     std::memset(&a, 0, sizeof a);
     a.x = x;
@@ -475,6 +486,8 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.sum_scale = d.sum_scale;
     a.coeff_conv = d.coeff_conv; a.coeff_res = d.coeff_res;
     a.scale_conv = op->out_scale; a.scale_res = d.scale_res;
+    a.y2 = y2;
+    a.K1 = op->pair_k1; a.K2 = op->pair_k2; a.relu2 = op->pair_relu2; a.out_dtype2 = op->pair_dtype2;
     if (!op->is_i8 && d.res_mode == SABER_HIP_RES_SUM_INPLACE) {
         // out = act(conv + bias + y): the activation belongs to the eltwise when fused
         a.relu = (d.res_act == SABER_HIP_ACT_RELU) || (d.act == SABER_HIP_ACT_RELU);
@@ -487,6 +500,7 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     if (!op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "set_weights not called");
     if (op->ws_bytes && !workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
     if (op->d.res_mode == SABER_HIP_RES_ELTWISE && !res) return fail(SABER_HIP_INVALID_VALUE, "residual tensor required");
+    if (op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "sibling pair: use saber_hip_conv2d_run_pair");
     hipStream_t s = (hipStream_t)stream;
     const saber_hip_conv_desc& d = op->d;
     const void* xin = x;
@@ -542,6 +556,7 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                               saber_hip_stream_t stream, int iters) {
     if (op->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
+    if (op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "sibling pair: use saber_hip_conv2d_autotune_pair");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -619,6 +634,109 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     op->dma = best_dma;
     op->ks = best_ks;
     op->tile = best_tile;
+    name_algo(op);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SABER_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sibling pair: two INT8 convs over one input in one launch (see saber_hip.h)
+// ------------------------------------------------------------------------------------------------
+int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv_t* b, saber_hip_conv_t** out) {
+    if (!a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv_desc &da = a->d, &db = b->d;
+    auto plain = [](const saber_hip_conv* o) {
+        return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV &&
+               o->d.res_mode == SABER_HIP_RES_NONE && !o->pre_quant && !o->pre_pad &&
+               (o->d.out_dtype == SABER_HIP_S8 || o->d.out_dtype == SABER_HIP_U8);
+    };
+    if (!plain(a) || !plain(b)) return fail(SABER_HIP_INVALID_VALUE, "pair: both ops must be plain INT8 implicit-GEMM convs with weights set");
+    if (da.n != db.n || da.h != db.h || da.w != db.w || da.c != db.c || da.kh != db.kh || da.kw != db.kw ||
+        da.pad_h != db.pad_h || da.pad_w != db.pad_w || da.stride_h != db.stride_h || da.stride_w != db.stride_w ||
+        da.dil_h != db.dil_h || da.dil_w != db.dil_w || da.in_dtype != db.in_dtype || a->Kg_pad != b->Kg_pad)
+        return fail(SABER_HIP_INVALID_VALUE, "pair: the two convs must share the input tensor and geometry");
+    if (da.k % 128 || db.k % 16) return fail(SABER_HIP_INVALID_VALUE, "pair: needs a.k % 128 == 0 and b.k % 16 == 0");
+    auto* op = new saber_hip_conv();
+    op->d = da;
+    op->d.k = da.k + db.k;
+    op->oh = a->oh; op->ow = a->ow;
+    op->algo = ALGO_IGEMM_I8;
+    op->epi = EPI_I8_CONV;
+    op->is_i8 = true;
+    op->x_dtype = a->x_dtype;
+    op->c_eff = a->c_eff;
+    op->Kg = a->Kg; op->Kg_pad = a->Kg_pad;
+    op->in_scale = a->in_scale; op->out_scale = a->out_scale;
+    op->pair_k1 = da.k; op->pair_k2 = db.k;
+    op->pair_relu2 = db.act == SABER_HIP_ACT_RELU;
+    op->pair_dtype2 = db.out_dtype;
+    const size_t k2_pad = round_up(db.k, 128), rows = (size_t)da.k + k2_pad;
+    auto cat = [&](auto& dst, const auto& sa, const auto& sb, size_t per_row) -> hipError_t {
+        hipError_t e = dst.alloc_zero(rows * per_row);
+        if (e != hipSuccess) return e;
+        typedef typename std::remove_reference<decltype(*dst.p)>::type T;
+        if (sa.p) e = hipMemcpy(dst.p, sa.p, (size_t)da.k * per_row * sizeof(T), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) return e;
+        if (sb.p) e = hipMemcpy(dst.p + (size_t)da.k * per_row, sb.p, k2_pad * per_row * sizeof(T), hipMemcpyDeviceToDevice);
+        return e;
+    };
+    hipError_t e = cat(op->d_w, a->d_w, b->d_w, (size_t)a->Kg_pad);
+    if (e == hipSuccess) e = cat(op->d_bias, a->d_bias, b->d_bias, 1);
+    if (e == hipSuccess) e = cat(op->d_scale, a->d_scale, b->d_scale, 1);
+    op->has_bias = a->has_bias || b->has_bias;
+    op->has_comp = a->has_comp;   // same input dtype -> both or neither
+    if (e == hipSuccess && op->has_comp) e = cat(op->d_comp, a->d_comp, b->d_comp, 1);
+    if (e != hipSuccess) {
+        delete op;
+        return hip_fail(e, "pair: device copies");
+    }
+    op->weights_set = true;
+    choose_tile(op);
+    op->ks = op->Kg >= 256 ? 4 : (op->Kg >= 128 ? 2 : 1);
+    name_algo(op);
+    *out = op;
+    return SABER_HIP_OK;
+}
+
+int saber_hip_conv2d_run_pair(saber_hip_conv_t* op, const void* x, void* y_a, void* y_b, saber_hip_stream_t stream) {
+    if (!op || !x || !y_a || !y_b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "not a sibling pair");
+    ConvKArgs a;
+    fill_args(op, a, x, y_a, nullptr, y_b);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
+    return SABER_HIP_OK;
+}
+
+int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_a, void* y_b, saber_hip_stream_t stream,
+                                   int iters) {
+    if (!op || !op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "not a sibling pair");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 1e30f;
+    int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
+    const int ks_list[3] = {1, 2, 4};
+    const int dma_list[4] = {0, 1, 2, 4};
+    for (int vi = 0; vi < 4; ++vi)
+        for (int t = 0; t < TILE_COUNT; ++t)
+            for (int ki = 0; ki < 3; ++ki) {
+                if (dma_list[vi] > 1 && (ks_list[ki] != 4 || t > TILE_64x64)) continue;
+                if (dma_list[vi] == 4 && t != TILE_32x32) continue;
+                op->tile = t; op->ks = ks_list[ki]; op->dma = dma_list[vi];
+                int rc = saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(e0, s));
+                for (int i = 0; i < iters; ++i) saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
+                HIP_TRY(hipEventRecord(e1, s));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) { best = ms; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
+            }
+    op->tile = best_tile; op->ks = best_ks; op->dma = best_dma;
     name_algo(op);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -834,13 +952,13 @@ int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hi
 // op-list executor
 // ================================================================================================
 namespace {
-enum OpKind { OP_CONV, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_SOFTMAX };
+enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_SOFTMAX };
 struct NetOp {
     OpKind kind;
     std::string name;
     saber_hip_conv* conv = nullptr;
     saber_hip_fc* fc = nullptr;
-    int in = -1, in2 = -1, out = -1;
+    int in = -1, in2 = -1, out = -1, out2 = -1;
     int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
     bool record = false;     // an op on the other lane consumes this op's output: record an event after it
     int p[16] = {0};
@@ -871,6 +989,7 @@ static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     void* ws = net->arena + net->ws_off;
     switch (o.kind) {
     case OP_CONV: return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
+    case OP_CONV_PAIR: return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
     case OP_FC: return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
     case OP_QUANT:
         return saber_hip_quantize_nchw_to_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.f[0],
@@ -923,6 +1042,14 @@ int saber_hip_net_add_conv(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id
     o.kind = OP_CONV; o.conv = op; o.in = in_id; o.out = out_id; o.in2 = res_id;
     o.name = std::string("conv:") + op->algo_name;
     if (op->ws_bytes > net->ws_bytes) net->ws_bytes = op->ws_bytes;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_conv_pair(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id, int out_a_id, int out_b_id) {
+    if (!op || !op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "not a sibling pair");
+    if (out_b_id < 0 || out_b_id >= (int)net->tensor_bytes.size()) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    NetOp o;
+    o.kind = OP_CONV_PAIR; o.conv = op; o.in = in_id; o.out = out_a_id; o.out2 = out_b_id;
+    o.name = std::string("conv:") + op->algo_name;
     return push(net, std::move(o));
 }
 int saber_hip_net_add_fc(saber_hip_net_t* net, saber_hip_fc_t* op, int in_id, int out_id) {
@@ -1040,6 +1167,7 @@ static int net_prepare_lanes(saber_hip_net* net) {
         for (int t : ins)
             if (t >= 0 && w[t] >= 0 && net->ops[w[t]].lane != o.lane) net->ops[w[t]].record = true;
         w[o.out] = i;
+        if (o.out2 >= 0) w[o.out2] = i;
     }
     if (net->has_side) {
         HIP_TRY(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
@@ -1083,6 +1211,7 @@ int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
         if (o.record) HIP_TRY(hipEventRecord(net->ev_op[i], s));
         if (o.lane) side_dirty = true;
         net->writer[o.out] = (int)i;
+        if (o.out2 >= 0) net->writer[o.out2] = (int)i;
     }
     if (side_dirty) {   // join: required before a capture ends, and so that the caller sees one ordered stream
         HIP_TRY(hipEventRecord(net->ev_join, net->side));
@@ -1144,6 +1273,12 @@ int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int 
 int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters) {
     auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
     for (NetOp& o : net->ops) {
+        if (o.kind == OP_CONV_PAIR) {
+            int rc = saber_hip_conv2d_autotune_pair(o.conv, T(o.in), T(o.out), T(o.out2), stream, iters);
+            if (rc) return rc;
+            o.name = std::string("conv:") + o.conv->algo_name;
+            continue;
+        }
         saber_hip_conv* c = o.kind == OP_CONV ? o.conv : (o.kind == OP_FC ? o.fc->conv : nullptr);
         if (!c) continue;
         const void* xin = T(o.in);

@@ -24,10 +24,10 @@ void tile_dims(int tile, int* bm_k, int* bn_pix) {
 }
 
 #define DECL(m, e) hipError_t launch_igemm_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
-DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3)
+DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(0, 4) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3)
 #undef DECL
 #define DECL(m, e) hipError_t launch_igemm_dma_m##m##_e##e(int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
-DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(2, 3)
+DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(0, 4) DECL(2, 3)
 #undef DECL
 
 hipError_t launch_halo_e0(int th, const ConvKArgs& a, hipStream_t s);
@@ -42,6 +42,7 @@ hipError_t launch_stem_e3(int f32_in, const ConvKArgs& a, hipStream_t s);
 
 static int epilogue_kind(int mode, const ConvKArgs& a) {
     int ek = 3;
+    if (mode == 0 && a.K2 > 0) return 4;   // sibling pair (api.hip checked the constraints)
     if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE) {
         if (a.res_mode == RES_ELTWISE) ek = 2;
         else if (a.out_dtype == DT_U8) ek = 1;
@@ -69,28 +70,30 @@ hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s) {
-    switch (mode * 4 + epilogue_kind(mode, a)) {
+    switch (mode * 8 + epilogue_kind(mode, a)) {
     case 0: return launch_igemm_dma_m0_e0(tile, ks, wg, a, s);
     case 1: return launch_igemm_dma_m0_e1(tile, ks, wg, a, s);
     case 2: return launch_igemm_dma_m0_e2(tile, ks, wg, a, s);
     case 3: return launch_igemm_dma_m0_e3(tile, ks, wg, a, s);
-    case 11: return launch_igemm_dma_m2_e3(tile, ks, wg, a, s);
+    case 4: return launch_igemm_dma_m0_e4(tile, ks, wg, a, s);
+    case 19: return launch_igemm_dma_m2_e3(tile, ks, wg, a, s);
     default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hipStream_t s) {
     // epilogue kind from the argument block (host side, once per launch)
-    switch (mode * 4 + epilogue_kind(mode, a)) {
+    switch (mode * 8 + epilogue_kind(mode, a)) {
     case 0: return launch_igemm_m0_e0(tile, ks, a, s);
     case 1: return launch_igemm_m0_e1(tile, ks, a, s);
     case 2: return launch_igemm_m0_e2(tile, ks, a, s);
     case 3: return launch_igemm_m0_e3(tile, ks, a, s);
-    case 4: return launch_igemm_m1_e0(tile, ks, a, s);
-    case 5: return launch_igemm_m1_e1(tile, ks, a, s);
-    case 6: return launch_igemm_m1_e2(tile, ks, a, s);
-    case 7: return launch_igemm_m1_e3(tile, ks, a, s);
-    case 11: return launch_igemm_m2_e3(tile, ks, a, s);
+    case 4: return launch_igemm_m0_e4(tile, ks, a, s);
+    case 8: return launch_igemm_m1_e0(tile, ks, a, s);
+    case 9: return launch_igemm_m1_e1(tile, ks, a, s);
+    case 10: return launch_igemm_m1_e2(tile, ks, a, s);
+    case 11: return launch_igemm_m1_e3(tile, ks, a, s);
+    case 19: return launch_igemm_m2_e3(tile, ks, a, s);
     default: return hipErrorInvalidValue;
     }
 }

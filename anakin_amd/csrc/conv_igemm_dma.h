@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             if constexpr (EK == EK_GEN) {
                 epilogue_i8<NV>(a, v, cp, p, kb);
+            } else if constexpr (EK == EK_PAIR) {
+                if (p < a.M) epilogue_i8_pair<NV>(a, v, cp, p, kb);
             } else {
                 if (p < a.M && kb < a.K) {
                     if ((kb + NV <= a.K) && (a.K % NV == 0)) epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);

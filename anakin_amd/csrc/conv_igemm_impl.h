@@ -214,7 +214,8 @@ __device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, const float (&a
 enum { EK_S8 = 0,   // INT8 conv -> s8 (relu optional)
        EK_U8 = 1,   // INT8 conv -> u8
        EK_ELT = 2,  // INT8 conv -> s8 -> fused SaberEltwise sum(+relu) -> s8
-       EK_GEN = 3 };// everything else (f32 outputs, FC epilogues, in-place JIT sum, FP32 conv)
+       EK_GEN = 3,  // everything else (f32 outputs, FC epilogues, in-place JIT sum, FP32 conv)
+       EK_PAIR = 4 };// two sibling INT8 convs (s8/u8 outputs) sharing the input: rows >= K1 go to the 2nd output
 
 // roundf (round half away from zero) == trunc(t + copysign(0.49999997f, t)) for every float with
 // |t| < 2^23 (exhaustively verified: oracle/saber_oracle.c orc_check_round_identity, tests/test_oracle_golden.py);
@@ -272,6 +273,43 @@ __device__ __forceinline__ void epilogue_i8_fast(const ConvKArgs& a, const int (
     else *(uint4*)(y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
+
+// Sibling-pair epilogue: the block tile lies entirely in the first (rows < K1) or the second conv
+// (K1 is a multiple of the largest block tile), so the selection is block-uniform. Same arithmetic as
+// the s8 / u8 fast epilogues with the clamp / offset chosen at run time:
+//   u8: cvt_pk_u8(max(q, lo) + 0)          s8: cvt_pk_u8(max(q, lo) + 128) ^ 0x80
+template <int NV>
+__device__ __forceinline__ void epilogue_i8_pair(const ConvKArgs& a, const int (&acc)[NV], const ChanParams<NV>& cp,
+                                                 int p, int kb) {
+    const bool second = kb >= a.K1;
+    const int kl = second ? kb - a.K1 : kb;
+    const int Ks = second ? a.K2 : a.K1;
+    if (kl >= Ks) return;                       // zero rows padding the second conv's last tile
+    uint8_t* y = (uint8_t*)(second ? a.y2 : a.y);
+    const bool u8 = (second ? a.out_dtype2 : a.out_dtype) == DT_U8;
+    const float lo = (second ? a.relu2 : a.relu) ? 0.f : -3.0e38f;
+    const float off = u8 ? 0.f : 128.f;
+    const unsigned xm = u8 ? 0u : 0x80808080u;
+    const size_t o = (size_t)p * Ks + kl;
+    unsigned pk[NV / 4];
+#pragma unroll
+    for (int v = 0; v < NV / 4; ++v) {
+        unsigned w = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = v * 4 + t;
+            float d = (float)(acc[r] + cp.comp[r]);
+            d = __fadd_rn(d, cp.bias[r]);
+            d = __fmul_rn(d, cp.scale[r]);
+            const float q = fmaxf(rintf(d), lo);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(q + off, t, w);
+        }
+        pk[v] = w ^ xm;
+    }
+    if constexpr (NV == 4) *(unsigned*)(y + o) = pk[0];
+    else if constexpr (NV == 8) *(uint2*)(y + o) = make_uint2(pk[0], pk[1]);
+    else *(uint4*)(y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
 
 // XCD-aware tile order (cdna_hip_programming.md T1): workgroup b runs on XCD b % 8; give every XCD a
 // CONTIGUOUS range of the ky-major tile list so the workgroups of one XCD share weight tiles in that
@@ -506,6 +544,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             if constexpr (EK == EK_GEN) {
                 epilogue_i8<NV>(a, v, cp, p, kb);
+            } else if constexpr (EK == EK_PAIR) {
+                if (p < a.M) epilogue_i8_pair<NV>(a, v, cp, p, kb);
             } else {
                 if (p < a.M && kb < a.K) {
                     if ((kb + NV <= a.K) && (a.K % NV == 0)) epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);

@@ -43,6 +43,10 @@ struct ConvKArgs {
     int epi;
     int res_mode, res_relu, res_dtype;
     float sum_scale, coeff_conv, coeff_res, scale_conv, scale_res;
+    // sibling pair (two convs over one input in one launch): rows [0,K1) -> y (stride K1, relu/out_dtype),
+    // rows [K1, K1+K2) -> y2 (stride K2, relu2/out_dtype2); K = K1 + K2. K2 == 0: ordinary conv.
+    void* y2;
+    int K1, K2, relu2, out_dtype2;
 };
 
 // tile ids for launch_conv_igemm

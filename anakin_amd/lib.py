@@ -24,6 +24,8 @@ SYMBOLS = [
     "saber_hip_conv2d_out_shape", "saber_hip_conv2d_run", "saber_hip_conv2d_destroy",
     "saber_hip_conv2d_get_quantized_weights", "saber_hip_conv2d_algo", "saber_hip_conv2d_set_tile",
     "saber_hip_conv2d_get_tile", "saber_hip_conv2d_autotune",
+    "saber_hip_conv2d_create_pair", "saber_hip_conv2d_run_pair", "saber_hip_conv2d_autotune_pair",
+    "saber_hip_net_add_conv_pair",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
     "saber_hip_fc_destroy", "saber_hip_gemm_f32",
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
@@ -92,6 +94,10 @@ def load():
     lib.saber_hip_conv2d_set_tile.argtypes = [P, I]
     lib.saber_hip_conv2d_get_tile.argtypes = [P]
     lib.saber_hip_conv2d_autotune.argtypes = [P, P, P, P, P, P, I]
+    lib.saber_hip_conv2d_create_pair.argtypes = [P, P, C.POINTER(P)]
+    lib.saber_hip_conv2d_run_pair.argtypes = [P, P, P, P, P]
+    lib.saber_hip_conv2d_autotune_pair.argtypes = [P, P, P, P, P, I]
+    lib.saber_hip_net_add_conv_pair.argtypes = [P, P, I, I, I]
     lib.saber_hip_fc_create.argtypes = [C.POINTER(FcDesc), C.POINTER(P)]
     lib.saber_hip_fc_set_weights.argtypes = [P, P, I, P, P, F, F]
     lib.saber_hip_fc_workspace_bytes.argtypes = [P]

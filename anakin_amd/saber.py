@@ -137,6 +137,37 @@ class SaberConv2D:
             pass
 
 
+class SaberConvPair:
+    """Two sibling INT8 convolutions over ONE input tensor (same kernel / pad / stride) in one launch
+    (saber_hip_conv2d_create_pair): ResNet's stage-entry `branch1` + `branch2a`. Outputs are bit-identical
+    to dispatching `a` and `b` one after the other, which is what the reference does (net.cpp:417-509)."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b          # keep the parents alive (and usable)
+        self.h = C.c_void_p()
+        L.check(L.load().saber_hip_conv2d_create_pair(a.h, b.h, C.byref(self.h)))
+
+    def dispatch(self, x, ya, yb):
+        L.check(L.load().saber_hip_conv2d_run_pair(self.h, _p(x), _p(ya), _p(yb), _stream()))
+        return ya, yb
+
+    def algo(self):
+        return L.load().saber_hip_conv2d_algo(self.h).decode()
+
+    def set_tile(self, tile):
+        L.check(L.load().saber_hip_conv2d_set_tile(self.h, tile))
+
+    def autotune(self, x, ya, yb, iters=5):
+        L.check(L.load().saber_hip_conv2d_autotune_pair(self.h, _p(x), _p(ya), _p(yb), _stream(), iters))
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_conv2d_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SaberFc:
     """Fc<MI355X, AK_FLOAT|AK_INT8> (saber/funcs/fc.h:48-127): out[m,n] = in[m,k] W[n,k]^T + bias."""
 
@@ -315,6 +346,10 @@ class Net:
         if rc < 0:
             L.check(rc)
         return rc
+
+    def add_conv_pair(self, pair, x, ya, yb):
+        self.keep.append(pair)
+        return self._chk(L.load().saber_hip_net_add_conv_pair(self.h, pair.h, self.tid(x), self.tid(ya), self.tid(yb)))
 
     def add_fc(self, fc, x, y):
         self.keep.append(fc)

@@ -175,8 +175,12 @@ def _out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False):
-    """ResNet INT8 op list on the device (see module docstring for the dtype rules)."""
+def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None):
+    """ResNet INT8 op list on the device (see module docstring for the dtype rules).
+
+    pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
+    read the same tensor with the same 1x1 geometry; they run as ONE launch (SaberConvPair), outputs
+    bit-identical to the two separate ops."""
     from . import lib as L
     from . import saber as S
     net = S.Net()
@@ -185,7 +189,11 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False)
     shape = {"data": (hw, 3)}        # name -> (spatial, channels)
     dtype = {"data": F32}
     pending = {}                     # branch2c convs waiting for their eltwise when fusing
-    for l in model["spec"]:
+    if pair_siblings is None:
+        pair_siblings = fuse_eltwise and not lanes
+    spec = model["spec"]
+    sib = {}                         # name of the first sibling -> (conv object, tensor name), waiting for the second
+    for li, l in enumerate(spec):
         kd, nm = l["kind"], l["name"]
         if kd == "conv":
             hin, cin = shape[l["src"]]
@@ -200,6 +208,17 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False)
             conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[l["src"]], odt, scales[l["src"]], scales[nm],
                                             in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
             net.add_tensor(nm, (B, ho, ho, l["cout"]), odt)
+            nxt = spec[li + 1] if li + 1 < len(spec) else None
+            geo = ("src", "k", "stride", "pad")
+            if pair_siblings and nxt is not None and nxt["kind"] == "conv" and "eltwise" not in nxt and \
+                    all(nxt[g] == l[g] for g in geo) and l["cout"] % 128 == 0 and nxt["cout"] % 16 == 0 and \
+                    dtype[l["src"]] != F32:
+                sib[nxt["name"]] = (conv, nm)      # launched together with the next conv
+                continue
+            if nm in sib:
+                first, first_nm = sib.pop(nm)
+                net.add_conv_pair(S.SaberConvPair(first, conv), l["src"], first_nm, nm)
+                continue
             idx = net.add_conv(conv, l["src"], nm)
             if lanes and nm.endswith("_branch1"):
                 net.set_lane(idx, 1)   # the shortcut projection is independent of branch2a/2b: side lane

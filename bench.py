@@ -191,8 +191,8 @@ def main():
                     mfma_frac=round(achieved_tops / peak_ops, 4), hbm_frac=round(achieved_gbs / HBM_PEAK_GBS, 4),
                     sum_all_op_us=round(sum(op_us), 1))
         if args.per_op:
-            for n, t in sorted(zip(names, op_us), key=lambda p: -p[1])[:25]:
-                print("%8.2f us  %s" % (t, n), file=sys.stderr)
+            for i, (n, t) in enumerate(zip(names, op_us)):   # execution order
+                print("%3d %8.2f us  %s" % (i, t, n), file=sys.stderr)
 
         # ---------------- batch-1 latency leg (the metric quotes p50 @ batch 1 and 8) ---------------
         b1 = None

@@ -306,6 +306,77 @@ def test_conv_i8_fused_eltwise_equals_two_ops(relu):
     assert np.array_equal(host(e), want)
 
 
+PAIR_CASES = [
+    # N, H, W, C, K1, K2, k, pad, stride
+    (2, 14, 14, 64, 256, 64, 1, 0, 1),      # res2a: branch1 + branch2a
+    (2, 14, 14, 256, 512, 128, 1, 0, 2),    # res3a (stride 2)
+    (1, 9, 7, 128, 128, 48, 1, 0, 2),       # K2 not a tile multiple, odd spatial dims
+    (1, 6, 6, 32, 128, 16, 3, 1, 1),        # 3x3 siblings
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+@pytest.mark.parametrize("idt", [O.U8, O.S8])
+def test_conv_i8_sibling_pair_equals_two_ops(case, idt):
+    """saber_hip_conv2d_create_pair: one launch, both outputs bit-identical to the oracle (= to the two
+    separate Saber ops of the reference op list), for every tile / staging variant."""
+    N, H, W, C, K1, K2, k, pad, stride = case
+    rng = np.random.default_rng(abs(hash((case, idt))) % 2**31)
+    x = (rng.integers(0, 256, (N, H, W, C)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, W, C)).astype(np.int8))
+    in_scale = 0.013
+    convs, wants = [], []
+    for K, odt, relu, out_scale in ((K1, O.S8, 0, 0.05), (K2, O.U8, 1, 0.031)):
+        w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+        b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+        ws = O.weight_scales(w)
+        bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, odt)
+        wants.append(O.conv_i8(x, O.quant_weights(w, ws), bp, sc, odt, relu, (pad, pad), (stride, stride)))
+        p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (1, 1), bool(relu))
+        convs.append(S.SaberConv2D(True).init((N, C, H, W), p, idt, odt, in_scale, out_scale))
+    pair = S.SaberConvPair(convs[0], convs[1])
+    assert pair.algo().startswith("pair_igemm_i8")
+    xd = dev(x)
+    variants = [None] + [t | (ks << 8) | (1 << 16) for t in range(6) for ks in (1, 2, 4)] + \
+               [t | (4 << 8) | (2 << 16) for t in range(6)] + [t | (4 << 8) | (3 << 16) for t in range(3)] + \
+               [0 | (4 << 8) | (4 << 16)]
+    for v in variants:
+        if v is not None:
+            pair.set_tile(v)
+        ya, yb = convs[0].new_output(), convs[1].new_output()
+        ya.fill_(77)
+        yb.fill_(77)
+        pair.dispatch(xd, ya, yb)
+        assert np.array_equal(host(ya), wants[0]), (pair.algo(), "first")
+        assert np.array_equal(host(yb), wants[1]), (pair.algo(), "second")
+    # the parents stay usable on their own
+    y0 = convs[0].new_output()
+    convs[0].dispatch(xd, y0)
+    assert np.array_equal(host(y0), wants[0])
+    pair.autotune(xd, ya, yb, iters=2)
+    pair.dispatch(xd, ya, yb)
+    assert np.array_equal(host(ya), wants[0]) and np.array_equal(host(yb), wants[1]), pair.algo()
+
+
+def test_conv_i8_sibling_pair_rejects_mismatches():
+    rng = np.random.default_rng(3)
+    def mk(K, C=32, k=1, stride=1, odt=O.S8):
+        w = rng.standard_normal((K, C, k, k)).astype(np.float32)
+        p = S.ConvParam(w, None, 1, (0, 0), (stride, stride), (1, 1), odt == O.U8)
+        return S.SaberConv2D(True).init((1, C, 8, 8), p, O.U8, odt, 0.02, 0.03)
+    a = mk(128)
+    with pytest.raises(L.SaberHipError):
+        S.SaberConvPair(a, mk(64, stride=2))          # different geometry
+    with pytest.raises(L.SaberHipError):
+        S.SaberConvPair(mk(64), mk(64))               # first K not a multiple of 128
+    with pytest.raises(L.SaberHipError):
+        S.SaberConvPair(a, mk(24))                    # second K not a multiple of 16
+    pair = S.SaberConvPair(a, mk(64, odt=O.U8))
+    y = a.new_output()
+    with pytest.raises(L.SaberHipError):              # a pair cannot go through the single-output entry point
+        L.check(L.load().saber_hip_conv2d_run(pair.h, S._p(y), S._p(y), None, None, None))
+
+
 def test_conv_i8_jit_sum_inplace():
     rng = np.random.default_rng(13)
     x = rng.integers(-128, 128, (1, 7, 7, 32)).astype(np.int8)
