@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsaber_mi355x.so")
+LIB_PATH = os.environ.get("SABER_MI355X_LIB") or os.path.join(HERE, "libsaber_mi355x.so")   # override: A/B builds
 
 F32, S8, U8, S32 = 0, 1, 2, 3
 NHWC, NCHW = 0, 1
