@@ -28,8 +28,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv_igemm_impl.h"), os.path.join(CSRC, "conv_igemm_dma.h"), os.path.join(CSRC, "conv3x3_halo.h"), os.path.join(CSRC, "conv_stem.h"),
-               os.path.join(HERE, "..", "include", "saber_hip.h")]
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "saber_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:
