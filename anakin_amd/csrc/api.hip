@@ -850,6 +850,12 @@ int saber_hip_fc_run(saber_hip_fc_t* fc, const void* x, float* y, void* workspac
     return saber_hip_conv2d_run(fc->conv, xin, y, nullptr, nullptr, stream);
 }
 
+int saber_hip_fc_run_q(saber_hip_fc_t* fc, const int8_t* xq, float* y, saber_hip_stream_t stream) {
+    if (!fc || !xq || !y) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!fc->d.int8_weights || fc->conv->x_dtype != DT_S8) return fail(SABER_HIP_INVALID_VALUE, "fc_run_q: INT8 fc with s8 operand only");
+    return saber_hip_conv2d_run(fc->conv, xq, y, nullptr, nullptr, stream);
+}
+
 void saber_hip_fc_destroy(saber_hip_fc_t* fc) {
     if (fc) saber_hip_conv2d_destroy(fc->conv);
     delete fc;
@@ -932,13 +938,20 @@ int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int
                               (hipStream_t)s));
     return SABER_HIP_OK;
 }
+int saber_hip_pool2d_f32_from_i8_q(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                                   int pw, int type, int in_dtype, float scale, const void* x, float* y, float q_scale,
+                                   int8_t* yq, saber_hip_stream_t s) {
+    if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
+    if (yq && !(q_scale > 0.f)) return fail(SABER_HIP_INVALID_VALUE, "bad quantisation scale");
+    HIP_TRY(launch_pool2d_f32_from_i8(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y, q_scale,
+                                      yq, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
 int saber_hip_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
                                  int pw, int type, int in_dtype, float scale, const void* x, float* y,
                                  saber_hip_stream_t s) {
-    if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
-    HIP_TRY(launch_pool2d_f32_from_i8(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y,
-                                      (hipStream_t)s));
-    return SABER_HIP_OK;
+    return saber_hip_pool2d_f32_from_i8_q(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y, 1.f,
+                                          nullptr, s);
 }
 int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t s) {
     if (rows <= 0 || cols <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad softmax shape");
@@ -952,7 +965,7 @@ int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hi
 // op-list executor
 // ================================================================================================
 namespace {
-enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_SOFTMAX };
+enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_FC_Q, OP_SOFTMAX };
 struct NetOp {
     OpKind kind;
     std::string name;
@@ -1013,9 +1026,10 @@ static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
         return saber_hip_pool2d_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.p[9],
                                     o.p[10], o.p[11], o.p[12], o.p[13], (const float*)T(o.in), (float*)T(o.out), s);
     case OP_POOL_F32_I8:
-        return saber_hip_pool2d_f32_from_i8(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
-                                            o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.f[0], T(o.in),
-                                            (float*)T(o.out), s);
+        return saber_hip_pool2d_f32_from_i8_q(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
+                                              o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.f[0], T(o.in),
+                                              (float*)T(o.out), o.f[1], (int8_t*)T(o.out2), s);
+    case OP_FC_Q: return saber_hip_fc_run_q(o.fc, (const int8_t*)T(o.in), (float*)T(o.out), s);
     case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
     }
     return SABER_HIP_UNIMPL;
@@ -1119,6 +1133,24 @@ int saber_hip_net_add_pool_f32_from_i8(saber_hip_net_t* net, int n, int h, int w
     const int v[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype};
     std::memcpy(o.p, v, sizeof v);
     o.f[0] = scale;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_f32_from_i8_q(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                                         int sh, int sw, int ph, int pw, int type, int in_dtype, float scale, int in_id,
+                                         int out_id, float q_scale, int q_out_id) {
+    if (q_out_id < 0 || q_out_id >= (int)net->tensor_bytes.size()) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    int idx = saber_hip_net_add_pool_f32_from_i8(net, n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale,
+                                                 in_id, out_id);
+    if (idx < 0) return idx;
+    net->ops[idx].out2 = q_out_id;
+    net->ops[idx].f[1] = q_scale;
+    net->ops[idx].name = "pool2d_f32_from_i8+quantize";
+    return idx;
+}
+int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id, int out_id) {
+    NetOp o;
+    o.kind = OP_FC_Q; o.fc = op; o.in = in_q_id; o.out = out_id;
+    o.name = std::string("fc:") + op->conv->algo_name;
     return push(net, std::move(o));
 }
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id) {
@@ -1279,7 +1311,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
             o.name = std::string("conv:") + o.conv->algo_name;
             continue;
         }
-        saber_hip_conv* c = o.kind == OP_CONV ? o.conv : (o.kind == OP_FC ? o.fc->conv : nullptr);
+        saber_hip_conv* c = o.kind == OP_CONV ? o.conv : ((o.kind == OP_FC || o.kind == OP_FC_Q) ? o.fc->conv : nullptr);
         if (!c) continue;
         const void* xin = T(o.in);
         if (o.kind == OP_FC && o.fc->pre_quant) {   // the GEMM reads the quantised copy in the workspace

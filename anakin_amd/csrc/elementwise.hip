@@ -492,23 +492,27 @@ __global__ __launch_bounds__(256) void pool2d_f32_from_i8_kernel(int n, int h, i
 }
 
 // Global average pool specialisation of the kernel above (window = whole image, no padding): one lane
-// per (image, 4 channels); pixels are fetched 25 at a time (independent dword loads in flight) and then
-// accumulated in (h, w) order, so the float sequence is unchanged.
-__global__ __launch_bounds__(256) void gpool_f32_from_i8_kernel(int n, int hw, int c, int type, int in_u8, float s,
-                                                                const uint8_t* __restrict__ x, float* __restrict__ y) {
+// per (image, 4 channels); up to 49 pixels (7x7) are fetched at once (independent dword loads in flight:
+// one exposed memory latency) and then accumulated in (h, w) order, so the float sequence is unchanged.
+// yq (optional): the s8 quantisation of the result with scale 1/qinv — the quantise-on-entry of a following
+// INT8 op (scale_fp32_int8, x86_utils.h:325-346) fused into the store.
+__global__ __launch_bounds__(64) void gpool_f32_from_i8_kernel(int n, int hw, int c, int type, int in_u8, float s,
+                                                               const uint8_t* __restrict__ x, float* __restrict__ y,
+                                                               float qinv, int8_t* __restrict__ yq) {
+    constexpr int B = 49;
     const int cg = c >> 2;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= n * cg) return;
     const int img = gid / cg, g = gid - img * cg;
     const unsigned* px = (const unsigned*)(x + (size_t)img * hw * c) + g;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     bool first = true;
-    for (int p0 = 0; p0 < hw; p0 += 25) {
-        unsigned v[25];
+    for (int p0 = 0; p0 < hw; p0 += B) {
+        unsigned v[B];
 #pragma unroll
-        for (int t = 0; t < 25; ++t) v[t] = (p0 + t < hw) ? px[(size_t)(p0 + t) * cg] : 0u;
+        for (int t = 0; t < B; ++t) v[t] = (p0 + t < hw) ? px[(size_t)(p0 + t) * cg] : 0u;
 #pragma unroll
-        for (int t = 0; t < 25; ++t) {
+        for (int t = 0; t < B; ++t) {
             if (p0 + t < hw) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -521,21 +525,32 @@ __global__ __launch_bounds__(256) void gpool_f32_from_i8_kernel(int n, int hw, i
             }
         }
     }
+    unsigned pk = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) y[(size_t)img * c + g * 4 + b] = type == 0 ? acc[b] : acc[b] / (float)hw;
+    for (int b = 0; b < 4; ++b) {
+        const float r = type == 0 ? acc[b] : acc[b] / (float)hw;
+        y[(size_t)img * c + g * 4 + b] = r;
+        int t = (int)round_away(__fmul_rn(r, qinv));
+        t = t > 127 ? 127 : t;
+        t = t < -128 ? -128 : t;
+        pk |= ((unsigned)t & 0xffu) << (8 * b);
+    }
+    if (yq) ((unsigned*)yq)[(size_t)img * cg + g] = pk;
 }
 hipError_t launch_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
                                      int pw, int type, int in_dtype, float scale, const void* x, float* y,
-                                     hipStream_t s) {
+                                     float q_scale, int8_t* yq, hipStream_t s) {
     const float sc = in_dtype == DT_U8 ? scale * (127.f / 255.f) : scale;
     if (oh == 1 && ow == 1 && kh == h && kw == w && ph == 0 && pw == 0 && (c & 3) == 0) {
-        hipLaunchKernelGGL(gpool_f32_from_i8_kernel, dim3((n * (c >> 2) + 255) / 256), dim3(256), 0, s, n, h * w, c, type,
-                           in_dtype == DT_U8, sc, (const uint8_t*)x, y);
+        hipLaunchKernelGGL(gpool_f32_from_i8_kernel, dim3((n * (c >> 2) + 63) / 64), dim3(64), 0, s, n, h * w, c, type,
+                           in_dtype == DT_U8, sc, (const uint8_t*)x, y, yq ? 1.f / q_scale : 0.f, yq);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(pool2d_f32_from_i8_kernel, dim3(grid_for((size_t)n * oh * ow * c)), dim3(256), 0, s, n, h, w, c,
                        oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype == DT_U8, sc, (const uint8_t*)x, y);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && yq) e = launch_quantize_flat_s8((size_t)n * c * oh * ow, q_scale, y, yq, s);
+    return e;
 }
 
 // ---- softmax over the last axis: one 256-thread block per row, wavefront shuffles ---------------

@@ -88,7 +88,7 @@ hipError_t launch_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh,
                              int pw, int type, int nchw, const float* x, float* y, hipStream_t s);
 hipError_t launch_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
                                      int pw, int type, int in_dtype, float scale, const void* x, float* y,
-                                     hipStream_t s);
+                                     float q_scale, int8_t* yq, hipStream_t s);   // yq: optional fused s8 quantisation
 hipError_t launch_softmax_f32(int rows, int cols, const float* x, float* y, hipStream_t s);
 hipError_t launch_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b,
                            float beta, float* c, hipStream_t s);

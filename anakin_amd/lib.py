@@ -31,7 +31,8 @@ SYMBOLS = [
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
-    "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_softmax_f32",
+    "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
+    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
@@ -117,6 +118,10 @@ def load():
     lib.saber_hip_pool2d_i8_nhwc.argtypes = [I] * 15 + [P, P, P]
     lib.saber_hip_pool2d_f32.argtypes = [I] * 14 + [P, P, P]
     lib.saber_hip_pool2d_f32_from_i8.argtypes = [I] * 14 + [F, P, P, P]
+    lib.saber_hip_pool2d_f32_from_i8_q.argtypes = [I] * 14 + [F, P, P, F, P, P]
+    lib.saber_hip_fc_run_q.argtypes = [P, P, P, P]
+    lib.saber_hip_net_add_pool_f32_from_i8_q.argtypes = [P] + [I] * 14 + [F, I, I, F, I]
+    lib.saber_hip_net_add_fc_q.argtypes = [P, P, I, I]
     lib.saber_hip_softmax_f32.argtypes = [I, I, P, P, P]
     lib.saber_hip_net_create.argtypes = [C.POINTER(P)]
     lib.saber_hip_net_add_tensor.argtypes = [P, Z]

@@ -195,6 +195,11 @@ class SaberFc:
         L.check(L.load().saber_hip_fc_run(self.h, _p(x), _p(y), _p(self.ws), _stream()))
         return y
 
+    def dispatch_q(self, xq, y):
+        """Input already quantised to s8 with in_scale (saber_hip_fc_run_q)."""
+        L.check(L.load().saber_hip_fc_run_q(self.h, _p(xq), _p(y), _stream()))
+        return y
+
     def __del__(self):
         try:
             if self.h:
@@ -297,8 +302,10 @@ def pooling_f32(x, window, stride, pad, pool_type, layout=L.NCHW, global_pooling
     return y
 
 
-def pooling_f32_from_i8(x, scale, window, stride, pad, pool_type, global_pooling=False, floor_mode=False):
-    """Pooling<MI355X, AK_FLOAT> fed an s8/u8 NHWC tensor: dequantise on entry, pool, f32 NCHW out."""
+def pooling_f32_from_i8(x, scale, window, stride, pad, pool_type, global_pooling=False, floor_mode=False,
+                        q_scale=None):
+    """Pooling<MI355X, AK_FLOAT> fed an s8/u8 NHWC tensor: dequantise on entry, pool, f32 NCHW out.
+    q_scale: also return the s8 quantisation of the result (the next INT8 op's quantise-on-entry, fused)."""
     n, h, w, c = x.shape
     if global_pooling:
         window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
@@ -306,6 +313,12 @@ def pooling_f32_from_i8(x, scale, window, stride, pad, pool_type, global_pooling
         oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
         ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
     y = torch.empty((n, c, oh, ow), dtype=torch.float32, device="cuda")
+    if q_scale is not None:
+        yq = torch.empty((n, c, oh, ow), dtype=torch.int8, device="cuda")
+        L.check(L.load().saber_hip_pool2d_f32_from_i8_q(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1],
+                                                        pad[0], pad[1], pool_type, dtype_code(x), float(scale), _p(x),
+                                                        _p(y), float(q_scale), _p(yq), _stream()))
+        return y, yq
     L.check(L.load().saber_hip_pool2d_f32_from_i8(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1],
                                                   pad[0], pad[1], pool_type, dtype_code(x), float(scale), _p(x), _p(y),
                                                   _stream()))
@@ -396,6 +409,17 @@ class Net:
         return self._chk(L.load().saber_hip_net_add_pool_f32_from_i8(self.h, n, h, w, c, oh, ow, win[0], win[1],
                                                                      stride[0], stride[1], pad[0], pad[1], ptype,
                                                                      in_dtype, float(scale), self.tid(x), self.tid(y)))
+
+    def add_pool_f32_from_i8_q(self, n, h, w, c, oh, ow, win, stride, pad, ptype, in_dtype, scale, x, y, q_scale, yq):
+        """pool + the s8 quantisation of its result (the next INT8 op's quantise-on-entry) in one launch."""
+        return self._chk(L.load().saber_hip_net_add_pool_f32_from_i8_q(
+            self.h, n, h, w, c, oh, ow, win[0], win[1], stride[0], stride[1], pad[0], pad[1], ptype, in_dtype,
+            float(scale), self.tid(x), self.tid(y), float(q_scale), self.tid(yq)))
+
+    def add_fc_q(self, fc, xq, y):
+        """INT8 fc reading an input already quantised with its in_scale (see add_pool_f32_from_i8_q)."""
+        self.keep.append(fc)
+        return self._chk(L.load().saber_hip_net_add_fc_q(self.h, fc.h, self.tid(xq), self.tid(y)))
 
     def add_softmax(self, rows, cols, x, y):
         return self._chk(L.load().saber_hip_net_add_softmax(self.h, rows, cols, self.tid(x), self.tid(y)))

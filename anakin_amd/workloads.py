@@ -192,6 +192,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     if pair_siblings is None:
         pair_siblings = fuse_eltwise and not lanes
     spec = model["spec"]
+    quantised = {}                   # f32 edge -> its s8 twin written by the producer (fused quantise-on-entry)
     sib = {}                         # name of the first sibling -> (conv object, tensor name), waiting for the second
     for li, l in enumerate(spec):
         kd, nm = l["kind"], l["name"]
@@ -249,14 +250,25 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             # FP32 pooling op fed an s8 NHWC edge: dequantise on entry (saber_pooling.cpp:399-402), then avg
             hin, c = shape[l["src"]]
             net.add_tensor(nm, (B, c, 1, 1), F32)
-            net.add_pool_f32_from_i8(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
-                                     scales[l["src"]], l["src"], nm)
+            nxt = spec[li + 1] if li + 1 < len(spec) else None
+            if fuse_eltwise and nxt is not None and nxt["kind"] == "fc" and nxt["src"] == nm:
+                # the fc quantises its f32 input on entry: fused into the pooling's store (same bytes)
+                net.add_tensor(nm + "_q", (B, c), S8)
+                net.add_pool_f32_from_i8_q(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
+                                           scales[l["src"]], l["src"], nm, scales[nm], nm + "_q")
+                quantised[nm] = nm + "_q"
+            else:
+                net.add_pool_f32_from_i8(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
+                                         scales[l["src"]], l["src"], nm)
             shape[nm], dtype[nm] = (1, c), F32
         elif kd == "fc":
             w, b = model["params"][nm]
             fc = S.SaberFc(True).init(B, l["cout"], l["cin"], w, b, F32, scales[l["src"]])
             net.add_tensor(nm, (B, l["cout"]), F32)
-            net.add_fc(fc, l["src"], nm)
+            if l["src"] in quantised:
+                net.add_fc_q(fc, quantised[l["src"]], nm)
+            else:
+                net.add_fc(fc, l["src"], nm)
         elif kd == "softmax":
             net.add_tensor(nm, (B, 1000), F32)
             net.add_softmax(B, 1000, l["src"], nm)

@@ -150,6 +150,9 @@ int saber_hip_fc_set_weights(saber_hip_fc_t* op, const void* w, int w_dtype, con
 size_t saber_hip_fc_workspace_bytes(const saber_hip_fc_t* op);
 /* out is f32 [m,n]. */
 int saber_hip_fc_run(saber_hip_fc_t* op, const void* x, float* y, void* workspace, saber_hip_stream_t stream);
+/* INT8 fc on an input that is ALREADY quantised to s8 with the op's in_scale (e.g. by pool2d_f32_from_i8_q): skips
+ * the quantise-on-entry kernel of an f32-input INT8 fc; identical result. */
+int saber_hip_fc_run_q(saber_hip_fc_t* op, const int8_t* xq, float* y, saber_hip_stream_t stream);
 void saber_hip_fc_destroy(saber_hip_fc_t* op);
 
 /* ------------------------------------------------------------------------------------------- */
@@ -197,6 +200,12 @@ int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int
 int saber_hip_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
                                  int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype, float scale,
                                  const void* x, float* y, saber_hip_stream_t stream);
+/* Same, and additionally writes yq = saturate_s8(roundf(y * (1/q_scale))) (flat, y's order): the quantise-on-entry of
+ * a following INT8 op (PackedMKLInt8Gemm::dispatch -> scale_fp32_int8, mkl_packed_int8_gemm.cpp:52-57) fused into
+ * the pooling's store. yq may be NULL. */
+int saber_hip_pool2d_f32_from_i8_q(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
+                                   int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype, float scale,
+                                   const void* x, float* y, float q_scale, int8_t* yq, saber_hip_stream_t stream);
 /* softmax over the last axis of [rows, cols] */
 int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t stream);
 
@@ -230,6 +239,10 @@ int saber_hip_net_add_pool_f32(saber_hip_net_t* net, int n, int h, int w, int c,
 int saber_hip_net_add_pool_f32_from_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh,
                                        int kw, int stride_h, int stride_w, int pad_h, int pad_w, int pool_type,
                                        int in_dtype, float scale, int in_id, int out_id);
+int saber_hip_net_add_pool_f32_from_i8_q(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                                         int stride_h, int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype,
+                                         float scale, int in_id, int out_id, float q_scale, int q_out_id);
+int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id, int out_id);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
 /* Lane of an op (graph::Lane, framework/core/net/operator_func.h:103-114; ParallScheduler): 0 = the caller's
  * stream, 1 = the net's side stream. Cross-lane tensor dependencies are ordered with events automatically and

@@ -502,6 +502,14 @@ def test_pooling_f32_from_i8_equals_dequant_then_pool():
         x = mk((2, 13, 13, 24))
         want = O.pool_f32_nchw(O.dequant_nhwc_to_nchw(x, 0.05), (3, 3), (2, 2), (1, 1), 0)
         assert np.array_equal(host(S.pooling_f32_from_i8(dev(x), 0.05, (3, 3), (2, 2), (1, 1), 0)), want)
+        # fused quantise-on-entry of the next INT8 op: same f32 result + its s8 quantisation (both kernel paths)
+        y, yq = S.pooling_f32_from_i8(dev(x), 0.05, (3, 3), (2, 2), (1, 1), 0, q_scale=0.011)
+        assert np.array_equal(host(y), want) and np.array_equal(host(yq), O.quant_flat_s8(want, 0.011))
+        x = mk((3, 7, 7, 2048))
+        want = O.pool_f32_nchw(O.dequant_nhwc_to_nchw(x, 0.37), None, None, None, 1, global_pool=True)
+        for qs in (0.2, 0.01):   # the small scale saturates
+            y, yq = S.pooling_f32_from_i8(dev(x), 0.37, None, None, None, 1, global_pooling=True, q_scale=qs)
+            assert np.array_equal(host(y), want) and np.array_equal(host(yq), O.quant_flat_s8(want, qs))
 
 
 def test_fc_vs_oracle():
@@ -518,6 +526,8 @@ def test_fc_vs_oracle():
     fc = S.SaberFc(True).init(M, N, K, w, b, L.F32, in_scale)
     y = torch.empty((M, N), dtype=torch.float32, device="cuda")
     assert np.array_equal(host(fc.dispatch(dev(xf), y)), want)
+    y.zero_()   # the same op fed the already-quantised input (producer fused the quantise-on-entry)
+    assert np.array_equal(host(fc.dispatch_q(dev(O.quant_flat_s8(xf, in_scale)), y)), want)
     # s8 input
     xs = rng.integers(-128, 128, (M, K)).astype(np.int8)
     fc = S.SaberFc(True).init(M, N, K, wq, b, L.S8, 0.031, w_scale=ws)
