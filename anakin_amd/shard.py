@@ -29,6 +29,43 @@ def gather_logits(local, world, out=None):
     return out
 
 
+class AsyncLogitGather:
+    """Per-step all-gather of the ranks' logits that overlaps with the next step: step i's collective is launched
+    asynchronously from a private copy of the logits (double-buffered) and waited for one step later, so the step
+    loop never stalls on the exchange; `flush()` waits for the last one. `latest()` is the newest complete result."""
+
+    def __init__(self, like, world):
+        self.world = world
+        shape = tuple(like.shape)
+        self.local = [torch.empty(shape, dtype=like.dtype, device=like.device) for _ in range(2)]
+        self.full = [torch.empty((world * shape[0],) + shape[1:], dtype=like.dtype, device=like.device)
+                     for _ in range(2)]
+        self.i = 0
+        self.pending = None
+        self.done = None
+
+    def step(self, logits):
+        b = self.i & 1
+        self.local[b].copy_(logits)
+        if dist.get_backend() == "gloo":
+            h = dist.all_gather(list(self.full[b].chunk(self.world, 0)), self.local[b], async_op=True)
+        else:
+            h = dist.all_gather_into_tensor(self.full[b], self.local[b], async_op=True)
+        self.flush()
+        self.pending = (h, b)
+        self.i += 1
+
+    def flush(self):
+        if self.pending is not None:
+            h, b = self.pending
+            h.wait()
+            self.done = b
+            self.pending = None
+
+    def latest(self):
+        return None if self.done is None else self.full[self.done]
+
+
 def max_over_ranks(seconds, device="cpu"):
     """The job's step time is the slowest rank's."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -175,12 +175,14 @@ def _out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None):
+def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
     read the same tensor with the same 1x1 geometry; they run as ONE launch (SaberConvPair), outputs
-    bit-identical to the two separate ops."""
+    bit-identical to the two separate ops.
+    fuse_tail (default: same as fuse_eltwise): the global average pool also writes the s8 quantisation that the
+    INT8 fc would otherwise compute on entry (same bytes, one launch fewer)."""
     from . import lib as L
     from . import saber as S
     net = S.Net()
@@ -191,6 +193,8 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     pending = {}                     # branch2c convs waiting for their eltwise when fusing
     if pair_siblings is None:
         pair_siblings = fuse_eltwise and not lanes
+    if fuse_tail is None:
+        fuse_tail = fuse_eltwise
     spec = model["spec"]
     quantised = {}                   # f32 edge -> its s8 twin written by the producer (fused quantise-on-entry)
     sib = {}                         # name of the first sibling -> (conv object, tensor name), waiting for the second
@@ -251,7 +255,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             hin, c = shape[l["src"]]
             net.add_tensor(nm, (B, c, 1, 1), F32)
             nxt = spec[li + 1] if li + 1 < len(spec) else None
-            if fuse_eltwise and nxt is not None and nxt["kind"] == "fc" and nxt["src"] == nm:
+            if fuse_tail and nxt is not None and nxt["kind"] == "fc" and nxt["src"] == nm:
                 # the fc quantises its f32 input on entry: fused into the pooling's store (same bytes)
                 net.add_tensor(nm + "_q", (B, c), S8)
                 net.add_pool_f32_from_i8_q(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],

@@ -58,7 +58,7 @@ def build_net(W, model, scales, batch, args):
     return W.build_fp32_net(model, batch)
 
 
-def timed_steps(net, steps, use_graph, gather=None):
+def timed_steps(net, steps, use_graph, gather=None, flush=None):
     import torch
     for _ in range(steps):
         if use_graph:
@@ -67,6 +67,8 @@ def timed_steps(net, steps, use_graph, gather=None):
             net.run()
         if gather is not None:
             gather()
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
 
 
@@ -110,23 +112,23 @@ def main():
         net.capture()
 
     logits = net.tensor("prob")
-    gather = None
+    gather = gather_flush = None
     if world > 1:
-        gathered = torch.empty((world * logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device="cuda")
+        # the path's only exchange: the per-rank logits over RCCL, double-buffered and asynchronous (step i's
+        # all-gather runs on RCCL's stream while step i+1 computes; every gather completes inside the timed region)
+        ag = shard.AsyncLogitGather(logits, world)
 
-        local = torch.empty(tuple(logits.shape), dtype=logits.dtype, device="cuda")
-
-        def gather():   # the path's only exchange: per-rank logits over RCCL (anakin_amd/shard.py)
-            local.copy_(logits)
-            shard.gather_logits(local, world, gathered)
+        def gather():
+            ag.step(logits)
+        gather_flush = ag.flush
 
     # ---------------- warm-up, then the timed region (barrier + synchronize on both sides) ----------
-    timed_steps(net, args.warmup, use_graph, gather)
+    timed_steps(net, args.warmup, use_graph, gather, gather_flush)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    timed_steps(net, args.steps, use_graph, gather)
+    timed_steps(net, args.steps, use_graph, gather, gather_flush)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

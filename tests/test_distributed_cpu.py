@@ -44,9 +44,19 @@ def _worker(rank, world, port, global_batch, ret):
     local = torch.from_numpy(_tiny_forward(x[start:start + count]))
     full = shard.gather_logits(local, world)
     t = shard.max_over_ranks(0.5 + rank)
+    # the bench's asynchronous per-step gather: three steps with different "logits", results one step behind
+    ag = shard.AsyncLogitGather(local, world)
+    seen = []
+    for step in range(3):
+        ag.step(local + step)
+        if ag.latest() is not None:
+            seen.append(ag.latest().numpy().copy())
+    ag.flush()
+    seen.append(ag.latest().numpy().copy())
     if rank == 0:
         ret["logits"] = full.numpy().copy()
         ret["t"] = t
+        ret["async"] = seen
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,3 +77,4 @@ def test_two_rank_gloo_matches_single_process():
     want = _tiny_forward(x)
     assert np.array_equal(ret["logits"], want)     # batch sharding changes nothing, bit for bit
     assert ret["t"] == 1.5                          # max over ranks
+    assert len(ret["async"]) == 3 and all(np.array_equal(a, want + i) for i, a in enumerate(ret["async"]))
