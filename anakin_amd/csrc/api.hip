@@ -88,6 +88,7 @@ struct saber_hip_conv {
     int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
     int dma = 0;             // 0: register-staged kernel; 1/2/4: LDS-DMA ring kernel with that many wave groups
     int stem = 0;            // 1: LDS-patch stem kernel (conv_stem.h) instead of the NHWC4 implicit GEMM
+    int pool_fused = 0, pool_oh = 0, pool_ow = 0;   // SaberConv2DPooling: fused stem conv + 3x3/2 max pooling
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
@@ -168,7 +169,8 @@ static void name_algo(saber_hip_conv* op) {
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
     char buf[64];
-    if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
+    if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
+    else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
         snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
@@ -278,8 +280,27 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
 }
 
 void saber_hip_conv2d_out_shape(const saber_hip_conv_t* op, int* oh, int* ow) {
-    if (oh) *oh = op->oh;
-    if (ow) *ow = op->ow;
+    if (oh) *oh = op->pool_fused ? op->pool_oh : op->oh;
+    if (ow) *ow = op->pool_fused ? op->pool_ow : op->ow;
+}
+
+int saber_hip_conv2d_set_pooling(saber_hip_conv_t* op, int pool_type, int kh, int kw, int stride_h, int stride_w,
+                                 int pad_h, int pad_w, int floor_mode) {
+    if (!op) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv_desc& d = op->d;
+    const bool fusable = stem_ok(op) && pool_type == SABER_HIP_POOL_MAX && kh == 3 && kw == 3 && stride_h == 2 &&
+                         stride_w == 2 && pad_h == 0 && pad_w == 0 && d.res_mode == SABER_HIP_RES_NONE &&
+                         (d.out_dtype == SABER_HIP_S8 || d.out_dtype == SABER_HIP_U8);
+    if (!fusable)
+        return fail(SABER_HIP_UNIMPL, "conv+pooling: no fused kernel for this combination (run the two ops)");
+    op->pool_oh = saber_hip_pool_out_dim(op->oh, pad_h, kh, stride_h, floor_mode);
+    op->pool_ow = saber_hip_pool_out_dim(op->ow, pad_w, kw, stride_w, floor_mode);
+    // every 3x3 window of the fused kernel must start inside the conv image (true for the ceil and floor shapes)
+    if ((op->pool_oh - 1) * 2 >= op->oh || (op->pool_ow - 1) * 2 >= op->ow)
+        return fail(SABER_HIP_UNIMPL, "conv+pooling: pooled shape outside the conv image");
+    op->pool_fused = 1;
+    name_algo(op);
+    return SABER_HIP_OK;
 }
 size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op) { return op->ws_bytes; }
 const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_name.c_str(); }
@@ -290,6 +311,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15,
     // optional staging variant in bits 16..23 (1 = register-staged, 2 = LDS-DMA ring, 3 / 4 = LDS-DMA ring
     // with 2 / 4 wave groups: needs stage depth 4 and a 32x32, 64x32 or 64x64 tile)
+    if (op->pool_fused) return fail(SABER_HIP_INVALID_VALUE, "fused conv+pooling has a single kernel");
     const int ks = (tile >> 8) & 0xff;
     const int var = (tile >> 16) & 0xff;
     tile &= 0xff;
@@ -504,6 +526,19 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     hipStream_t s = (hipStream_t)stream;
     const saber_hip_conv_desc& d = op->d;
     const void* xin = x;
+    if (op->pool_fused) {
+        ConvKArgs a;
+        if (op->pre_pad) {
+            HIP_TRY(launch_pad_channels_i8((size_t)d.n * d.h * d.w, d.c, 4, x, workspace, s));
+            xin = workspace;
+        }
+        fill_args(op, a, xin, y, res);
+        a.pool_oh = op->pool_oh; a.pool_ow = op->pool_ow;
+        a.Cin = d.c;
+        a.qinv = 1.f / op->in_scale;
+        HIP_TRY(launch_conv_stem_pool(op->pre_quant ? 1 : 0, a, s));
+        return SABER_HIP_OK;
+    }
     if (op->stem && op->pre_quant) {
         // fused: the stem kernel reads the f32 NCHW image and quantises while staging its LDS patch
         ConvKArgs a;
@@ -555,7 +590,7 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
 // of the implicit-GEMM kernel on the real tensors and keep the fastest. Leaves y with valid output.
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                               saber_hip_stream_t stream, int iters) {
-    if (op->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
+    if (op->algo > ALGO_IGEMM_F32 || op->pool_fused) return SABER_HIP_OK;   // (one fused conv+pooling kernel)
     if (op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "sibling pair: use saber_hip_conv2d_autotune_pair");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;

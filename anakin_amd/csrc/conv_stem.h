@@ -16,6 +16,11 @@
 namespace saber_mi355x {
 
 typedef int v2i __attribute__((ext_vector_type(2)));
+typedef unsigned short us2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16_(unsigned a, unsigned b) {   // two independent 16-bit unsigned maxima
+    const us2_ r = __builtin_elementwise_max(__builtin_bit_cast(us2_, a), __builtin_bit_cast(us2_, b));
+    return __builtin_bit_cast(unsigned, r);
+}
 
 template <int EK, bool F32IN>
 __global__ __launch_bounds__(256) void conv_stem7x7s2_kernel(const ConvKArgs a) {
@@ -154,6 +159,189 @@ static hipError_t launch_conv_stem_inst(int f32_in, const ConvKArgs& a, hipStrea
     dim3 grid(b.npx * b.nky), block(256);
     if (f32_in) hipLaunchKernelGGL((conv_stem7x7s2_kernel<EK, true>), grid, block, 0, s, b);
     else hipLaunchKernelGGL((conv_stem7x7s2_kernel<EK, false>), grid, block, 0, s, b);
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// SaberConv2DPooling<MI355X, AK_INT8> for the stem: the 7x7/2 convolution above followed by the 3x3 / stride-2 /
+// pad-0 max pooling (ResNet conv1 + pool1), in one kernel; role in the reference: SaberConv2DPooling<X86,AK_INT8>
+// (saber_conv_pooling.cpp:60-160: conv into an inner tensor, then pooling). A workgroup owns a 4 x 8 tile of POOLED
+// pixels of one image and 64 channels: it computes the 9 x 17 convolution outputs under it (the one-pixel overlap
+// with the neighbouring tiles is recomputed: +19 %), keeps them in LDS as bytes in unsigned order, and takes the
+// window maxima from there. The 112x112x64 conv tensor is never written. Max pooling of the requantised bytes is
+// exact, so the result equals pool(conv(x)) byte for byte; windows are clipped at the image border as
+// SaberPooling does (ceil-mode output shape).
+template <bool F32IN>
+__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) {
+    constexpr int PH = 4, PW = 8;
+    constexpr int CR = 2 * PH + 1, CC = 2 * PW + 1, NPX = CR * CC;      // 9 x 17 = 153 conv outputs
+    constexpr int NG = (NPX + 15) / 16, TN = NG / 2;                    // 10 MFMA pixel groups, 5 per wave column
+    constexpr int IR = (CR - 1) * 2 + 7 + 1, ICP = (CC - 1) * 2 + 8;    // 24 x 40 input pixels
+    constexpr int TM = 2, NV = 8, WCH = 64 * 16;
+    static_assert(NG % 2 == 0, "pixel groups split over two wave columns");
+
+    __shared__ v4i lds_w[WCH];
+    __shared__ unsigned lds_x[IR * ICP];
+    __shared__ uint2 lds_c[NG * 16 * 8];       // conv tile [pixel][64 channels], bytes in unsigned order
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    int ptile, tile_ky;
+    xcd_tile(a, ptile, tile_ky);
+    const int tiles_x = (a.pool_ow + PW - 1) / PW, tiles_y = (a.pool_oh + PH - 1) / PH;
+    const int per_img = tiles_x * tiles_y;
+    const int n = ptile / per_img;
+    const int trem = ptile - n * per_img;
+    const int py0 = (trem / tiles_x) * PH, px0 = (trem % tiles_x) * PW;   // pooled tile origin
+    const int cy0 = py0 * 2, cx0 = px0 * 2;                               // conv-output origin (pool stride 2, pad 0)
+    const int k_base = tile_ky * 64;
+
+    const int kb = k_base + wm * 32 + fq * NV;
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
+
+    const v4i* w16 = (const v4i*)a.w;
+    const int w_row_chunks = a.Kg_pad >> 4;
+    v4i wv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 256;
+        wv[it] = w16[(size_t)(k_base + (idx >> 4)) * w_row_chunks + (idx & 15)];
+    }
+    const int iy0 = cy0 * 2 - a.pad_h, ix0 = cx0 * 2 - a.pad_w;
+    const unsigned xmask = a.in_u8 ? 0x80808080u : 0u;
+    for (int idx = tid; idx < IR * ICP; idx += 256) {
+        const int r = idx / ICP, c = idx - r * ICP;
+        const int iy = iy0 + r, ix = ix0 + c;
+        unsigned pk = 0;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+            if constexpr (F32IN) {
+                const float* xp = (const float*)a.x + ((size_t)n * a.Cin * a.H + iy) * a.W + ix;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    if (ch < a.Cin) {
+                        float v = __fmul_rn(xp[(size_t)ch * a.H * a.W], a.qinv);
+                        v = truncf(v + copysignf(0x1.fffffep-2f, v));          // roundf (conv_igemm_impl.h)
+                        v = v < -128.f ? -128.f : (v > 127.f ? 127.f : v);      // saturate<int8_t>
+                        pk |= ((unsigned)((int)v) & 0xffu) << (8 * ch);
+                    }
+                }
+            } else {
+                pk = ((const unsigned*)a.x)[((size_t)n * a.H + iy) * a.W + ix];
+            }
+        }
+        lds_x[idx] = pk ^ xmask;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 4, q = idx & 15;
+        const int rr = r & 31, wmr = r >> 5;
+        const int lrow = (wmr * 2 + ((rr >> 2) & 1)) * 16 + (rr >> 3) * 4 + (rr & 3);
+        lds_w[lrow * 16 + (q ^ (lrow & 15))] = wv[it];
+    }
+    __syncthreads();
+
+    v4i acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    int a_idx[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 16 + frow;
+        a_idx[i] = row * 16 + (fq ^ (row & 15));
+    }
+    int b_off[TN];       // this lane's conv pixel of group j: flat index q -> (row q / CC, col q % CC) of the conv tile
+    bool ok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int q = (wn * TN + j) * 16 + frow;
+        const int qq = q < NPX ? q : NPX - 1;
+        const int r = qq / CC, c = qq - r * CC;
+        b_off[j] = (2 * r + (fq >> 1)) * ICP + 2 * c + 4 * (fq & 1);
+        ok[j] = q < NPX && cy0 + r < a.OH && cx0 + c < a.OW;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        v4i af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = lds_w[a_idx[i] ^ (ks << 2)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const v2i* p = (const v2i*)&lds_x[b_off[j] + ks * 2 * ICP];
+            const v2i lo = p[0], hi = p[1];
+            bf[j] = v4i{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
+    }
+
+    // conv epilogue -> LDS bytes in unsigned order (u8 as is, s8 + 128); positions outside the conv image hold 0,
+    // the minimum, so a clipped window ignores them
+    const bool u8 = a.out_dtype == DT_U8;
+    const float lo_clamp = a.relu ? 0.f : -3.0e38f;
+    const float off = u8 ? 0.f : 128.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int q = (wn * TN + j) * 16 + frow;
+        unsigned pk[2] = {0u, 0u};
+        if (ok[j]) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                unsigned w = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float d = (float)(acc[v][j][t] + cp.comp[v * 4 + t]);
+                    d = __fadd_rn(d, cp.bias[v * 4 + t]);
+                    d = __fmul_rn(d, cp.scale[v * 4 + t]);
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaxf(rintf(d), lo_clamp) + off, t, w);
+                }
+                pk[v] = w;
+            }
+        }
+        lds_c[q * 8 + wm * 4 + fq] = make_uint2(pk[0], pk[1]);
+    }
+    __syncthreads();
+
+    // 3x3 / stride 2 window maxima: one lane per (pooled pixel, 8 channels)
+    const int pp = tid >> 3, cg = tid & 7;
+    const int ppy = pp / PW, ppx = pp - ppy * PW;
+    const int poy = py0 + ppy, pox = px0 + ppx;
+    const int kc = k_base + cg * 8;
+    if (poy < a.pool_oh && pox < a.pool_ow && kc < a.K) {
+        unsigned ev[2] = {0, 0}, od[2] = {0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const uint2 v = lds_c[((2 * ppy + dy) * CC + 2 * ppx + dx) * 8 + cg];
+                ev[0] = pk_max_u16_(ev[0], v.x & 0x00ff00ffu);
+                od[0] = pk_max_u16_(od[0], (v.x >> 8) & 0x00ff00ffu);
+                ev[1] = pk_max_u16_(ev[1], v.y & 0x00ff00ffu);
+                od[1] = pk_max_u16_(od[1], (v.y >> 8) & 0x00ff00ffu);
+            }
+        const unsigned flip = u8 ? 0u : 0x80808080u;
+        const uint2 o = make_uint2((ev[0] | (od[0] << 8)) ^ flip, (ev[1] | (od[1] << 8)) ^ flip);
+        uint8_t* y = (uint8_t*)a.y + (((size_t)n * a.pool_oh + poy) * a.pool_ow + pox) * a.K + kc;
+        if (kc + 8 <= a.K) *(uint2*)y = o;
+        else for (int t = 0; t < a.K - kc; ++t) y[t] = (uint8_t)((t < 4 ? o.x : o.y) >> (8 * (t & 3)));
+    }
+}
+
+static hipError_t launch_conv_stem_pool_inst(int f32_in, const ConvKArgs& a, hipStream_t s) {
+    ConvKArgs b = a;
+    b.npx = a.N * ((a.pool_ow + 7) / 8) * ((a.pool_oh + 3) / 4);
+    b.nky = (a.K + 63) / 64;
+    dim3 grid(b.npx * b.nky), block(256);
+    if (f32_in) hipLaunchKernelGGL((conv_stem_pool_kernel<true>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((conv_stem_pool_kernel<false>), grid, block, 0, s, b);
     return hipGetLastError();
 }
 

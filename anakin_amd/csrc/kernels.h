@@ -47,6 +47,7 @@ struct ConvKArgs {
     // rows [K1, K1+K2) -> y2 (stride K2, relu2/out_dtype2); K = K1 + K2. K2 == 0: ordinary conv.
     void* y2;
     int K1, K2, relu2, out_dtype2;
+    int pool_oh, pool_ow;   // fused 3x3 / stride-2 max pooling (conv_stem_pool_kernel): pooled output dims
 };
 
 // tile ids for launch_conv_igemm
@@ -63,6 +64,8 @@ hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvK
 hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s);
 // ResNet stem (7x7 stride 2, <= 4 channels) with the input patch in LDS; f32_in: fuse the quantise-on-entry
 hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s);
+// ... followed by the 3x3 / stride-2 / pad-0 max pooling in the same kernel (s8 / u8 outputs only)
+hipError_t launch_conv_stem_pool(int f32_in, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

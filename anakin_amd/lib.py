@@ -23,7 +23,7 @@ SYMBOLS = [
     "saber_hip_conv2d_create", "saber_hip_conv2d_set_weights", "saber_hip_conv2d_workspace_bytes",
     "saber_hip_conv2d_out_shape", "saber_hip_conv2d_run", "saber_hip_conv2d_destroy",
     "saber_hip_conv2d_get_quantized_weights", "saber_hip_conv2d_algo", "saber_hip_conv2d_set_tile",
-    "saber_hip_conv2d_get_tile", "saber_hip_conv2d_autotune",
+    "saber_hip_conv2d_get_tile", "saber_hip_conv2d_autotune", "saber_hip_conv2d_set_pooling",
     "saber_hip_conv2d_create_pair", "saber_hip_conv2d_run_pair", "saber_hip_conv2d_autotune_pair",
     "saber_hip_net_add_conv_pair",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
@@ -94,6 +94,7 @@ def load():
     lib.saber_hip_conv2d_algo.restype = C.c_char_p
     lib.saber_hip_conv2d_set_tile.argtypes = [P, I]
     lib.saber_hip_conv2d_get_tile.argtypes = [P]
+    lib.saber_hip_conv2d_set_pooling.argtypes = [P] + [I] * 8
     lib.saber_hip_conv2d_autotune.argtypes = [P, P, P, P, P, P, I]
     lib.saber_hip_conv2d_create_pair.argtypes = [P, P, C.POINTER(P)]
     lib.saber_hip_conv2d_run_pair.argtypes = [P, P, P, P, P]
@@ -157,9 +158,14 @@ def load():
     return lib
 
 
+UNIMPL = -3   # SABER_HIP_UNIMPL -> SaberUnImplError
+
+
 def check(rc):
     if rc != 0:
-        raise SaberHipError("saber_hip status %d: %s" % (rc, load().saber_hip_last_error().decode()))
+        e = SaberHipError("saber_hip status %d: %s" % (rc, load().saber_hip_last_error().decode()))
+        e.status = rc
+        raise e
 
 
 def require_device():

@@ -137,6 +137,59 @@ class SaberConv2D:
             pass
 
 
+class SaberConv2DPooling:
+    """SaberConv2DPooling<MI355X, AK_INT8> (saber/funcs/conv_pooling.h, ConvPoolingParam): conv followed by pooling.
+    One fused kernel where the library has one (saber_hip_conv2d_set_pooling: the ResNet stem + 3x3/2 max pooling);
+    otherwise the conv runs into an inner tensor and the pooling is a second launch, exactly the structure of
+    SaberConv2DPooling<X86,AK_FLOAT> (saber_conv_pooling.cpp:13-57). Same bytes either way."""
+
+    def __init__(self):
+        self.conv = SaberConv2D(True)
+        self.fused = False
+        self.inner = None
+
+    def init(self, in_shape_nchw, conv_param, pool_type, window, stride, pad, in_dtype, out_dtype, in_scale=1.0,
+             out_scale=1.0, floor_mode=False, in_layout=None):
+        self.conv.init(in_shape_nchw, conv_param, in_dtype, out_dtype, in_scale, out_scale, in_layout=in_layout)
+        self.pool = (pool_type, tuple(window), tuple(stride), tuple(pad), floor_mode)
+        n = in_shape_nchw[0]
+        ch, cw = self.conv.out_hw
+        rc = L.load().saber_hip_conv2d_set_pooling(self.conv.h, pool_type, window[0], window[1], stride[0], stride[1],
+                                                   pad[0], pad[1], 1 if floor_mode else 0)
+        if rc == 0:
+            self.fused = True
+            oh, ow = C.c_int(), C.c_int()
+            L.load().saber_hip_conv2d_out_shape(self.conv.h, C.byref(oh), C.byref(ow))
+            self.out_hw = (oh.value, ow.value)
+        elif rc == L.UNIMPL:
+            self.inner = torch.empty((n, ch, cw, self.conv.desc.k), dtype=_TORCH_DT[out_dtype], device="cuda")
+            self.out_hw = (pool_out_dim(ch, pad[0], window[0], stride[0], floor_mode),
+                           pool_out_dim(cw, pad[1], window[1], stride[1], floor_mode))
+        else:
+            L.check(rc)
+        self.h = self.conv.h
+        return self
+
+    def new_output(self):
+        d = self.conv.desc
+        return torch.empty((d.n, self.out_hw[0], self.out_hw[1], d.k), dtype=_TORCH_DT[d.out_dtype], device="cuda")
+
+    def algo(self):
+        return self.conv.algo()
+
+    def dispatch(self, x, y):
+        if self.fused:
+            return self.conv.dispatch(x, y)
+        self.conv.dispatch(x, self.inner)
+        pt, win, st, pd, _ = self.pool
+        d = self.conv.desc
+        n, ch, cw, k = self.inner.shape
+        L.check(L.load().saber_hip_pool2d_i8_nhwc(n, ch, cw, k, self.out_hw[0], self.out_hw[1], win[0], win[1], st[0],
+                                                  st[1], pd[0], pd[1], pt, d.out_dtype, d.out_dtype, _p(self.inner),
+                                                  _p(y), _stream()))
+        return y
+
+
 class SaberConvPair:
     """Two sibling INT8 convolutions over ONE input tensor (same kernel / pad / stride) in one launch
     (saber_hip_conv2d_create_pair): ResNet's stage-entry `branch1` + `branch2a`. Outputs are bit-identical

@@ -175,14 +175,17 @@ def _out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None):
+def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
     read the same tensor with the same 1x1 geometry; they run as ONE launch (SaberConvPair), outputs
     bit-identical to the two separate ops.
     fuse_tail (default: same as fuse_eltwise): the global average pool also writes the s8 quantisation that the
-    INT8 fc would otherwise compute on entry (same bytes, one launch fewer)."""
+    INT8 fc would otherwise compute on entry (same bytes, one launch fewer).
+    fuse_pool (default: same as fuse_eltwise): a conv whose only consumer is a max pooling becomes one
+    SaberConv2DPooling op where the library has a fused kernel (the stem: conv1 + pool1); the conv's own output
+    edge then does not exist."""
     from . import lib as L
     from . import saber as S
     net = S.Net()
@@ -195,11 +198,21 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
         pair_siblings = fuse_eltwise and not lanes
     if fuse_tail is None:
         fuse_tail = fuse_eltwise
+    if fuse_pool is None:
+        fuse_pool = fuse_eltwise
+    consumers = {}
+    for e in model["spec"]:
+        for key in ("src", "a", "b"):
+            if key in e:
+                consumers[e[key]] = consumers.get(e[key], 0) + 1
     spec = model["spec"]
+    done = set()                     # ops already emitted as part of a fused predecessor
     quantised = {}                   # f32 edge -> its s8 twin written by the producer (fused quantise-on-entry)
     sib = {}                         # name of the first sibling -> (conv object, tensor name), waiting for the second
     for li, l in enumerate(spec):
         kd, nm = l["kind"], l["name"]
+        if nm in done:
+            continue
         if kd == "conv":
             hin, cin = shape[l["src"]]
             ho = _out_hw(hin, l["k"], l["stride"], l["pad"])
@@ -210,6 +223,23 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             if fuse_eltwise and "eltwise" in l:
                 pending[l["eltwise"]] = (l, p, hin, cin, ho)
                 continue
+            nxt = spec[li + 1] if li + 1 < len(spec) else None
+            if fuse_pool and nxt is not None and nxt["kind"] == "pool" and nxt["src"] == nm and consumers.get(nm) == 1 \
+                    and nxt["type"] == 0:
+                cp = S.SaberConv2DPooling().init((B, cin, hin, hin), p, nxt["type"], (nxt["win"],) * 2,
+                                                 (nxt["stride"],) * 2, (nxt["pad"],) * 2, dtype[l["src"]], odt,
+                                                 scales[l["src"]], scales[nm],
+                                                 in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
+                if cp.fused:
+                    pn = nxt["name"]
+                    po = cp.out_hw[0]
+                    shape[pn], dtype[pn] = (po, l["cout"]), odt
+                    scales[pn] = scales[nm]
+                    net.add_tensor(pn, (B, po, po, l["cout"]), odt)
+                    net.add_conv(cp.conv, l["src"], pn)
+                    net.keep.append(cp)
+                    done.add(pn)
+                    continue
             conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[l["src"]], odt, scales[l["src"]], scales[nm],
                                             in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
             net.add_tensor(nm, (B, ho, ho, l["cout"]), odt)

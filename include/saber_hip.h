@@ -110,6 +110,15 @@ void saber_hip_conv2d_out_shape(const saber_hip_conv_t* op, int* oh, int* ow);
 int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                          saber_hip_stream_t stream);
 void saber_hip_conv2d_destroy(saber_hip_conv_t* op);
+/* SaberConv2DPooling (saber/funcs/conv_pooling.h; ConvPoolingParam, saber_funcs_param.h:647-677): attaches a pooling
+ * stage to an INT8 conv. On success the op's output IS the pooled tensor (out_shape reports the pooled dims;
+ * Pooling<>::compute_output_shape, pooling.h:92-121) and `run` is one kernel; the bytes equal pooling(conv(x)).
+ * Returns SABER_HIP_UNIMPL when no fused kernel covers the combination — the caller then dispatches the conv into an
+ * inner tensor and the pooling as a second op, as SaberConv2DPooling<X86,AK_FLOAT> does (saber_conv_pooling.cpp:13-57).
+ * Fused today: 7x7 / stride-2 conv with <= 4 input channels (the ResNet stem, optionally quantising its f32 input)
+ * + 3x3 / stride-2 / pad-0 max pooling, s8 or u8 output. Call before the first run. */
+int saber_hip_conv2d_set_pooling(saber_hip_conv_t* op, int pool_type, int kh, int kw, int stride_h, int stride_w,
+                                 int pad_h, int pad_w, int floor_mode);
 /* Debug / parity helpers: copy out the quantised weights (OIHW s8) and their scales. */
 int saber_hip_conv2d_get_quantized_weights(const saber_hip_conv_t* op, int8_t* wq_oihw, float* w_scale);
 /* Name of the kernel variant `run` will launch (e.g. "igemm_i8_64x64"), for profiling/tests. */

@@ -9,9 +9,10 @@ from anakin_amd import lib as L, workloads as W
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 VARIANTS = {
     "reference op list (no fusion)": dict(fuse_eltwise=False),
-    "fused eltwise only": dict(fuse_eltwise=True, pair_siblings=False, fuse_tail=False),
-    "+ sibling pairs": dict(fuse_eltwise=True, pair_siblings=True, fuse_tail=False),
-    "+ fused tail quantise (default)": dict(fuse_eltwise=True),
+    "fused eltwise only": dict(fuse_eltwise=True, pair_siblings=False, fuse_tail=False, fuse_pool=False),
+    "+ sibling pairs": dict(fuse_eltwise=True, pair_siblings=True, fuse_tail=False, fuse_pool=False),
+    "+ fused tail quantise": dict(fuse_eltwise=True, fuse_pool=False),
+    "+ conv1+pool1 (default)": dict(fuse_eltwise=True),
 }
 L.require_device()
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)

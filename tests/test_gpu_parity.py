@@ -251,6 +251,57 @@ def test_conv_stem_vs_oracle(case, combo):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", [(2, 224, 224, 64, "f32"), (1, 61, 47, 64, "f32"), (2, 33, 40, 72, "s8"),
+                                  (1, 30, 30, 64, "u8"), (1, 18, 23, 16, "f32")])
+@pytest.mark.parametrize("odt", [O.U8, O.S8])
+def test_conv_pooling_stem_fused_vs_oracle(case, odt):
+    """SaberConv2DPooling: 7x7/2 stem + 3x3/2 max pooling in one kernel == oracle conv followed by oracle pooling,
+    byte for byte (f32 image quantised on entry / s8 / u8 NHWC inputs, ragged sizes, ceil-mode windows clipped)."""
+    N, H, W, K, kind = case
+    rng = np.random.default_rng(abs(hash((case, odt))) % 2**31)
+    w = (rng.standard_normal((K, 3, 7, 7)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    in_scale, out_scale = 1 / 127.0, 0.02
+    relu = odt == O.U8
+    if kind == "f32":
+        xf = rng.uniform(-1, 1, (N, 3, H, W)).astype(np.float32)
+        xq = O.quant_nchw_to_nhwc(xf, in_scale, O.S8)
+        x_dev, idt, in_layout = dev(xf), L.F32, L.NCHW
+    else:
+        xq = (rng.integers(0, 256, (N, H, W, 3)).astype(np.uint8) if kind == "u8"
+              else rng.integers(-128, 128, (N, H, W, 3)).astype(np.int8))
+        x_dev, idt, in_layout = dev(xq), O.code_of(xq), L.NHWC
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, O.code_of(xq), odt)
+    conv_out = O.conv_i8(xq, O.quant_weights(w, ws), bp, sc, odt, relu, (3, 3), (2, 2))
+    want = O.pool_i8_nhwc(conv_out, (3, 3), (2, 2), (0, 0), 0)
+    p = S.ConvParam(w, b, 1, (3, 3), (2, 2), (1, 1), relu)
+    cp = S.SaberConv2DPooling().init((N, 3, H, W), p, L.POOL_MAX, (3, 3), (2, 2), (0, 0), idt, odt, in_scale,
+                                     out_scale, in_layout=in_layout)
+    assert cp.fused and "maxpool" in cp.algo()
+    y = cp.new_output()
+    y.fill_(9)
+    cp.dispatch(x_dev, y)
+    got = host(y)
+    assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), cp.algo()
+
+
+def test_conv_pooling_unfused_fallback_is_two_ops():
+    """No fused kernel for this combination: conv into an inner tensor, then pooling (SaberConv2DPooling<X86,AK_FLOAT>
+    structure); same bytes as the oracle."""
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 256, (2, 14, 14, 32)).astype(np.uint8)
+    w = (rng.standard_normal((64, 32, 3, 3)) * 0.1).astype(np.float32)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, None, 0.02, 0.05, O.U8, O.U8)
+    want = O.pool_i8_nhwc(O.conv_i8(x, O.quant_weights(w, ws), None, sc, O.U8, 1, (1, 1)), (2, 2), (2, 2), (0, 0), 0)
+    cp = S.SaberConv2DPooling().init((2, 32, 14, 14), S.ConvParam(w, None, 1, (1, 1), (1, 1), (1, 1), True),
+                                     L.POOL_MAX, (2, 2), (2, 2), (0, 0), O.U8, O.U8, 0.02, 0.05)
+    assert not cp.fused
+    y = cp.new_output()
+    assert np.array_equal(host(cp.dispatch(dev(x), y)), want)
+
+
 def test_conv_i8_f32_input_quantises_on_entry():
     """SaberConv2D<X86,AK_INT8> handed an f32 NCHW tensor (first layer): reorder_nhwc_nchw then conv."""
     rng = np.random.default_rng(11)

@@ -27,10 +27,13 @@ def _h(t):
     return t.cpu().numpy()
 
 
-@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("fuse", [False, "lanes", True])
 def test_resnet50_int8_every_edge_bit_exact(setup, fuse):
+    """False: the reference op list one to one. True: the default executor options (fused eltwise epilogues, sibling
+    pairs, conv1+pool1 as SaberConv2DPooling, pool5 writing the fc's quantised input). "lanes": fused epilogues with
+    two-lane execution instead of the pairs."""
     model, x, scales, ref = setup
-    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=fuse, lanes=fuse)   # the fused case also exercises two-lane execution
+    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=bool(fuse), lanes=fuse == "lanes")
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     checked = 0
@@ -46,7 +49,7 @@ def test_resnet50_int8_every_edge_bit_exact(setup, fuse):
             else:
                 assert np.array_equal(got, want), name
             checked += 1
-    assert checked >= (40 if fuse else 70)
+    assert checked >= (39 if fuse else 70)
     # hipGraph replay must reproduce the eager result; so must the autotuned (RUNTIME) tiles
     logits = _h(net.tensor("fc1000")).copy()
     net.tensor("fc1000").zero_()
