@@ -140,7 +140,8 @@ def main():
     out = None
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"value": round(value, 1), "unit": "images/s", "ms_per_step": round(ms_per_step, 4)}))
+            print(json.dumps({"value": round(value, 1), "unit": "images/s", "ms_per_step": round(ms_per_step, 4),
+                              "ops": net.num_ops()}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -186,7 +187,7 @@ def main():
                 roof["traffic_note"] = "traffic = PMC HBM bytes per launch / avg launch time, GB/s (same unit as achieved)"
         except (OSError, ValueError, KeyError):
             pass
-        roof.update(kernel="conv_igemm_kernel / conv_igemm_dma_kernel / conv3x3_halo_kernel (all %d conv/fc launches of one forward)" % n_conv,
+        roof.update(kernel="conv_igemm_kernel / conv_igemm_dma_kernel / conv3x3_halo_kernel / conv_stem_pool_kernel (all %d conv/fc launches of one forward)" % n_conv,
                     launches=n_conv, avg_launch_us=round(conv_us / n_conv, 3),
                     algorithmic_bytes_per_launch=int(alg_bytes / n_conv),
                     algorithmic_bytes_per_forward=int(alg_bytes), algorithmic_ops_per_forward=int(alg_ops),

@@ -16,7 +16,7 @@ n_conv = 0
 for _, ev, name in rows:
     v = c.execute(f"select sum(e.value) from {pe} e join {ip} i on e.pmc_id=i.id where e.event_id={ev} and i.name='{counter}'").fetchone()[0] or 0.0
     tot_all += v
-    if "conv_igemm" in name or "conv3x3_halo" in name:
+    if "conv_igemm" in name or "conv3x3_halo" in name or "conv_stem" in name:
         tot_conv += v
         n_conv += 1
 print(json.dumps({"counter": counter, "dispatches": len(rows), "conv_dispatches": n_conv,
