@@ -8,6 +8,7 @@
 using namespace anakin::saber;
 template class anakin::saber::SaberConvEltwiseMI355X<X86, AK_INT8>;
 template class anakin::saber::SaberConvEltwiseMI355X<X86, AK_FLOAT>;
+template class anakin::saber::SaberConv2DPoolingMI355X<X86, AK_INT8>;
 template class anakin::saber::SaberFcMI355X<X86, AK_INT8>;
 template class anakin::saber::SaberFcMI355X<X86, AK_FLOAT>;
 template class anakin::saber::SaberGemmMI355X<X86>;

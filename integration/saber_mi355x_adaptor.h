@@ -1,7 +1,7 @@
 // integration/saber_mi355x_adaptor.h — the reference-side binding of the MI355X Saber target.
 //
 // This is the code a maintainer drops into the reference as
-//   saber/funcs/impl/mi355x/saber_conv.h, saber_conv_eltwise.h, saber_fc.h, saber_gemm.h
+//   saber/funcs/impl/mi355x/saber_conv.h, saber_conv_eltwise.h, saber_conv_pooling.h, saber_fc.h, saber_gemm.h
 // (one `SaberXxx<MI355X, OpDtype>` partial specialisation per operator, the pattern of
 // saber/funcs/impl/x86/saber_conv.h:24-69) and includes from the facade headers' target ladder
 // (saber/funcs/conv.h:23-50). It only marshals Tensor / Param objects into the POD descriptors of
@@ -118,6 +118,88 @@ private:
     saber_hip_conv_t* _op;
     void* _ws;
     size_t _ws_bytes;
+};
+
+// SaberConv2DPooling<MI355X, AK_INT8> (saber/funcs/conv_pooling.h; x86: saber_conv_pooling.cpp). One fused kernel when
+// saber_hip_conv2d_set_pooling accepts the combination (the ResNet stem + 3x3/2 max pooling); otherwise the conv runs
+// into an inner tensor and the pooling is a second launch, the structure of SaberConv2DPooling<X86,AK_FLOAT> (:13-57).
+template <typename TargetType, DataType OpDtype>
+class SaberConv2DPoolingMI355X : public ImplBase<TargetType, OpDtype, ConvPoolingParam<TargetType> > {
+public:
+    SaberConv2DPoolingMI355X() : _op(nullptr), _ws(nullptr), _fused(false) {}
+    ~SaberConv2DPoolingMI355X() { if (_op) saber_hip_conv2d_destroy(_op); }
+
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                             ConvPoolingParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        return create(inputs, outputs, param, ctx);
+    }
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                               ConvPoolingParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        ConvParam<TargetType>& cp = param.conv_param;
+        PoolingParam<TargetType>& pp = param.pooling_param;
+        Tensor<TargetType>* in = inputs[0];
+        Tensor<TargetType>* out = outputs[0];
+        if (OpDtype != AK_INT8 || in->get_layout() != Layout_NHWC && in->get_dtype() != AK_FLOAT) return SaberUnImplError;
+        saber_hip_conv_desc d;
+        memset(&d, 0, sizeof d);
+        d.n = in->num(); d.c = in->channel(); d.h = in->height(); d.w = in->width();
+        d.k = cp.weight()->num(); d.kh = cp.weight()->height(); d.kw = cp.weight()->width();
+        d.pad_h = cp.pad_h; d.pad_w = cp.pad_w; d.stride_h = cp.stride_h; d.stride_w = cp.stride_w;
+        d.dil_h = cp.dilation_h; d.dil_w = cp.dilation_w; d.group = cp.group;
+        d.in_dtype = mi355x_dtype(in->get_dtype());
+        d.out_dtype = mi355x_dtype(out->get_dtype());
+        d.in_layout = mi355x_layout(in->get_layout());
+        d.out_layout = SABER_HIP_NHWC;
+        d.int8_weights = 1;
+        d.act = (cp.activation_param.has_active && cp.activation_param.active == Active_relu) ? SABER_HIP_ACT_RELU
+                                                                                              : SABER_HIP_ACT_NONE;
+        if (_op) { saber_hip_conv2d_destroy(_op); _op = nullptr; }
+        int rc = saber_hip_conv2d_create(&d, &_op);
+        if (rc) return mi355x_status(rc);
+        const Tensor<TargetType>* w = cp.weight();
+        const Tensor<TargetType>* b = cp.bias();
+        // the pooling keeps the conv's scale (SaberPooling<X86,AK_INT8>::init): the op's output scale is the conv's
+        rc = saber_hip_conv2d_set_weights(_op, w->data(), mi355x_dtype(w->get_dtype()),
+                                          w->get_scale().size() ? w->get_scale().data() : nullptr,
+                                          (b && b->valid_size() > 0) ? (const float*)b->data() : nullptr,
+                                          in->get_scale().size() ? in->get_scale()[0] : 1.f,
+                                          out->get_scale().size() ? out->get_scale()[0] : 1.f);
+        if (rc) return mi355x_status(rc);
+        _type = pp.pooling_type == Pooling_max ? SABER_HIP_POOL_MAX
+                : (pp.pooling_type == Pooling_average_include_padding ? SABER_HIP_POOL_AVG_INCL : SABER_HIP_POOL_AVG_EXCL);
+        saber_hip_conv2d_out_shape(_op, &_ch, &_cw);
+        _kh = pp.global_pooling ? _ch : pp.window_h; _kw = pp.global_pooling ? _cw : pp.window_w;
+        _sh = pp.global_pooling ? _ch : pp.stride_h; _sw = pp.global_pooling ? _cw : pp.stride_w;
+        _ph = pp.global_pooling ? 0 : pp.pad_h; _pw = pp.global_pooling ? 0 : pp.pad_w;
+        rc = saber_hip_conv2d_set_pooling(_op, _type, _kh, _kw, _sh, _sw, _ph, _pw, pp.cmp_out_shape_floor_as_conv ? 1 : 0);
+        _fused = rc == SABER_HIP_OK;
+        if (!_fused && rc != SABER_HIP_UNIMPL) return mi355x_status(rc);
+        if (!_fused) {   // inner tensor of the conv's shape, NHWC, the output's dtype (target allocator in the real target)
+            _inner.re_alloc(Shape({d.n, _ch, _cw, d.k}, Layout_NHWC), out->get_dtype());
+        }
+        return SaberSuccess;
+    }
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                                 ConvPoolingParam<TargetType>& param) {
+        saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
+        if (_fused)
+            return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), nullptr, _ws, stream));
+        int rc = saber_hip_conv2d_run(_op, inputs[0]->data(), _inner.mutable_data(), nullptr, _ws, stream);
+        if (rc) return mi355x_status(rc);
+        const int dt = mi355x_dtype(outputs[0]->get_dtype());
+        return mi355x_status(saber_hip_pool2d_i8_nhwc(_inner.num(), _ch, _cw, _inner.channel(), outputs[0]->height(),
+                                                      outputs[0]->width(), _kh, _kw, _sh, _sw, _ph, _pw, _type, dt, dt,
+                                                      _inner.data(), outputs[0]->mutable_data(), stream));
+    }
+
+private:
+    saber_hip_conv_t* _op;
+    void* _ws;
+    bool _fused;
+    int _type, _ch, _cw, _kh, _kw, _sh, _sw, _ph, _pw;
+    Tensor<TargetType> _inner;
 };
 
 // Fc<MI355X, OpDtype> (saber/funcs/fc.h:48-127)
