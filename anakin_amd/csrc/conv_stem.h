@@ -22,6 +22,58 @@ __device__ __forceinline__ unsigned pk_max_u16_(unsigned a, unsigned b) {   // t
     return __builtin_bit_cast(unsigned, r);
 }
 
+// Input patch -> LDS as one dword per pixel (<= 4 channels), quantising f32 NCHW planes on the way
+// (saturate(roundf(x * 1/scale)), saber_util.h:759-781). All of a thread's global loads are issued before the first
+// conversion so that the patch costs one exposed memory latency, not one per pass.
+template <bool F32IN, int NPIX, int ICP>
+__device__ __forceinline__ void stage_input_patch(const ConvKArgs& a, int n, int iy0, int ix0, unsigned xmask, int tid,
+                                                  unsigned* lds_x) {
+    constexpr int NIT = (NPIX + 255) / 256;
+    float fv[NIT][4];
+    unsigned pv[NIT];
+    bool ok[NIT];
+    const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx / ICP, c = idx - r * ICP;
+        const int iy = iy0 + r, ix = ix0 + c;
+        ok[it] = idx < NPIX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        pv[it] = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) fv[it][ch] = 0.f;
+        if (ok[it]) {
+            if constexpr (F32IN) {
+                const float* xp = (const float*)a.x + ((size_t)n * a.Cin * a.H + iy) * a.W + ix;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+                    if (ch < a.Cin) fv[it][ch] = xp[ch * plane];
+            } else {
+                pv[it] = ((const unsigned*)a.x)[((size_t)n * a.H + iy) * a.W + ix];
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        unsigned pk = pv[it];
+        if constexpr (F32IN) {
+            if (ok[it]) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    if (ch < a.Cin) {
+                        float v = __fmul_rn(fv[it][ch], a.qinv);
+                        v = truncf(v + copysignf(0x1.fffffep-2f, v));          // roundf (conv_igemm_impl.h)
+                        v = v < -128.f ? -128.f : (v > 127.f ? 127.f : v);      // saturate<int8_t>
+                        pk |= ((unsigned)((int)v) & 0xffu) << (8 * ch);
+                    }
+                }
+            }
+        }
+        if (idx < NPIX) lds_x[idx] = pk ^ xmask;   // padding becomes -128 for u8 inputs (compensated through comp)
+    }
+}
+
 template <int EK, bool F32IN>
 __global__ __launch_bounds__(256) void conv_stem7x7s2_kernel(const ConvKArgs a) {
     constexpr int TH = 8, TW = 16;
@@ -62,28 +114,7 @@ __global__ __launch_bounds__(256) void conv_stem7x7s2_kernel(const ConvKArgs a) 
     // ---- input patch -> LDS, quantising on the way ---------------------------------------------------
     const int iy0 = ty0 * 2 - a.pad_h, ix0 = tx0 * 2 - a.pad_w;
     const unsigned xmask = a.in_u8 ? 0x80808080u : 0u;
-    for (int idx = tid; idx < IR * ICP; idx += 256) {
-        const int r = idx / ICP, c = idx - r * ICP;
-        const int iy = iy0 + r, ix = ix0 + c;
-        unsigned pk = 0;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            if constexpr (F32IN) {
-                const float* xp = (const float*)a.x + ((size_t)n * a.Cin * a.H + iy) * a.W + ix;
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    if (ch < a.Cin) {
-                        float v = __fmul_rn(xp[(size_t)ch * a.H * a.W], a.qinv);
-                        v = truncf(v + copysignf(0x1.fffffep-2f, v));          // roundf (conv_igemm_impl.h)
-                        v = v < -128.f ? -128.f : (v > 127.f ? 127.f : v);      // saturate<int8_t>
-                        pk |= ((unsigned)((int)v) & 0xffu) << (8 * ch);
-                    }
-                }
-            } else {
-                pk = ((const unsigned*)a.x)[((size_t)n * a.H + iy) * a.W + ix];
-            }
-        }
-        lds_x[idx] = pk ^ xmask;   // padding becomes -128 for u8 inputs (compensated through comp)
-    }
+    stage_input_patch<F32IN, IR * ICP, ICP>(a, n, iy0, ix0, xmask, tid, lds_x);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = tid + it * 256;
@@ -213,28 +244,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) 
     }
     const int iy0 = cy0 * 2 - a.pad_h, ix0 = cx0 * 2 - a.pad_w;
     const unsigned xmask = a.in_u8 ? 0x80808080u : 0u;
-    for (int idx = tid; idx < IR * ICP; idx += 256) {
-        const int r = idx / ICP, c = idx - r * ICP;
-        const int iy = iy0 + r, ix = ix0 + c;
-        unsigned pk = 0;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            if constexpr (F32IN) {
-                const float* xp = (const float*)a.x + ((size_t)n * a.Cin * a.H + iy) * a.W + ix;
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    if (ch < a.Cin) {
-                        float v = __fmul_rn(xp[(size_t)ch * a.H * a.W], a.qinv);
-                        v = truncf(v + copysignf(0x1.fffffep-2f, v));          // roundf (conv_igemm_impl.h)
-                        v = v < -128.f ? -128.f : (v > 127.f ? 127.f : v);      // saturate<int8_t>
-                        pk |= ((unsigned)((int)v) & 0xffu) << (8 * ch);
-                    }
-                }
-            } else {
-                pk = ((const unsigned*)a.x)[((size_t)n * a.H + iy) * a.W + ix];
-            }
-        }
-        lds_x[idx] = pk ^ xmask;
-    }
+    stage_input_patch<F32IN, IR * ICP, ICP>(a, n, iy0, ix0, xmask, tid, lds_x);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = tid + it * 256;

@@ -105,7 +105,7 @@ def main():
     net.run()
     torch.cuda.synchronize()
     if not args.no_autotune:
-        net.autotune(iters=10)   # RUNTIME strategy (BaseFunc::pick_best_runtime), once, outside the timed region
+        net.autotune(iters=20)   # RUNTIME strategy (BaseFunc::pick_best_runtime), once, outside the timed region
         net.tensor("data").copy_(torch.from_numpy(x).cuda())
     use_graph = not args.no_graph
     if use_graph:
@@ -204,7 +204,7 @@ def main():
             net1.tensor("data").copy_(torch.from_numpy(W.make_input(1)).cuda())
             net1.run()
             if not args.no_autotune:
-                net1.autotune(iters=10)
+                net1.autotune(iters=20)
             if use_graph:
                 net1.capture()
             timed_steps(net1, 20, use_graph)
