@@ -32,6 +32,8 @@ enum DataType { AK_INVALID = 0, AK_HALF = 1, AK_FLOAT = 2, AK_DOUBLE = 3, AK_INT
 enum LayoutType { Layout_invalid = 0, Layout_NCHW = 2, Layout_NHWC = 3 };
 enum ActiveType { Active_unknow = 0, Active_relu = 2 };
 enum EltwiseType { Eltwise_unknow = 0, Eltwise_prod = 1, Eltwise_sum = 2, Eltwise_max = 3 };
+enum PoolingType { Pooling_unknow = 0, Pooling_max = 1, Pooling_average_include_padding = 2,
+                   Pooling_average_exclude_padding = 3 };   // saber_types.h:305-311
 
 inline SaberStatus to_status(int rc) {
     switch (rc) {
@@ -198,6 +200,28 @@ struct ConvEltwiseParam {
 };
 
 template <typename TargetType>
+struct PoolingParam {   // saber_funcs_param.h:2085-2153
+    PoolingParam() : window_h(-1), window_w(-1), pad_h(-1), pad_w(-1), stride_h(-1), stride_w(-1),
+                     pooling_type(Pooling_unknow), global_pooling(false), cmp_out_shape_floor_as_conv(false) {}
+    PoolingParam(int window_h_in, int window_w_in, int pad_h_in, int pad_w_in, int stride_h_in, int stride_w_in,
+                 PoolingType type, bool global_pooling_in = false, bool cmp_out_shape_floor_as_conv_in = false)
+        : window_h(window_h_in), window_w(window_w_in), pad_h(pad_h_in), pad_w(pad_w_in), stride_h(stride_h_in),
+          stride_w(stride_w_in), pooling_type(type), global_pooling(global_pooling_in),
+          cmp_out_shape_floor_as_conv(cmp_out_shape_floor_as_conv_in) {}
+    int window_h, window_w, pad_h, pad_w, stride_h, stride_w;
+    PoolingType pooling_type;
+    bool global_pooling, cmp_out_shape_floor_as_conv;
+};
+
+template <typename TargetType>
+struct ConvPoolingParam {   // saber_funcs_param.h:647-677
+    ConvPoolingParam() {}
+    ConvPoolingParam(ConvParam<TargetType> c, PoolingParam<TargetType> p) : conv_param(c), pooling_param(p) {}
+    ConvParam<TargetType> conv_param;
+    PoolingParam<TargetType> pooling_param;
+};
+
+template <typename TargetType>
 struct FcParam {
     FcParam() : weights(nullptr), bias(nullptr), num_output(0), axis(1), is_transpose_weights(false) {}
     FcParam(HostBlob* w, HostBlob* b, int num_output_in, int axis_in = 1, bool is_transpose_weights_in = false)
@@ -286,10 +310,77 @@ public:
                                               (saber_hip_stream_t)_ctx->get_compute_stream()));
     }
     const char* algo() const { return _op ? saber_hip_conv2d_algo(_op) : ""; }
+    saber_hip_conv_t* handle() { return _op; }   // for the ops that build on a conv (SaberConv2DPooling)
 
 private:
     saber_hip_conv_t* _op;
     void* _ws;
+    Context<TargetType>* _ctx;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// SaberConv2DPooling<MI355X, AK_INT8> (saber/funcs/conv_pooling.h; x86: saber_conv_pooling.cpp). outputs[0] is the
+// POOLED tensor. One fused kernel where saber_hip_conv2d_set_pooling has one (the ResNet stem + 3x3/2 max pooling);
+// otherwise conv into an inner tensor + a pooling launch, the structure of SaberConv2DPooling<X86,AK_FLOAT> (:13-57).
+// ---------------------------------------------------------------------------------------------------
+template <typename TargetType, DataType OpDtype>
+class SaberConv2DPooling {
+public:
+    SaberConv2DPooling() : _fused(false), _ctx(nullptr) {}
+    SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                     ConvPoolingParam<TargetType>& param, Context<TargetType>& ctx) {
+        return create(inputs, outputs, param, ctx);
+    }
+    SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                       ConvPoolingParam<TargetType>& param, Context<TargetType>& ctx) {
+        if (OpDtype != AK_INT8) return SaberUnImplError;
+        _ctx = &ctx;
+        const ConvParam<TargetType>& cp = param.conv_param;
+        const PoolingParam<TargetType>& pp = param.pooling_param;
+        const Tensor<TargetType>* in = inputs[0];
+        if (!cp.weight()) return SaberInvalidValue;
+        const int k = cp.weight()->shape[0], kh = cp.weight()->shape[2], kw = cp.weight()->shape[3];
+        _ch = (in->height() + 2 * cp.pad_h - (cp.dilation_h * (kh - 1) + 1)) / cp.stride_h + 1;   // funcs_utils.h:29-53
+        _cw = (in->width() + 2 * cp.pad_w - (cp.dilation_w * (kw - 1) + 1)) / cp.stride_w + 1;
+        // the conv's own output: same dtype and scale as the op's output (the pooling keeps both)
+        _inner.re_alloc(Shape({in->num(), _ch, _cw, k}, Layout_NHWC), outputs[0]->get_dtype());
+        _inner.set_scale(outputs[0]->get_scale());
+        _inner_v.assign(1, &_inner);
+        _cep = ConvEltwiseParam<TargetType>(cp, EltwiseParam<TargetType>());
+        SaberStatus st = _conv.create(inputs, _inner_v, _cep, ctx);
+        if (st != SaberSuccess) return st;
+        _type = pp.pooling_type == Pooling_max ? SABER_HIP_POOL_MAX
+                : (pp.pooling_type == Pooling_average_include_padding ? SABER_HIP_POOL_AVG_INCL : SABER_HIP_POOL_AVG_EXCL);
+        _kh = pp.global_pooling ? _ch : pp.window_h; _kw = pp.global_pooling ? _cw : pp.window_w;
+        _sh = pp.global_pooling ? _ch : pp.stride_h; _sw = pp.global_pooling ? _cw : pp.stride_w;
+        _ph = pp.global_pooling ? 0 : pp.pad_h; _pw = pp.global_pooling ? 0 : pp.pad_w;
+        const int rc = saber_hip_conv2d_set_pooling(_conv.handle(), _type, _kh, _kw, _sh, _sw, _ph, _pw,
+                                                    pp.cmp_out_shape_floor_as_conv ? 1 : 0);
+        _fused = rc == SABER_HIP_OK;
+        if (!_fused && rc != SABER_HIP_UNIMPL) return to_status(rc);
+        return SaberSuccess;
+    }
+    SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                         ConvPoolingParam<TargetType>&) {
+        if (_fused) return _conv.dispatch(inputs, outputs, _cep);
+        SaberStatus st = _conv.dispatch(inputs, _inner_v, _cep);
+        if (st != SaberSuccess) return st;
+        const int dt = to_hip_dtype(outputs[0]->get_dtype());
+        return to_status(saber_hip_pool2d_i8_nhwc(_inner.num(), _ch, _cw, _inner.channel(), outputs[0]->height(),
+                                                  outputs[0]->width(), _kh, _kw, _sh, _sw, _ph, _pw, _type, dt, dt,
+                                                  _inner.data(), outputs[0]->mutable_data(),
+                                                  (saber_hip_stream_t)_ctx->get_compute_stream()));
+    }
+    bool fused() const { return _fused; }
+    const char* algo() const { return _conv.algo(); }
+
+private:
+    SaberConvEltwise<TargetType, OpDtype> _conv;
+    ConvEltwiseParam<TargetType> _cep;
+    Tensor<TargetType> _inner;
+    std::vector<Tensor<TargetType>*> _inner_v;
+    bool _fused;
+    int _type, _ch, _cw, _kh, _kw, _sh, _sw, _ph, _pw;
     Context<TargetType>* _ctx;
 };
 

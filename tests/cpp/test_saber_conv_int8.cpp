@@ -26,6 +26,10 @@ int orc_conv_i8(int N, int H, int W, int C, int K, int kh, int kw, int pad_h, in
                 void* out);
 void orc_eltwise_i8(size_t n, const int8_t* a, const int8_t* b, float sa, float sb, float c0, float c1, int with_relu,
                     int8_t* out);
+int orc_pool_out_dim(int in, int pad, int window, int stride, int floor_mode);
+int orc_pool_i8_nhwc(int N, int H, int W, int C, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw, int type,
+                      int in_dtype, int out_dtype, const void* x, void* out);
+void orc_quant_nchw_to_nhwc(int N, int C, int H, int W, int out_dtype, float scale, const float* x, void* y);
 }
 
 static int g_fail = 0, g_run = 0;
@@ -112,6 +116,64 @@ static void test_conv_int8(int N, int C, int H, int W, int K, int k, int pad, in
     }
 }
 
+// SaberConv2DPooling: conv + pooling through the Saber interface == oracle conv followed by oracle pooling.
+// stem = true: 7x7/2 conv over a 3-channel f32 NCHW image + 3x3/2 max pooling (fused kernel); else a 3x3 conv + 2x2/2
+// max pooling (two launches behind the same interface).
+static void test_conv_pooling(bool stem, Context<MI355X>& ctx) {
+    std::mt19937 rng(stem ? 77 : 78);
+    const int N = 2, C = stem ? 3 : 32, H = stem ? 75 : 14, W = stem ? 62 : 14, K = 64;
+    const int k = stem ? 7 : 3, pad = stem ? 3 : 1, stride = stem ? 2 : 1;
+    const int pk = stem ? 3 : 2, ps = 2;
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    const int PH = orc_pool_out_dim(OH, 0, pk, ps, 0), PW = orc_pool_out_dim(OW, 0, pk, ps, 0);
+    const float in_scale = stem ? 1.f / 127.f : 0.02f, out_scale = 0.05f;
+    std::vector<float> w((size_t)K * C * k * k), b(K), xf((size_t)N * C * H * W);
+    std::normal_distribution<float> nd(0.f, 0.1f);
+    std::uniform_real_distribution<float> ud(-1.f, 1.f);
+    for (auto& v : w) v = nd(rng);
+    for (auto& v : b) v = nd(rng);
+    for (auto& v : xf) v = ud(rng);
+    std::vector<uint8_t> xq((size_t)N * H * W * C);
+    const int in_dt = stem ? 1 : 2;
+    if (stem) orc_quant_nchw_to_nhwc(N, C, H, W, 1, in_scale, xf.data(), xq.data());
+    else for (auto& v : xq) v = (uint8_t)(rng() % 256);
+    std::vector<float> ws(K), bp(K), sc(K);
+    std::vector<int8_t> wq(w.size());
+    orc_weight_scales(w.data(), K, C * k * k, ws.data());
+    orc_quant_weights(w.data(), K, C * k * k, ws.data(), wq.data());
+    orc_conv_i8_prepare(K, ws.data(), b.data(), in_scale, out_scale, in_dt, 2, bp.data(), sc.data());
+    std::vector<uint8_t> conv_out((size_t)N * OH * OW * K), want((size_t)N * PH * PW * K), got(want.size());
+    orc_conv_i8(N, H, W, C, K, k, k, pad, pad, stride, stride, 1, 1, 1, in_dt, 2, 1, xq.data(), wq.data(), bp.data(),
+                sc.data(), nullptr, nullptr, conv_out.data());
+    orc_pool_i8_nhwc(N, OH, OW, K, PH, PW, pk, pk, ps, ps, 0, 0, 0, 2, 2, conv_out.data(), want.data());
+
+    Tensor<MI355X> tin(stem ? Shape({N, C, H, W}, Layout_NCHW) : Shape({N, H, W, C}, Layout_NHWC), stem ? AK_FLOAT : AK_UINT8);
+    Tensor<MI355X> tout(Shape({N, PH, PW, K}, Layout_NHWC), AK_UINT8);
+    tin.set_scale({in_scale});
+    tout.set_scale({out_scale});
+    tin.copy_from_host(stem ? (const void*)xf.data() : (const void*)xq.data());
+    HostBlob hw(Shape({K, C, k, k}), AK_FLOAT, w.data());
+    HostBlob hb(Shape({1, K, 1, 1}), AK_FLOAT, b.data());
+    ConvParam<MI355X> cp(1, pad, pad, stride, stride, 1, 1, &hw, &hb, ActivationParam<MI355X>(Active_relu));
+    PoolingParam<MI355X> pp(pk, pk, 0, 0, ps, ps, Pooling_max);
+    ConvPoolingParam<MI355X> cpp(cp, pp);
+    std::vector<Tensor<MI355X>*> ins{&tin}, outs{&tout};
+    SaberConv2DPooling<MI355X, AK_INT8> op;
+    SaberStatus st = op.init(ins, outs, cpp, ctx);
+    if (st == SaberSuccess) st = op.dispatch(ins, outs, cpp);
+    hipStreamSynchronize(ctx.get_compute_stream());
+    tout.copy_to_host(got.data());
+    ++g_run;
+    size_t diff = 0;
+    if (st != SaberSuccess || op.fused() != stem) diff = want.size();
+    else for (size_t i = 0; i < want.size(); ++i) diff += want[i] != got[i];
+    if (diff) {
+        ++g_fail;
+        printf("FAIL conv+pooling stem=%d fused=%d status=%d mismatching bytes=%zu/%zu [%s]\n", (int)stem, (int)op.fused(),
+               (int)st, diff, want.size(), op.algo());
+    }
+}
+
 int main() {
     if (!saber_hip_device_ok()) {
         printf("no gfx950 device: the MI355X Saber target has no fallback\n");
@@ -137,6 +199,8 @@ int main() {
     test_conv_int8(2, 512, 7, 7, 512, 3, 1, 1, 1, true, true, 2, 0, false, ctx);       // f32 output
     test_conv_int8(2, 64, 56, 56, 256, 1, 0, 1, 1, true, false, 2, 1, true, ctx);      // res2 2c + fused eltwise
     test_conv_int8(1, 512, 7, 7, 2048, 1, 0, 1, 1, true, false, 2, 1, true, ctx);      // res5 2c + fused eltwise
+    test_conv_pooling(true, ctx);     // SaberConv2DPooling: fused stem + max pooling
+    test_conv_pooling(false, ctx);    // SaberConv2DPooling: two launches behind the same interface
     printf("%d/%d cases bit-exact\n", g_run - g_fail, g_run);
     return g_fail ? 1 : 0;
 }
