@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr int WIT = (BMK + RPP - 1) / RPP;
     constexpr int XIT = (BNP + RPP - 1) / RPP;
     constexpr int NV = TM * 4;
+    constexpr bool W_FULL = BMK % RPP == 0;   // every staging pass covers rows of the tile only: no row predicate
+    constexpr bool X_FULL = BNP % RPP == 0;
     using acc_t = typename std::conditional<F32, v4f, v4i>::type;
 
     __shared__ v4i lds[2][(BMK + BNP) * CPR];
@@ -415,14 +417,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int r = lr + it * RPP;
-            if (r < BMK) wv[it] = w16[(size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
+            if (W_FULL || r < BMK) wv[it] = w16[(size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
         }
         const bool tap_ok = cur_i < a.kh;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            v4i v = {0, 0, 0, 0};
             const int ih = x_ih0[it] + cur_i * a.dil_h;
             const bool row_ok = x_ok[it] && tap_ok && (ih >= 0) && (ih < a.H);
+            v4i v = {0, 0, 0, 0};
             if (C4) {
                 const unsigned* xp = (const unsigned*)a.x;
 #pragma unroll
@@ -431,11 +433,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                     if (row_ok && iw >= 0 && iw < a.W) v[t] = (int)xp[(x_base[it] >> 2) + ih * a.W + iw];
                 }
             } else {
+                // branch-free: an out-of-image tap reads the zero page instead of being predicated off, so the whole
+                // stage body is one basic block and its address arithmetic can be scheduled between the MFMAs
                 const int iw = x_iw0[it] + cur_j * a.dil_w;
-                if (row_ok && iw >= 0 && iw < a.W) {
-                    const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES;
-                    v = *(const v4i*)xp;
-                }
+                const bool ok = row_ok && iw >= 0 && iw < a.W;
+                const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES;
+                v = *(const v4i*)(ok ? xp : (const char*)a.zero);
             }
             if (!F32 && a.in_u8) {
                 v.x ^= 0x80808080; v.y ^= 0x80808080; v.z ^= 0x80808080; v.w ^= 0x80808080;
@@ -446,19 +449,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         if (C4) {
             cur_j += CPR;
             while (cur_j >= cpr4) { cur_j -= cpr4; ++cur_i; }
-        } else {
-            cur_c += ESTAGE;
-            while (cur_c >= a.C) {
-                cur_c -= a.C;
-                if (++cur_j == a.kw) { cur_j = 0; ++cur_i; }
-            }
+        } else {   // selects only: (adv_c, adv_i, adv_j) = stage length split into channels / tap rows / tap columns
+            cur_c += a.adv_c;
+            const int wrap_c = cur_c >= a.C;
+            cur_c -= wrap_c ? a.C : 0;
+            cur_j += a.adv_j + wrap_c;
+            const int wrap_j = cur_j >= a.kw;
+            cur_j -= wrap_j ? a.kw : 0;
+            cur_i += a.adv_i + wrap_j;
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int r = lr + it * RPP;
-            if (r < BMK) {
+            if (W_FULL || r < BMK) {
                 // permuted LDS row so that MFMA tile (wm, tm) reads 16 consecutive rows (conflict-free)
                 const int rr = r % (TM * 16), wmr = r / (TM * 16);
                 const int lrow = (wmr * TM + ((rr >> 2) % TM)) * 16 + (rr / (TM * 4)) * 4 + (rr & 3);
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int r = lr + it * RPP;
-            if (r < BNP) lds[buf][(BMK + r) * CPR + phys_chunk<CPR>(r, lq)] = xv[it];
+            if (X_FULL || r < BNP) lds[buf][(BMK + r) * CPR + phys_chunk<CPR>(r, lq)] = xv[it];
         }
     };
 
@@ -563,6 +568,13 @@ static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     ConvKArgs b = a;
     b.npx = (a.M + bnp - 1) / bnp;
     b.nky = (a.K + bmk - 1) / bmk;
+    if (MODE != 1) {   // gather-cursor increments of one stage (4*KS chunks of 16 bytes)
+        const int estage = 4 * KS * (MODE == 2 ? 4 : 16);
+        const int taps = estage / a.C;
+        b.adv_c = estage - taps * a.C;
+        b.adv_i = taps / a.kw;
+        b.adv_j = taps - b.adv_i * a.kw;
+    }
     dim3 grid(b.npx * b.nky);
     dim3 block(256);
     switch (tile) {

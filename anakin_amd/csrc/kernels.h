@@ -47,6 +47,8 @@ struct ConvKArgs {
     // rows [K1, K1+K2) -> y2 (stride K2, relu2/out_dtype2); K = K1 + K2. K2 == 0: ordinary conv.
     void* y2;
     int K1, K2, relu2, out_dtype2;
+    int adv_c, adv_i, adv_j;   // per pipeline stage, the gather cursor advances by adv_c channels, adv_i / adv_j taps
+                               // (stage elements = adv_c + C * (adv_i * kw + adv_j); set by the launcher)
     int pool_oh, pool_ow;   // fused 3x3 / stride-2 max pooling (conv_stem_pool_kernel): pooled output dims
 };
 
