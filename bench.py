@@ -72,6 +72,26 @@ def timed_steps(net, steps, use_graph, gather=None, flush=None):
     torch.cuda.synchronize()
 
 
+def pick_launch_mode(net, steps=60):
+    """hipGraph replay against eager launches (the C++ op loop of saber_hip_net_run) of the same op list, timed once
+    before the timed region; the faster one is used. On this host the eager loop keeps the GPU fed and is ~1 % faster
+    than the graph; and occasionally (2 of ~30 runs) a process gets a graph whose replay is 25-30 % slower than the sum
+    of its kernels while eager per-op times are normal."""
+    import torch
+    t = {}
+    for mode in ("graph", "eager", "graph", "eager"):
+        for _ in range(5):
+            net.replay() if mode == "graph" else net.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.replay() if mode == "graph" else net.run()
+        torch.cuda.synchronize()
+        t[mode] = min(t.get(mode, 1e9), (time.perf_counter() - t0) * 1e3 / steps)
+    use_graph = t["graph"] <= t["eager"]
+    return use_graph, {"graph_ms": round(t["graph"], 4), "eager_ms": round(t["eager"], 4)}
+
+
 def main():
     args = parse()
     import torch
@@ -108,8 +128,10 @@ def main():
         net.autotune(iters=20)   # RUNTIME strategy (BaseFunc::pick_best_runtime), once, outside the timed region
         net.tensor("data").copy_(torch.from_numpy(x).cuda())
     use_graph = not args.no_graph
+    launch_probe = None
     if use_graph:
         net.capture()
+        use_graph, launch_probe = pick_launch_mode(net)
 
     logits = net.tensor("prob")
     gather = gather_flush = None
@@ -141,7 +163,7 @@ def main():
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"value": round(value, 1), "unit": "images/s", "ms_per_step": round(ms_per_step, 4),
-                              "ops": net.num_ops()}))
+                              "ops": net.num_ops(), "hip_graph": use_graph, "launch_probe": launch_probe}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -205,13 +227,15 @@ def main():
             net1.run()
             if not args.no_autotune:
                 net1.autotune(iters=20)
-            if use_graph:
+            g1 = not args.no_graph
+            if g1:
                 net1.capture()
-            timed_steps(net1, 20, use_graph)
+                g1, _ = pick_launch_mode(net1)
+            timed_steps(net1, 20, g1)
             ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
             for a, b in ev1:
                 a.record()
-                net1.replay() if use_graph else net1.run()
+                net1.replay() if g1 else net1.run()
                 b.record()
             torch.cuda.synchronize()
             l1 = sorted(a.elapsed_time(b) for a, b in ev1)
@@ -254,6 +278,7 @@ def main():
             "config": {"workload": "%s %s post-fusion op list, batch %d per GPU, 224x224" %
                                    (args.model, args.precision, B),
                        "global_batch": B * n_gpus, "ops": net.num_ops(), "hip_graph": use_graph,
+                       "launch_probe": launch_probe,
                        "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus},
             "latency_ms": {"batch": B, "p50": round(p50, 4), "p99": round(p99, 4)},
             "batch1": b1,
