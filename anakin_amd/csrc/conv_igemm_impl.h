@@ -240,6 +240,8 @@ __device__ __forceinline__ void epilogue_i8_fast(const ConvKArgs& a, const int (
         else { const uint4 t = *(const uint4*)((const uint8_t*)a.res + o); rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
     }
     const float lo = a.relu ? 0.f : -3.0e38f;
+    const float lo_s8 = a.relu ? 0.f : -128.f;          // lower clamp of the s8 saturation with the relu folded in
+    const float res_lo = a.res_relu ? 0.f : -3.0e38f;
 #pragma unroll
     for (int v = 0; v < NV / 4; ++v) {
         unsigned w = 0;
@@ -256,12 +258,11 @@ __device__ __forceinline__ void epilogue_i8_fast(const ConvKArgs& a, const int (
                 q = fmaxf(q, lo);
                 w = __builtin_amdgcn_cvt_pk_u8_f32(q + 128.f, t, w);
             } else {  // EK_ELT: the branch2c conv has no relu of its own unless a.relu
-                q = fmaxf(q, lo);
-                q = __builtin_amdgcn_fmed3f(q, -128.f, 127.f);          // q = sat_s8(rne(d)) as float
+                q = __builtin_amdgcn_fmed3f(q, lo_s8, 127.f);           // q = sat_s8(relu?(rne(d))) as float
                 const float rv = (float)(int)(int8_t)(rs[v] >> (8 * t));
                 float e = __fmul_rn(__fmul_rn(a.coeff_conv, q), a.scale_conv);
                 e = __fadd_rn(e, __fmul_rn(__fmul_rn(a.coeff_res, rv), a.scale_res));
-                if (a.res_relu) e = fmaxf(e, 0.f);
+                e = fmaxf(e, res_lo);                                   // relu of the eltwise (or no-op)
                 w = __builtin_amdgcn_cvt_pk_u8_f32(round_half_away(e) + 128.f, t, w);
             }
         }
