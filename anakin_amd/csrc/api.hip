@@ -682,11 +682,15 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
     if (!a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const saber_hip_conv_desc &da = a->d, &db = b->d;
     auto plain = [](const saber_hip_conv* o) {
-        return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV &&
-               o->d.res_mode == SABER_HIP_RES_NONE && !o->pre_quant && !o->pre_pad &&
-               (o->d.out_dtype == SABER_HIP_S8 || o->d.out_dtype == SABER_HIP_U8);
+        if (!o->weights_set || o->d.res_mode != SABER_HIP_RES_NONE || o->pair_k2 || o->pool_fused) return false;
+        if (o->is_i8)
+            return o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && !o->pre_quant && !o->pre_pad &&
+                   (o->d.out_dtype == SABER_HIP_S8 || o->d.out_dtype == SABER_HIP_U8);
+        return o->algo == ALGO_IGEMM_F32 && !o->pre_transpose && o->d.out_layout == SABER_HIP_NHWC;   // FP32: NHWC in / out
     };
-    if (!plain(a) || !plain(b)) return fail(SABER_HIP_INVALID_VALUE, "pair: both ops must be plain INT8 implicit-GEMM convs with weights set");
+    if (!plain(a) || !plain(b) || a->is_i8 != b->is_i8)
+        return fail(SABER_HIP_INVALID_VALUE, "pair: both ops must be plain implicit-GEMM convs of one precision (INT8 with 8-bit NHWC "
+                                              "outputs, or FP32 NHWC) with weights set");
     if (da.n != db.n || da.h != db.h || da.w != db.w || da.c != db.c || da.kh != db.kh || da.kw != db.kw ||
         da.pad_h != db.pad_h || da.pad_w != db.pad_w || da.stride_h != db.stride_h || da.stride_w != db.stride_w ||
         da.dil_h != db.dil_h || da.dil_w != db.dil_w || da.in_dtype != db.in_dtype || a->Kg_pad != b->Kg_pad)
@@ -696,9 +700,9 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
     op->d = da;
     op->d.k = da.k + db.k;
     op->oh = a->oh; op->ow = a->ow;
-    op->algo = ALGO_IGEMM_I8;
-    op->epi = EPI_I8_CONV;
-    op->is_i8 = true;
+    op->algo = a->algo;
+    op->epi = a->epi;
+    op->is_i8 = a->is_i8;
     op->x_dtype = a->x_dtype;
     op->c_eff = a->c_eff;
     op->Kg = a->Kg; op->Kg_pad = a->Kg_pad;
@@ -716,9 +720,9 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
         if (sb.p) e = hipMemcpy(dst.p + (size_t)da.k * per_row, sb.p, k2_pad * per_row * sizeof(T), hipMemcpyDeviceToDevice);
         return e;
     };
-    hipError_t e = cat(op->d_w, a->d_w, b->d_w, (size_t)a->Kg_pad);
+    hipError_t e = cat(op->d_w, a->d_w, b->d_w, (size_t)a->Kg_pad * (a->is_i8 ? 1 : sizeof(float)));
     if (e == hipSuccess) e = cat(op->d_bias, a->d_bias, b->d_bias, 1);
-    if (e == hipSuccess) e = cat(op->d_scale, a->d_scale, b->d_scale, 1);
+    if (e == hipSuccess && a->is_i8) e = cat(op->d_scale, a->d_scale, b->d_scale, 1);
     op->has_bias = a->has_bias || b->has_bias;
     op->has_comp = a->has_comp;   // same input dtype -> both or neither
     if (e == hipSuccess && op->has_comp) e = cat(op->d_comp, a->d_comp, b->d_comp, 1);
@@ -728,7 +732,10 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
     }
     op->weights_set = true;
     choose_tile(op);
-    op->ks = op->Kg >= 256 ? 4 : (op->Kg >= 128 ? 2 : 1);
+    {
+        const int kbytes = op->Kg * (op->is_i8 ? 1 : 4);
+        op->ks = kbytes >= 256 ? 4 : (kbytes >= 128 ? 2 : 1);
+    }
     name_algo(op);
     *out = op;
     return SABER_HIP_OK;
@@ -740,7 +747,8 @@ int saber_hip_conv2d_run_pair(saber_hip_conv_t* op, const void* x, void* y_a, vo
     ConvKArgs a;
     fill_args(op, a, x, y_a, nullptr, y_b);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(op->dma ? launch_conv_igemm_dma(0, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(0, op->tile, op->ks, a, s));
+    const int mode = op->is_i8 ? 0 : 2;
+    HIP_TRY(op->dma ? launch_conv_igemm_dma(mode, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(mode, op->tile, op->ks, a, s));
     return SABER_HIP_OK;
 }
 

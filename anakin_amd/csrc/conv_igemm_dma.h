@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             int n = 0, sp = 0;
             if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
-            epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
+            if (a.K2 > 0) epilogue_f32_pair<NV>(a, v, cp, p, kb);
+            else epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
         } else {
             int v[NV];
 #pragma unroll

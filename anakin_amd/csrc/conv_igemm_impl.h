@@ -209,6 +209,28 @@ __device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, const float (&a
     }
 }
 
+// FP32 sibling pair (see epilogue_i8_pair): rows >= K1 belong to the second conv; NHWC outputs, no residual.
+template <int NV>
+__device__ __forceinline__ void epilogue_f32_pair(const ConvKArgs& a, const float (&acc)[NV], const ChanParams<NV>& cp,
+                                                  int p, int kb) {
+    if (p >= a.M) return;
+    const bool second = kb >= a.K1;
+    const int kl = second ? kb - a.K1 : kb;
+    const int Ks = second ? a.K2 : a.K1;
+    if (kl >= Ks) return;
+    float* y = (float*)(second ? a.y2 : a.y) + (size_t)p * Ks + kl;
+    const bool relu = second ? a.relu2 : a.relu;
+#pragma unroll
+    for (int v = 0; v < NV; v += 4) {
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float d = __fadd_rn(acc[v + t], cp.bias[v + t]);
+            o[t] = relu ? (d > 0.f ? d : 0.f) : d;
+        }
+        *(float4*)(y + v) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
 
 // Epilogue kinds compiled into separate kernels so the hot variants carry no dead arithmetic:
 enum { EK_S8 = 0,   // INT8 conv -> s8 (relu optional)
@@ -541,7 +563,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             int n = 0, sp = 0;
             if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
-            epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
+            if (a.K2 > 0) epilogue_f32_pair<NV>(a, v, cp, p, kb);
+            else epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
         } else {
             int v[NV];
 #pragma unroll

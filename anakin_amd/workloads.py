@@ -310,7 +310,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     return net
 
 
-def build_fp32_net(model, batch, hw=224):
+def build_fp32_net(model, batch, hw=224, pair_siblings=True):
     """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
     does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132)."""
     from . import lib as L
@@ -325,7 +325,9 @@ def build_fp32_net(model, batch, hw=224):
 
     def T(n):
         return alias.get(n, n)
-    for l in model["spec"]:
+    spec = model["spec"]
+    sib = {}
+    for li, l in enumerate(spec):
         kd, nm = l["kind"], l["name"]
         if kd == "conv":
             hin, cin = shape[T(l["src"])]
@@ -347,6 +349,17 @@ def build_fp32_net(model, batch, hw=224):
             conv = S.SaberConv2D(False).init((B, cin, hin, hin), p, F32, F32, in_layout=L.NHWC, out_layout=L.NHWC)
             net.add_tensor(nm, (B, ho, ho, l["cout"]), F32)
             shape[nm] = (ho, l["cout"])
+            # sibling pair (stage-entry branch1 + branch2a share input and geometry): one launch, two outputs
+            nxt = spec[li + 1] if li + 1 < len(spec) else None
+            geo = ("src", "k", "stride", "pad")
+            if pair_siblings and nxt is not None and nxt["kind"] == "conv" and "eltwise" not in nxt and \
+                    all(nxt[g] == l[g] for g in geo) and l["cout"] % 128 == 0 and nxt["cout"] % 16 == 0 and cin % 4 == 0:
+                sib[nxt["name"]] = (conv, nm)
+                continue
+            if nm in sib:
+                first, first_nm = sib.pop(nm)
+                net.add_conv_pair(S.SaberConvPair(first, conv), T(l["src"]), first_nm, nm)
+                continue
             net.add_conv(conv, T(l["src"]), nm)
         elif kd == "pool":
             hin, c = shape[T(l["src"])]

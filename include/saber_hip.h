@@ -131,12 +131,12 @@ int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op);
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                               saber_hip_stream_t stream, int iters);
 
-/* Sibling pair: two INT8 convolutions that read the SAME input tensor with the same geometry (kernel,
+/* Sibling pair: two convolutions (both INT8, or both FP32 with NHWC tensors) that read the SAME input tensor with the same geometry (kernel,
  * pad, stride, dilation; e.g. ResNet's stage-entry `branch1` projection and `branch2a`) executed by ONE
  * launch — the input tile is staged once and multiplied against both weight sets. An executor-level
  * optimisation (the reference dispatches the two Saber ops one after the other, net.cpp:417-509);
  * the outputs are bit-identical to running `a` and `b` separately. Both ops must already have their
- * weights set, be plain INT8 convs (no residual mode) with 8-bit NHWC in- and outputs,
+ * weights set, be plain convs (no residual mode; INT8: 8-bit NHWC in- and outputs, FP32: NHWC in- and outputs),
  * a.k % 128 == 0 and b.k % 16 == 0. The pair keeps its own copy of the packed weights; a and b stay usable. */
 int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv_t* b, saber_hip_conv_t** out);
 int saber_hip_conv2d_run_pair(saber_hip_conv_t* pair, const void* x, void* y_a, void* y_b, saber_hip_stream_t stream);

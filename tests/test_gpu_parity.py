@@ -409,6 +409,51 @@ def test_conv_i8_sibling_pair_equals_two_ops(case, idt):
     assert np.array_equal(host(ya), wants[0]) and np.array_equal(host(yb), wants[1]), pair.algo()
 
 
+@pytest.mark.parametrize("case", [(2, 14, 14, 64, 256, 64, 1, 0, 1), (1, 9, 7, 128, 128, 48, 1, 0, 2),
+                                  (1, 6, 6, 32, 128, 16, 3, 1, 1)])
+def test_conv_f32_sibling_pair_equals_two_ops(case):
+    """FP32 sibling pair: both outputs bit-identical to dispatching the two FP32 convs separately (same reduction
+    order), and within 1e-4 of the oracle."""
+    N, H, W, C, K1, K2, k, pad, stride = case
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    convs, wants = [], []
+    for K, relu in ((K1, False), (K2, True)):
+        w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+        b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+        wants.append(O.conv_f32_nchw(np.ascontiguousarray(x.transpose(0, 3, 1, 2)), w, b, relu, (pad, pad),
+                                     (stride, stride)).transpose(0, 2, 3, 1))
+        p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (1, 1), relu)
+        convs.append(S.SaberConv2D(False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC))
+    xd = dev(x)
+    sep = []
+    for c in convs:
+        y = c.new_output()
+        c.dispatch(xd, y)
+        sep.append(host(y).copy())
+    pair = S.SaberConvPair(convs[0], convs[1])
+    assert pair.algo().startswith("pair_igemm_f32")
+    for v in [None, 0 | (1 << 8) | (1 << 16), 2 | (2 << 8) | (1 << 16), 3 | (4 << 8) | (1 << 16), 5 | (1 << 8) | (1 << 16),
+              2 | (4 << 8) | (2 << 16), 1 | (4 << 8) | (3 << 16), 0 | (4 << 8) | (4 << 16)]:
+        if v is not None:
+            pair.set_tile(v)
+            for c in convs:
+                c.set_tile(v)       # same tile -> same reduction order -> identical bits
+                y = c.new_output()
+        ya, yb = convs[0].new_output(), convs[1].new_output()
+        ya.fill_(7.0)
+        yb.fill_(7.0)
+        pair.dispatch(xd, ya, yb)
+        if v is not None:
+            for i, c in enumerate(convs):
+                y = c.new_output()
+                c.dispatch(xd, y)
+                sep[i] = host(y).copy()
+        for got, ref2, want in ((host(ya), sep[0], wants[0]), (host(yb), sep[1], wants[1])):
+            assert np.array_equal(got, ref2), pair.algo()
+            assert np.abs(got - want).max() <= FP32_RTOL * np.abs(want).max(), pair.algo()
+
+
 def test_conv_i8_sibling_pair_rejects_mismatches():
     rng = np.random.default_rng(3)
     def mk(K, C=32, k=1, stride=1, odt=O.S8):
