@@ -439,8 +439,60 @@ __global__ __launch_bounds__(256) void pool2d_f32_kernel(int n, int h, int w, in
         y[gid] = acc;
     }
 }
+// NHWC with c % 4 == 0: one lane per (output pixel, 4 channels), 16-byte loads; per channel the same window order
+// and the same float operations as the scalar kernel above.
+__global__ __launch_bounds__(256) void pool2d_f32_nhwc_vec4_kernel(int n, int h, int w, int c, int oh, int ow, int kh,
+                                                                   int kw, int sh, int sw, int ph, int pw, int type,
+                                                                   const float4* __restrict__ x, float4* __restrict__ y) {
+    const int cg = c >> 2;
+    const size_t total = (size_t)n * oh * ow * cg;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+        size_t r = gid;
+        const int g = (int)(r % cg); r /= cg;
+        const int ox = (int)(r % ow); r /= ow;
+        const int oy = (int)(r % oh);
+        const int img = (int)(r / oh);
+        int hs = oy * sh - ph, ws = ox * sw - pw;
+        int he = hs + kh, we = ws + kw;
+        hs = hs < 0 ? 0 : hs;
+        ws = ws < 0 ? 0 : ws;
+        he = he > h ? h : he;
+        we = we > w ? w : we;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) {
+                const float4 q = x[(((size_t)img * h + iy) * w + ix) * cg + g];
+                const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (type == 0) acc[t] = first ? v[t] : (acc[t] >= v[t] ? acc[t] : v[t]);
+                    else acc[t] = __fadd_rn(acc[t], v[t]);
+                }
+                first = false;
+            }
+        float div = 1.f;
+        if (type == 1) {  // divisor clipped at in+pad on the far edge (saber_pooling.cpp:466-480)
+            int bh = kh, bw = kw;
+            if (we == w) bw = (ws + kw >= w + pw ? w + pw : ws + kw) - ws;
+            if (he == h) bh = (hs + kh >= h + ph ? h + ph : hs + kh) - hs;
+            div = (float)(bh * bw);
+        }
+        if (type == 2) div = (float)((he - hs) * (we - ws));
+        if (type != 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = acc[t] / div;
+        }
+        y[gid] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
 hipError_t launch_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
                              int pw, int type, int nchw, const float* x, float* y, hipStream_t s) {
+    if (!nchw && (c & 3) == 0) {
+        hipLaunchKernelGGL(pool2d_f32_nhwc_vec4_kernel, dim3(grid_for((size_t)n * oh * ow * (c >> 2))), dim3(256), 0, s,
+                           n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, (const float4*)x, (float4*)y);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pool2d_f32_kernel, dim3(grid_for((size_t)n * oh * ow * c)), dim3(256), 0, s, n, h, w, c, oh,
                        ow, kh, kw, sh, sw, ph, pw, type, nchw, x, y);
     return hipGetLastError();

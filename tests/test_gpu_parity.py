@@ -585,6 +585,15 @@ def test_pooling_f32_vs_oracle():
         assert np.array_equal(got, want), (win, st, pad, pt)
     want = O.pool_f32_nchw(x, None, None, None, 1, global_pool=True)
     assert np.array_equal(host(S.pooling_f32(dev(x), None, None, None, 1, global_pooling=True)), want)
+    # NHWC: the float4-vectorised kernel (c % 4 == 0) and the scalar one (c = 6) — same bits as the NCHW oracle
+    for c in (16, 6):
+        xc = rng.standard_normal((2, c, 11, 14)).astype(np.float32)
+        xh = np.ascontiguousarray(xc.transpose(0, 2, 3, 1))
+        for (win, st, pad, pt) in [((3, 3), (2, 2), (0, 0), 0), ((3, 3), (2, 2), (1, 1), 1), ((2, 2), (2, 2), (0, 0), 2),
+                                   ((3, 3), (1, 1), (1, 1), 0)]:
+            want = O.pool_f32_nchw(xc, win, st, pad, pt).transpose(0, 2, 3, 1)
+            got = host(S.pooling_f32(dev(xh), win, st, pad, pt, layout=L.NHWC))
+            assert np.array_equal(got, want), (c, win, st, pad, pt)
 
 
 def test_pooling_f32_from_i8_equals_dequant_then_pool():
