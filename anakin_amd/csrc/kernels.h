@@ -1,6 +1,7 @@
 // anakin_amd/csrc/kernels.h — internal declarations shared by the HIP kernel TUs and the C-ABI TU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace saber_mi355x {
@@ -17,28 +18,38 @@ enum {
 enum { RES_NONE = 0, RES_SUM_INPLACE = 1, RES_ELTWISE = 2 };
 
 struct ConvKArgs {
+    // ---- first 128 bytes (two 64-byte lines of the kernel-argument segment): everything the prologue needs to issue
+    // its first global loads. hipcc fetches kernel arguments lazily with scalar loads, and every line touched before
+    // the first operand load is an exposed scalar-cache miss (measured: loading all five lines of this block up front
+    // costs +0.4 us per launch); keep the hot fields together and the rest behind them.
     const void* x;
     const void* w;      // repacked weights [K_pad][Kg_pad] (s8 or f32), zero padded
+    const void* zero;   // >= 16 zero bytes in device memory (source of padded taps)
+    int npx, nky;       // pixel tiles / out-channel tiles of the launch (1-D grid, XCD-aware tile order)
+    int Kg_pad;         // reduction length padded to a multiple of the widest stage
+    int M;              // N*OH*OW output pixels (GEMM columns)
+    int OH, OW;
+    float inv_ohw, inv_ow;  // 1/(OH*OW), 1/OW for the exact float-reciprocal div/mod
+    int H, W, C;
+    int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int kh, kw;
+    int steps;          // number of pipeline stages = ceil(Kg / elements-per-stage)
+    int adv_c, adv_i, adv_j;   // per pipeline stage, the gather cursor advances by adv_c channels, adv_i / adv_j taps
+                               // (stage elements = adv_c + C * (adv_i * kw + adv_j); set by the launcher)
+    int in_u8;          // activations are u8: shift to s8 by XOR 0x80 (compensated through comp)
+    int kw_pad;         // C4 mode: kw rounded up to 4
+    // ---- the rest: epilogue and special-kernel parameters (fetched while the first loads are in flight) -----------
     void* y;
     const void* res;
     const float* bias;  // INT8 conv: pre-scaled bias_p; FC/F32: plain bias; may be null
     const float* scale; // per out-channel scale (INT8 paths)
     const int* comp;    // per out-channel int32 offset (u8 shift compensation [+ FC int bias]); may be null
-    const void* zero;   // >= 16 zero bytes in device memory (source of padded taps for the LDS-DMA kernels)
-    int N, H, W, C, K, OH, OW;
-    int kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
-    int M;        // N*OH*OW output pixels (GEMM columns)
-    int Kg;       // real reduction length in elements (kh*kw*C, or kh*kw_pad*4 in C4 mode)
-    int Kg_pad;   // padded to a multiple of one K-step
-    int steps;    // number of pipeline stages = ceil(Kg / elements-per-stage)
-    int Cin;        // stem kernel with fused quantisation: channels of the f32 NCHW image (<= 4)
-    float qinv;     // ... and 1/in_scale
-    int npx, nky;   // pixel tiles / out-channel tiles of the launch (1-D grid, XCD-aware tile order)
-    float inv_ohw, inv_ow;  // 1/(OH*OW), 1/OW for the exact float-reciprocal div/mod
-    int kw_pad;   // C4 mode: kw rounded up to 4
-    int in_u8;    // activations are u8: shift to s8 by XOR 0x80 (compensated through comp)
+    int N, K;
+    int Kg;             // real reduction length in elements (kh*kw*C, or kh*kw_pad*4 in C4 mode)
+    int Cin;            // stem kernel with fused quantisation: channels of the f32 NCHW image (<= 4)
+    float qinv;         // ... and 1/in_scale
     int out_dtype;
-    int out_nchw; // f32 outputs only
+    int out_nchw;       // f32 outputs only
     int relu;
     int epi;
     int res_mode, res_relu, res_dtype;
@@ -47,10 +58,9 @@ struct ConvKArgs {
     // rows [K1, K1+K2) -> y2 (stride K2, relu2/out_dtype2); K = K1 + K2. K2 == 0: ordinary conv.
     void* y2;
     int K1, K2, relu2, out_dtype2;
-    int adv_c, adv_i, adv_j;   // per pipeline stage, the gather cursor advances by adv_c channels, adv_i / adv_j taps
-                               // (stage elements = adv_c + C * (adv_i * kw + adv_j); set by the launcher)
     int pool_oh, pool_ow;   // fused 3x3 / stride-2 max pooling (conv_stem_pool_kernel): pooled output dims
 };
+static_assert(offsetof(ConvKArgs, y) == 128, "hot kernel arguments fill exactly the first two 64-byte lines");
 
 // tile ids for launch_conv_igemm
 enum { TILE_32x32 = 0, TILE_64x32 = 1, TILE_64x64 = 2, TILE_128x64 = 3, TILE_64x128 = 4, TILE_128x128 = 5,
