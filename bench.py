@@ -105,8 +105,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1: dry run of the N > 1 control flow on a single GPU (every rank on
+        # cuda:0, logits exchanged through gloo); the real runs use RCCL with one GPU per rank
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        dev_index = 0 if os.environ.get("BENCH_SHARE_GPU") == "1" else local_rank
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     L.require_device()   # no fallback: the HIP library and a gfx950 device are mandatory
