@@ -1,4 +1,4 @@
-// anakin_amd/csrc/conv_igemm.hip — implicit-GEMM convolution on CDNA4 matrix cores (gfx950 only).
+// anakin_amd/csrc/conv_igemm_impl.h — implicit-GEMM convolution on CDNA4 matrix cores (gfx950 only).
 //
 // Role: the MI355X counterpart of the kernels behind SaberConv2D / SaberConvEltwise / SaberFc
 // (reference: x86 GemmX8S8S32XConv::sub_dispatch, gemm_x8s8s32x_conv.cpp:187-288 for the INT8
