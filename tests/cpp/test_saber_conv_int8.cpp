@@ -93,14 +93,14 @@ static void test_conv_int8(int N, int C, int H, int W, int K, int k, int pad, in
         SaberConvEltwise<MI355X, AK_INT8> op;
         st = op.init(ins, outs, cep, ctx);
         if (st == SaberSuccess) st = op.dispatch(ins, outs, cep);
-        hipStreamSynchronize(ctx.get_compute_stream());
+        (void)hipStreamSynchronize(ctx.get_compute_stream());
         algo = op.algo();
         tout.copy_to_host(got.data());
     } else {
         SaberConv2D<MI355X, AK_INT8> op;
         st = op.init(ins, outs, cp, ctx);
         if (st == SaberSuccess) st = op.dispatch(ins, outs, cp);
-        hipStreamSynchronize(ctx.get_compute_stream());
+        (void)hipStreamSynchronize(ctx.get_compute_stream());
         algo = op.algo();
         tout.copy_to_host(got.data());
     }
@@ -161,7 +161,7 @@ static void test_conv_pooling(bool stem, Context<MI355X>& ctx) {
     SaberConv2DPooling<MI355X, AK_INT8> op;
     SaberStatus st = op.init(ins, outs, cpp, ctx);
     if (st == SaberSuccess) st = op.dispatch(ins, outs, cpp);
-    hipStreamSynchronize(ctx.get_compute_stream());
+    (void)hipStreamSynchronize(ctx.get_compute_stream());
     tout.copy_to_host(got.data());
     ++g_run;
     size_t diff = 0;
