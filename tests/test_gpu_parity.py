@@ -454,6 +454,51 @@ def test_conv_f32_sibling_pair_equals_two_ops(case):
             assert np.abs(got - want).max() <= FP32_RTOL * np.abs(want).max(), pair.algo()
 
 
+def test_full_size_fused_ops_equal_their_unfused_gpu_forms():
+    """Size-independent properties at BASELINE.json's full batch-8 sizes (the oracle would take minutes there): every
+    fused executor op must reproduce, byte for byte, the separate ops it replaces when both run on the GPU —
+    sibling pair vs two convs (res3a: 8x56x56x256 -> 512 / 128, stride 2), SaberConv2DPooling vs conv then pooling
+    (conv1 + pool1 on 8x3x224x224), fused pool5 quantise vs pool then quantise."""
+    rng = np.random.default_rng(2026)
+    # --- sibling pair, res3a geometry
+    N, H, C, K1, K2 = 8, 56, 256, 512, 128
+    x = dev(rng.integers(0, 256, (N, H, H, C)).astype(np.uint8))
+    convs = []
+    for K, odt, relu, osc in ((K1, O.S8, False, 0.05), (K2, O.U8, True, 0.03)):
+        w = (rng.standard_normal((K, C, 1, 1)) * np.sqrt(2.0 / C)).astype(np.float32)
+        b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+        p = S.ConvParam(w, b, 1, (0, 0), (2, 2), (1, 1), relu)
+        convs.append(S.SaberConv2D(True).init((N, C, H, H), p, O.U8, odt, 0.013, osc))
+    sep = [c.dispatch(x, c.new_output()) for c in convs]
+    pair = S.SaberConvPair(convs[0], convs[1])
+    ya, yb = convs[0].new_output(), convs[1].new_output()
+    pair.autotune(x, ya, yb, iters=2)
+    ya.zero_(), yb.zero_()
+    pair.dispatch(x, ya, yb)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, sep[0]) and torch.equal(yb, sep[1]), pair.algo()
+    # --- conv1 + pool1
+    xf = dev(rng.uniform(-1, 1, (8, 3, 224, 224)).astype(np.float32))
+    w = (rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    p = S.ConvParam(w, b, 1, (3, 3), (2, 2), (1, 1), True)
+    conv = S.SaberConv2D(True).init((8, 3, 224, 224), p, L.F32, O.U8, 1 / 127.0, 0.02, in_layout=L.NCHW)
+    mid = conv.dispatch(xf, conv.new_output())
+    want = S.pooling_i8(mid, (3, 3), (2, 2), (0, 0), L.POOL_MAX)
+    cp = S.SaberConv2DPooling().init((8, 3, 224, 224), p, L.POOL_MAX, (3, 3), (2, 2), (0, 0), L.F32, O.U8, 1 / 127.0, 0.02,
+                                     in_layout=L.NCHW)
+    assert cp.fused
+    got = cp.dispatch(xf, cp.new_output())
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.equal(got, want)
+    # --- pool5 + quantise
+    x5 = dev(rng.integers(-128, 128, (8, 7, 7, 2048)).astype(np.int8))
+    y = S.pooling_f32_from_i8(x5, 0.06, None, None, None, 1, global_pooling=True)
+    y2, yq = S.pooling_f32_from_i8(x5, 0.06, None, None, None, 1, global_pooling=True, q_scale=0.011)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and np.array_equal(host(yq), O.quant_flat_s8(host(y), 0.011))
+
+
 def test_conv_i8_sibling_pair_rejects_mismatches():
     rng = np.random.default_rng(3)
     def mk(K, C=32, k=1, stride=1, odt=O.S8):
