@@ -905,6 +905,63 @@ void saber_hip_fc_destroy(saber_hip_fc_t* fc) {
 }
 
 // ================================================================================================
+// INT8 GEMM: C[m,n] (int32) = op(A)[m,k] (s8|u8) x op(B)[k,n] (s8), exact; B packed at create time
+// (MklDnnGemm<int8_t|uint8_t, int8_t, int> in PACKED_MKLGEMM mode, saber/funcs/impl/x86/mkl_gemm.cpp:138-256).
+// Runs on the implicit-GEMM kernel as a 1x1 convolution over [m,1,1,k] with the raw-accumulator epilogue.
+// ================================================================================================
+struct saber_hip_gemm_i8 {
+    int trans_a = 0, m = 0, n = 0, k = 0, k_pad = 0;
+    saber_hip_conv* conv = nullptr;
+};
+
+int saber_hip_gemm_i8_create(int trans_a, int trans_b, int m, int n, int k, int a_dtype, const int8_t* b_host,
+                             saber_hip_gemm_i8_t** out) {
+    if (!out || !b_host) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
+    if (a_dtype != SABER_HIP_S8 && a_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "A must be s8 or u8");
+    auto* g = new saber_hip_gemm_i8();
+    g->trans_a = trans_a ? 1 : 0; g->m = m; g->n = n; g->k = k; g->k_pad = round_up(k, 16);
+    saber_hip_conv_desc c;
+    std::memset(&c, 0, sizeof c);
+    c.n = m; c.h = 1; c.w = 1; c.c = g->k_pad; c.k = n; c.kh = c.kw = 1;
+    c.stride_h = c.stride_w = c.dil_h = c.dil_w = c.group = 1;
+    c.in_layout = c.out_layout = SABER_HIP_NHWC;
+    c.in_dtype = a_dtype;
+    c.out_dtype = SABER_HIP_F32;       // 4-byte outputs: the raw epilogue stores int32 bit patterns
+    c.int8_weights = 1;
+    int rc = saber_hip_conv2d_create(&c, &g->conv);
+    if (rc) { delete g; return rc; }
+    // op(B)[k,n] -> weight rows [n][k_pad]
+    std::vector<int8_t> w((size_t)n * g->k_pad, 0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < k; ++i) w[(size_t)j * g->k_pad + i] = trans_b ? b_host[(size_t)j * k + i] : b_host[(size_t)i * n + j];
+    std::vector<float> ones(n, 1.f);
+    rc = saber_hip_conv2d_set_weights(g->conv, w.data(), SABER_HIP_S8, ones.data(), nullptr, 1.f, 1.f);
+    if (rc) { saber_hip_conv2d_destroy(g->conv); delete g; return rc; }
+    g->conv->epi = EPI_I8_RAW_S32;
+    *out = g;
+    return SABER_HIP_OK;
+}
+size_t saber_hip_gemm_i8_workspace_bytes(const saber_hip_gemm_i8_t* g) {
+    return (g->trans_a || g->k_pad != g->k) ? (size_t)g->m * g->k_pad : 0;
+}
+int saber_hip_gemm_i8_run(saber_hip_gemm_i8_t* g, const void* a, int32_t* c, void* workspace, saber_hip_stream_t stream) {
+    if (!g || !a || !c) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const void* ain = a;
+    if (saber_hip_gemm_i8_workspace_bytes(g)) {
+        if (!workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
+        if (g->trans_a) HIP_TRY(launch_transpose_bytes(g->k, g->m, g->k_pad, a, workspace, (hipStream_t)stream));   // A is [k][m]
+        else HIP_TRY(launch_pad_channels_i8((size_t)g->m, g->k, g->k_pad, a, workspace, (hipStream_t)stream));
+        ain = workspace;
+    }
+    return saber_hip_conv2d_run(g->conv, ain, c, nullptr, nullptr, stream);
+}
+void saber_hip_gemm_i8_destroy(saber_hip_gemm_i8_t* g) {
+    if (g) saber_hip_conv2d_destroy(g->conv);
+    delete g;
+}
+
+// ================================================================================================
 // thin wrappers
 // ================================================================================================
 int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b, float beta,

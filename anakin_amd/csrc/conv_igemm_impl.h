@@ -143,6 +143,8 @@ __device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, const int (&acc)
             } else {
                 outq[r] = sat_s8(rintf(d));
             }
+        } else if (a.epi == EPI_I8_RAW_S32) {
+            outf[r] = __int_as_float(v);                                  // exact int32, stored through the 4-byte path
         } else if (a.epi == EPI_I8_FC_S8) {
             outf[r] = __fadd_rn(__fmul_rn(d, cp.scale[r]), cp.bias[r]);   // v*scale (+ bias; +0 when absent)
         } else {  // EPI_I8_FC_U8 (int bias already folded into comp)

@@ -175,6 +175,30 @@ hipError_t launch_pad_channels_i8(size_t pixels, int c, int c_pad, const void* x
     return hipGetLastError();
 }
 
+// ---- byte transpose [rows][cols] -> [cols][rows_pad] through a 32x33 LDS tile (coalesced both ways) ----------------
+__global__ __launch_bounds__(256) void transpose_bytes_kernel(int rows, int cols, int rows_pad, const uint8_t* __restrict__ x,
+                                                              uint8_t* __restrict__ y) {
+    __shared__ uint8_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        tile[ty + i][tx] = (r < rows && c < cols) ? x[(size_t)r * cols + c] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (c < cols && r < rows_pad) y[(size_t)c * rows_pad + r] = tile[tx][ty + i];
+    }
+}
+hipError_t launch_transpose_bytes(int rows, int cols, int rows_pad, const void* x, void* y, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_bytes_kernel, dim3((cols + 31) / 32, (rows_pad + 31) / 32), dim3(256), 0, s, rows, cols,
+                       rows_pad, (const uint8_t*)x, (uint8_t*)y);
+    return hipGetLastError();
+}
+
 // ---- flat f32 -> s8, ScaleUtils::scale_fp32_int8 (x86_utils.h:325-346) ------------------------
 __global__ __launch_bounds__(256) void quantize_flat_s8_kernel(size_t count, float inv, const float* __restrict__ x,
                                                                int8_t* __restrict__ y) {

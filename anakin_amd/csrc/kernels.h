@@ -13,7 +13,8 @@ enum {
     EPI_I8_CONV = 0,   // d=(float)acc; d+=bias; d*=scale; relu; [residual]; rne+saturate | f32
     EPI_I8_FC_S8 = 1,  // v=(float)acc*scale; v+=bias                (mkl_packed_int8_gemm.cpp:78-81)
     EPI_I8_FC_U8 = 2,  // acc+=bias_i (folded into comp); v = scale==1 ? (float)acc : scale*(float)acc
-    EPI_F32 = 3        // d=acc [+ prev]; d+=bias; relu
+    EPI_F32 = 3,       // d=acc [+ prev]; d+=bias; relu
+    EPI_I8_RAW_S32 = 4 // the exact int32 accumulator (+ comp), stored as int32 (INT8 GEMM, MklDnnGemm<s8|u8, s8, int>)
 };
 enum { RES_NONE = 0, RES_SUM_INPLACE = 1, RES_ELTWISE = 2 };
 
@@ -91,6 +92,8 @@ hipError_t launch_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_p
 hipError_t launch_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
                                              hipStream_t s);
 hipError_t launch_pad_channels_i8(size_t pixels, int c, int c_pad, const void* x, void* y, hipStream_t s);
+// bytes [rows][cols] -> [cols][rows_pad] (zero filled beyond rows): op(A) = A^T staging of the INT8 GEMM
+hipError_t launch_transpose_bytes(int rows, int cols, int rows_pad, const void* x, void* y, hipStream_t s);
 hipError_t launch_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, hipStream_t s);
 hipError_t launch_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float sa, float sb, float c0,
                                  float c1, int relu, int8_t* y, hipStream_t s);

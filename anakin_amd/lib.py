@@ -28,6 +28,7 @@ SYMBOLS = [
     "saber_hip_net_add_conv_pair",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
     "saber_hip_fc_destroy", "saber_hip_gemm_f32",
+    "saber_hip_gemm_i8_create", "saber_hip_gemm_i8_workspace_bytes", "saber_hip_gemm_i8_run", "saber_hip_gemm_i8_destroy",
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
@@ -108,6 +109,12 @@ def load():
     lib.saber_hip_fc_destroy.argtypes = [P]
     lib.saber_hip_fc_destroy.restype = None
     lib.saber_hip_gemm_f32.argtypes = [I, I, I, I, I, F, P, P, F, P, P]
+    lib.saber_hip_gemm_i8_create.argtypes = [I, I, I, I, I, I, P, C.POINTER(P)]
+    lib.saber_hip_gemm_i8_workspace_bytes.argtypes = [P]
+    lib.saber_hip_gemm_i8_workspace_bytes.restype = Z
+    lib.saber_hip_gemm_i8_run.argtypes = [P, P, P, P, P]
+    lib.saber_hip_gemm_i8_destroy.argtypes = [P]
+    lib.saber_hip_gemm_i8_destroy.restype = None
     lib.saber_hip_quantize_nchw_to_nhwc.argtypes = [I, I, I, I, I, I, F, P, P, P]
     lib.saber_hip_dequantize_nhwc_to_nchw.argtypes = [I, I, I, I, I, F, P, P, P]
     lib.saber_hip_transpose_nchw_to_nhwc_f32.argtypes = [I, I, I, I, I, P, P, P]

@@ -261,6 +261,37 @@ class SaberFc:
             pass
 
 
+class GemmInt8:
+    """MklDnnGemm<int8_t|uint8_t, int8_t, int> (saber/funcs/impl/x86/mkl_gemm.cpp:138-256), PACKED mode: row-major
+    C[m,n] (int32) = op(A)[m,k] (s8 or u8, device) x op(B)[k,n] (s8, packed at init from a host array). Exact."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        self.ws = None
+
+    def init(self, trans_a, trans_b, m, n, k, b_host, a_dtype=L.S8):
+        b_np = np.ascontiguousarray(b_host, np.int8)
+        L.check(L.load().saber_hip_gemm_i8_create(int(trans_a), int(trans_b), m, n, k, a_dtype, _np_ptr(b_np),
+                                                  C.byref(self.h)))
+        self.m, self.n = m, n
+        nbytes = L.load().saber_hip_gemm_i8_workspace_bytes(self.h)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes else None
+        return self
+
+    def dispatch(self, a, c=None):
+        if c is None:
+            c = torch.empty((self.m, self.n), dtype=torch.int32, device="cuda")
+        L.check(L.load().saber_hip_gemm_i8_run(self.h, _p(a), _p(c), _p(self.ws), _stream()))
+        return c
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_gemm_i8_destroy(self.h)
+        except Exception:
+            pass
+
+
 def gemm(trans_a, trans_b, m, n, k, alpha, a, b, beta, c):
     """Gemm<MI355X, SABER_IMPL, float, float>::dispatch (saber/funcs/gemm.h:30-40), raw row-major."""
     L.check(L.load().saber_hip_gemm_f32(int(trans_a), int(trans_b), m, n, k, float(alpha), _p(a), _p(b),

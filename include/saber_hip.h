@@ -170,6 +170,18 @@ void saber_hip_fc_destroy(saber_hip_fc_t* op);
 int saber_hip_gemm_f32(int trans_a, int trans_b, int m, int n, int k, float alpha, const float* a,
                        const float* b, float beta, float* c, saber_hip_stream_t stream);
 
+/* INT8 GEMM (MklDnnGemm<int8_t | uint8_t, int8_t, int>, saber/funcs/impl/x86/mkl_gemm.cpp:138-256; its test
+ * test/saber/test_saber_gemm_int8.cpp): row-major C[m,n] (int32) = op(A)[m,k] x op(B)[k,n], exact integer
+ * arithmetic (i8 MFMA, int32 accumulate). B (s8, HOST pointer) is constant and packed at create time — the
+ * reference's PACKED_MKLGEMM mode; A (s8 or u8) and C are device pointers. trans_a: A is stored [k,m];
+ * trans_b: B is stored [n,k]. Workspace (device) is needed when trans_a or k % 16 != 0. */
+typedef struct saber_hip_gemm_i8 saber_hip_gemm_i8_t;
+int saber_hip_gemm_i8_create(int trans_a, int trans_b, int m, int n, int k, int a_dtype, const int8_t* b_host,
+                             saber_hip_gemm_i8_t** out);
+size_t saber_hip_gemm_i8_workspace_bytes(const saber_hip_gemm_i8_t* g);
+int saber_hip_gemm_i8_run(saber_hip_gemm_i8_t* g, const void* a, int32_t* c, void* workspace, saber_hip_stream_t stream);
+void saber_hip_gemm_i8_destroy(saber_hip_gemm_i8_t* g);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Quantise / dequantise + layout (reorder_nhwc_nchw)                                           */
 /* ------------------------------------------------------------------------------------------- */

@@ -707,6 +707,27 @@ def test_gemm_f32_vs_oracle(ta, tb):
     assert np.abs(host(c) - want).max() <= FP32_RTOL * np.abs(want).max()
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("adt", [O.S8, O.U8])
+def test_gemm_i8_exact(ta, tb, adt):
+    """INT8 GEMM (MklDnnGemm<s8|u8, s8, int>): int32 results equal the integer matrix product exactly, for every
+    transpose combination, ragged sizes (k % 16 != 0) and accumulators far beyond 2^24."""
+    rng = np.random.default_rng(abs(hash((ta, tb, adt))) % 2**31)
+    for M, N, K in ((70, 130, 45), (8, 1000, 2048), (33, 64, 4000)):
+        A = (rng.integers(0, 256, (M, K)).astype(np.uint8) if adt == O.U8 else rng.integers(-128, 128, (M, K)).astype(np.int8))
+        B = rng.integers(-128, 128, (K, N)).astype(np.int8)
+        if (M, N, K) == (33, 64, 4000):   # saturate the operands: |acc| up to 4000 * 255 * 128 ~ 1.3e8
+            A[:] = 255 if adt == O.U8 else -128
+            B[:, ::2] = -128
+            B[:, 1::2] = 127
+        want = A.astype(np.int64) @ B.astype(np.int64)
+        assert np.abs(want).max() < 2**31
+        a_dev = dev(np.ascontiguousarray(A.T) if ta else A)
+        g = S.GemmInt8().init(ta, tb, M, N, K, np.ascontiguousarray(B.T) if tb else B, adt)
+        got = host(g.dispatch(a_dev))
+        assert got.dtype == np.int32 and np.array_equal(got.astype(np.int64), want), (M, N, K)
+
+
 def test_softmax_vs_oracle():
     rng = np.random.default_rng(61)
     x = (rng.standard_normal((8, 1000)) * 4).astype(np.float32)
