@@ -186,6 +186,9 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
         d.stride_h <= 0 || d.stride_w <= 0 || d.dil_h <= 0 || d.dil_w <= 0 || d.pad_h < 0 || d.pad_w < 0)
         return fail(SABER_HIP_INVALID_VALUE, "bad conv geometry");
     if (d.c % d.group || d.k % d.group) return fail(SABER_HIP_INVALID_VALUE, "invalid input_channel or output_channel");
+    if ((d.act != SABER_HIP_ACT_NONE && d.act != SABER_HIP_ACT_RELU) ||
+        (d.res_act != SABER_HIP_ACT_NONE && d.res_act != SABER_HIP_ACT_RELU))
+        return fail(SABER_HIP_UNIMPL, "only ReLU is fused into the convolution (as in the x86 INT8 path); other activations are separate ops");
     const int oh = conv_out(d.h, d.pad_h, d.kh, d.dil_h, d.stride_h);
     const int ow = conv_out(d.w, d.pad_w, d.kw, d.dil_w, d.stride_w);
     if (oh <= 0 || ow <= 0) return fail(SABER_HIP_INVALID_VALUE, "empty output");

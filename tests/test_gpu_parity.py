@@ -211,6 +211,17 @@ def test_conv_i8_accumulators_beyond_2_pow_24():
             assert np.array_equal(got, want), conv.algo()
 
 
+def test_conv_rejects_unknown_activation():
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.c, d.k, d.kh, d.kw = 1, 8, 8, 16, 16, 1, 1
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.group = 1
+    d.in_dtype, d.out_dtype, d.in_layout, d.out_layout, d.int8_weights = L.U8, L.U8, L.NHWC, L.NHWC, 1
+    d.act = 5   # e.g. a sigmoid: not fused, must not be silently dropped
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.load().saber_hip_conv2d_create(C.byref(d), C.byref(h)) == L.UNIMPL
+
+
 def test_conv_i8_empty_and_invalid():
     lib = L.load()
     import ctypes as C
