@@ -369,6 +369,29 @@ def ref_conv1x1_f32(x, w, bias, relu, residual=None):
     return out
 
 
+def ref_fc_i8_packed(x_f32, w_nk_f32, bias, in_scale):
+    """The reference's INT8 fc for an f32 input (VenderFc<X86,AK_INT8> -> PackedMKLInt8Gemm): f32 [M,N]."""
+    x = np.ascontiguousarray(x_f32, np.float32)
+    w = np.ascontiguousarray(w_nk_f32, np.float32)
+    M, K = x.shape
+    N = w.shape[0]
+    out = np.empty((M, N), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rc = ref().ref_fc_i8_packed(M, N, K, _ptr(x), _ptr(w), _ptr(b), _f(in_scale), _ptr(out))
+    assert rc == 0, rc
+    return out
+
+
+def ref_gemm_s8s8s32(a, b, M, N, K, trans_a=False, trans_b=False):
+    """MklDnnGemm<int8_t,int8_t,int> (packed B): s32 [M,N]."""
+    a = np.ascontiguousarray(a, np.int8)
+    b = np.ascontiguousarray(b, np.int8)
+    out = np.empty((M, N), np.int32)
+    rc = ref().ref_gemm_s8s8s32(int(trans_a), int(trans_b), M, N, K, _ptr(a), _ptr(b), _ptr(out))
+    assert rc == 0, rc
+    return out
+
+
 def ref_conv_basic_check_f32(x, w, bias, relu, pad=(0, 0), stride=(1, 1), dil=(1, 1), group=1):
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)

@@ -14,6 +14,8 @@
 //   reorder_nhwc_nchw                    saber/funcs/saber_util.h:637-803
 //   SaberEltwise<X86,AK_INT8/AK_FLOAT>   saber/funcs/impl/x86/saber_eltwise.cpp:71-113
 //   SaberConv1X1<AK_FLOAT>               saber/funcs/impl/x86/saber_conv_1x1.cpp:28-108
+//   PackedMKLInt8Gemm::init/dispatch     saber/funcs/impl/x86/mkl_packed_int8_gemm.cpp:22-97 (INT8 fc arithmetic)
+//   MklDnnGemm<int8_t,int8_t,int>        saber/funcs/impl/x86/mkl_gemm.cpp:138-196 (INT8 GEMM, packed B)
 //   conv_basic_check / conv_basic_check_int8 / pool_basic_check_int8
 //                                        test/saber/conv_func_helper.h:29-264
 #include "anakin_config.h"
@@ -25,6 +27,8 @@
 #include "saber/funcs/impl/x86/saber_conv_1x1.h"
 #include "saber/funcs/impl/x86/saber_eltwise.h"
 #include "saber/funcs/impl/x86/x86_utils.h"
+#include "saber/funcs/impl/x86/mkl_gemm.h"
+#include "saber/funcs/impl/x86/mkl_packed_int8_gemm.h"
 #include "test/saber/conv_func_helper.h"
 
 #include <cstring>
@@ -259,6 +263,42 @@ int ref_pool_basic_check_int8(int N, int H, int W, int C, int OH, int OW, int kh
                      : Pooling_average_exclude_padding;
     pool_basic_check_int8<X86>(tin, tout, kw, kh, stride_w, stride_h, pad_w, pad_h, pt);
     memcpy(out, tout.data(), (size_t)N * OH * OW * C);
+    return 0;
+}
+
+// cblas_sgemm_alloc / cblas_sgemm_free: referenced by mkl_gemm.cpp's FP32 packed path, no longer exported by the
+// container's oneMKL. Equivalent definitions on top of the routines it does export (never called by the tests).
+float* cblas_sgemm_alloc(const CBLAS_IDENTIFIER identifier, const MKL_INT M, const MKL_INT N, const MKL_INT K) {
+    return (float*)mkl_malloc(cblas_sgemm_pack_get_size(identifier, M, N, K), 64);
+}
+void cblas_sgemm_free(float* dest) { mkl_free(dest); }
+
+// INT8 fully connected exactly as VenderFc<X86,AK_INT8> drives it for f32 / s8 inputs (vender_fc.cpp:252-262):
+// PackedMKLInt8Gemm::init(false, true, m, n, k, weights[n,k] f32, in_scale) quantises the weights per output row
+// (scale_gemm_xw_weights_to_nchw_host), dispatch quantises the f32 input (scale_fp32_int8), runs s8 x s8 -> s32 and
+// applies out = (float)acc * (w_scale[n] * in_scale) + bias[n]. x: f32 [m,k]; out: f32 [m,n].
+int ref_fc_i8_packed(int m, int n, int k, const float* x, const float* w_nk, const float* bias, float in_scale, float* out) {
+    ctx();
+    Tensor<X86> wt(Shape({1, 1, n, k}, Layout_NCHW), AK_FLOAT);
+    memcpy(wt.mutable_data(), w_nk, sizeof(float) * (size_t)n * k);
+    PackedMKLInt8Gemm g;
+    if (g.init(false, true, m, n, k, wt, in_scale) != SaberSuccess) return 1;
+    Tensor<X86> a(Shape({m, k, 1, 1}, Layout_NCHW), AK_FLOAT);
+    a.set_scale({in_scale});
+    memcpy(a.mutable_data(), x, sizeof(float) * (size_t)m * k);
+    Tensor<X86> c(Shape({m, n, 1, 1}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> b(Shape({1, n, 1, 1}, Layout_NCHW), AK_FLOAT);
+    if (bias) memcpy(b.mutable_data(), bias, sizeof(float) * n);
+    if (g.dispatch(1.f, 0.f, m, a, c, bias ? &b : nullptr) != SaberSuccess) return 2;
+    memcpy(out, c.data(), sizeof(float) * (size_t)m * n);
+    return 0;
+}
+
+// INT8 GEMM, packed B: C[m,n] (s32) = op(A)[m,k] (s8) x op(B)[k,n] (s8)   (MklDnnGemm<int8_t,int8_t,int>)
+int ref_gemm_s8s8s32(int trans_a, int trans_b, int m, int n, int k, const int8_t* a, const int8_t* b, int32_t* c) {
+    MklDnnGemm<int8_t, int8_t, int> g;
+    if (g.init(trans_a != 0, trans_b != 0, m, n, k, ctx(), b, PACKED_MKLGEMM) != SaberSuccess) return 1;
+    if (g.dispatch(1.f, 0.f, m, a, b, c) != SaberSuccess) return 2;
     return 0;
 }
 

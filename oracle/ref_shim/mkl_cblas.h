@@ -10,6 +10,7 @@
 extern "C" {
 #endif
 typedef int MKL_INT;
+typedef int8_t MKL_INT8_OR_INT;   /* ao / bo of the s8u8s32 routines */
 typedef enum { CblasRowMajor = 101, CblasColMajor = 102 } CBLAS_LAYOUT;
 typedef enum { CblasNoTrans = 111, CblasTrans = 112, CblasConjTrans = 113 } CBLAS_TRANSPOSE;
 typedef enum { CblasRowOffset = 171, CblasColOffset = 172, CblasFixOffset = 173 } CBLAS_OFFSET;

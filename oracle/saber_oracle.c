@@ -331,7 +331,8 @@ void orc_dequant_nhwc_to_nchw(int N, int C, int H, int W, int in_dtype, float sc
                 }
 }
 
-/* [unpinned: restates x86_utils.h:325-346] ScaleUtils::scale_fp32_int8 (same layout, flat):
+/* [pinned through the INT8 fc: tests/test_oracle_vs_ref.py::test_fc_i8_matches_reference_packed_gemm]
+ * ScaleUtils::scale_fp32_int8 (x86_utils.h:325-346; same layout, flat):
  * secur_cast2char(x * (1.f/scale)) = clamp((int)roundf(v), -128, 127). Used by the INT8 FC when
  * handed an f32 input (mkl_packed_int8_gemm.cpp:52-57). */
 void orc_quant_flat_s8(size_t n, float scale, const float* x, int8_t* out) {
@@ -506,7 +507,8 @@ void orc_fc_f32(int M, int N, int Kd, const float* in, const float* Wt, int w_is
         }
 }
 
-/* [unpinned: MKL-packed path] VenderFc<X86, AK_INT8> with s8 (or f32, quantised first by
+/* [pinned: bit-exact against the compiled PackedMKLInt8Gemm, tests/test_oracle_vs_ref.py + tests/golden/fc_i8_f32in.npz]
+ * VenderFc<X86, AK_INT8> with s8 (or f32, quantised first by
  * orc_quant_flat_s8) input and f32 output = PackedMKLInt8Gemm::dispatch
  * (mkl_packed_int8_gemm.cpp:46-90; init :22-45):
  *   scale[n] = w_scale[n] * in_scale ;  out = (float)acc32 * scale[n] + bias[n]

@@ -4,7 +4,7 @@ Run in the build container only (needs /root/reference + oracle/_ref):
     python tests/golden/make_golden.py
 Every output array in a fixture is produced by the reference's own, unmodified x86 Saber sources
 (oracle/_ref/libanakin_x86_ref.so — GemmX8S8S32XConv, reorder_nhwc_nchw, SaberEltwise,
-scale_conv_weights_to_nchw_host, conv_basic_check), never by oracle/saber_oracle.c. The reference's
+scale_conv_weights_to_nchw_host, conv_basic_check, PackedMKLInt8Gemm), never by oracle/saber_oracle.c. The reference's
 tests have no golden vectors of their own (inputs come from std::random_device, SURVEY.md §4), so
 these seeded fixtures are what pins bit-level parity; the GPU box has no /root/reference and reads
 only the committed .npz files.
@@ -111,6 +111,21 @@ def gen_conv_f32(seed):
                         res=res, y=y)
 
 
+def gen_fc_i8(seed):
+    """INT8 fc with an f32 input through the reference's PackedMKLInt8Gemm (k = 2048 as ResNet50's fc1000, 128 of its
+    outputs, 2 rows). The weights are float16-representable so that the fixture can store them in half the bytes."""
+    rng = np.random.default_rng(seed)
+    M, N, K = 2, 128, 2048
+    x = (rng.standard_normal((M, K)) * 0.8).astype(np.float32)
+    in_scale = np.float32(np.abs(x).max() / 127.0)
+    x[0, :3] = [0.5 * in_scale, -0.5 * in_scale, 2.5 * in_scale]   # exact ties: round half away from zero
+    w16 = (rng.standard_normal((N, K)) * 0.03).astype(np.float16)
+    w = w16.astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    y = O.ref_fc_i8_packed(x, w, bias, float(in_scale))
+    np.savez_compressed(os.path.join(OUT, "fc_i8_f32in.npz"), x=x, w=w16, bias=bias, in_scale=in_scale, y=y)
+
+
 if __name__ == "__main__":
     assert O.ref_available(), "build oracle/_ref first (make -C oracle ref)"
     for i, (name, spec) in enumerate(CONV_I8.items()):
@@ -118,4 +133,5 @@ if __name__ == "__main__":
     gen_quant(2000)
     gen_eltwise(2001)
     gen_conv_f32(2002)
+    gen_fc_i8(2003)
     print("golden vectors written to", OUT)

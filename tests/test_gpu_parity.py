@@ -673,6 +673,17 @@ def test_pooling_f32_from_i8_equals_dequant_then_pool():
             assert np.array_equal(host(y), want) and np.array_equal(host(yq), O.quant_flat_s8(want, qs))
 
 
+def test_fc_i8_golden():
+    """INT8 fc (f32 input quantised on entry) against the fixture produced by the reference's PackedMKLInt8Gemm."""
+    g = load("fc_i8_f32in")
+    w = g["w"].astype(np.float32)
+    N, K = w.shape
+    M = g["x"].shape[0]
+    fc = S.SaberFc(True).init(M, N, K, w, g["bias"], L.F32, float(g["in_scale"]))
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    assert np.array_equal(host(fc.dispatch(dev(g["x"]), y)), g["y"])
+
+
 def test_fc_vs_oracle():
     rng = np.random.default_rng(41)
     M, N, K = 8, 1000, 2048

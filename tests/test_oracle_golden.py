@@ -51,6 +51,17 @@ def test_conv_f32_residual_mkl_golden():
     assert np.abs(y - g["y"]).max() <= 1e-4 * np.abs(g["y"]).max()  # MKL sgemm order: tolerance
 
 
+def test_fc_i8_golden():
+    """INT8 fc, f32 input: restatement == the reference's PackedMKLInt8Gemm output stored in the fixture."""
+    g = load("fc_i8_f32in")
+    w = g["w"].astype(np.float32)
+    N, K = w.shape
+    ws = O.weight_scales(w.reshape(N, K, 1, 1))
+    wq = O.quant_weights(w.reshape(N, K, 1, 1), ws).reshape(N, K)
+    got = O.fc_i8(O.quant_flat_s8(g["x"], float(g["in_scale"])), wq, ws, float(g["in_scale"]), g["bias"])
+    assert np.array_equal(got, g["y"])
+
+
 def test_conv_i8_properties():
     """Size-independent properties: linearity of the int32 accumulator in x and in w; fused
     eltwise epilogue == conv followed by the eltwise op."""

@@ -154,3 +154,34 @@ def test_pool_matches_reference_test_oracle():
     got = O.pool_i8_nhwc(x, (3, 3), (2, 2), (0, 0), 1).astype(np.int32)
     want = O.ref_pool_basic_check_int8(x, oh, oh, (3, 3), (2, 2), (0, 0), 1).astype(np.int32)
     assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+@pytest.mark.parametrize("shape", [(8, 1000, 2048), (3, 17, 50), (1, 64, 512)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_fc_i8_matches_reference_packed_gemm(shape, with_bias):
+    """INT8 fc, f32 input: the restatement (flat quantise -> per-row truncating weight quantisation -> exact s32 ->
+    (float)acc * (w_scale*in_scale) + bias) equals VenderFc<X86,AK_INT8>'s PackedMKLInt8Gemm bit for bit."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 1000 + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    x[0, :4] = [0.5 * 0.031, -0.5 * 0.031, 1.5 * 0.031, 200.0]      # ties (round half away) and saturation
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+    in_scale = 0.031
+    want = O.ref_fc_i8_packed(x, w, b, in_scale)
+    ws = O.weight_scales(w.reshape(N, K, 1, 1))
+    wq = O.quant_weights(w.reshape(N, K, 1, 1), ws).reshape(N, K)
+    got = O.fc_i8(O.quant_flat_s8(x, in_scale), wq, ws, in_scale, b)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1)])
+def test_gemm_s8s8s32_matches_reference(ta, tb):
+    """INT8 GEMM: the integer product the HIP path is tested against equals MklDnnGemm<int8_t,int8_t,int>."""
+    rng = np.random.default_rng(9 + ta * 2 + tb)
+    M, N, K = 33, 70, 130
+    A = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    B = rng.integers(-128, 128, (K, N)).astype(np.int8)
+    want = (A.astype(np.int64) @ B.astype(np.int64)).astype(np.int32)
+    got = O.ref_gemm_s8s8s32(np.ascontiguousarray(A.T) if ta else A, np.ascontiguousarray(B.T) if tb else B, M, N, K, ta, tb)
+    assert np.array_equal(got, want)
