@@ -382,6 +382,33 @@ def ref_fc_i8_packed(x_f32, w_nk_f32, bias, in_scale):
     return out
 
 
+def ref_vender_fc_i8(x, w_nk_f32, bias, in_scale, out_scale=1.0):
+    """The reference's whole VenderFc<X86,AK_INT8> operator (f32 / s8 / u8 input [M,K], f32 weights [N,K]) -> f32 [M,N]."""
+    x = np.ascontiguousarray(x)
+    w = np.ascontiguousarray(w_nk_f32, np.float32)
+    M, K = x.shape
+    N = w.shape[0]
+    out = np.empty((M, N), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rc = ref().ref_vender_fc_i8(M, N, K, code_of(x), _ptr(x), _ptr(w), _ptr(b), _f(in_scale), _f(out_scale), _ptr(out))
+    assert rc == 0, rc
+    return out
+
+
+def ref_bn_fold(w, bias, bn_scale, eps, mean, var, scale_w, scale_b):
+    """WeightsFusion<float,X86>::update_weights on the compiled reference: (folded weights, folded bias)."""
+    w = np.ascontiguousarray(w, np.float32).copy()
+    K, Cc, kh, kw = w.shape
+    has_bias = bias is not None
+    b = np.ascontiguousarray(bias, np.float32).copy() if has_bias else np.zeros(K, np.float32)
+    sb = None if scale_b is None else np.ascontiguousarray(scale_b, np.float32)
+    rc = ref().ref_bn_fold(K, Cc, kh, kw, _ptr(w), _ptr(b), int(has_bias), _f(bn_scale), _f(eps),
+                           _ptr(np.ascontiguousarray(mean, np.float32)), _ptr(np.ascontiguousarray(var, np.float32)),
+                           _ptr(np.ascontiguousarray(scale_w, np.float32)), _ptr(sb))
+    assert rc == 0, rc
+    return w, b
+
+
 def ref_gemm_s8s8s32(a, b, M, N, K, trans_a=False, trans_b=False):
     """MklDnnGemm<int8_t,int8_t,int> (packed B): s32 [M,N]."""
     a = np.ascontiguousarray(a, np.int8)

@@ -16,6 +16,8 @@
 //   SaberConv1X1<AK_FLOAT>               saber/funcs/impl/x86/saber_conv_1x1.cpp:28-108
 //   PackedMKLInt8Gemm::init/dispatch     saber/funcs/impl/x86/mkl_packed_int8_gemm.cpp:22-97 (INT8 fc arithmetic)
 //   MklDnnGemm<int8_t,int8_t,int>        saber/funcs/impl/x86/mkl_gemm.cpp:138-196 (INT8 GEMM, packed B)
+//   VenderFc<X86,AK_INT8>::init/dispatch saber/funcs/impl/x86/vender_fc.cpp:224-422 (f32 / s8 / u8 inputs, f32 output)
+//   WeightsFusion<float,X86>::update_weights   framework/utils/parameter_fusion.cpp:88-131 (BN + Scale folding)
 //   conv_basic_check / conv_basic_check_int8 / pool_basic_check_int8
 //                                        test/saber/conv_func_helper.h:29-264
 #include "anakin_config.h"
@@ -29,7 +31,9 @@
 #include "saber/funcs/impl/x86/x86_utils.h"
 #include "saber/funcs/impl/x86/mkl_gemm.h"
 #include "saber/funcs/impl/x86/mkl_packed_int8_gemm.h"
+#include "saber/funcs/impl/x86/vender_fc.h"
 #include "test/saber/conv_func_helper.h"
+#include "framework/utils/parameter_fusion.h"
 
 #include <cstring>
 #include <vector>
@@ -291,6 +295,46 @@ int ref_fc_i8_packed(int m, int n, int k, const float* x, const float* w_nk, con
     if (bias) memcpy(b.mutable_data(), bias, sizeof(float) * n);
     if (g.dispatch(1.f, 0.f, m, a, c, bias ? &b : nullptr) != SaberSuccess) return 2;
     memcpy(out, c.data(), sizeof(float) * (size_t)m * n);
+    return 0;
+}
+
+// The whole VenderFc<X86,AK_INT8> operator: x [m,k] of in_dtype (0 f32, 1 s8, 2 u8), f32 weights [n,k], f32 bias or
+// null, f32 output [m,n]. f32 / s8 inputs go through PackedMKLInt8Gemm, u8 through the cblas_gemm_s8u8s32 path with the
+// truncated integer bias (vender_fc.cpp:284-300,324-335).
+int ref_vender_fc_i8(int m, int n, int k, int in_dtype, const void* x, const float* w_nk, const float* bias, float in_scale,
+                     float out_scale, float* out) {
+    Tensor<X86> tin(Shape({m, k, 1, 1}, Layout_NCHW), to_dtype(in_dtype));
+    Tensor<X86> tout(Shape({m, n, 1, 1}, Layout_NCHW), AK_FLOAT);
+    tin.set_scale({in_scale});
+    tout.set_scale({out_scale});
+    memcpy(tin.mutable_data(), x, dsize(in_dtype) * (size_t)m * k);
+    Tensor<X86> wt(Shape({1, 1, n, k}, Layout_NCHW), AK_FLOAT), bt(Shape({1, n, 1, 1}, Layout_NCHW), AK_FLOAT);
+    memcpy(wt.mutable_data(), w_nk, sizeof(float) * (size_t)n * k);
+    if (bias) memcpy(bt.mutable_data(), bias, sizeof(float) * n);
+    FcParam<X86> param(&wt, bias ? &bt : nullptr, n, 1, false);
+    std::vector<Tensor<X86>*> ins{&tin}, outs{&tout};
+    VenderFc<X86, AK_INT8> fc;
+    if (fc.init(ins, outs, param, ctx()) != SaberSuccess) return 1;
+    if (fc.dispatch(ins, outs, param) != SaberSuccess) return 2;
+    memcpy(out, tout.data(), sizeof(float) * (size_t)m * n);
+    return 0;
+}
+
+// BatchNorm + Scale folded into conv weights / bias at init: WeightsFusion<float,X86>::update_weights. w [K,C,kh,kw]
+// and bias [K] are updated in place (bias is the conv's own bias when has_bias, else starts at zero).
+int ref_bn_fold(int K, int C, int kh, int kw, float* w, float* bias, int has_bias, float bn_scale, float eps,
+                const float* mean, const float* var, const float* scale_w, const float* scale_b) {
+    ctx();
+    Shape ws({K, C, kh, kw}, Layout_NCHW), bs({1, K, 1, 1}, Layout_NCHW);
+    anakin::PBlock<X86> pw(ws), pb(bs);
+    memcpy(pw.h_tensor().mutable_data(), w, sizeof(float) * (size_t)K * C * kh * kw);
+    if (has_bias) memcpy(pb.h_tensor().mutable_data(), bias, sizeof(float) * K);
+    std::vector<float> vm(mean, mean + K), vv(var, var + K), vsw(scale_w, scale_w + K), vsb;
+    if (scale_b) vsb.assign(scale_b, scale_b + K);
+    anakin::WeightsFusion<float, X86>::update_weights(pw, pb, K, C, kh, kw, has_bias != 0, bn_scale, eps, vm, vv, vsw, vsb,
+                                                      scale_b != nullptr);
+    memcpy(w, pw.h_tensor().data(), sizeof(float) * (size_t)K * C * kh * kw);
+    memcpy(bias, pb.h_tensor().data(), sizeof(float) * K);
     return 0;
 }
 

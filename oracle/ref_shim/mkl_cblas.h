@@ -24,6 +24,7 @@ void cblas_sgemm(const CBLAS_LAYOUT Layout, const CBLAS_TRANSPOSE TransA,
                  const CBLAS_TRANSPOSE TransB, const MKL_INT M, const MKL_INT N, const MKL_INT K,
                  const float alpha, const float* A, const MKL_INT lda, const float* B,
                  const MKL_INT ldb, const float beta, float* C, const MKL_INT ldc);
+void cblas_saxpy(const MKL_INT N, const float alpha, const float* X, const MKL_INT incX, float* Y, const MKL_INT incY);
 #ifdef __cplusplus
 }
 #endif

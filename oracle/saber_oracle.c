@@ -528,7 +528,8 @@ void orc_fc_i8_s8in(int M, int N, int Kd, const int8_t* in, const int8_t* wq, co
         }
 }
 
-/* [unpinned] VenderFc<X86, AK_INT8> with u8 input, f32 output (vender_fc.cpp:253-300,318-422):
+/* [pinned: bit-exact against the compiled VenderFc<X86,AK_INT8>, tests/test_oracle_vs_ref.py]
+ * VenderFc<X86, AK_INT8> with u8 input, f32 output (vender_fc.cpp:253-300,318-422):
  *   scale[n]  = (in_scale * w_scale[n]) / out_scale           (no 127/255 factor — reference quirk)
  *   bias_i[n] = (int)(bias[n] / scale[n])                     (truncation, x86_utils.h:276-291)
  *   out       = scale[n]==1 ? (float)(acc+bias_i) : scale[n] * (float)(acc + bias_i) */
@@ -548,7 +549,8 @@ void orc_fc_i8_u8in(int M, int N, int Kd, const uint8_t* in, const int8_t* wq, c
 
 /* ---- BN + Scale folding (cold path; defines the weights the hot path sees) ------------------- */
 
-/* [unpinned: framework TU not built] WeightsFusion<float,T>::update_weights
+/* [pinned: bit-exact against the compiled framework/utils/parameter_fusion.cpp, tests/test_oracle_vs_ref.py]
+ * WeightsFusion<float,T>::update_weights
  * (framework/utils/parameter_fusion.cpp:88-131), all in f32, in this order:
  *   s = bn_scale==0 ? 1 : 1/bn_scale; alpha = 1/sqrtf(var*s + eps); beta = -(mean*s)*alpha;
  *   alpha = scale_w*alpha; beta = beta*scale_w (+ scale_b);

@@ -185,3 +185,50 @@ def test_gemm_s8s8s32_matches_reference(ta, tb):
     want = (A.astype(np.int64) @ B.astype(np.int64)).astype(np.int32)
     got = O.ref_gemm_s8s8s32(np.ascontiguousarray(A.T) if ta else A, np.ascontiguousarray(B.T) if tb else B, M, N, K, ta, tb)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("has_bias", [False, True])
+@pytest.mark.parametrize("scale_bias", [False, True])
+@pytest.mark.parametrize("bn_scale", [0.0, 1.0, 0.999])
+def test_bn_fold_matches_reference(has_bias, scale_bias, bn_scale):
+    """BatchNorm + Scale folding: the restatement (and the numpy version the workloads use) == the compiled
+    WeightsFusion<float,X86>::update_weights, bit for bit."""
+    from anakin_amd import workloads as W
+    rng = np.random.default_rng(77 + int(has_bias) + 2 * int(scale_bias))
+    K, C, k = 24, 16, 3
+    w = rng.standard_normal((K, C, k, k)).astype(np.float32)
+    bias = rng.standard_normal(K).astype(np.float32) if has_bias else None
+    mean = rng.uniform(-0.5, 0.5, K).astype(np.float32)
+    var = rng.uniform(0.2, 2.0, K).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    beta = rng.uniform(-0.3, 0.3, K).astype(np.float32) if scale_bias else None
+    want_w, want_b = O.ref_bn_fold(w, bias, bn_scale, 1e-5, mean, var, gamma, beta)
+    got_w, got_b = O.bn_fold(w, bias, bn_scale, 1e-5, mean, var, gamma, beta)
+    assert np.array_equal(got_w, want_w) and np.array_equal(got_b, want_b)
+    np_w, np_b = W.fold_bn(w, bias, bn_scale, 1e-5, mean, var, gamma, beta)
+    assert np.array_equal(np_w, want_w) and np.array_equal(np_b, want_b)
+
+
+@pytest.mark.parametrize("in_kind", ["f32", "u8"])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_vender_fc_i8_operator_matches_reference(in_kind, with_bias):
+    """The whole VenderFc<X86,AK_INT8> operator (init + dispatch) with an f32 output: f32 input (quantised on entry)
+    through PackedMKLInt8Gemm; u8 input through the cblas_gemm_s8u8s32 path with its truncated integer bias and
+    scale = in_scale*w_scale/out_scale. Restatement == compiled reference, bit for bit. (An s8 input with an f32
+    output is not a reference combination: PackedMKLInt8Gemm::dispatch only offers s8 -> s32 for it, which is the
+    INT8 GEMM pinned above.)"""
+    M, N, K = 5, 40, 96
+    rng = np.random.default_rng(hash(in_kind) % 1000 + int(with_bias))
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+    in_scale, out_scale = 0.031, 0.5
+    ws = O.weight_scales(w.reshape(N, K, 1, 1))
+    wq = O.quant_weights(w.reshape(N, K, 1, 1), ws).reshape(N, K)
+    if in_kind == "f32":
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        got = O.fc_i8(O.quant_flat_s8(x, in_scale), wq, ws, in_scale, b)
+    else:
+        x = rng.integers(0, 256, (M, K)).astype(np.uint8)
+        got = O.fc_i8(x, wq, ws, in_scale, b, out_scale)
+    want = O.ref_vender_fc_i8(x, w, b, in_scale, out_scale)
+    assert np.array_equal(got, want)
