@@ -271,7 +271,8 @@ int ref_pool_basic_check_int8(int N, int H, int W, int C, int OH, int OW, int kh
 }
 
 // cblas_sgemm_alloc / cblas_sgemm_free: referenced by mkl_gemm.cpp's FP32 packed path, no longer exported by the
-// container's oneMKL. Equivalent definitions on top of the routines it does export (never called by the tests).
+// container's oneMKL. Equivalent definitions on top of the routines it does export (the FP32 packed paths that use
+// them are not driven here: VenderFc<X86,AK_FLOAT> through them crashes inside this oneMKL's pack API).
 float* cblas_sgemm_alloc(const CBLAS_IDENTIFIER identifier, const MKL_INT M, const MKL_INT N, const MKL_INT K) {
     return (float*)mkl_malloc(cblas_sgemm_pack_get_size(identifier, M, N, K), 64);
 }

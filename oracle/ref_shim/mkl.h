@@ -2,7 +2,7 @@
  * (saber/funcs/impl/x86/mkl_gemm_int8.h:19; mkl_gemm.cpp, mkl_gemm_int8.cpp, mkl_packed_int8_gemm.cpp).
  * The symbols come from the container's /opt/conda/lib/libmkl_rt.so at link time, except cblas_sgemm_alloc /
  * cblas_sgemm_free, which newer oneMKL no longer exports: oracle/ref_driver.cpp provides them on top of
- * cblas_sgemm_pack_get_size + mkl_malloc (FP32 packed path only, not exercised by the parity tests).
+ * cblas_sgemm_pack_get_size + mkl_malloc (used by the FP32 packed paths of mkl_gemm.cpp / vender_fc.cpp).
  * TEST INFRASTRUCTURE ONLY (oracle/_ref). */
 #ifndef ORACLE_SHIM_MKL_H
 #define ORACLE_SHIM_MKL_H
