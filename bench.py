@@ -280,7 +280,9 @@ def main():
             "value": round(value, 1), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "s8/u8 x s8 -> s32 (MFMA i8), f32 epilogue" if args.precision == "int8" else "f32",
+            "dtype": "int8" if args.precision == "int8" else "f32",
+            "dtype_detail": "s8/u8 x s8 -> s32 (MFMA i8), f32 requantisation epilogue" if args.precision == "int8"
+            else "f32 (v_mfma_f32_16x16x4_f32)",
             "data": "synthetic (seeded uniform images, He-init weights with folded BN, MAXABS scales)",
             "config": {"workload": "%s %s post-fusion op list, batch %d per GPU, 224x224" %
                                    (args.model, args.precision, B),
