@@ -72,21 +72,20 @@ def timed_steps(net, steps, use_graph, gather=None, flush=None):
     torch.cuda.synchronize()
 
 
-def pick_launch_mode(net, steps=60):
+def pick_launch_mode(net, steps=60, gather=None, flush=None):
     """hipGraph replay against eager launches (the C++ op loop of saber_hip_net_run) of the same op list, timed once
-    before the timed region; the faster one is used. On this host the eager loop keeps the GPU fed and is ~1 % faster
-    than the graph; and occasionally (2 of ~30 runs) a process gets a graph whose replay is 25-30 % slower than the sum
-    of its kernels while eager per-op times are normal."""
+    before the timed region — with the per-step logits gather when there is one, since the eager loop costs ~275 us of
+    host time per step (graph: ~30 us) and leaves little room for anything else on the launching thread; the faster
+    one is used. On this host, single GPU, the eager loop keeps the GPU fed and is ~1 % faster than the graph; and
+    occasionally (2 of ~30 runs) a process gets a graph whose replay is 25-30 % slower than the sum of its kernels
+    while eager per-op times are normal."""
     import torch
     t = {}
     for mode in ("graph", "eager", "graph", "eager"):
-        for _ in range(5):
-            net.replay() if mode == "graph" else net.run()
+        timed_steps(net, 5, mode == "graph", gather, flush)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            net.replay() if mode == "graph" else net.run()
-        torch.cuda.synchronize()
+        timed_steps(net, steps, mode == "graph", gather, flush)
         t[mode] = min(t.get(mode, 1e9), (time.perf_counter() - t0) * 1e3 / steps)
     use_graph = t["graph"] <= t["eager"]
     return use_graph, {"graph_ms": round(t["graph"], 4), "eager_ms": round(t["eager"], 4)}
@@ -138,7 +137,6 @@ def main():
     launch_probe = None
     if use_graph:
         net.capture()
-        use_graph, launch_probe = pick_launch_mode(net)
 
     logits = net.tensor("prob")
     gather = gather_flush = None
@@ -150,6 +148,13 @@ def main():
         def gather():
             ag.step(logits)
         gather_flush = ag.flush
+
+    if use_graph:
+        use_graph, launch_probe = pick_launch_mode(net, gather=gather, flush=gather_flush)
+        if world > 1:   # every rank uses the same mode (the slowest rank sets the step time anyway)
+            flag = torch.tensor([1 if use_graph else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            use_graph = bool(flag.item())
 
     # ---------------- warm-up, then the timed region (barrier + synchronize on both sides) ----------
     timed_steps(net, args.warmup, use_graph, gather, gather_flush)
