@@ -101,7 +101,14 @@ int ref_conv_i8(int N, int H, int W, int C, int K, int kh, int kw, int pad_h, in
     if (impl.init(ins, outs, cep, ctx()) != SaberSuccess) {
         return 1;
     }
-    if (impl.dispatch(ins, outs, cep) != SaberSuccess) {
+    if (in_dtype == 2 && out_dtype == 1) {
+        // u8 -> s8: dispatch() has no branch for it (gemm_x8s8s32x_conv.cpp:290-308); call the public member template
+        // the reference defines for every dtype pair (instantiated in oracle/ref_gemm_conv_u8s8.cpp); the scale it
+        // uses was computed by the init()/create() above (gemm_x8s8s32x_conv.cpp:163-166)
+        if (impl.sub_dispatch<uint8_t, int8_t>(ins, outs, cep) != SaberSuccess) {
+            return 2;
+        }
+    } else if (impl.dispatch(ins, outs, cep) != SaberSuccess) {
         return 2;
     }
     memcpy(out, tout.data(), (size_t)N * OH * OW * K * dsize(out_dtype));

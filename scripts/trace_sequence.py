@@ -1,0 +1,39 @@
+"""Per-dispatch view of ONE forward pass out of a rocprofv3 rocpd sqlite database (kernel trace): the last `nops`
+dispatches in launch order with their device duration, the idle gap since the previous kernel ended, grid size, VGPRs
+and LDS bytes — the table that shows where a latency-bound op list loses its time (kernel body vs. boundary).
+
+usage: python scripts/trace_sequence.py <results.db> <nops> [forwards_to_average]
+"""
+import sqlite3
+import sys
+
+
+def main(path, nops, nfwd=1):
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    rows = c.execute(f"select d.start, d.end, s.kernel_name, d.grid_size_x*d.grid_size_y/d.workgroup_size_x, "
+                     f"d.workgroup_size_x, s.arch_vgpr_count, d.group_segment_size from {kd} d join {ks} s "
+                     f"on d.kernel_id=s.id order by d.start").fetchall()
+    rows = rows[-nops * nfwd:]
+    dur = [0.0] * nops
+    gap = [0.0] * nops
+    for f in range(nfwd):
+        seg = rows[f * nops:(f + 1) * nops]
+        for i, r in enumerate(seg):
+            dur[i] += (r[1] - r[0]) / 1e3 / nfwd
+            if i:
+                gap[i] += (r[0] - seg[i - 1][1]) / 1e3 / nfwd
+    seg = rows[-nops:]
+    span = (seg[-1][1] - seg[0][0]) / 1e3
+    print("one forward: %d dispatches, span %.1f us, sum of kernel durations %.1f us, sum of gaps %.1f us (avg over %d)"
+          % (nops, span, sum(dur), sum(gap), nfwd))
+    print("%3s %8s %7s %7s %6s %5s %7s  %s" % ("#", "dur_us", "gap_us", "blocks", "wgsz", "vgpr", "lds", "kernel"))
+    for i, r in enumerate(seg):
+        name = r[2].replace("_ZN12saber_mi355x", "").replace("NS_9ConvKArgsE", "")[:70]
+        print("%3d %8.2f %7.2f %7d %6d %5d %7d  %s" % (i, dur[i], gap[i], r[3], r[4], r[5], r[6], name))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 1)

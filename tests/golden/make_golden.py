@@ -34,6 +34,11 @@ CONV_I8 = {
     "conv_i8_ragged_dil2_s8s8": (2, 11, 9, 24, 20, 3, 2, 1, 2, 1, O.S8, O.S8, 0),
     "conv_i8_group4_u8u8": (1, 9, 9, 32, 32, 3, 1, 1, 1, 4, O.U8, O.U8, 1),
     "conv_i8_5x5_s8f32": (1, 7, 7, 20, 24, 5, 2, 1, 1, 1, O.S8, O.F32, 1),
+    # (appended in round 2; seeds follow the position in this dict, so new cases go at the end)
+    # u8 -> s8 (all 16 branch2c expand convs and res2a_branch1): GemmX8S8S32XConv::sub_dispatch<uint8_t,int8_t>
+    "conv_i8_res2_2c_1x1_u8s8": (2, 14, 14, 64, 256, 1, 0, 1, 1, 1, O.U8, O.S8, 0),
+    "conv_i8_res5_2c_1x1_u8s8": (2, 7, 7, 512, 256, 1, 0, 1, 1, 1, O.U8, O.S8, 0),
+    "conv_i8_res2a_branch1_1x1_u8s8": (1, 14, 14, 64, 128, 1, 0, 1, 1, 1, O.U8, O.S8, 0),
 }
 
 
@@ -128,8 +133,14 @@ def gen_fc_i8(seed):
 
 if __name__ == "__main__":
     assert O.ref_available(), "build oracle/_ref first (make -C oracle ref)"
+    only_new = "--all" not in sys.argv   # default: keep the committed fixtures, write only the missing ones
     for i, (name, spec) in enumerate(CONV_I8.items()):
+        if only_new and os.path.exists(os.path.join(OUT, name + ".npz")):
+            continue
         gen_conv_i8(name, spec, 1000 + i)
+    if only_new:
+        print("new conv fixtures written to", OUT)
+        sys.exit(0)
     gen_quant(2000)
     gen_eltwise(2001)
     gen_conv_f32(2002)

@@ -66,7 +66,8 @@ def test_conv_i8_golden(name):
 @pytest.mark.parametrize("name", ["conv_i8_res2a_2b_3x3_u8u8", "conv_i8_res3a_2a_1x1s2_s8u8",
                                   "conv_i8_res4_2c_1x1_u8f32", "conv_i8_conv1_7x7s2_s8u8",
                                   "conv_i8_branch1_1x1s2_s8s8", "conv_i8_res5_2a_1x1_s8u8",
-                                  "conv_i8_res5_2b_3x3_u8u8"])
+                                  "conv_i8_res5_2b_3x3_u8u8", "conv_i8_res2_2c_1x1_u8s8",
+                                  "conv_i8_res5_2c_1x1_u8s8"])
 def test_conv_i8_golden_every_tile(name, tile, ks, var):
     """Every (block tile, stage depth, staging) variant of the implicit-GEMM kernel reproduces the golden bytes."""
     g = load(name)

@@ -39,9 +39,10 @@ def _mk(case, in_dtype, seed):
 def test_conv_i8_matches_reference(case, in_dtype, out_dtype, relu):
     if out_dtype == O.U8 and not relu:
         pytest.skip("u8 output without relu is undefined in the reference GEMM path")
-    if in_dtype == O.U8 and out_dtype == O.S8:
-        pytest.skip("u8->s8: create() computes the scale (gemm_x8s8s32x_conv.cpp:163-166) but "
-                    "dispatch() LOG(FATAL)s 'not support' (:304-306); only the JIT path runs it")
+    # u8 -> s8 (every ResNet50 branch2c and res2a_branch1): the reference's dispatch() has no branch for it
+    # (gemm_x8s8s32x_conv.cpp:290-308), so oracle/_ref calls the public member template
+    # GemmX8S8S32XConv::sub_dispatch<uint8_t,int8_t> (gemm_x8s8s32x_conv.h:72) after the reference's own init()/create()
+    # computed the scale (:163-166) - see oracle/ref_gemm_conv_u8s8.cpp
     N, H, W, C, K, k, pad, stride, dil, group = case
     x, w, b = _mk(case, in_dtype, seed=hash((case, in_dtype)) % 2**31)
     in_scale = 0.02
