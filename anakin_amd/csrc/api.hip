@@ -9,6 +9,7 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -90,6 +91,9 @@ struct saber_hip_conv {
     int stem = 0;            // 1: LDS-patch stem kernel (conv_stem.h) instead of the NHWC4 implicit GEMM
     int pool_fused = 0, pool_oh = 0, pool_ow = 0;   // SaberConv2DPooling: fused stem conv + 3x3/2 max pooling
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
+    int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
+    int img_ib = 0, img_rb = 0, img_nw = 4;   // img_rb > 0: small-image 3x3 kernel (conv3x3_img.h): images / output rows
+                                              // per workgroup slab, waves per workgroup (4 or 8)
     int epi = EPI_I8_CONV;
     bool is_i8 = false;
     int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
@@ -158,6 +162,13 @@ static bool halo_ok(const saber_hip_conv* op) {
            d.pad_w <= 1;
 }
 
+namespace { bool fc_small_ok(const saber_hip_conv* op); }
+
+static bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb) {
+    return halo_ok(op) && !op->pair_k2 && op->d.res_mode != SABER_HIP_RES_SUM_INPLACE &&
+           conv3x3_img_feasible(op->c_eff, op->ow, op->oh, op->d.n, nw, ib, rb);
+}
+
 static bool stem_ok(const saber_hip_conv* op) {
     const saber_hip_conv_desc& d = op->d;
     return op->algo == ALGO_IGEMM_I8_C4 && op->epi == EPI_I8_CONV && d.kh == 7 && d.kw == 7 && d.stride_h == 2 &&
@@ -171,6 +182,8 @@ static void name_algo(saber_hip_conv* op) {
     char buf[64];
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
+    else if (op->fc_small) snprintf(buf, sizeof buf, "fc_i8_small_16xk4");
+    else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
         snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
@@ -327,15 +340,34 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         name_algo(op);
         return SABER_HIP_OK;
     }
+    if (var == 10) {   // small-batch fc kernel
+        if (!fc_small_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "small-batch fc kernel: INT8 fc with <= 16 rows and k <= 4096");
+        op->fc_small = 1;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
+    if (var == 9) {   // small-image 3x3 kernel: output rows per slab in the low byte, images per slab in bits 8..15
+        const int rb = tile, ib = ks & 0x7f, nw = (ks & 0x80) ? 8 : 4;   // bit 15: 8 waves per workgroup
+        if (!img_ok(op, nw, ib, rb))
+            return fail(SABER_HIP_INVALID_VALUE, "small-image 3x3 kernel: needs an INT8 3x3 stride-1 conv with C in {64,128,256,512} "
+                                                 "and a slab (images x rows) that fits its LDS / accumulator budget");
+        op->img_ib = ib; op->img_rb = rb; op->img_nw = nw;
+        op->halo = 0;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
     if (var == 5 || var == 6) {   // LDS-halo 3x3 kernel, 4 / 8 tile rows
         if (!halo_ok(op) || op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "halo kernel needs an INT8 3x3 stride-1 conv with C % 64 == 0");
         op->halo = var == 5 ? 4 : 8;
+        op->img_ib = op->img_rb = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
     if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
         op->halo = 0;
         op->stem = 0;
+        op->img_ib = op->img_rb = 0;
+        op->fc_small = 0;
     }
     if (var > 4 || (var >= 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
     if ((var >= 3 && ((ks ? ks : op->ks) != 4 || tile > TILE_64x64)) || (var == 4 && tile != TILE_32x32))
@@ -349,6 +381,8 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
+    if (op->fc_small) return 10 << 16;
+    if (op->img_rb) return op->img_rb | ((op->img_ib | (op->img_nw == 8 ? 0x80 : 0)) << 8) | (9 << 16);
     if (op->halo) return op->tile | (op->ks << 8) | ((op->halo == 4 ? 5 : 6) << 16);
     const int var = op->dma == 0 ? 1 : (op->dma == 1 ? 2 : (op->dma == 2 ? 3 : 4));
     return op->tile | (op->ks << 8) | (var << 16);
@@ -566,6 +600,14 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     fill_args(op, a, xin, y, res);
     switch (op->algo) {
     case ALGO_IGEMM_I8:
+        if (op->fc_small) {
+            HIP_TRY(launch_fc_i8_small(a, s));
+            break;
+        }
+        if (op->img_rb) {
+            HIP_TRY(launch_conv3x3_img(a, op->img_nw, op->img_ib, op->img_rb, s));
+            break;
+        }
         if (op->halo) {
             HIP_TRY(launch_conv3x3_halo(op->halo, a, s));
             break;
@@ -589,93 +631,124 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     return SABER_HIP_OK;
 }
 
-// RUNTIME strategy (BaseFunc::pick_best_runtime, saber/funcs/base.h:194,205-247): time every tile
-// of the implicit-GEMM kernel on the real tensors and keep the fastest. Leaves y with valid output.
-int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
-                              saber_hip_stream_t stream, int iters) {
+// RUNTIME strategy (BaseFunc::pick_best_runtime, saber/funcs/base.h:194,205-247): time every kernel variant
+// (implicit-GEMM tiles x stage depths x stagings, stem, LDS-halo, small-image) on the real tensors and keep the
+// fastest. Leaves y with one clean output of the selected kernel - except for RES_SUM_INPLACE ops, whose timed
+// launches accumulate into y (the caller re-initialises it). On error the entry selection is restored.
+namespace {
+// one selection of kernel variant for an op (what the autotuner saves / restores)
+struct ConvChoice {
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small;
+};
+ConvChoice get_choice(const saber_hip_conv* op) {
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small};
+}
+void set_choice(saber_hip_conv* op, const ConvChoice& c) {
+    op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small;
+}
+bool fc_small_ok(const saber_hip_conv* op) {
+    return op->algo == ALGO_IGEMM_I8 && (op->epi == EPI_I8_FC_S8 || op->epi == EPI_I8_FC_U8) && op->d.h == 1 && op->d.w == 1 &&
+           fc_i8_small_ok(op->d.n, op->c_eff, op->Kg_pad);
+}
+struct EventPair {   // RAII: destroyed on every exit path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t init() {
+        hipError_t e = hipEventCreate(&e0);
+        return e != hipSuccess ? e : hipEventCreate(&e1);
+    }
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+}  // namespace
+
+extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
+                                         saber_hip_stream_t stream, int iters) {
     if (op->algo > ALGO_IGEMM_F32 || op->pool_fused) return SABER_HIP_OK;   // (one fused conv+pooling kernel)
     if (op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "sibling pair: use saber_hip_conv2d_autotune_pair");
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    EventPair ev;
+    HIP_TRY(ev.init());
+    const ConvChoice entry = get_choice(op);
+    ConvChoice best_c = entry;
     float best = 1e30f;
-    int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
-    op->halo = 0;
-    op->stem = 0;   // the tile sweep below times the implicit-GEMM path; the stem kernel is timed after it
+    int err = SABER_HIP_OK;
+    // times the op's CURRENT selection; a variant that fails to launch is skipped (its error is kept only if nothing works)
+    auto time_current = [&]() {
+        int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);   // warm-up
+        if (rc) { err = rc; return; }
+        if (hipEventRecord(ev.e0, s) != hipSuccess) { err = SABER_HIP_RUNTIME_ERROR; return; }
+        for (int i = 0; i < iters; ++i) rc |= saber_hip_conv2d_run(op, x, y, res, workspace, s);
+        float ms = 0;
+        if (rc || hipEventRecord(ev.e1, s) != hipSuccess || hipEventSynchronize(ev.e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, ev.e0, ev.e1) != hipSuccess) {
+            err = rc ? rc : SABER_HIP_RUNTIME_ERROR;
+            return;
+        }
+        if (ms < best) {
+            best = ms;
+            best_c = get_choice(op);
+        }
+    };
+    ConvChoice c = {op->tile, op->ks, 0, 0, 0, 0, 0, 4, 0};
+    if (op->fc_small && fc_small_ok(op)) return SABER_HIP_OK;   // small-batch fc: one launch at the latency floor, nothing to tune
     const int ks_list[3] = {1, 2, 4};
     const int dma_list[4] = {0, 1, 2, 4};
     const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 4;
-    for (int vi = 0; vi < nvar; ++vi) {
-        for (int t = 0; t < TILE_COUNT; ++t) {
+    for (int vi = 0; vi < nvar; ++vi)
+        for (int t = 0; t < TILE_COUNT; ++t)
             for (int ki = 0; ki < 3; ++ki) {
                 if (dma_list[vi] > 1 && (ks_list[ki] != 4 || t > TILE_64x64)) continue;
                 if (dma_list[vi] == 4 && t != TILE_32x32) continue;
-                op->tile = t;
-                op->ks = ks_list[ki];
-                op->dma = dma_list[vi];
-                int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);  // warm-up
-                if (rc) return rc;
-                HIP_TRY(hipEventRecord(e0, s));
-                for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
-                HIP_TRY(hipEventRecord(e1, s));
-                HIP_TRY(hipEventSynchronize(e1));
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-                if (ms < best) {
-                    best = ms;
-                    best_tile = t;
-                    best_ks = ks_list[ki];
-                    best_dma = dma_list[vi];
-                }
+                c.tile = t; c.ks = ks_list[ki]; c.dma = dma_list[vi];
+                set_choice(op, c);
+                time_current();
             }
-        }
+    c = best_c;
+    if (fc_small_ok(op)) {
+        ConvChoice cf = c;
+        cf.fc_small = 1;
+        set_choice(op, cf);
+        time_current();
     }
-    int best_stem = 0;
-    op->stem = 0;
     if (stem_ok(op)) {
-        op->stem = 1;
-        int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
-        HIP_TRY(hipEventRecord(e1, s));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (ms < best) {
-            best = ms;
-            best_stem = 1;
-        }
-        op->stem = 0;
+        ConvChoice cs = c;
+        cs.stem = 1;
+        set_choice(op, cs);
+        time_current();
     }
-    int best_halo = 0;
     if (halo_ok(op)) {
         for (int th = 4; th <= 8; th += 4) {
-            op->halo = th;
-            int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(e0, s));
-            for (int i = 0; i < iters; ++i) saber_hip_conv2d_run(op, x, y, res, workspace, s);
-            HIP_TRY(hipEventRecord(e1, s));
-            HIP_TRY(hipEventSynchronize(e1));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best) {
-                best = ms;
-                best_halo = th;
-            }
+            ConvChoice ch = c;
+            ch.halo = th;
+            set_choice(op, ch);
+            time_current();
         }
+        // small-image kernel: every feasible (images, rows) slab
+        const int rbs[] = {1, 2, 3, 4, 7, 8, 14};
+        const int ibs[] = {1, 2, 4};
+        static const bool no_img = getenv("SABER_NO_IMG") != nullptr;   // TEMP A/B knob
+        for (int nw = 4; nw <= 8 && !no_img; nw += 4)
+            for (int ib : ibs)
+                for (int rb : rbs) {
+                    if (!img_ok(op, nw, ib, rb)) continue;
+                    ConvChoice ci = c;
+                    ci.img_ib = ib; ci.img_rb = rb; ci.img_nw = nw;
+                    set_choice(op, ci);
+                    time_current();
+                }
     }
-    op->halo = best_halo;
-    op->stem = best_stem;
-    op->dma = best_dma;
-    op->ks = best_ks;
-    op->tile = best_tile;
+    if (best >= 1e30f) {   // nothing ran: restore the entry selection and report the last error
+        set_choice(op, entry);
+        name_algo(op);
+        return err ? err : fail(SABER_HIP_RUNTIME_ERROR, "autotune: no variant ran");
+    }
+    set_choice(op, best_c);
     name_algo(op);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return SABER_HIP_OK;
+    // leave y holding one clean result of the selected kernel
+    return saber_hip_conv2d_run(op, x, y, res, workspace, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -827,6 +900,10 @@ int saber_hip_fc_create(const saber_hip_fc_desc* desc, saber_hip_fc_t** out) {
             return fail(SABER_HIP_UNIMPL, "INT8 fc needs k % 16 == 0");
         }
         fc->conv->epi = c.in_dtype == SABER_HIP_U8 ? EPI_I8_FC_U8 : EPI_I8_FC_S8;
+        if (fc_small_ok(fc->conv)) {   // STATIC choice for inference batches (<= 16 rows): the weight-streaming kernel
+            fc->conv->fc_small = 1;
+            name_algo(fc->conv);
+        }
     }
     *out = fc;
     return SABER_HIP_OK;
@@ -902,6 +979,11 @@ int saber_hip_fc_run_q(saber_hip_fc_t* fc, const int8_t* xq, float* y, saber_hip
     return saber_hip_conv2d_run(fc->conv, xq, y, nullptr, nullptr, stream);
 }
 
+const char* saber_hip_fc_algo(const saber_hip_fc_t* fc) { return fc ? fc->conv->algo_name.c_str() : ""; }
+int saber_hip_fc_set_tile(saber_hip_fc_t* fc, int tile) {
+    if (!fc) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    return saber_hip_conv2d_set_tile(fc->conv, tile);
+}
 void saber_hip_fc_destroy(saber_hip_fc_t* fc) {
     if (fc) saber_hip_conv2d_destroy(fc->conv);
     delete fc;
@@ -1406,6 +1488,12 @@ int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     return SABER_HIP_OK;
 }
 int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters) {
+    if (net->exec) {   // a captured graph holds the OLD kernel selections: drop it, the caller captures again
+        (void)hipGraphExecDestroy(net->exec);
+        (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
     auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
     for (NetOp& o : net->ops) {
         if (o.kind == OP_CONV_PAIR) {

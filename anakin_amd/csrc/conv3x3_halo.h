@@ -33,6 +33,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     constexpr int BUF = XCH + WCH;                  // chunks per buffer
 
     __shared__ v4i lds[NBUF][BUF];
+    SABER_TL_DECL;
+    SABER_TL(0);
+    pin_hot_args(a);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -49,10 +52,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
     const int k_base = tile_ky * 64;
 
-    // ---- per-channel constants first (latency hidden behind the main loop) -------------------------
     const int kb = k_base + wm * 32 + fq * NV;
-    ChanParams<NV> cp;
-    load_chan_params<NV>(a, kb, cp);
 
     // ---- staging assignments (fixed per thread) -----------------------------------------------------
     int x_off[XIT];                                 // element offset of the halo pixel (chunk q), or -1 if padding
@@ -123,9 +123,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     for (int j = 0; j < TN; ++j) b_hp[j] = (wn * TN + j) * HW_ + frow;
 
     const int nchunks = a.C >> 6;
+    SABER_TL(1);
     load_chunk(0);
+    ChanParams<NV> cp;   // per-channel constants: behind the first operand loads (cold argument fields), ahead of the loop
+    load_chan_params<NV>(a, kb, cp);
     store_chunk(0);
     __syncthreads();
+    SABER_TL(2);
     for (int cc = 0; cc < nchunks; ++cc) {
         const int buf = MULTI ? (cc & 1) : 0;
         if (MULTI && cc + 1 < nchunks) load_chunk(cc + 1);
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
         }
     }
 
+    SABER_TL(3);
     // ---- epilogue ------------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -172,6 +177,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
             }
         }
     }
+    SABER_TL(4);
+    SABER_TL_FLUSH();
 }
 
 // th: 4 or 8 tile rows. Requires kh = kw = 3, stride 1, dilation 1, C % 64 == 0, group 1.
@@ -181,6 +188,7 @@ static hipError_t launch_conv3x3_halo_inst(int th, const ConvKArgs& a, hipStream
     const int tiles = ((a.OW + 15) / 16) * ((a.OH + th - 1) / th);
     b.npx = a.N * tiles;
     b.nky = (a.K + 63) / 64;
+    b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     dim3 grid(b.npx * b.nky), block(256);
     const bool multi = a.C > 64;
     if (th == 4) {

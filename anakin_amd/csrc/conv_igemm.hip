@@ -35,6 +35,10 @@ hipError_t launch_halo_e1(int th, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_halo_e2(int th, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_halo_e3(int th, const ConvKArgs& a, hipStream_t s);
 
+hipError_t launch_img_e0(const ConvKArgs& a, int nw, int ib, int rb, hipStream_t s);
+hipError_t launch_img_e1(const ConvKArgs& a, int nw, int ib, int rb, hipStream_t s);
+hipError_t launch_img_e3(const ConvKArgs& a, int nw, int ib, int rb, hipStream_t s);
+
 hipError_t launch_stem_e0(int f32_in, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_stem_e1(int f32_in, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_stem_e2(int f32_in, const ConvKArgs& a, hipStream_t s);
@@ -66,6 +70,14 @@ hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s) {
     case 1: return launch_halo_e1(th, a, s);
     case 2: return launch_halo_e2(th, a, s);
     default: return launch_halo_e3(th, a, s);
+    }
+}
+
+hipError_t launch_conv3x3_img(const ConvKArgs& a, int nw, int ib, int rb, hipStream_t s) {
+    switch (epilogue_kind(0, a)) {
+    case 0: return launch_img_e0(a, nw, ib, rb, s);
+    case 1: return launch_img_e1(a, nw, ib, rb, s);
+    default: return launch_img_e3(a, nw, ib, rb, s);   // generic epilogue (f32 outputs, fused eltwise, in-place sum)
     }
 }
 

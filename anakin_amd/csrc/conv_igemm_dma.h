@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
     using acc_t = typename std::conditional<F32, v4f, v4i>::type;
 
     __shared__ v4i lds[NS][STAGE];
+    SABER_TL_DECL;
+    SABER_TL(0);
+    pin_hot_args(a);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,11 +157,8 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
         }
     };
 
-    // per-channel epilogue constants: requested BEFORE the reduction loop so their latency is hidden behind it
     const int frow = lane & 15, fq = lane >> 4;
     const int kb = k_base + wm * (TM * 16) + fq * NV;
-    ChanParams<NV> cp;
-    load_chan_params<NV>(a, kb, cp);
 
     acc_t acc[TM][TN];
 #pragma unroll
@@ -168,7 +168,15 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
 
     const int steps = a.steps;
     const int pre = steps < NS - 1 ? steps : NS - 1;
+    SABER_TL(1);
     for (int s = 0; s < pre; ++s) issue_stage(s);
+    SABER_TL(2);
+    // per-channel epilogue constants, requested behind the ring prefetch (their pointers are in the cold part of the
+    // argument block; see conv_igemm_impl.h). These ordinary loads sit between the prefetched stages and the later refills
+    // in the in-order VMEM queue, so the counted waits below (which let only the YOUNGEST n requests stay outstanding) can
+    // only wait longer than needed at the first stages, never too little.
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
 
     const unsigned xmask = (!F32 && a.in_u8) ? 0x80808080u : 0u;
     // fragment chunk indices for this wave group's k-step 0; phys_chunk(row, c ^ (ks*4)) == phys_chunk(row, c) ^ (ks*4)
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
         }
     }
 
+    SABER_TL(3);
     // ---- intra-block split-K: groups 1..WG-1 hand their partial accumulators to group 0 via LDS ------
     if constexpr (WG > 1) {
         __syncthreads();                 // all DMA consumed (every wait above ended at vmcnt(0)), ring is free
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
         }
         __syncthreads();
         if (grp > 0) return;
+        SABER_TL(5);
 #pragma unroll
         for (int g = 1; g < WG; ++g)
 #pragma unroll
@@ -262,6 +272,8 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
             }
         }
     }
+    SABER_TL(4);
+    SABER_TL_FLUSH();
 }
 
 template <int MODE, int KS, int EK, int WG>
@@ -271,6 +283,7 @@ static hipError_t launch_dma_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     ConvKArgs b = a;
     b.npx = (a.M + bnp - 1) / bnp;
     b.nky = (a.K + bmk - 1) / bmk;
+    b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     dim3 grid(b.npx * b.nky);
     dim3 block(256 * WG);
     switch (tile) {

@@ -29,6 +29,7 @@
 #pragma once
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace saber_mi355x {
@@ -253,17 +254,21 @@ __device__ __forceinline__ float round_half_away(float t) {
 //   u8: saturate_u8(rne(d))             == v_cvt_pk_u8_f32(rndne(d))  (the convert saturates to [0,255];
 //                                          relu is implied by the lower clamp: rne is monotone, rne(0)=0)
 //   s8: saturate_s8(rne(relu?(d)))      == (v_cvt_pk_u8_f32(max?(rndne(d),0) + 128) ^ 0x80)
+// NV residual bytes (the fused eltwise's second operand) of pixel p, channels kb..kb+NV-1: one vector load
+template <int NV>
+__device__ __forceinline__ void load_residual(const ConvKArgs& a, int p, int kb, unsigned (&rs)[NV / 4]) {
+    const uint8_t* src = (const uint8_t*)a.res + (size_t)p * a.K + kb;
+    if constexpr (NV == 4) rs[0] = *(const unsigned*)src;
+    else if constexpr (NV == 8) { const uint2 t = *(const uint2*)src; rs[0] = t.x; rs[1] = t.y; }
+    else { const uint4 t = *(const uint4*)src; rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
+}
 template <int NV, int EK>
 __device__ __forceinline__ void epilogue_i8_fast(const ConvKArgs& a, const int (&acc)[NV], const ChanParams<NV>& cp,
                                                  int p, int kb) {
     const size_t o = (size_t)p * a.K + kb;
     unsigned pk[NV / 4];
     unsigned rs[NV / 4];
-    if constexpr (EK == EK_ELT) {
-        if constexpr (NV == 4) rs[0] = *(const unsigned*)((const uint8_t*)a.res + o);
-        else if constexpr (NV == 8) { const uint2 t = *(const uint2*)((const uint8_t*)a.res + o); rs[0] = t.x; rs[1] = t.y; }
-        else { const uint4 t = *(const uint4*)((const uint8_t*)a.res + o); rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
-    }
+    if constexpr (EK == EK_ELT) load_residual<NV>(a, p, kb, rs);
     const float lo = a.relu ? 0.f : -3.0e38f;
     const float lo_s8 = a.relu ? 0.f : -128.f;          // lower clamp of the s8 saturation with the relu folded in
     const float res_lo = a.res_relu ? 0.f : -3.0e38f;
@@ -359,8 +364,18 @@ __device__ __forceinline__ void xcd_tile(const ConvKArgs& a, int& px, int& ky) {
     const int q = T >> 3, r = T & 7;
     const int xcd = b & 7, idx = b >> 3;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    ky = L / a.npx;
+    // L / npx without the ~40-instruction integer division: exact multiply-high by ceil(2^32 / npx) (set by the launcher
+    // when it is exact for every tile index; 0 otherwise)
+    ky = a.mg_npx ? (int)__umulhi((unsigned)L, a.mg_npx) : (a.npx == 1 ? L : L / a.npx);
     px = L - ky * a.npx;
+}
+
+// ceil(2^32 / d) if __umulhi(n, .) == n / d for every 0 <= n < n_max, else 0 (host side)
+static inline unsigned magic_div(int d, long long n_max) {
+    static const bool off = getenv("SABER_NO_MAGIC") != nullptr;   // TEMP A/B knob
+    if (off) return 0u;
+    if (d < 2 || n_max * d >= 0x100000000ll) return 0u;
+    return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
 }
 
 // exact p / d and p % d for 0 <= p < 2^24 using a precomputed float reciprocal (+ one fix-up step)
@@ -405,6 +420,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     using acc_t = typename std::conditional<F32, v4f, v4i>::type;
 
     __shared__ v4i lds[2][(BMK + BNP) * CPR];
+    SABER_TL_DECL;
+    SABER_TL(0);
+    pin_hot_args(a);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -516,11 +534,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         }
     };
 
-    // per-channel epilogue constants: requested BEFORE the reduction loop so their latency is hidden behind it
     const int frow = lane & 15, fq = lane >> 4;
     const int kb = k_base + wm * (TM * 16) + fq * NV;
-    ChanParams<NV> cp;
-    load_chan_params<NV>(a, kb, cp);
 
     acc_t acc[TM][TN];
 #pragma unroll
@@ -528,9 +543,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
+    SABER_TL(1);
     load_stage(0);
+    // per-channel epilogue constants: requested before the reduction loop so their latency hides behind it, but AFTER the
+    // first operand loads - their pointers live in the cold part of the argument block, and waiting for that second
+    // batch of scalar loads ahead of the first operand request costs every launch ~0.1 us
+    ChanParams<NV> cp;
+    load_chan_params<NV>(a, kb, cp);
     store_stage(0);
     __syncthreads();
+    SABER_TL(2);
 
     // LDS row of the weight tile feeding MFMA tile i (rows were permuted when staged)
     int wrow[TM];
@@ -567,6 +589,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         __syncthreads();
     }
 
+    SABER_TL(3);
     // ---- epilogue: lane owns channels kb .. kb+NV-1 of pixels p(j) -------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -599,6 +622,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             }
         }
     }
+    SABER_TL(4);
+    SABER_TL_FLUSH();
 }
 
 template <int MODE, int KS, int EK>
@@ -608,6 +633,7 @@ static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     ConvKArgs b = a;
     b.npx = (a.M + bnp - 1) / bnp;
     b.nky = (a.K + bmk - 1) / bmk;
+    b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     if (MODE != 1) {   // gather-cursor increments of one stage (4*KS chunks of 16 bytes)
         const int estage = 4 * KS * (MODE == 2 ? 4 : 16);
         const int taps = estage / a.C;

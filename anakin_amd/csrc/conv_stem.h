@@ -187,6 +187,7 @@ static hipError_t launch_conv_stem_inst(int f32_in, const ConvKArgs& a, hipStrea
     ConvKArgs b = a;
     b.npx = a.N * ((a.OW + 15) / 16) * ((a.OH + 7) / 8);
     b.nky = (a.K + 63) / 64;
+    b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     dim3 grid(b.npx * b.nky), block(256);
     if (f32_in) hipLaunchKernelGGL((conv_stem7x7s2_kernel<EK, true>), grid, block, 0, s, b);
     else hipLaunchKernelGGL((conv_stem7x7s2_kernel<EK, false>), grid, block, 0, s, b);
@@ -349,6 +350,7 @@ static hipError_t launch_conv_stem_pool_inst(int f32_in, const ConvKArgs& a, hip
     ConvKArgs b = a;
     b.npx = a.N * ((a.pool_ow + 7) / 8) * ((a.pool_oh + 3) / 4);
     b.nky = (a.K + 63) / 64;
+    b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     dim3 grid(b.npx * b.nky), block(256);
     if (f32_in) hipLaunchKernelGGL((conv_stem_pool_kernel<true>), grid, block, 0, s, b);
     else hipLaunchKernelGGL((conv_stem_pool_kernel<false>), grid, block, 0, s, b);

@@ -567,58 +567,54 @@ __global__ __launch_bounds__(256) void pool2d_f32_from_i8_kernel(int n, int h, i
     }
 }
 
-// Global average pool specialisation of the kernel above (window = whole image, no padding): one lane
-// per (image, 4 channels); up to 49 pixels (7x7) are fetched at once (independent dword loads in flight:
-// one exposed memory latency) and then accumulated in (h, w) order, so the float sequence is unchanged.
-// yq (optional): the s8 quantisation of the result with scale 1/qinv — the quantise-on-entry of a following
+// Global pool specialisation of the kernel above (window = whole image of <= 64 pixels, no padding). The float
+// accumulation order of the reference (h, w order, one running sum per channel) is a serial chain and has to stay, but
+// the memory side does not: a workgroup owns one image x 128 channels, its 256 threads fetch the 49 (7x7) pixel rows
+// 8 at a time into LDS (every load of the image in flight at once: one exposed memory latency), then 128 threads walk
+// one channel each through LDS in (h, w) order. 8 x 16 workgroups at batch 8 (the round-1 kernel: one lane per 4
+// channels serially fetching 49 strided dwords, 64 workgroups of one wave, 8 us).
+// yq (optional): the s8 quantisation of the result with scale 1/qinv - the quantise-on-entry of a following
 // INT8 op (scale_fp32_int8, x86_utils.h:325-346) fused into the store.
-__global__ __launch_bounds__(64) void gpool_f32_from_i8_kernel(int n, int hw, int c, int type, int in_u8, float s,
+__global__ __launch_bounds__(256) void gpool_f32_from_i8_kernel(int n, int hw, int c, int type, int in_u8, float s,
                                                                const uint8_t* __restrict__ x, float* __restrict__ y,
                                                                float qinv, int8_t* __restrict__ yq) {
-    constexpr int B = 49;
-    const int cg = c >> 2;
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= n * cg) return;
-    const int img = gid / cg, g = gid - img * cg;
-    const unsigned* px = (const unsigned*)(x + (size_t)img * hw * c) + g;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    bool first = true;
-    for (int p0 = 0; p0 < hw; p0 += B) {
-        unsigned v[B];
-#pragma unroll
-        for (int t = 0; t < B; ++t) v[t] = (p0 + t < hw) ? px[(size_t)(p0 + t) * cg] : 0u;
-#pragma unroll
-        for (int t = 0; t < B; ++t) {
-            if (p0 + t < hw) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int q = (v[t] >> (8 * b)) & 0xff;
-                    const float f = __fmul_rn(in_u8 ? (float)q : (float)(int8_t)q, s);
-                    if (type == 0) acc[b] = first ? f : (acc[b] >= f ? acc[b] : f);
-                    else acc[b] = __fadd_rn(acc[b], f);
-                }
-                first = false;
-            }
-        }
+    __shared__ unsigned raw[64][32];
+    const int cgs = c >> 2;                          // dwords per pixel
+    const int nblk = (cgs + 31) >> 5;
+    const int img = blockIdx.x / nblk, cb = blockIdx.x - img * nblk;
+    {
+        const int l = threadIdx.x & 31, slot = threadIdx.x >> 5;
+        const int g = cb * 32 + l;
+        const unsigned* px = (const unsigned*)(x + (size_t)img * hw * c);
+        if (g < cgs)
+            for (int p = slot; p < hw; p += 8) raw[p][l] = px[(size_t)p * cgs + g];
     }
-    unsigned pk = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const float r = type == 0 ? acc[b] : acc[b] / (float)hw;
-        y[(size_t)img * c + g * 4 + b] = r;
+    __syncthreads();
+    const int ch = threadIdx.x;                      // channel within the 128-channel window
+    if (ch >= 128 || cb * 128 + ch >= c) return;
+    float acc = 0.f;
+    for (int p = 0; p < hw; ++p) {
+        const int q = (raw[p][ch >> 2] >> (8 * (ch & 3))) & 0xff;
+        const float f = __fmul_rn(in_u8 ? (float)q : (float)(int8_t)q, s);
+        if (type == 0) acc = p == 0 ? f : (acc >= f ? acc : f);
+        else acc = __fadd_rn(acc, f);
+    }
+    const float r = type == 0 ? acc : acc / (float)hw;
+    const size_t o = (size_t)img * c + cb * 128 + ch;
+    y[o] = r;
+    if (yq) {
         int t = (int)round_away(__fmul_rn(r, qinv));
         t = t > 127 ? 127 : t;
         t = t < -128 ? -128 : t;
-        pk |= ((unsigned)t & 0xffu) << (8 * b);
+        yq[o] = (int8_t)t;
     }
-    if (yq) ((unsigned*)yq)[(size_t)img * cg + g] = pk;
 }
 hipError_t launch_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
                                      int pw, int type, int in_dtype, float scale, const void* x, float* y,
                                      float q_scale, int8_t* yq, hipStream_t s) {
     const float sc = in_dtype == DT_U8 ? scale * (127.f / 255.f) : scale;
-    if (oh == 1 && ow == 1 && kh == h && kw == w && ph == 0 && pw == 0 && (c & 3) == 0) {
-        hipLaunchKernelGGL(gpool_f32_from_i8_kernel, dim3((n * (c >> 2) + 63) / 64), dim3(64), 0, s, n, h * w, c, type,
+    if (oh == 1 && ow == 1 && kh == h && kw == w && ph == 0 && pw == 0 && (c & 3) == 0 && h * w <= 64) {
+        hipLaunchKernelGGL(gpool_f32_from_i8_kernel, dim3(n * (((c >> 2) + 31) / 32)), dim3(256), 0, s, n, h * w, c, type,
                            in_dtype == DT_U8, sc, (const uint8_t*)x, y, yq ? 1.f / q_scale : 0.f, yq);
         return hipGetLastError();
     }

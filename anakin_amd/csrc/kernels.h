@@ -4,6 +4,24 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// In-kernel phase stamps for scripts/probe/timeline_probe.hip (compiled with -DSABER_TIMELINE): every thread keeps the
+// 100 MHz wall clock of each phase boundary in registers and thread 0 of every workgroup writes them out at the end
+// (no memory traffic at the stamps themselves). Expands to nothing in the product build.
+#ifdef SABER_TIMELINE
+extern __device__ unsigned long long* saber_tl_buf;   // [blocks][8]
+#define SABER_TL_DECL unsigned long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define SABER_TL(i) tl_[i] = wall_clock64()
+#define SABER_TL_FLUSH()                                                                   \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && saber_tl_buf)                                              \
+            for (int i_ = 0; i_ < 8; ++i_) saber_tl_buf[(size_t)blockIdx.x * 8 + i_] = tl_[i_]; \
+    } while (0)
+#else
+#define SABER_TL_DECL do { } while (0)
+#define SABER_TL(i) do { } while (0)
+#define SABER_TL_FLUSH() do { } while (0)
+#endif
+
 namespace saber_mi355x {
 
 enum { DT_F32 = 0, DT_S8 = 1, DT_U8 = 2 };
@@ -27,6 +45,9 @@ struct ConvKArgs {
     const void* w;      // repacked weights [K_pad][Kg_pad] (s8 or f32), zero padded
     const void* zero;   // >= 16 zero bytes in device memory (source of padded taps)
     int npx, nky;       // pixel tiles / out-channel tiles of the launch (1-D grid, XCD-aware tile order)
+    unsigned mg_npx;    // ceil(2^32 / npx) when npx >= 2 and tiles * npx < 2^32, else 0: xcd_tile divides by __umulhi.
+                        // Sits next to npx / nky on purpose: hipcc fetches it with the same wide scalar load (at the end of
+                        // the block it cost a second, dependent scalar-load round trip: +0.2 us on every launch)
     int Kg_pad;         // reduction length padded to a multiple of the widest stage
     int M;              // N*OH*OW output pixels (GEMM columns)
     int OH, OW;
@@ -61,7 +82,26 @@ struct ConvKArgs {
     int K1, K2, relu2, out_dtype2;
     int pool_oh, pool_ow;   // fused 3x3 / stride-2 max pooling (conv_stem_pool_kernel): pooled output dims
 };
+
+// conv3x3_img_kernel takes the common block plus its slab geometry (kept out of ConvKArgs: every byte of kernel
+// argument is copied per launch by the eager path, measured +0.2 us per launch for +48 bytes)
+struct ImgKArgs {
+    ConvKArgs c;
+    int ib, rb, nw, nrs;    // images / output rows per workgroup slab, waves per workgroup, row slabs per image
+    unsigned mg[6];         // ceil(2^32 / d) for d = halo pixels per image, halo width, OW, rb*OW, tail_rows*OW, nrs
+                            // (q = __umulhi(n, mg) == n / d for every n * d < 2^32, d >= 2: no integer division on device)
+};
 static_assert(offsetof(ConvKArgs, y) == 128, "hot kernel arguments fill exactly the first two 64-byte lines");
+
+// hipcc fetches kernel arguments lazily with scalar loads and places each load near its first use; every batch that is
+// issued after an `s_waitcnt lgkmcnt(0)` is one more DEPENDENT round trip (~0.2-0.25 us, measured) before the kernel's
+// first operand load. Naming the hot fields in one empty asm statement makes all of them live at that point, so their
+// loads are issued together ahead of a single wait.
+__device__ __forceinline__ void pin_hot_args(const ConvKArgs& a) {
+    asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.zero), "s"(a.npx), "s"(a.nky), "s"(a.mg_npx), "s"(a.Kg_pad), "s"(a.M), "s"(a.OH),
+                 "s"(a.OW), "s"(a.inv_ohw), "s"(a.inv_ow), "s"(a.H), "s"(a.W), "s"(a.C), "s"(a.stride_h), "s"(a.stride_w),
+                 "s"(a.pad_h), "s"(a.pad_w), "s"(a.dil_h), "s"(a.dil_w), "s"(a.kh), "s"(a.kw), "s"(a.steps), "s"(a.in_u8));
+}
 
 // tile ids for launch_conv_igemm
 enum { TILE_32x32 = 0, TILE_64x32 = 1, TILE_64x64 = 2, TILE_128x64 = 3, TILE_64x128 = 4, TILE_128x128 = 5,
@@ -75,6 +115,14 @@ hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hip
 hipError_t launch_conv_igemm_dma(int mode, int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
 // INT8 3x3 / stride 1 / dilation 1 / C % 64 == 0 with an LDS-resident input halo; th = 4 or 8 tile rows
 hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s);
+// INT8 3x3 / stride 1 / C in {64,128,256,512} on small feature maps: image slabs (a.ib images x a.rb rows) resident in
+// LDS, 16 output channels per workgroup with the weights in registers (conv3x3_img.h)
+hipError_t launch_conv3x3_img(const ConvKArgs& a, int nw, int ib, int rb, hipStream_t s);
+bool conv3x3_img_feasible(int C, int OW, int OH, int N, int nw, int ib, int rb);
+// INT8 fc for <= 16 batch rows: 16 outputs per workgroup, reduction split over its 4 waves, operands loaded straight
+// into MFMA registers (fc_small.hip). a.M rows, a.C reduction, a.K outputs, FC epilogues only.
+hipError_t launch_fc_i8_small(const ConvKArgs& a, hipStream_t s);
+bool fc_i8_small_ok(int m, int c, int kg_pad);
 // ResNet stem (7x7 stride 2, <= 4 channels) with the input patch in LDS; f32_in: fuse the quantise-on-entry
 hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s);
 // ... followed by the 3x3 / stride-2 / pad-0 max pooling in the same kernel (s8 / u8 outputs only)

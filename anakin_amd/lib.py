@@ -27,7 +27,7 @@ SYMBOLS = [
     "saber_hip_conv2d_create_pair", "saber_hip_conv2d_run_pair", "saber_hip_conv2d_autotune_pair",
     "saber_hip_net_add_conv_pair",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
-    "saber_hip_fc_destroy", "saber_hip_gemm_f32",
+    "saber_hip_fc_destroy", "saber_hip_fc_algo", "saber_hip_fc_set_tile", "saber_hip_gemm_f32",
     "saber_hip_gemm_i8_create", "saber_hip_gemm_i8_workspace_bytes", "saber_hip_gemm_i8_run", "saber_hip_gemm_i8_destroy",
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
@@ -107,6 +107,9 @@ def load():
     lib.saber_hip_fc_workspace_bytes.restype = Z
     lib.saber_hip_fc_run.argtypes = [P, P, P, P, P]
     lib.saber_hip_fc_destroy.argtypes = [P]
+    lib.saber_hip_fc_algo.argtypes = [P]
+    lib.saber_hip_fc_algo.restype = C.c_char_p
+    lib.saber_hip_fc_set_tile.argtypes = [P, I]
     lib.saber_hip_fc_destroy.restype = None
     lib.saber_hip_gemm_f32.argtypes = [I, I, I, I, I, F, P, P, F, P, P]
     lib.saber_hip_gemm_i8_create.argtypes = [I, I, I, I, I, I, P, C.POINTER(P)]

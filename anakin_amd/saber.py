@@ -248,6 +248,12 @@ class SaberFc:
         L.check(L.load().saber_hip_fc_run(self.h, _p(x), _p(y), _p(self.ws), _stream()))
         return y
 
+    def algo(self):
+        return L.load().saber_hip_fc_algo(self.h).decode()
+
+    def set_tile(self, tile):
+        L.check(L.load().saber_hip_fc_set_tile(self.h, int(tile)))
+
     def dispatch_q(self, xq, y):
         """Input already quantised to s8 with in_scale (saber_hip_fc_run_q)."""
         L.check(L.load().saber_hip_fc_run_q(self.h, _p(xq), _p(y), _stream()))

@@ -125,7 +125,11 @@ int saber_hip_conv2d_get_quantized_weights(const saber_hip_conv_t* op, int8_t* w
 const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op);
 /* Implementation selection. `create` picks a tile statically (BaseFunc STATIC strategy,
  * saber/funcs/base.h:173-192); `autotune` is the RUNTIME strategy (base.h:194,205-247): it times every
- * tile of the implicit-GEMM kernel on the given device tensors and keeps the fastest. */
+ * tile of the implicit-GEMM kernel on the given device tensors and keeps the fastest.
+ * set_tile argument: tile id in the low byte, stage depth (1/2/4) in bits 8..15, variant in bits 16..23:
+ *   1 register-staged implicit GEMM, 2 LDS-DMA ring, 3 / 4 ring with 2 / 4 wave groups, 5 / 6 LDS-halo 3x3 (4 / 8 rows),
+ *   7 / 8 stem kernel on / off, 9 small-image 3x3 (low byte = output rows per slab, bits 8..15 = images per slab),
+ *   10 small-batch fc. */
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile);
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op);
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
@@ -162,6 +166,10 @@ int saber_hip_fc_run(saber_hip_fc_t* op, const void* x, float* y, void* workspac
 /* INT8 fc on an input that is ALREADY quantised to s8 with the op's in_scale (e.g. by pool2d_f32_from_i8_q): skips
  * the quantise-on-entry kernel of an f32-input INT8 fc; identical result. */
 int saber_hip_fc_run_q(saber_hip_fc_t* op, const int8_t* xq, float* y, saber_hip_stream_t stream);
+/* Kernel selection of the INT8 fc, same encoding as saber_hip_conv2d_set_tile: variant 10 (<< 16) = the small-batch
+ * weight-streaming kernel (m <= 16, k <= 4096; the STATIC choice when eligible), 1..4 = implicit-GEMM variants. */
+const char* saber_hip_fc_algo(const saber_hip_fc_t* op);
+int saber_hip_fc_set_tile(saber_hip_fc_t* op, int tile);
 void saber_hip_fc_destroy(saber_hip_fc_t* op);
 
 /* ------------------------------------------------------------------------------------------- */

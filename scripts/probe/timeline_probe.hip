@@ -1,0 +1,217 @@
+// scripts/probe/timeline_probe.hip — where does a latency-bound kernel spend its microseconds?
+//
+// Builds the PRODUCT kernels (fc_small.hip, conv3x3_img.h) with -DSABER_TIMELINE, which makes wave 0 of every workgroup
+// store the 100 MHz wall clock at a few phase boundaries, launches them cold (after a kernel that streams 192 MB, so
+// the XCD L2s hold none of the operands; the 256 MB Infinity Cache may) and warm (back to back), and prints per phase
+// the min / median / max over workgroups relative to the first stamp of the launch, next to the hipEvent time.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSABER_TIMELINE -I anakin_amd/csrc \
+//         scripts/probe/timeline_probe.hip -o scripts/probe/timeline_probe.bin
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+__device__ unsigned long long* saber_tl_buf = nullptr;
+
+#include "../../anakin_amd/csrc/fc_small.hip"
+#include "../../anakin_amd/csrc/img_e1.hip"
+#include "../../anakin_amd/csrc/igemm_m0_e1.hip"
+#include "../../anakin_amd/csrc/igemm_m0_e2.hip"
+#include "../../anakin_amd/csrc/igemm_dma_m0_e1.hip"
+#include "../../anakin_amd/csrc/halo_e1.hip"
+namespace saber_mi355x {
+void tile_dims(int tile, int* bm_k, int* bn_pix) {
+    static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
+    *bm_k = d[tile][0];
+    *bn_pix = d[tile][1];
+}
+}  // namespace saber_mi355x
+
+using namespace saber_mi355x;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void flush_kernel(const uint4* big, size_t n, unsigned* out) {
+    unsigned s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { uint4 v = big[i]; s ^= v.x ^ v.w; }
+    if (s == 0x12345u) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void null_kernel(unsigned* out) {
+    if (out == nullptr) out[threadIdx.x] = 0;
+}
+
+static void* dalloc(size_t bytes, int fill) {
+    void* p;
+    CK(hipMalloc(&p, bytes));
+    std::vector<unsigned char> h(bytes);
+    for (size_t i = 0; i < bytes; ++i) h[i] = fill < 0 ? (unsigned char)(rand() & 0xff) : (unsigned char)fill;
+    CK(hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+    return p;
+}
+
+struct Probe {
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    uint4* big;
+    size_t nbig;
+    unsigned* out;
+    unsigned long long* tl;
+    int maxblocks = 8192;
+};
+
+template <typename F>
+static void run(Probe& P, const char* name, int blocks, int nph, F launch) {
+    std::vector<unsigned long long> h((size_t)blocks * 8);
+    for (int cold = 1; cold >= 0; --cold) {
+        std::vector<float> ev;
+        std::vector<std::vector<double>> ph(nph);   // per phase: all (block, rep) samples, us since the launch's first stamp
+        for (int rep = 0; rep < 12; ++rep) {
+            if (cold) hipLaunchKernelGGL(flush_kernel, dim3(2048), dim3(256), 0, P.st, P.big, P.nbig, P.out);
+            else launch();
+            CK(hipMemsetAsync(P.tl, 0, (size_t)blocks * 64, P.st));
+            CK(hipEventRecord(P.e0, P.st));
+            launch();
+            CK(hipEventRecord(P.e1, P.st));
+            CK(hipEventSynchronize(P.e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, P.e0, P.e1));
+            if (rep < 2) continue;
+            ev.push_back(ms * 1000.f);
+            CK(hipMemcpy(h.data(), P.tl, (size_t)blocks * 64, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < blocks; ++b) if (h[(size_t)b * 8]) t0 = std::min(t0, h[(size_t)b * 8]);
+            for (int b = 0; b < blocks; ++b)
+                for (int i = 0; i < nph; ++i)
+                    if (h[(size_t)b * 8 + i]) ph[i].push_back((double)(h[(size_t)b * 8 + i] - t0) * 0.01);
+        }
+        std::sort(ev.begin(), ev.end());
+        float chain = 0;
+        {   // 40 dependent launches between one event pair: the steady-state cost per launch of a same-stream chain
+            launch();
+            CK(hipEventRecord(P.e0, P.st));
+            for (int i = 0; i < 40; ++i) launch();
+            CK(hipEventRecord(P.e1, P.st));
+            CK(hipEventSynchronize(P.e1));
+            CK(hipEventElapsedTime(&chain, P.e0, P.e1));
+            chain *= 1000.f / 40;
+        }
+        printf("%-44s %s  hipEvent median %.2f us (min %.2f); chain of 40: %.2f us per launch\n", name, cold ? "cold" : "warm",
+               ev[ev.size() / 2], ev[0], chain);
+        for (int i = 0; i < nph; ++i) {
+            if (ph[i].empty()) continue;
+            std::sort(ph[i].begin(), ph[i].end());
+            printf("    phase %d: min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us   (%zu samples)\n", i, ph[i].front(),
+                   ph[i][ph[i].size() / 2], ph[i][ph[i].size() * 9 / 10], ph[i].back(), ph[i].size());
+        }
+    }
+}
+
+int main() {
+    Probe P;
+    CK(hipStreamCreate(&P.st));
+    CK(hipEventCreate(&P.e0));
+    CK(hipEventCreate(&P.e1));
+    P.nbig = (size_t)192 << 16;   // 192 MB of uint4
+    P.big = (uint4*)dalloc(P.nbig * 16, 3);
+    P.out = (unsigned*)dalloc(4096, 0);
+    CK(hipMalloc((void**)&P.tl, (size_t)P.maxblocks * 64));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(saber_tl_buf), &P.tl, sizeof(P.tl)));
+    void* zero = dalloc(256, 0);
+
+    run(P, "empty kernel (256 WGs)", 256, 1, [&] { hipLaunchKernelGGL(null_kernel, dim3(256), dim3(256), 0, P.st, P.out); });
+    {   // ---- fc1000 of ResNet50, batch 8: phases 0 entry, 1 loads issued, 2 MFMAs done, 3 after the reduce barrier, 4 stored
+        ConvKArgs a;
+        memset(&a, 0, sizeof a);
+        a.M = 8; a.C = 2048; a.K = 1000; a.Kg_pad = 2048; a.N = 8; a.H = a.W = a.OH = a.OW = 1; a.kh = a.kw = 1;
+        a.x = dalloc(8 * 2048, -1); a.w = dalloc(1024 * 2048, -1); a.zero = zero;
+        a.y = dalloc(8 * 1000 * 4, 0); a.scale = (const float*)dalloc(1024 * 4, 0); a.bias = (const float*)dalloc(1024 * 4, 0);
+        a.epi = EPI_I8_FC_S8;
+        run(P, "fc_i8_small 8x2048 -> 1000 (63 WGs)", 63, 6, [&] { launch_fc_i8_small(a, P.st); });
+    }
+    struct Img { const char* name; int N, HW, C, K, ib, rb, nw; };
+    const Img imgs[] = {
+        {"img3x3 res4 14x14x256 b8  1img x 7rows w4", 8, 14, 256, 256, 1, 7, 4},
+        {"img3x3 res4 14x14x256 b8  1img x 7rows w8", 8, 14, 256, 256, 1, 7, 8},
+        {"img3x3 res4 14x14x256 b8  1img x 4rows w8", 8, 14, 256, 256, 1, 4, 8},
+        {"img3x3 res5 7x7x512 b8   2img x 7rows w8", 8, 7, 512, 512, 2, 7, 8},
+        {"img3x3 res5 7x7x512 b8   1img x 7rows w4", 8, 7, 512, 512, 1, 7, 4},
+        {"img3x3 res5 7x7x512 b8   1img x 7rows w8", 8, 7, 512, 512, 1, 7, 8},
+        {"img3x3 res3 28x28x128 b8 1img x 7rows w8", 8, 28, 128, 128, 1, 7, 8},
+        {"img3x3 res3 28x28x128 b8 1img x 4rows w8", 8, 28, 128, 128, 1, 4, 8},
+        {"img3x3 res2 56x56x64 b8  1img x 2rows w8", 8, 56, 64, 64, 1, 2, 8},
+        {"img3x3 res4 14x14x256 b1  1img x 7rows w8", 1, 14, 256, 256, 1, 7, 8},
+        {"img3x3 res4 14x14x256 b1  1img x 2rows w8", 1, 14, 256, 256, 1, 2, 8},
+    };
+    // phases: 0 entry, 1 weights requested + table built, 2 DMA issued, 3 own DMA landed, 4 everyone's landed, 5 MFMAs done, 6 stored
+    for (const Img& g : imgs) {
+        ConvKArgs a;
+        memset(&a, 0, sizeof a);
+        const int kg = 9 * g.C, kgp = (kg + 1023) / 1024 * 1024;
+        a.N = g.N; a.H = a.W = a.OH = a.OW = g.HW; a.C = g.C; a.K = g.K; a.kh = a.kw = 3; a.pad_h = a.pad_w = 1;
+        a.stride_h = a.stride_w = a.dil_h = a.dil_w = 1;
+        a.M = g.N * g.HW * g.HW; a.Kg = kg; a.Kg_pad = kgp; a.in_u8 = 1; a.out_dtype = DT_U8; a.relu = 1; a.epi = EPI_I8_CONV;
+        a.x = dalloc((size_t)a.M * g.C, -1); a.w = dalloc((size_t)((g.K + 127) / 128 * 128) * kgp, -1); a.zero = zero;
+        a.y = dalloc((size_t)a.M * g.K, 0);
+        a.scale = (const float*)dalloc(2048 * 4, 0); a.bias = (const float*)dalloc(2048 * 4, 0); a.comp = (const int*)dalloc(2048 * 4, 0);
+        
+        const int blocks = ((g.N + g.ib - 1) / g.ib) * ((g.HW + g.rb - 1) / g.rb) * ((g.K + 15) / 16);
+        run(P, g.name, blocks, 7, [&] { launch_img_e1(a, g.nw, g.ib, g.rb, P.st); });
+    }
+    // ---- the implicit-GEMM / halo kernels on typical ResNet50 layers (batch 8 and batch 1) -----------------------------
+    // phases: 0 entry, 1 gather state set up, 2 first stage in LDS (dma: ring prefetch issued), 3 reduction done, 4 stored
+    struct Lay { const char* name; int N, HW, C, K, k, stride, pad, elt, kind, tile, ks, wg, early; };   // kind 0 reg, 1 dma, 2 halo(th=tile)
+    const Lay lays[] = {
+        {"res2 expand 64->256 @56 +eltwise  64x64 k1", 8, 56, 64, 256, 1, 1, 0, 1, 0, TILE_64x64, 1, 0, 0},
+        {"res2 reduce 256->64 @56           64x128 k2", 8, 56, 256, 64, 1, 1, 0, 0, 0, TILE_64x128, 2, 0, 0},
+        {"res2 3x3 64->64 @56               halo 4x16", 8, 56, 64, 64, 3, 1, 1, 0, 2, 4, 0, 0, 0},
+        {"res3 expand 128->512 @28 +eltwise 64x64 k1", 8, 28, 128, 512, 1, 1, 0, 1, 0, TILE_64x64, 1, 0, 0},
+        {"res3 3x3 128->128 @28             halo 4x16", 8, 28, 128, 128, 3, 1, 1, 0, 2, 4, 0, 0, 0},
+        {"res4 reduce 1024->256 @14         64x32 k4 dma wg2", 8, 14, 1024, 256, 1, 1, 0, 0, 1, TILE_64x32, 4, 2, 0},
+        {"res4 3x3 256->256 @14             64x32 k4 dma wg2", 8, 14, 256, 256, 3, 1, 1, 0, 1, TILE_64x32, 4, 2, 0},
+        {"res4 expand 256->1024 @14 +elt    128x64 k4 reg", 8, 14, 256, 1024, 1, 1, 0, 1, 0, TILE_128x64, 4, 0, 0},
+        {"res5 3x3 512->512 @7              32x32 k4 dma wg4", 8, 7, 512, 512, 3, 1, 1, 0, 1, TILE_32x32, 4, 4, 0},
+        {"res2 expand 64->256 @56 +eltwise  64x64 k1 EARLY", 8, 56, 64, 256, 1, 1, 0, 1, 0, TILE_64x64, 1, 0, 1},
+        {"res4 expand 256->1024 @14 +elt    128x64 k4 reg EARLY", 8, 14, 256, 1024, 1, 1, 0, 1, 0, TILE_128x64, 4, 0, 1},
+        {"b1 res2 expand 64->256 @56 +elt   64x64 k1 EARLY", 1, 56, 64, 256, 1, 1, 0, 1, 0, TILE_64x64, 1, 0, 1},
+        {"b1 res2 expand 64->256 @56 +elt   64x64 k1", 1, 56, 64, 256, 1, 1, 0, 1, 0, TILE_64x64, 1, 0, 0},
+        {"b1 res4 3x3 256->256 @14          32x32 k4 dma wg4", 1, 14, 256, 256, 3, 1, 1, 0, 1, TILE_32x32, 4, 4, 0},
+    };
+    for (const Lay& g : lays) {
+        ConvKArgs a;
+        memset(&a, 0, sizeof a);
+        const int OHW = (g.HW + 2 * g.pad - g.k) / g.stride + 1;
+        const int kg = g.k * g.k * g.C, kgp = (kg + 1023) / 1024 * 1024;
+        a.N = g.N; a.H = a.W = g.HW; a.OH = a.OW = OHW; a.C = g.C; a.K = g.K; a.kh = a.kw = g.k; a.pad_h = a.pad_w = g.pad;
+        a.stride_h = a.stride_w = g.stride; a.dil_h = a.dil_w = 1;
+        a.M = g.N * OHW * OHW; a.Kg = kg; a.Kg_pad = kgp; a.in_u8 = 1; a.epi = EPI_I8_CONV;
+        a.inv_ohw = 1.f / (OHW * OHW); a.inv_ow = 1.f / OHW;
+        a.x = dalloc((size_t)g.N * g.HW * g.HW * g.C, -1); a.w = dalloc((size_t)((g.K + 127) / 128 * 128) * kgp, -1); a.zero = zero;
+        a.y = dalloc((size_t)a.M * g.K, 0);
+        a.scale = (const float*)dalloc(2048 * 4, 0); a.bias = (const float*)dalloc(2048 * 4, 0); a.comp = (const int*)dalloc(2048 * 4, 0);
+        if (g.elt) {
+            a.out_dtype = DT_S8; a.relu = 0; a.res_mode = RES_ELTWISE; a.res_relu = 1; a.res = dalloc((size_t)a.M * g.K, -1);
+            a.coeff_conv = a.coeff_res = 1.f; a.scale_conv = 0.05f; a.scale_res = 0.04f; a.res_dtype = DT_S8;
+        } else {
+            a.out_dtype = DT_U8; a.relu = 1;
+        }
+        int blocks;
+        if (g.kind == 2) {
+            blocks = g.N * ((OHW + 15) / 16) * ((OHW + g.tile - 1) / g.tile) * ((g.K + 63) / 64);
+            run(P, g.name, blocks, 5, [&] { launch_halo_e1(g.tile, a, P.st); });
+        } else {
+            int bmk, bnp;
+            tile_dims(g.tile, &bmk, &bnp);
+            blocks = ((a.M + bnp - 1) / bnp) * ((g.K + bmk - 1) / bmk);
+            const int estage = 64 * g.ks * (g.wg > 1 ? g.wg : 1);
+            a.steps = (kg + estage - 1) / estage;
+            if (g.kind == 1) run(P, g.name, blocks, 6, [&] { launch_igemm_dma_m0_e1(g.tile, g.ks, g.wg, a, P.st); });
+            else if (g.elt) run(P, g.name, blocks, 5, [&] { launch_igemm_m0_e2(g.tile, g.ks, a, P.st); });
+            else run(P, g.name, blocks, 5, [&] { launch_igemm_m0_e1(g.tile, g.ks, a, P.st); });
+        }
+    }
+    return 0;
+}

@@ -108,6 +108,77 @@ def test_conv3x3_halo_vs_oracle(case, combo, var):
     assert got.dtype == want.dtype and np.array_equal(got, want), conv.algo()
 
 
+# small-image 3x3 kernel (conv3x3_img.h): (images per slab, rows per slab) variants over the ResNet 3x3 geometries
+# + ragged / unpadded / partial-slab cases; every epilogue kind
+IMG_CASES = [
+    # N, H, W, C, K, pad, [(ib, rb), ...]
+    (8, 14, 14, 256, 256, 1, [(1, 7), (1, 4), (1, 2)]),          # res4 branch2b
+    (8, 7, 7, 512, 512, 1, [(1, 7), (2, 7), (2, 4), (4, 3)]),    # res5 branch2b
+    (2, 28, 28, 128, 128, 1, [(1, 7), (1, 4), (2, 3), (1, 3)]),  # res3 branch2b
+    (2, 56, 56, 64, 64, 1, [(1, 4), (1, 2), (2, 1)]),            # res2 branch2b
+    (3, 7, 7, 512, 80, 1, [(2, 7), (3, 2)]),                     # ragged batch (3 images in slabs of 2 / 4), K % 16 = 0
+    (5, 9, 11, 256, 40, 1, [(1, 4), (2, 2), (1, 9)]),            # odd sizes, rows not a multiple of the slab, K = 40
+    (2, 10, 9, 128, 64, 0, [(1, 4), (2, 3)]),                    # no padding
+    (1, 13, 13, 64, 24, 1, [(1, 7), (1, 13)]),                   # K not a multiple of 16
+]
+
+
+@pytest.mark.parametrize("combo", [(O.U8, O.U8, 1), (O.S8, O.S8, 0), (O.U8, O.F32, 0), (O.U8, O.S8, 1)])
+@pytest.mark.parametrize("case", IMG_CASES)
+def test_conv3x3_img_vs_oracle(case, combo):
+    N, H, W, C, K, pad, slabs = case
+    idt, odt, relu = combo
+    rng = np.random.default_rng(abs(hash((case[:6], combo))) % 2**31)
+    x = (rng.integers(0, 256, (N, H, W, C)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, W, C)).astype(np.int8))
+    w = (rng.standard_normal((K, C, 3, 3)) * np.sqrt(2.0 / (C * 9))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    in_scale, out_scale = 0.017, 0.041
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, odt)
+    want = O.conv_i8(x, wq, bp, sc, odt, relu, (pad, pad))
+    ran8 = 0
+    for ib, rb in slabs:
+        got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, 1, 1, 1,
+                                tile=rb | (ib << 8) | (9 << 16))
+        assert conv.algo().startswith("img3x3") and conv.algo().endswith("_w4"), conv.algo()
+        assert got.dtype == want.dtype and np.array_equal(got, want), (conv.algo(), ib, rb)
+        try:   # the same slab with 8 waves per workgroup (refused when a wave would get more than 4 pixel groups)
+            got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, 1, 1, 1,
+                                    tile=rb | ((ib | 0x80) << 8) | (9 << 16))
+        except L.SaberHipError:
+            continue
+        ran8 += 1
+        assert conv.algo().endswith("_w8") and np.array_equal(got, want), (conv.algo(), ib, rb)
+    assert ran8 > 0
+
+
+def test_conv3x3_img_fused_eltwise_and_rejects():
+    rng = np.random.default_rng(15)
+    x = rng.integers(0, 256, (2, 14, 14, 256)).astype(np.uint8)
+    w = (rng.standard_normal((64, 256, 3, 3)) * 0.04).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.5).astype(np.float32)
+    res = rng.integers(-128, 128, (2, 14, 14, 64)).astype(np.int8)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, 0.02, 0.05, O.U8, O.S8)
+    y1 = O.conv_i8(x, O.quant_weights(w, ws), bp, sc, O.S8, 0, (1, 1))
+    want = O.eltwise_i8(y1, res, 0.05, 0.043, 20.0, 20.0, True)
+    got, conv = run_conv_i8(x, w, None, b, 0.02, 0.05, O.S8, 0, 1, 1, 1, 1, tile=7 | (1 << 8) | (9 << 16),
+                            res_param=(L.RES_ELTWISE, True, 1.0, (20.0, 20.0), 0.043), res=res)
+    assert conv.algo().startswith("img3x3") and np.array_equal(got, want)
+    # slabs beyond the LDS / accumulator budget, and non-3x3 geometry, are refused (the autotuner never offers them)
+    p = S.ConvParam(w, b, 1, (1, 1), (1, 1), (1, 1), True)
+    conv = S.SaberConv2D(True).init((2, 256, 14, 14), p, L.U8, L.U8, 0.02, 0.05)
+    for bad in (14 | (1 << 8) | (9 << 16), 7 | (4 << 8) | (9 << 16)):
+        with pytest.raises(L.SaberHipError):
+            conv.set_tile(bad)
+    p1 = S.ConvParam(w[:, :, :1, :1].copy(), b, 1, (0, 0), (1, 1), (1, 1), True)
+    conv1 = S.SaberConv2D(True).init((2, 256, 14, 14), p1, L.U8, L.U8, 0.02, 0.05)
+    with pytest.raises(L.SaberHipError):
+        conv1.set_tile(7 | (1 << 8) | (9 << 16))
+
+
 def test_conv3x3_halo_fused_eltwise():
     rng = np.random.default_rng(14)
     x = rng.integers(0, 256, (2, 28, 28, 128)).astype(np.uint8)
@@ -362,6 +433,13 @@ def test_conv_i8_fused_eltwise_equals_two_ops(relu):
     got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, O.S8, 0, 0, 1, 1, 1,
                             res_param=(L.RES_ELTWISE, bool(relu), 1.0, (c, c), s_res), res=res)
     assert np.array_equal(got, want), conv.algo()
+    # every tile / staging variant
+    for var, ks, tiles in ((1, 1, range(len(L.TILES))), (2, 1, range(len(L.TILES))), (3, 4, (0, 1, 2)), (4, 4, (0,))):
+        for tile in tiles:
+            got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, O.S8, 0, 0, 1, 1, 1,
+                                    tile=tile | (ks << 8) | (var << 16),
+                                    res_param=(L.RES_ELTWISE, bool(relu), 1.0, (c, c), s_res), res=res)
+            assert np.array_equal(got, want), conv.algo()
     # and the unfused device ops agree too
     y1d, _ = run_conv_i8(x, w, None, b, in_scale, out_scale, O.S8, 0, 0, 1, 1, 1)
     assert np.array_equal(y1d, y1)
@@ -697,8 +775,13 @@ def test_fc_vs_oracle():
     in_scale = float(np.abs(xf).max() / 127)
     want = O.fc_i8(O.quant_flat_s8(xf, in_scale), wq, ws, in_scale, b)
     fc = S.SaberFc(True).init(M, N, K, w, b, L.F32, in_scale)
+    assert fc.algo() == "fc_i8_small_16xk4", fc.algo()   # STATIC choice for <= 16 rows
     y = torch.empty((M, N), dtype=torch.float32, device="cuda")
     assert np.array_equal(host(fc.dispatch(dev(xf), y)), want)
+    fc.set_tile(0 | (4 << 8) | (1 << 16))   # the implicit-GEMM kernel computes the same bits
+    y.zero_()
+    assert fc.algo().startswith("igemm_i8") and np.array_equal(host(fc.dispatch(dev(xf), y)), want)
+    fc.set_tile(10 << 16)
     y.zero_()   # the same op fed the already-quantised input (producer fused the quantise-on-entry)
     assert np.array_equal(host(fc.dispatch_q(dev(O.quant_flat_s8(xf, in_scale)), y)), want)
     # s8 input
@@ -715,6 +798,33 @@ def test_fc_vs_oracle():
     assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * np.abs(want).max()
     fc = S.SaberFc(False).init(M, N, K, np.ascontiguousarray(w.T), b, L.F32, w_is_kn=True)
     assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * np.abs(want).max()
+
+
+@pytest.mark.parametrize("shape", [(1, 1000, 2048), (16, 1000, 2048), (5, 24, 4096), (3, 1000, 528), (8, 50, 16),
+                                   (17, 64, 2048), (4, 64, 4112)])
+@pytest.mark.parametrize("idt", [O.S8, O.U8])
+def test_fc_small_batch_kernel(shape, idt):
+    """fc_small.hip over batch rows 1..16, ragged n, reduction lengths that leave partial / empty k-steps; shapes outside
+    its limits (m > 16, k > 4096) keep the implicit-GEMM kernel. Both must equal the oracle bit for bit."""
+    M, N, K = shape
+    rng = np.random.default_rng(abs(hash((shape, idt))) % 2**31)
+    wq = rng.integers(-127, 128, (N, K)).astype(np.int8)
+    ws = (rng.random(N).astype(np.float32) * 0.01 + 0.001)
+    b = rng.standard_normal(N).astype(np.float32)
+    x = (rng.integers(0, 256, (M, K)).astype(np.uint8) if idt == O.U8 else rng.integers(-128, 128, (M, K)).astype(np.int8))
+    fc = S.SaberFc(True).init(M, N, K, wq, b, idt, 0.031, 0.5, w_scale=ws)
+    small = M <= 16 and K <= 4096
+    assert (fc.algo() == "fc_i8_small_16xk4") == small, (fc.algo(), shape)
+    want = O.fc_i8(x, wq, ws, 0.031, b, 0.5) if idt == O.U8 else O.fc_i8(x, wq, ws, 0.031, b)
+    y = torch.full((M, N), -7.0, dtype=torch.float32, device="cuda")
+    assert np.array_equal(host(fc.dispatch(dev(x), y)), want)
+    if small:
+        fc.set_tile(0 | (4 << 8) | (1 << 16))
+        y.fill_(-7.0)
+        assert fc.algo().startswith("igemm_i8") and np.array_equal(host(fc.dispatch(dev(x), y)), want)
+    else:
+        with pytest.raises(L.SaberHipError):
+            fc.set_tile(10 << 16)
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
