@@ -29,7 +29,6 @@
 #pragma once
 #include "kernels.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace saber_mi355x {
@@ -372,8 +371,6 @@ __device__ __forceinline__ void xcd_tile(const ConvKArgs& a, int& px, int& ky) {
 
 // ceil(2^32 / d) if __umulhi(n, .) == n / d for every 0 <= n < n_max, else 0 (host side)
 static inline unsigned magic_div(int d, long long n_max) {
-    static const bool off = getenv("SABER_NO_MAGIC") != nullptr;   // TEMP A/B knob
-    if (off) return 0u;
     if (d < 2 || n_max * d >= 0x100000000ll) return 0u;
     return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
 }

@@ -92,3 +92,103 @@ def run_fp32(model, x):
         elif kd == "softmax":
             t[nm] = O.softmax_f32(t[l["src"]])
     return t
+
+
+class RefNet:
+    """The ResNet INT8 op list run by the REFERENCE'S OWN compiled x86 objects (oracle/_ref, ref_net_* in
+    oracle/ref_driver.cpp): GemmX8S8S32XConv per conv (init once, dispatch per forward), SaberEltwise<X86,AK_INT8>,
+    PackedMKLInt8Gemm for the fc. Used by bench.py's cpu_baseline ("kind": "reference") and pinned against
+    run_int8 above (same logits, bit for bit) in tests/test_oracle_vs_ref.py. TEST / BASELINE INFRASTRUCTURE ONLY."""
+
+    def __init__(self, model, scales, batch, hw=224):
+        import ctypes as C
+        self.C = C
+        self.R = R = O.ref()
+        R.ref_net_new.restype = C.c_void_p
+        R.ref_net_time_ms.restype = C.c_double
+        R.ref_net_tensor.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_float]
+        R.ref_net_conv.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
+        R.ref_net_eltwise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+        R.ref_net_maxpool.argtypes = [C.c_void_p] + [C.c_int] * 5
+        R.ref_net_gpool_fc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float]
+        R.ref_net_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        R.ref_net_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        R.ref_net_time_ms.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        R.ref_net_free.argtypes = [C.c_void_p]
+        self.h = C.c_void_p(R.ref_net_new())
+        scales = dict(scales)
+        B = batch
+        self.ids, self.shape, self.dt = {}, {}, {}
+        self.keep = []
+
+        def tensor(name, c, s, dtype, scale):
+            self.ids[name] = R.ref_net_tensor(self.h, B, c, s, s, dtype, float(scale))
+            self.shape[name], self.dt[name] = (c, s), dtype
+        tensor("data", 3, hw, F32, scales["data"])
+        spec = model["spec"]
+        for li, l in enumerate(spec):
+            kd, nm = l["kind"], l["name"]
+            if kd == "conv":
+                cin, hin = self.shape[l["src"]]
+                ho = (hin + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+                w, b = model["params"][nm]
+                tensor(nm, l["cout"], ho, U8 if l["relu"] else S8, scales[nm])
+                w = np.ascontiguousarray(w, np.float32)
+                b = np.ascontiguousarray(b, np.float32)
+                self.keep += [w, b]
+                rc = R.ref_net_conv(self.h, self.ids[l["src"]], self.ids[nm], l["cout"], cin, l["k"], l["pad"], l["stride"],
+                                    int(l["relu"]), w.ctypes.data, b.ctypes.data)
+                assert rc == 0, (nm, rc)
+            elif kd == "pool":
+                c, hin = self.shape[l["src"]]
+                ho = O.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
+                scales[nm] = scales[l["src"]]
+                tensor(nm, c, ho, self.dt[l["src"]], scales[nm])
+                assert l["type"] == 0
+                R.ref_net_maxpool(self.h, self.ids[l["src"]], self.ids[nm], l["win"], l["stride"], l["pad"])
+            elif kd == "eltwise":
+                c, s = self.shape[l["a"]]
+                tensor(nm, c, s, S8, scales[nm])
+                rc = R.ref_net_eltwise(self.h, self.ids[l["a"]], self.ids[l["b"]], self.ids[nm], 1.0 / scales[nm], int(l["relu"]))
+                assert rc == 0
+            elif kd == "gpool":
+                nxt = spec[li + 1]
+                assert nxt["kind"] == "fc" and nxt["src"] == nm
+                w, b = model["params"][nxt["name"]]
+                w = np.ascontiguousarray(w, np.float32)
+                b = np.ascontiguousarray(b, np.float32)
+                self.keep += [w, b]
+                self.n_out = nxt["cout"]
+                self.ids[nxt["name"]] = R.ref_net_tensor(self.h, B, self.n_out, 1, 1, F32, 1.0)
+                rc = R.ref_net_gpool_fc(self.h, self.ids[l["src"]], self.ids[nxt["name"]], self.n_out, w.ctypes.data,
+                                        b.ctypes.data, float(scales[nm]))
+                assert rc == 0
+                self.out_name = nxt["name"]
+            # fc handled with gpool; softmax is not part of the timed reference list (a 1000-element row)
+        self.batch, self.hw = B, hw
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty((self.batch, self.n_out), np.float32)
+        rc = self.R.ref_net_run(self.h, self.ids["data"], x.ctypes.data, self.ids[self.out_name], out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
+    def read(self, name):
+        c, s = self.shape[name]
+        a = np.empty((self.batch, s, s, c), np.uint8 if self.dt[name] == U8 else np.int8)
+        self.R.ref_net_read(self.h, self.ids[name], a.ctypes.data)
+        return a
+
+    def time_ms(self, warmup=10, iters=200):
+        return float(self.R.ref_net_time_ms(self.h, warmup, iters))
+
+    def __del__(self):
+        try:
+            self.R.ref_net_free(self.h)
+        except Exception:
+            pass
+
+
+def ref_set_threads(n):
+    O.ref().ref_set_threads(int(n))

@@ -355,3 +355,241 @@ int ref_gemm_s8s8s32(int trans_a, int trans_b, int m, int n, int k, const int8_t
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// ref_net_*: the ResNet INT8 op list executed by the reference's OWN x86 objects, for bench.py's
+// cpu_baseline ("kind": "reference") and for tests/test_oracle_vs_ref.py (its logits must equal
+// the restated oracle's bit for bit). One persistent object per operator (init once, dispatch per forward,
+// as Net::init / Net::prediction do), tensors per edge, timing with std::chrono around the whole list
+// (README.md:85-86 protocol: warm-up 10, average of N runs; threads = MKL/OpenMP, GemmX8S8S32XConv's own
+// outer loop is single-threaded, gemm_x8s8s32x_conv.cpp:218-220).
+//   conv      GemmX8S8S32XConv::init / dispatch (u8 -> s8 through sub_dispatch<uint8_t,int8_t>);
+//             an f32 NCHW input is quantised on entry by reorder_nhwc_nchw as SaberConv2D<X86,AK_INT8>::dispatch
+//             does (saber_conv.cpp:308)
+//   eltwise   SaberEltwise<X86,AK_INT8>
+//   max pool  restated in place (the reference's x86 INT8 pooling is an xbyak JIT kernel that cannot be built here, and
+//             its naive test helper pool_basic_check_int8 reads u8 bytes as signed)
+//   gpool+fc  reorder_nhwc_nchw (dequantise) + a plain (h, w)-ordered float average (SaberPooling<X86,AK_FLOAT>
+//             includes the JIT headers: restated here) + PackedMKLInt8Gemm (VenderFc<X86,AK_INT8>, f32 input)
+// ================================================================================================
+#include <algorithm>
+#include <chrono>
+#include <memory>
+#include <omp.h>
+
+namespace {
+struct RefOp {
+    int kind;   // 0 conv, 1 eltwise, 2 maxpool, 3 gpool+fc
+    int in = -1, in2 = -1, out = -1;
+    // conv
+    std::unique_ptr<GemmX8S8S32XConv> conv;
+    std::unique_ptr<Tensor<X86>> w, b, xq;   // weights, bias, quantised copy of an f32 input
+    std::unique_ptr<ConvEltwiseParam<X86>> cep;
+    bool u8s8 = false;
+    // eltwise
+    std::unique_ptr<SaberEltwise<X86, AK_INT8>> elt;
+    std::unique_ptr<EltwiseParam<X86>> ep;
+    // pool
+    int win = 0, stride = 0, pad = 0;
+    // gpool + fc
+    std::unique_ptr<PackedMKLInt8Gemm> fc;
+    std::unique_ptr<Tensor<X86>> deq, pooled, fb, fout;
+    int m = 0, n = 0, k = 0;
+};
+struct RefNet {
+    std::vector<std::unique_ptr<Tensor<X86>>> t;
+    std::vector<std::unique_ptr<RefOp>> ops;
+    int in_id = -1, out_id = -1;
+};
+}  // namespace
+
+extern "C" {
+
+void ref_set_threads(int n) {
+    omp_set_num_threads(n);
+    mkl_set_num_threads(n);
+}
+
+void* ref_net_new(void) {
+    ctx();
+    return new RefNet();
+}
+void ref_net_free(void* h) { delete (RefNet*)h; }
+
+// layout: 0 NCHW (f32 tensors), 1 NHWC (8-bit tensors). Returns the tensor id.
+int ref_net_tensor(void* h, int n, int c, int hh, int ww, int dtype, float scale) {
+    RefNet* net = (RefNet*)h;
+    Shape sh = dtype == 0 ? Shape({n, c, hh, ww}, Layout_NCHW) : Shape({n, hh, ww, c}, Layout_NHWC);
+    net->t.emplace_back(new Tensor<X86>(sh, to_dtype(dtype)));
+    net->t.back()->set_scale({scale});
+    return (int)net->t.size() - 1;
+}
+
+int ref_net_conv(void* h, int in_id, int out_id, int K, int C, int k, int pad, int stride, int with_relu, const float* w,
+                 const float* bias) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 0; op->in = in_id; op->out = out_id;
+    Tensor<X86>* tin = net->t[in_id].get();
+    Tensor<X86>* tout = net->t[out_id].get();
+    if (tin->get_dtype() == AK_FLOAT) {   // quantise on entry into an s8 NHWC twin
+        Shape s = tin->valid_shape();
+        op->xq.reset(new Tensor<X86>(Shape({s[0], s[2], s[3], s[1]}, Layout_NHWC), AK_INT8));
+        op->xq->set_scale(tin->get_scale());
+        tin = op->xq.get();
+    }
+    op->w.reset(new Tensor<X86>(Shape({K, C, k, k}, Layout_NCHW), AK_FLOAT));
+    memcpy(op->w->mutable_data(), w, sizeof(float) * (size_t)K * C * k * k);
+    if (bias) {
+        op->b.reset(new Tensor<X86>(Shape({1, K, 1, 1}, Layout_NCHW), AK_FLOAT));
+        memcpy(op->b->mutable_data(), bias, sizeof(float) * K);
+    }
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    ConvParam<X86> cp(1, pad, pad, stride, stride, 1, 1, op->w.get(), bias ? op->b.get() : nullptr, act);
+    EltwiseParam<X86> ep(Eltwise_sum);
+    ep.has_eltwise = false;
+    op->cep.reset(new ConvEltwiseParam<X86>(cp, ep));
+    op->conv.reset(new GemmX8S8S32XConv());
+    std::vector<Tensor<X86>*> ins{tin}, outs{tout};
+    if (op->conv->init(ins, outs, *op->cep, ctx()) != SaberSuccess) return -1;
+    op->u8s8 = tin->get_dtype() == AK_UINT8 && tout->get_dtype() == AK_INT8;
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
+int ref_net_eltwise(void* h, int a_id, int b_id, int out_id, float coeff, int with_relu) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 1; op->in = a_id; op->in2 = b_id; op->out = out_id;
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    op->ep.reset(new EltwiseParam<X86>(Eltwise_sum, {coeff, coeff}, act));
+    op->elt.reset(new SaberEltwise<X86, AK_INT8>());
+    std::vector<Tensor<X86>*> ins{net->t[a_id].get(), net->t[b_id].get()}, outs{net->t[out_id].get()};
+    if (op->elt->init(ins, outs, *op->ep, ctx()) != SaberSuccess) return -1;
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
+int ref_net_maxpool(void* h, int in_id, int out_id, int win, int stride, int pad) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 2; op->in = in_id; op->out = out_id; op->win = win; op->stride = stride; op->pad = pad;
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
+// in: 8-bit NHWC [m, hh, ww, k]; out: f32 [m, n]. fc weights f32 [n, k]; fc input scale = pooled edge's scale.
+int ref_net_gpool_fc(void* h, int in_id, int out_id, int n, const float* w_nk, const float* bias, float fc_in_scale) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 3; op->in = in_id; op->out = out_id;
+    Shape s = net->t[in_id]->valid_shape();   // NHWC
+    const int m = s[0], hh = s[1], ww = s[2], k = s[3];
+    op->m = m; op->n = n; op->k = k;
+    op->deq.reset(new Tensor<X86>(Shape({m, k, hh, ww}, Layout_NCHW), AK_FLOAT));
+    op->deq->set_scale(net->t[in_id]->get_scale());
+    op->pooled.reset(new Tensor<X86>(Shape({m, k, 1, 1}, Layout_NCHW), AK_FLOAT));
+    op->pooled->set_scale({fc_in_scale});
+    Tensor<X86> wt(Shape({1, 1, n, k}, Layout_NCHW), AK_FLOAT);
+    memcpy(wt.mutable_data(), w_nk, sizeof(float) * (size_t)n * k);
+    op->fc.reset(new PackedMKLInt8Gemm());
+    if (op->fc->init(false, true, m, n, k, wt, fc_in_scale) != SaberSuccess) return -1;
+    if (bias) {
+        op->fb.reset(new Tensor<X86>(Shape({1, n, 1, 1}, Layout_NCHW), AK_FLOAT));
+        memcpy(op->fb->mutable_data(), bias, sizeof(float) * n);
+    }
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
+static int ref_net_forward(RefNet* net) {
+    for (auto& up : net->ops) {
+        RefOp* op = up.get();
+        if (op->kind == 0) {
+            Tensor<X86>* tin = net->t[op->in].get();
+            if (op->xq) {
+                reorder_nhwc_nchw(*tin, *op->xq);
+                tin = op->xq.get();
+            }
+            std::vector<Tensor<X86>*> ins{tin}, outs{net->t[op->out].get()};
+            SaberStatus st = op->u8s8 ? op->conv->sub_dispatch<uint8_t, int8_t>(ins, outs, *op->cep)
+                                      : op->conv->dispatch(ins, outs, *op->cep);
+            if (st != SaberSuccess) return 1;
+        } else if (op->kind == 1) {
+            std::vector<Tensor<X86>*> ins{net->t[op->in].get(), net->t[op->in2].get()}, outs{net->t[op->out].get()};
+            if (op->elt->dispatch(ins, outs, *op->ep) != SaberSuccess) return 2;
+        } else if (op->kind == 2) {
+            // max pooling, NHWC 8-bit (u8 after a relu'd conv). Restated: the reference's x86 INT8 pooling is an xbyak JIT
+            // kernel (not buildable here) and its naive test helper pool_basic_check_int8 reads the bytes as signed char,
+            // which is wrong for the u8 tensor this op sees in the ResNet list. A max has no rounding to pin.
+            Tensor<X86>* ti = net->t[op->in].get();
+            Tensor<X86>* to = net->t[op->out].get();
+            Shape si = ti->valid_shape(), so = to->valid_shape();
+            const int N = si[0], H = si[1], W = si[2], Cc = si[3], OH = so[1], OW = so[2];
+            const bool is_u8 = ti->get_dtype() == AK_UINT8;
+            const uint8_t* src = (const uint8_t*)ti->data();
+            uint8_t* dst = (uint8_t*)to->mutable_data();
+#pragma omp parallel for collapse(2)
+            for (int n = 0; n < N; ++n)
+                for (int oy = 0; oy < OH; ++oy)
+                    for (int ox = 0; ox < OW; ++ox) {
+                        const int hs = std::max(oy * op->stride - op->pad, 0), ws = std::max(ox * op->stride - op->pad, 0);
+                        const int he = std::min(oy * op->stride - op->pad + op->win, H);
+                        const int we = std::min(ox * op->stride - op->pad + op->win, W);
+                        for (int c = 0; c < Cc; ++c) {
+                            int best = -1000;
+                            for (int iy = hs; iy < he; ++iy)
+                                for (int ix = ws; ix < we; ++ix) {
+                                    const uint8_t v = src[(((size_t)n * H + iy) * W + ix) * Cc + c];
+                                    const int iv = is_u8 ? (int)v : (int)(int8_t)v;
+                                    best = iv > best ? iv : best;
+                                }
+                            dst[(((size_t)n * OH + oy) * OW + ox) * Cc + c] = (uint8_t)best;
+                        }
+                    }
+        } else {
+            reorder_nhwc_nchw(*net->t[op->in], *op->deq);
+            const float* d = (const float*)op->deq->data();
+            float* p = (float*)op->pooled->mutable_data();
+            Shape s = op->deq->valid_shape();
+            const int hw = s[2] * s[3];
+            for (int i = 0; i < op->m * op->k; ++i) {   // SaberPooling<X86,AK_FLOAT> average, (h, w) order
+                float acc = 0.f;
+                for (int j = 0; j < hw; ++j) acc += d[(size_t)i * hw + j];
+                p[i] = acc / (float)hw;
+            }
+            if (op->fc->dispatch(1.f, 0.f, op->m, *op->pooled, *net->t[op->out], op->fb.get()) != SaberSuccess) return 3;
+        }
+    }
+    return 0;
+}
+
+// x: f32 NCHW input of tensor in_id; copies the f32 output tensor out_id to `out` (may be null).
+int ref_net_run(void* h, int in_id, const float* x, int out_id, float* out) {
+    RefNet* net = (RefNet*)h;
+    memcpy(net->t[in_id]->mutable_data(), x, sizeof(float) * net->t[in_id]->valid_size());
+    int rc = ref_net_forward(net);
+    if (rc) return rc;
+    if (out) memcpy(out, net->t[out_id]->data(), sizeof(float) * net->t[out_id]->valid_size());
+    return 0;
+}
+// copies any 8-bit / f32 edge out (parity checks of intermediate tensors)
+int ref_net_read(void* h, int id, void* dst) {
+    RefNet* net = (RefNet*)h;
+    Tensor<X86>* t = net->t[id].get();
+    memcpy(dst, t->data(), t->valid_size() * (t->get_dtype() == AK_FLOAT ? 4 : 1));
+    return 0;
+}
+// milliseconds per forward: warm-up runs, then `iters` timed runs (steady_clock around the whole op list)
+double ref_net_time_ms(void* h, int warmup, int iters) {
+    RefNet* net = (RefNet*)h;
+    for (int i = 0; i < warmup; ++i)
+        if (ref_net_forward(net)) return -1.0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i)
+        if (ref_net_forward(net)) return -1.0;
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+}
+
+}  // extern "C"

@@ -34,3 +34,13 @@ void mkl_free(void* p);
 }
 #endif
 #endif
+
+/* thread control (ref_driver.cpp's ref_set_threads) */
+#ifdef __cplusplus
+extern "C" {
+#endif
+void MKL_Set_Num_Threads(int nth);
+#define mkl_set_num_threads MKL_Set_Num_Threads
+#ifdef __cplusplus
+}
+#endif

@@ -233,3 +233,24 @@ def test_vender_fc_i8_operator_matches_reference(in_kind, with_bias):
         got = O.fc_i8(x, wq, ws, in_scale, b, out_scale)
     want = O.ref_vender_fc_i8(x, w, b, in_scale, out_scale)
     assert np.array_equal(got, want)
+
+
+def test_resnet50_int8_op_list_through_reference_objects():
+    """The whole unfused ResNet50 INT8 op list (batch 1, 224x224) through the reference's own compiled objects
+    (oracle/net_oracle.RefNet: GemmX8S8S32XConv incl. sub_dispatch<uint8_t,int8_t> for the 17 u8 -> s8 convs,
+    SaberEltwise<X86,AK_INT8>, PackedMKLInt8Gemm) equals the restated oracle op list on EVERY edge and on the logits,
+    bit for bit. Scales carry 25 % head-room so that no requantisation saturates: the GEMM path casts without
+    saturating (gemm_x8s8s32x_conv.cpp:278, undefined on overflow) where the pinned contract saturates (JIT semantics)."""
+    from anakin_amd import workloads as W
+    from oracle import net_oracle as NO
+    model = W.build_model("resnet50")
+    xs = W.make_input(1)
+    scales = {k: v * 1.25 for k, v in W.calibrate(model, W.make_input(2)).items()}
+    rn = NO.RefNet(model, scales, 1)
+    y = rn.run(xs)
+    ref = NO.run_int8(model, dict(scales), xs)
+    assert np.array_equal(y, ref["fc1000"].reshape(y.shape))
+    edges = [nm for nm in rn.shape if nm != "data" and nm in ref]
+    assert len(edges) >= 70
+    for nm in edges:
+        assert np.array_equal(rn.read(nm), ref[nm]), nm
