@@ -248,6 +248,12 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
         else op->algo = ALGO_DIRECT_I8;
         if (op->algo == ALGO_DIRECT_I8 && d.res_mode == SABER_HIP_RES_NONE) { /* fine */ }
         op->epi = EPI_I8_CONV;
+        if (d.res_mode == SABER_HIP_RES_SUM_INPLACE && d.res_has_dtype &&
+            ((d.out_dtype == SABER_HIP_F32) != (d.res_dtype == SABER_HIP_F32) ||
+             (d.res_dtype != SABER_HIP_F32 && d.res_dtype != SABER_HIP_S8 && d.res_dtype != SABER_HIP_U8))) {
+            delete op;
+            return fail(SABER_HIP_INVALID_VALUE, "RES_SUM_INPLACE: the bytes in y must have the output's element size (s8 / u8 into an 8-bit output)");
+        }
         if (d.res_mode == SABER_HIP_RES_ELTWISE && d.out_dtype != SABER_HIP_S8) {
             delete op;
             return fail(SABER_HIP_INVALID_VALUE, "RES_ELTWISE produces s8 (SaberEltwise<X86,AK_INT8>)");
@@ -540,7 +546,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.epi = op->epi;
     a.res_mode = d.res_mode;
     a.res_relu = d.res_act == SABER_HIP_ACT_RELU;
-    a.res_dtype = d.out_dtype;
+    a.res_dtype = d.res_has_dtype ? d.res_dtype : d.out_dtype;
     a.sum_scale = d.sum_scale;
     a.coeff_conv = d.coeff_conv; a.coeff_res = d.coeff_res;
     a.scale_conv = op->out_scale; a.scale_res = d.scale_res;

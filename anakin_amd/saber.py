@@ -47,6 +47,7 @@ class ConvParam:
         self.res_mode = L.RES_NONE
         self.res_relu = False
         self.sum_scale = 1.0
+        self.res_dtype = None        # RES_SUM_INPLACE: dtype of the bytes already in y (ConvParam.beta_type); None = out dtype
         self.coeff = (1.0, 1.0)
         self.scale_res = 1.0
 
@@ -82,6 +83,8 @@ class SaberConv2D:
         d.res_mode = param.res_mode
         d.res_act = L.ACT_RELU if param.res_relu else L.ACT_NONE
         d.sum_scale = param.sum_scale
+        if getattr(param, "res_dtype", None) is not None:
+            d.res_has_dtype, d.res_dtype = 1, int(param.res_dtype)
         d.coeff_conv, d.coeff_res = param.coeff
         d.scale_res = param.scale_res
         d.int8_weights = 1 if self.int8 else 0

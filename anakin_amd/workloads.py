@@ -327,6 +327,12 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
         return alias.get(n, n)
     spec = model["spec"]
     sib = {}
+    produced = []   # (op index, logical edge name the op has just produced): lets a test check every edge right after its op,
+                    # before a later in-place residual sum overwrites the buffer
+
+    def mark(*names):
+        for n_ in names:
+            produced.append((net.num_ops() - 1, n_))
     for li, l in enumerate(spec):
         kd, nm = l["kind"], l["name"]
         if kd == "conv":
@@ -343,6 +349,7 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
                 conv = S.SaberConv2D(False).init((B, cin, hin, hin), p, F32, F32, in_layout=L.NHWC, out_layout=L.NHWC)
                 # identity blocks: the shortcut is the block input, still needed? no - branch2a already consumed it
                 net.add_conv(conv, T(l["src"]), T(el["b"]))
+                mark(el["name"])
                 alias[el["name"]] = T(el["b"])
                 shape[T(el["b"])] = (ho, l["cout"])
                 continue
@@ -359,8 +366,10 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
             if nm in sib:
                 first, first_nm = sib.pop(nm)
                 net.add_conv_pair(S.SaberConvPair(first, conv), T(l["src"]), first_nm, nm)
+                mark(first_nm, nm)
                 continue
             net.add_conv(conv, T(l["src"]), nm)
+            mark(nm)
         elif kd == "pool":
             hin, c = shape[T(l["src"])]
             ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
@@ -368,6 +377,7 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
             shape[nm] = (ho, c)
             net.add_pool_f32(B, hin, hin, c, ho, ho, (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"],
                              L.NHWC, T(l["src"]), nm)
+            mark(nm)
         elif kd == "eltwise":
             pass  # fused into branch2c above
         elif kd == "gpool":
@@ -375,6 +385,7 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
             net.add_tensor(nm, (B, c), F32)
             shape[nm] = (1, c)
             net.add_pool_f32(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, L.NHWC, T(l["src"]), nm)
+            mark(nm)
         elif kd == "fc":
             w, b = model["params"][nm]
             if "flatten_chw" in l:   # NCHW-flattened weights -> our NHWC flatten order
@@ -386,10 +397,13 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
             if l.get("relu"):
                 net.keep.append("relu-after-fc: applied by eltwise(x, x, 0.5, 0.5, relu)")
                 net.add_eltwise_f32(B * l["cout"], 0.5, 0.5, True, nm, nm, nm)
+            mark(nm)
         elif kd == "softmax":
             net.add_tensor(nm, (B, 1000), F32)
             net.add_softmax(B, 1000, T(l["src"]), nm)
+            mark(nm)
     net.alias = alias
+    net.produced = produced
     net.finalize()
     return net
 

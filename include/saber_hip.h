@@ -88,10 +88,15 @@ typedef struct {
     int act;                     /* ActivationParam of the conv (relu) */
     int res_mode;                /* saber_hip_res_mode */
     int res_act;                 /* activation of the eltwise (RES_ELTWISE / FP32 SUM_INPLACE) */
-    float sum_scale;             /* RES_SUM_INPLACE INT8 */
+    float sum_scale;             /* RES_SUM_INPLACE INT8: multiplies the bytes already in y. The reference derives it in the
+                                    impl, not the caller: beta / out_scale with a 255/127 (s8 added into u8) or 127/255
+                                    (u8 into s8) factor (jit_avx512_core_x8s8s32x_conv.cpp:174-189); the adaptors do that */
     float coeff_conv, coeff_res; /* RES_ELTWISE: EltwiseParam.coeff[0], coeff[1] */
     float scale_res;             /* RES_ELTWISE: scale of the residual tensor */
     int int8_weights;            /* 1: INT8 arithmetic (AK_INT8 op), 0: FP32 arithmetic */
+    int res_has_dtype;           /* RES_SUM_INPLACE INT8: 1 = res_dtype below is the dtype of the bytes already in y */
+    int res_dtype;               /* ... ConvParam.beta_type (s8 or u8; may differ from out_dtype, same element size).
+                                    res_has_dtype == 0: the bytes in y have out_dtype */
 } saber_hip_conv_desc;
 
 typedef struct saber_hip_conv saber_hip_conv_t;

@@ -177,7 +177,21 @@ struct ConvParam {
     HostBlob* bias_tensor;
     ActivationParam<TargetType> activation_param;
     float alpha, beta;
+    DataType beta_type = AK_FLOAT;   // dtype of the tensor being added (saber_funcs_param.h:574, default AK_FLOAT)
 };
+
+// INT8 conv + sum: the factor applied to the bytes already in the output, derived as the x86 impl does
+// (jit_avx512_core_x8s8s32x_conv.cpp:174-189): the framework sets ConvParam::beta to the added tensor's scale
+// (fusion_ops/conv_eltwise.cpp:185-187), the impl divides by the output scale and converts between the s8 (x/127) and
+// u8 (x/255) conventions. Returns false for the combinations the reference rejects.
+inline bool conv_sum_scale(float beta, DataType beta_type, DataType out_dtype, float out_scale, float* sum_scale) {
+    if (beta_type == AK_INT8 && out_dtype == AK_UINT8) *sum_scale = beta * (255.f / 127.f) / out_scale;
+    else if (beta_type == AK_UINT8 && out_dtype == AK_INT8) *sum_scale = beta * (127.f / 255.f) / out_scale;
+    else if ((beta_type == AK_UINT8 && out_dtype == AK_UINT8) || (beta_type == AK_INT8 && out_dtype == AK_INT8))
+        *sum_scale = beta / out_scale;
+    else return false;
+    return true;
+}
 
 template <typename TargetType>
 struct EltwiseParam {
@@ -283,7 +297,15 @@ public:
                 d.scale_res = inputs[1]->get_scale().size() ? inputs[1]->get_scale()[0] : 1.f;
             } else {
                 d.res_mode = SABER_HIP_RES_SUM_INPLACE;
-                d.sum_scale = cp.beta;
+                if (OpDtype == AK_INT8) {
+                    const float out_scale = out->get_scale().size() ? out->get_scale()[0] : 1.f;
+                    if (!conv_sum_scale(cp.beta, cp.beta_type, out->get_dtype(), out_scale, &d.sum_scale)) return SaberUnImplError;
+                    d.res_has_dtype = 1;
+                    d.res_dtype = to_hip_dtype(cp.beta_type);
+                } else {
+                    if (cp.beta != 1.f) return SaberUnImplError;   // FP32: out = act(conv + bias + 1 * out)
+                    d.sum_scale = 1.f;
+                }
             }
         }
         if (_op) { saber_hip_conv2d_destroy(_op); _op = nullptr; }

@@ -20,6 +20,8 @@
 #include "saber/saber_funcs_param.h"
 #include "saber_hip.h"
 
+#include <vector>
+
 namespace anakin {
 namespace saber {
 
@@ -37,15 +39,46 @@ inline int mi355x_dtype(DataType t) {
 }
 inline int mi355x_layout(LayoutType l) { return l == Layout_NHWC ? SABER_HIP_NHWC : SABER_HIP_NCHW; }
 
+// Host view of a parameter tensor (weights / bias / scales are consumed on the host by saber_hip_*_set_weights): a host
+// target hands out its own pointer, a device target (MI355X) is copied down with the target's TargetWrapper, exactly once
+// per init/create (cold path).
+template <typename TargetType>
+inline const void* mi355x_host_view(const Tensor<TargetType>& t, std::vector<char>& buf, __host_target) {
+    return t.data();
+}
+template <typename TargetType>
+inline const void* mi355x_host_view(const Tensor<TargetType>& t, std::vector<char>& buf, __device_target) {
+    const size_t bytes = (size_t)t.valid_size() * t.get_dtype_size();
+    buf.resize(bytes ? bytes : 1);
+    TargetWrapper<TargetType>::sync_memcpy(buf.data(), 0, 0, t.data(), 0, t.device_id(), bytes, __DtoH());
+    return buf.data();
+}
+template <typename TargetType>
+inline const void* mi355x_host_view(const Tensor<TargetType>& t, std::vector<char>& buf) {
+    return mi355x_host_view(t, buf, typename TargetTypeTraits<TargetType>::target_category());
+}
+
+// The factor the INT8 conv + sum post-op applies to the bytes already in the output tensor, derived as the x86 impl does
+// (jit_avx512_core_x8s8s32x_conv.cpp:174-189): the framework sets ConvParam::beta to the added tensor's scale
+// (framework/operators/fusion_ops/conv_eltwise.cpp:185-187); the impl divides by the output scale and converts between
+// the s8 (x/127) and u8 (x/255) conventions. false for the dtype pairs the reference rejects.
+inline bool mi355x_conv_sum_scale(float beta, DataType beta_type, DataType out_dtype, float out_scale, float* sum_scale) {
+    if (beta_type == AK_INT8 && out_dtype == AK_UINT8) *sum_scale = beta * (255.f / 127.f) / out_scale;
+    else if (beta_type == AK_UINT8 && out_dtype == AK_INT8) *sum_scale = beta * (127.f / 255.f) / out_scale;
+    else if ((beta_type == AK_UINT8 && out_dtype == AK_UINT8) || (beta_type == AK_INT8 && out_dtype == AK_INT8))
+        *sum_scale = beta / out_scale;
+    else return false;
+    return true;
+}
+
 // SaberConv2D<MI355X, OpDtype> and SaberConvEltwise<MI355X, OpDtype> share this body
 // (ConvEltwiseParam = ConvParam + EltwiseParam, saber_funcs_param.h:586-615).
 template <typename TargetType, DataType OpDtype>
 class SaberConvEltwiseMI355X : public ImplBase<TargetType, OpDtype, ConvEltwiseParam<TargetType> > {
 public:
-    SaberConvEltwiseMI355X() : _op(nullptr), _ws(nullptr), _ws_bytes(0) {}
+    SaberConvEltwiseMI355X() : _op(nullptr) {}
     ~SaberConvEltwiseMI355X() {
         if (_op) saber_hip_conv2d_destroy(_op);
-        // workspace is released through the target's TargetWrapper<...>::mem_free in the real target
     }
 
     virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs,
@@ -64,6 +97,8 @@ public:
         EltwiseParam<TargetType>& ep = param.eltwise_param;
         Tensor<TargetType>* in = inputs[0];
         Tensor<TargetType>* out = outputs[0];
+        const float in_scale = in->get_scale().size() ? in->get_scale()[0] : 1.f;
+        const float out_scale = out->get_scale().size() ? out->get_scale()[0] : 1.f;
         saber_hip_conv_desc d;
         memset(&d, 0, sizeof d);
         d.n = in->num(); d.c = in->channel(); d.h = in->height(); d.w = in->width();
@@ -82,22 +117,33 @@ public:
             d.res_mode = SABER_HIP_RES_SUM_INPLACE;
             d.res_act = (ep.activation_param.has_active && ep.activation_param.active == Active_relu)
                             ? SABER_HIP_ACT_RELU : SABER_HIP_ACT_NONE;
-            d.sum_scale = cp.beta;   // the INT8 caller pre-divides by the output scale as jit_..._conv.cpp:175-189 does
+            if (OpDtype == AK_INT8) {
+                if (!mi355x_conv_sum_scale(cp.beta, cp.beta_type, out->get_dtype(), out_scale, &d.sum_scale))
+                    return SaberUnImplError;
+                d.res_has_dtype = 1;
+                d.res_dtype = mi355x_dtype(cp.beta_type);   // the bytes in y may be s8 under a u8 output and vice versa
+            } else {
+                if (cp.beta != 1.f) return SaberUnImplError;   // FP32: out = act(conv + bias + 1 * out)
+                d.sum_scale = 1.f;
+            }
         }
         if (_op) { saber_hip_conv2d_destroy(_op); _op = nullptr; }
         int rc = saber_hip_conv2d_create(&d, &_op);
         if (rc) return mi355x_status(rc);
         const Tensor<TargetType>* w = cp.weight();
         const Tensor<TargetType>* b = cp.bias();
-        const float in_scale = in->get_scale().size() ? in->get_scale()[0] : 1.f;
-        const float out_scale = out->get_scale().size() ? out->get_scale()[0] : 1.f;
-        // weights/bias: the PBlock's HOST copy in the real target (PBlock::h_tensor(), parameter.h:192+)
-        rc = saber_hip_conv2d_set_weights(_op, w->data(), mi355x_dtype(w->get_dtype()),
-                                          w->get_scale().size() ? w->get_scale().data() : nullptr,
-                                          (b && b->valid_size() > 0) ? (const float*)b->data() : nullptr,
+        std::vector<char> wbuf, bbuf;
+        const void* wh = mi355x_host_view(*w, wbuf);
+        const void* bh = (b && b->valid_size() > 0) ? mi355x_host_view(*b, bbuf) : nullptr;
+        rc = saber_hip_conv2d_set_weights(_op, wh, mi355x_dtype(w->get_dtype()),
+                                          w->get_scale().size() ? w->get_scale().data() : nullptr, (const float*)bh,
                                           in_scale, out_scale);
-        _ws_bytes = saber_hip_conv2d_workspace_bytes(_op);   // allocate _ws with the target's mem_alloc
-        return mi355x_status(rc);
+        if (rc) return mi355x_status(rc);
+        // workspace (f32 NCHW inputs are quantised / transposed into it): a tensor of the target, so its memory comes from
+        // the target's TargetWrapper::mem_alloc and is released with the impl
+        const size_t ws_bytes = saber_hip_conv2d_workspace_bytes(_op);
+        if (ws_bytes) _ws.re_alloc(Shape({1, 1, 1, (int)ws_bytes}, Layout_NCHW), AK_INT8);
+        return SaberSuccess;
     }
 
     // dispatch: enqueue on the context's compute stream, never sync (net.cpp:456-458 records the event)
@@ -105,19 +151,19 @@ public:
                                  std::vector<Tensor<TargetType>*>& outputs,
                                  ConvEltwiseParam<TargetType>& param) {
         saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
-        return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), nullptr, _ws,
-                                                  stream));
+        void* ws = saber_hip_conv2d_workspace_bytes(_op) ? _ws.mutable_data() : nullptr;
+        return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), nullptr, ws, stream));
     }
 
     // Conv<>::trans_weights static_casts to this (conv.h:103-119): the repack already happened in create()
     SaberStatus trans_weights(Tensor<TargetType>&, Tensor<TargetType>&, int, int, int, int, int, int, int) {
         return SaberSuccess;
     }
+    const char* algo() const { return _op ? saber_hip_conv2d_algo(_op) : ""; }
 
 private:
     saber_hip_conv_t* _op;
-    void* _ws;
-    size_t _ws_bytes;
+    Tensor<TargetType> _ws;
 };
 
 // SaberConv2DPooling<MI355X, AK_INT8> (saber/funcs/conv_pooling.h; x86: saber_conv_pooling.cpp). One fused kernel when
@@ -161,12 +207,17 @@ public:
         const Tensor<TargetType>* w = cp.weight();
         const Tensor<TargetType>* b = cp.bias();
         // the pooling keeps the conv's scale (SaberPooling<X86,AK_INT8>::init): the op's output scale is the conv's
-        rc = saber_hip_conv2d_set_weights(_op, w->data(), mi355x_dtype(w->get_dtype()),
-                                          w->get_scale().size() ? w->get_scale().data() : nullptr,
-                                          (b && b->valid_size() > 0) ? (const float*)b->data() : nullptr,
+        std::vector<char> wbuf, bbuf;
+        const void* wh = mi355x_host_view(*w, wbuf);
+        const void* bh = (b && b->valid_size() > 0) ? mi355x_host_view(*b, bbuf) : nullptr;
+        rc = saber_hip_conv2d_set_weights(_op, wh, mi355x_dtype(w->get_dtype()),
+                                          w->get_scale().size() ? w->get_scale().data() : nullptr, (const float*)bh,
                                           in->get_scale().size() ? in->get_scale()[0] : 1.f,
                                           out->get_scale().size() ? out->get_scale()[0] : 1.f);
         if (rc) return mi355x_status(rc);
+        const size_t ws_bytes = saber_hip_conv2d_workspace_bytes(_op);
+        if (ws_bytes) _wst.re_alloc(Shape({1, 1, 1, (int)ws_bytes}, Layout_NCHW), AK_INT8);
+        _ws = ws_bytes ? _wst.mutable_data() : nullptr;
         _type = pp.pooling_type == Pooling_max ? SABER_HIP_POOL_MAX
                 : (pp.pooling_type == Pooling_average_include_padding ? SABER_HIP_POOL_AVG_INCL : SABER_HIP_POOL_AVG_EXCL);
         saber_hip_conv2d_out_shape(_op, &_ch, &_cw);
@@ -199,7 +250,7 @@ private:
     void* _ws;
     bool _fused;
     int _type, _ch, _cw, _kh, _kw, _sh, _sw, _ph, _pw;
-    Tensor<TargetType> _inner;
+    Tensor<TargetType> _inner, _wst;
 };
 
 // Fc<MI355X, OpDtype> (saber/funcs/fc.h:48-127)
@@ -231,12 +282,18 @@ public:
         if (rc) return mi355x_status(rc);
         const Tensor<TargetType>* w = param.weights;
         const Tensor<TargetType>* b = param.bias;
-        rc = saber_hip_fc_set_weights(_op, w->data(), mi355x_dtype(w->get_dtype()),
-                                      w->get_scale().size() ? w->get_scale().data() : nullptr,
-                                      (b && b->valid_size() > 0) ? (const float*)b->data() : nullptr,
+        std::vector<char> wbuf, bbuf;
+        const void* wh = mi355x_host_view(*w, wbuf);
+        const void* bh = (b && b->valid_size() > 0) ? mi355x_host_view(*b, bbuf) : nullptr;
+        rc = saber_hip_fc_set_weights(_op, wh, mi355x_dtype(w->get_dtype()),
+                                      w->get_scale().size() ? w->get_scale().data() : nullptr, (const float*)bh,
                                       inputs[0]->get_scale().size() ? inputs[0]->get_scale()[0] : 1.f,
                                       outputs[0]->get_scale().size() ? outputs[0]->get_scale()[0] : 1.f);
-        return mi355x_status(rc);
+        if (rc) return mi355x_status(rc);
+        const size_t ws_bytes = saber_hip_fc_workspace_bytes(_op);   // an f32 input of an INT8 fc is quantised into it
+        if (ws_bytes) _wst.re_alloc(Shape({1, 1, 1, (int)ws_bytes}, Layout_NCHW), AK_INT8);
+        _ws = ws_bytes ? _wst.mutable_data() : nullptr;
+        return SaberSuccess;
     }
     virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs,
                                  std::vector<Tensor<TargetType>*>& outputs, FcParam<TargetType>& param) {
@@ -247,6 +304,7 @@ public:
 private:
     saber_hip_fc_t* _op;
     void* _ws;
+    Tensor<TargetType> _wst;
 };
 
 // Gemm<MI355X, SABER_IMPL, float, float> (saber/funcs/gemm.h:27-66): raw row-major pointers

@@ -25,3 +25,29 @@ def test_cpp_test_binary_is_built():
     from anakin_amd import build as B
     B.build_cpp_tests()
     assert os.path.exists(BIN)
+
+
+MI355X_BIN = os.path.join(ROOT, "integration", "_build", "test_saber_conv_mi355x.bin")
+
+
+@pytest.mark.gpu
+def test_mi355x_target_inside_the_reference_operator_stack():
+    """The MI355X target executed by the reference's OWN Saber code (b, f-4 saber half):
+    integration/test_saber_conv_mi355x.cpp is compiled against a patched copy of /root/reference/saber
+    (integration/apply_mi355x_target.py: eMI355X, TargetWrapper<MI355X> on HIP, Device / Env / Context, SaberTimer,
+    the Conv facade ladder) and drives Conv<MI355X,AK_INT8>::init -> BaseFunc::operator() (incl. the shape-change
+    re-create path, base.h:151-161) -> SaberConv2D<MI355X> -> integration/saber_mi355x_adaptor.h -> the C ABI;
+    every output byte equals the oracle's."""
+    assert os.path.exists(MI355X_BIN), "integration/_build/test_saber_conv_mi355x.bin is missing: run __graft_entry__.build()"
+    p = subprocess.run([MI355X_BIN], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 failed" in p.stdout and "bit-exact" in p.stdout and "SaberTimer<MI355X>" in p.stdout
+
+
+def test_mi355x_target_test_binary_is_built():
+    """CPU-side: where the reference tree is available, the patched Saber tree + test build (g++ against the reference's
+    headers, linked to the HIP library); elsewhere the prebuilt binary must be present."""
+    script = os.path.join(ROOT, "integration", "build_mi355x_test.sh")
+    if os.path.isdir("/root/reference/saber"):
+        subprocess.check_call(["bash", script])
+    assert os.path.exists(MI355X_BIN)

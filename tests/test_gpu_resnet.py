@@ -62,6 +62,73 @@ def test_resnet50_int8_every_edge_bit_exact(setup, fuse):
     assert np.array_equal(_h(net.tensor("fc1000")), logits)
 
 
+FP32_RTOL = 1e-4   # BASELINE.json north_star: FP32 "within 1e-4 rel"
+
+
+def _fp32_every_edge(model_name, batch):
+    """FP32 op list at BASELINE.json's full input size: EVERY logical edge is compared with the oracle right after the op
+    that produces it (later in-place residual sums reuse the buffers), with two criteria:
+      max-norm      max|got - ref| / max|ref|                         <= 1e-4   (tensor_cmp_host style)
+      element-wise  max over elements |got - ref| / (|ref| + mean|ref|) <= 1e-4   (relative, with the tensor's mean
+                    magnitude as the absolute floor: outputs that cancel to ~0 have no meaningful relative error)
+    Returns the worst of each for the assertion message."""
+    model = W.build_model(model_name)
+    x = W.make_input(batch, hw=224)
+    ref = NO.run_fp32(model, x)
+    net = W.build_fp32_net(model, batch, hw=224)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    done, worst_max, worst_el, checked = -1, 0.0, 0.0, 0
+    for idx, name in net.produced:
+        while done < idx:
+            done += 1
+            net.run_op(done)
+        got = _h(net.tensor(net.alias.get(name, name)))
+        want = ref[name]
+        got = got.transpose(0, 3, 1, 2) if got.ndim == 4 else got.reshape(want.reshape(got.shape[0], -1).shape)
+        want = want.reshape(got.shape)
+        d = np.abs(got - want)
+        e_max = float(d.max() / np.abs(want).max())
+        e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+        assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (model_name, name, e_max, e_el)
+        worst_max, worst_el, checked = max(worst_max, e_max), max(worst_el, e_el), checked + 1
+    assert done == net.num_ops() - 1
+    return checked, worst_max, worst_el
+
+
+def test_resnet50_fp32_batch2_full_size_every_edge():
+    """BASELINE.json config 2 at its stated size (224x224), batch 2: 53 convs (16 with the fused in-place residual sum),
+    2 pools, fc, softmax - every edge within 1e-4."""
+    checked, worst_max, worst_el = _fp32_every_edge("resnet50", 2)
+    assert checked >= 56, checked
+
+
+def test_vgg16_fp32_full_size_every_edge_to_the_logits():
+    """BASELINE.json config 4 (VGG16 FP32) at 224x224, batch 1: all 13 convs, 5 max pools, 3 fc (with the NCHW-flatten
+    weight reorder) and the softmax against the oracle's full forward."""
+    checked, worst_max, worst_el = _fp32_every_edge("vgg16", 1)
+    assert checked >= 22, checked
+
+
+def test_resnet101_int8_full_size_every_edge_bit_exact():
+    """BASELINE.json config 4 (ResNet101 INT8) at 224x224, batch 1: every edge the fused op list materialises (70+: all
+    branch2a / 2b outputs, the 33 block outputs, pools, logits) bit-identical to the oracle's unfused op list."""
+    model = W.build_model("resnet101")
+    x = W.make_input(1, hw=224)
+    scales = W.calibrate(model, x)
+    ref = NO.run_int8(model, scales, x)
+    net = W.build_int8_net(model, dict(scales), 1)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    checked = 0
+    for name in net.tensors:
+        if name in ref and name not in ("data", "prob"):
+            got, want = _h(net.tensor(name)), ref[name]
+            assert np.array_equal(got, want.reshape(got.shape)), name
+            checked += 1
+    assert checked >= 70, checked
+    assert "fc1000" in net.tensors and "res4b22" in net.tensors and "res5c" in net.tensors
+
+
 def test_resnet50_fp32_within_tolerance():
     model = W.build_model("resnet50")
     x = W.make_input(1, hw=64)
