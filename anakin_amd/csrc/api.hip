@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <type_traits>
 #include <vector>
 
@@ -106,6 +107,7 @@ struct saber_hip_conv {
     bool weights_set = false;
     std::vector<int8_t> wq_oihw;
     std::vector<float> w_scale;
+    std::vector<float> bias_host;   // the op's f32 bias as handed to set_weights (saber_hip_net_optimize re-creates ops from it)
     DevBuf<uint8_t> d_w;
     DevBuf<float> d_bias, d_scale;
     DevBuf<int> d_comp;
@@ -402,6 +404,8 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
     op->in_scale = in_scale;
     op->out_scale = out_scale;
     op->has_bias = bias != nullptr;
+    if (bias) op->bias_host.assign(bias, bias + K);
+    else op->bias_host.clear();
     const int K_pad = round_up(K, 128);
     if (op->is_i8) {
         // ---- weights: quantise (if f32) exactly as scale_conv_weights_to_nchw_host -------------
@@ -1184,6 +1188,7 @@ struct saber_hip_net {
     std::vector<hipEvent_t> ev_op;     // one per op that needs to publish its output to the other lane
     std::vector<int> writer;           // tensor id -> index of the op that last wrote it (-1: external)
     bool lanes_ready = false, has_side = false;
+    std::vector<saber_hip_conv*> owned;   // ops created by saber_hip_net_optimize (destroyed with the net)
 };
 
 static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
@@ -1347,6 +1352,179 @@ int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_i
     o.kind = OP_SOFTMAX; o.in = in_id; o.out = out_id; o.name = "softmax_f32";
     o.p[0] = rows; o.p[1] = cols;
     return push(net, std::move(o));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Executor-level fusions, host side C++ (north star: "host side stays C++"): the reference's graph optimiser rewrites
+// the operator graph before Net::init (framework/graph/llvm/fusion/fusion_op_register.cpp:45-175 is its pattern
+// catalogue: Conv+Eltwise, Conv+Pooling, ...); this is the same step for an op list handed to the MI355X executor
+// UNFUSED (one op per reference operator). Every rewrite keeps the bytes of every surviving edge identical:
+//   1  conv (-> s8, single consumer) + INT8 eltwise sum        -> one conv with the RES_ELTWISE epilogue
+//   2  two convs over the same tensor with the same geometry   -> one sibling-pair launch (saber_hip_conv2d_create_pair)
+//   4  conv + max pooling (single consumer)                    -> SaberConv2DPooling where a fused kernel exists
+//   8  global pooling feeding an INT8 fc that quantises on entry -> the pooling also writes the fc's s8 operand
+// New ops are re-created from the originals' quantised weights / scales / bias and owned by the net. Call before
+// saber_hip_net_finalize. Returns the number of launches removed, or a negative status.
+// ------------------------------------------------------------------------------------------------
+static int clone_conv_i8(const saber_hip_conv* src, const saber_hip_conv_desc& d, saber_hip_conv** out) {
+    int rc = saber_hip_conv2d_create(&d, out);
+    if (rc) return rc;
+    rc = saber_hip_conv2d_set_weights(*out, src->wq_oihw.data(), SABER_HIP_S8, src->w_scale.data(),
+                                      src->has_bias ? src->bias_host.data() : nullptr, src->in_scale, src->out_scale);
+    if (rc) {
+        saber_hip_conv2d_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
+    if (!net) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (net->finalized) return fail(SABER_HIP_INVALID_VALUE, "optimize must run before finalize");
+    std::vector<NetOp>& ops = net->ops;
+    const int nt = (int)net->tensor_bytes.size();
+    std::vector<char> dead(ops.size(), 0);
+    int removed = 0;
+    auto consumers = [&](int t) {
+        int c = 0;
+        for (size_t i = 0; i < ops.size(); ++i)
+            if (!dead[i]) c += (ops[i].in == t) + (ops[i].in2 == t);
+        return c;
+    };
+    auto producer = [&](int t, int before) {   // last live op before `before` that writes tensor t
+        for (int i = before - 1; i >= 0; --i)
+            if (!dead[i] && (ops[i].out == t || ops[i].out2 == t)) return i;
+        return -1;
+    };
+    auto plain_i8_conv = [&](const NetOp& o) {
+        return o.kind == OP_CONV && o.conv && o.conv->is_i8 && o.conv->weights_set && o.conv->epi == EPI_I8_CONV &&
+               o.conv->d.res_mode == SABER_HIP_RES_NONE && !o.conv->pair_k2 && !o.conv->pool_fused && o.lane == 0;
+    };
+    // ---- 1: conv + eltwise -----------------------------------------------------------------------------------
+    if (flags & 1) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (dead[i] || ops[i].kind != OP_ELT_I8) continue;
+            NetOp& e = ops[i];
+            for (int side = 0; side < 2; ++side) {
+                const int tc = side == 0 ? e.in : e.in2, tr = side == 0 ? e.in2 : e.in;   // conv-side / residual-side tensors
+                const float s_conv = e.f[side], s_res = e.f[1 - side], c_conv = e.f[2 + side], c_res = e.f[3 - side];
+                const int p = producer(tc, (int)i);
+                if (p < 0 || !plain_i8_conv(ops[p]) || consumers(tc) != 1 || tc == tr) continue;
+                const saber_hip_conv* src = ops[p].conv;
+                if (src->d.out_dtype != SABER_HIP_S8 || src->out_scale != s_conv) continue;
+                if (net->tensor_bytes[tc] != net->tensor_bytes[e.out] || e.count != net->tensor_bytes[tc]) continue;
+                const int pr = producer(tr, (int)i);
+                if (pr >= p) continue;   // the residual must exist when the conv runs (external tensors: pr == -1)
+                saber_hip_conv_desc d = src->d;
+                d.res_mode = SABER_HIP_RES_ELTWISE;
+                d.res_act = e.p[0] ? SABER_HIP_ACT_RELU : SABER_HIP_ACT_NONE;
+                d.coeff_conv = c_conv; d.coeff_res = c_res; d.scale_res = s_res;
+                saber_hip_conv* fused = nullptr;
+                int rc = clone_conv_i8(src, d, &fused);
+                if (rc) return rc;
+                net->owned.push_back(fused);
+                ops[p].conv = fused;
+                ops[p].in2 = tr;
+                ops[p].out = e.out;
+                ops[p].name = std::string("conv:") + fused->algo_name;
+                dead[i] = 1;
+                net->tensor_bytes[tc] = 0;   // the conv's own output edge no longer exists
+                ++removed;
+                break;
+            }
+        }
+    }
+    // ---- 4: conv + max pooling ----------------------------------------------------------------------------------
+    if (flags & 4) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (dead[i] || ops[i].kind != OP_POOL_I8) continue;
+            NetOp& q = ops[i];
+            const int p = producer(q.in, (int)i);
+            if (p < 0 || !plain_i8_conv(ops[p]) || consumers(q.in) != 1) continue;
+            const saber_hip_conv* src = ops[p].conv;
+            saber_hip_conv* fused = nullptr;
+            int rc = clone_conv_i8(src, src->d, &fused);
+            if (rc) return rc;
+            // p[] = n,h,w,c,oh,ow,kh,kw,sh,sw,ph,pw,type,in_dtype,out_dtype (saber_hip_net_add_pool_i8)
+            const int floor_mode = saber_hip_pool_out_dim(q.p[1], q.p[10], q.p[6], q.p[8], 0) == q.p[4] ? 0 : 1;
+            rc = saber_hip_conv2d_set_pooling(fused, q.p[12], q.p[6], q.p[7], q.p[8], q.p[9], q.p[10], q.p[11], floor_mode);
+            int oh = 0, ow = 0;
+            if (rc == SABER_HIP_OK) saber_hip_conv2d_out_shape(fused, &oh, &ow);
+            if (rc != SABER_HIP_OK || oh != q.p[4] || ow != q.p[5] || q.p[13] != q.p[14]) {   // no fused kernel: keep the two ops
+                saber_hip_conv2d_destroy(fused);
+                continue;
+            }
+            net->owned.push_back(fused);
+            ops[p].conv = fused;
+            const int dead_t = ops[p].out;
+            ops[p].out = q.out;
+            ops[p].name = std::string("conv:") + fused->algo_name;
+            dead[i] = 1;
+            net->tensor_bytes[dead_t] = 0;
+            ++removed;
+        }
+    }
+    // ---- 2: sibling pairs -------------------------------------------------------------------------------------
+    if (flags & 2) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (dead[i] || !plain_i8_conv(ops[i])) continue;
+            for (size_t j = i + 1; j < ops.size(); ++j) {
+                if (dead[j]) continue;
+                if (ops[j].out == ops[i].in || ops[j].out2 == ops[i].in) break;   // the shared input is rewritten: stop
+                if (!plain_i8_conv(ops[j]) || ops[j].in != ops[i].in) continue;
+                saber_hip_conv* pair = nullptr;
+                bool swapped = false;
+                if (saber_hip_conv2d_create_pair(ops[i].conv, ops[j].conv, &pair) != SABER_HIP_OK) {
+                    // the first rows must be a multiple of the largest block tile: try the other order
+                    if (saber_hip_conv2d_create_pair(ops[j].conv, ops[i].conv, &pair) != SABER_HIP_OK) continue;
+                    swapped = true;
+                }
+                // hoisting op j to position i is safe: it only reads the shared input, and nothing between reads its output
+                // before j (a consumer of j's output cannot precede j in a valid list)
+                net->owned.push_back(pair);
+                ops[i].kind = OP_CONV_PAIR;
+                ops[i].conv = pair;
+                ops[i].out2 = ops[j].out;
+                if (swapped) std::swap(ops[i].out, ops[i].out2);
+                ops[i].name = std::string("conv:") + pair->algo_name;
+                dead[j] = 1;
+                ++removed;
+                break;
+            }
+        }
+    }
+    // ---- 8: global pooling writes the fc's quantised operand ---------------------------------------------------------
+    if (flags & 8) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (dead[i] || ops[i].kind != OP_FC || !ops[i].fc->pre_quant) continue;
+            const int p = producer(ops[i].in, (int)i);
+            if (p < 0 || ops[p].kind != OP_POOL_F32_I8 || ops[p].out2 >= 0) continue;
+            const saber_hip_fc* fc = ops[i].fc;
+            // the pooled tensor must be exactly the fc's [m, k] operand
+            if ((size_t)ops[p].p[0] * ops[p].p[3] * ops[p].p[4] * ops[p].p[5] != (size_t)fc->d.m * fc->d.k) continue;
+            const int qt = saber_hip_net_add_tensor(net, (size_t)fc->d.m * fc->d.k);
+            ops[p].out2 = qt;
+            ops[p].f[1] = fc->in_scale;
+            ops[p].name = "pool2d_f32_from_i8+quantize";
+            ops[i].kind = OP_FC_Q;
+            ops[i].in = qt;
+            ++removed;   // the fc's quantise-on-entry kernel
+        }
+    }
+    (void)nt;
+    std::vector<NetOp> live;
+    for (size_t i = 0; i < ops.size(); ++i)
+        if (!dead[i]) live.push_back(std::move(ops[i]));
+    ops.swap(live);
+    // the shared workspace only has to cover the surviving ops
+    net->ws_bytes = 0;
+    for (const NetOp& o : ops) {
+        size_t w = 0;
+        if ((o.kind == OP_CONV) && o.conv) w = o.conv->ws_bytes;
+        if (o.kind == OP_FC && o.fc) w = saber_hip_fc_workspace_bytes(o.fc);
+        if (w > net->ws_bytes) net->ws_bytes = w;
+    }
+    return removed;
 }
 
 int saber_hip_net_finalize(saber_hip_net_t* net) {
@@ -1525,6 +1703,7 @@ void saber_hip_net_destroy(saber_hip_net_t* net) {
     if (net->exec) (void)hipGraphExecDestroy(net->exec);
     if (net->graph) (void)hipGraphDestroy(net->graph);
     if (net->arena) (void)hipFree(net->arena);
+    for (saber_hip_conv* c : net->owned) saber_hip_conv2d_destroy(c);
     for (hipEvent_t e : net->ev_op)
         if (e) (void)hipEventDestroy(e);
     if (net->ev_start) (void)hipEventDestroy(net->ev_start);

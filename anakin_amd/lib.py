@@ -33,7 +33,7 @@ SYMBOLS = [
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
-    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q",
+    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
@@ -107,6 +107,7 @@ def load():
     lib.saber_hip_fc_workspace_bytes.restype = Z
     lib.saber_hip_fc_run.argtypes = [P, P, P, P, P]
     lib.saber_hip_fc_destroy.argtypes = [P]
+    lib.saber_hip_net_optimize.argtypes = [P, I]
     lib.saber_hip_fc_algo.argtypes = [P]
     lib.saber_hip_fc_algo.restype = C.c_char_p
     lib.saber_hip_fc_set_tile.argtypes = [P, I]

@@ -520,6 +520,14 @@ class Net:
     def set_lane(self, op_index, lane):
         L.check(L.load().saber_hip_net_set_lane(self.h, op_index, lane))
 
+    def optimize(self, flags=15):
+        """Executor-level fusions in C++ (saber_hip_net_optimize) on an op list added unfused; before finalize().
+        Returns the number of launches removed."""
+        rc = L.load().saber_hip_net_optimize(self.h, int(flags))
+        if rc < 0:
+            L.check(rc)
+        return rc
+
     def finalize(self):
         L.check(L.load().saber_hip_net_finalize(self.h))
         self.finalized = True

@@ -175,7 +175,8 @@ def _out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None):
+def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
+                   cxx_optimize=False):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
@@ -188,6 +189,10 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     edge then does not exist."""
     from . import lib as L
     from . import saber as S
+    if cxx_optimize:
+        # the reference op list one to one; the fusions below are then found by the C++ host side
+        # (saber_hip_net_optimize), not by this builder
+        fuse_eltwise, pair_siblings, fuse_tail, fuse_pool, lanes = False, False, False, False, False
     net = S.Net()
     B = batch
     net.add_tensor("data", (B, 3, hw, hw), F32)
@@ -306,6 +311,9 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
         elif kd == "softmax":
             net.add_tensor(nm, (B, 1000), F32)
             net.add_softmax(B, 1000, l["src"], nm)
+    if cxx_optimize:
+        net.unfused_ops = net.num_ops()
+        net.removed = net.optimize(15)
     net.finalize()
     return net
 

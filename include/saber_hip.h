@@ -277,6 +277,12 @@ int saber_hip_net_add_pool_f32_from_i8_q(saber_hip_net_t* net, int n, int h, int
                                          int stride_h, int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype,
                                          float scale, int in_id, int out_id, float q_scale, int q_out_id);
 int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id, int out_id);
+/* Executor-level fusions on an op list added UNFUSED (one op per reference operator), before finalize: the counterpart
+ * of the reference's graph optimiser (framework/graph/llvm/fusion/fusion_op_register.cpp:45-175) for this executor.
+ * flags: 1 conv + INT8 eltwise -> fused epilogue, 2 sibling convs -> one pair launch, 4 conv + max pooling ->
+ * SaberConv2DPooling where a fused kernel exists, 8 global pooling also writes the INT8 fc's quantised operand;
+ * 15 = all. Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
+int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
 /* Lane of an op (graph::Lane, framework/core/net/operator_func.h:103-114; ParallScheduler): 0 = the caller's
  * stream, 1 = the net's side stream. Cross-lane tensor dependencies are ordered with events automatically and

@@ -196,3 +196,26 @@ def test_resnet50_int8_batch_invariance_full_size(setup):
         net1.tensor("data").copy_(torch.from_numpy(x8[i:i + 1]).cuda())
         net1.run()
         assert np.array_equal(_h(net1.tensor("fc1000"))[0], l8[i]), i
+
+
+def test_cxx_net_optimize_equals_python_fused_list(setup):
+    """saber_hip_net_optimize (C++ host side) on the reference op list handed over UNFUSED finds the same fusions the
+    Python list builder applies (16 conv+eltwise, 4 sibling pairs, conv1+pool1, pool5 -> fc quantisation): 73 ops -> 52
+    launches, and every surviving edge + the logits are bit-identical to the Python-fused list's and to the oracle's."""
+    model, x, scales, ref = setup
+    a = W.build_int8_net(model, dict(scales), 2)                       # fused by workloads.py
+    b = W.build_int8_net(model, dict(scales), 2, cxx_optimize=True)    # unfused list + saber_hip_net_optimize
+    assert b.unfused_ops == 73 and b.removed == 22 and b.num_ops() == a.num_ops() == 52, (b.unfused_ops, b.removed, b.num_ops())
+    assert [a.op_name(i) for i in range(52)] == [b.op_name(i) for i in range(52)]
+    for net in (a, b):
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+    checked = 0
+    for name in a.tensors:
+        if name in b.tensors and name != "data":
+            ga, gb = _h(a.tensor(name)), _h(b.tensor(name))
+            assert np.array_equal(ga, gb), name
+            if name in ref and name != "prob":
+                assert np.array_equal(ga, ref[name].reshape(ga.shape)), name
+            checked += 1
+    assert checked >= 39, checked
