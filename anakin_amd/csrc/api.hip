@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <type_traits>
@@ -63,18 +64,30 @@ struct DevBuf {
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e != hipSuccess) return e;
         n = count;
-        return hipMemset(p, 0, count * sizeof(T));
+        e = hipMemset(p, 0, count * sizeof(T));
+        return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
     }
 };
 
-// 256 zero bytes in device memory, shared by every op (padded taps of the LDS-DMA kernels)
+// 256 zero bytes in device memory per device, shared by every op created on it (padded taps of the LDS-DMA kernels).
+// One page per device (an op on a second GPU must not DMA from the first one's memory), created under a lock, and
+// the memset is complete before any kernel on a non-blocking stream can read it.
 void* zero_page() {
-    static void* p = nullptr;
-    if (!p) {
+    static std::mutex mu;
+    static void* pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pages[dev]) {
+        void* p = nullptr;
         if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(p, 0, 256);
+        if (hipMemset(p, 0, 256) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        pages[dev] = p;
     }
-    return p;
+    return pages[dev];
 }
 
 enum Algo { ALGO_IGEMM_I8 = 0, ALGO_IGEMM_I8_C4 = 1, ALGO_IGEMM_F32 = 2, ALGO_DIRECT_I8 = 3, ALGO_DIRECT_F32 = 4 };
@@ -90,6 +103,7 @@ struct saber_hip_conv {
     int dma = 0;             // 0: register-staged kernel; 1/2/4: LDS-DMA ring kernel with that many wave groups
     int stem = 0;            // 1: LDS-patch stem kernel (conv_stem.h) instead of the NHWC4 implicit GEMM
     int pool_fused = 0, pool_oh = 0, pool_ow = 0;   // SaberConv2DPooling: fused stem conv + 3x3/2 max pooling
+    int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
     int img_ib = 0, img_rb = 0, img_nw = 4;   // img_rb > 0: small-image 3x3 kernel (conv3x3_img.h): images / output rows
@@ -128,11 +142,12 @@ extern "C" {
 
 const char* saber_hip_last_error(void) { return g_err.c_str(); }
 
-int saber_hip_device_ok(void) {
-    int n = 0;
+int saber_hip_device_ok(void) {   // the CURRENT device of the calling thread must be a gfx950
+    int n = 0, dev = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
     return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
@@ -166,8 +181,7 @@ static bool halo_ok(const saber_hip_conv* op) {
 namespace { bool fc_small_ok(const saber_hip_conv* op); }
 
 static bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb) {
-    return halo_ok(op) && !op->pair_k2 && op->d.res_mode != SABER_HIP_RES_SUM_INPLACE &&
-           conv3x3_img_feasible(op->c_eff, op->ow, op->oh, op->d.n, nw, ib, rb);
+    return halo_ok(op) && !op->pair_k2 && conv3x3_img_feasible(op->c_eff, op->ow, op->oh, op->d.n, nw, ib, rb);
 }
 
 static bool stem_ok(const saber_hip_conv* op) {
@@ -187,8 +201,9 @@ static void name_algo(saber_hip_conv* op) {
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
-        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s", an[op->algo], bmk, bnp, op->ks,
-                 op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")));
+        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s", an[op->algo], bmk, bnp, op->ks,
+                 op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")),
+                 op->pool2 ? "+maxpool2x2" : "");
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
     op->algo_name = std::string(op->pair_k2 ? "pair_" : "") + buf;
 }
@@ -303,14 +318,25 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
 }
 
 void saber_hip_conv2d_out_shape(const saber_hip_conv_t* op, int* oh, int* ow) {
-    if (oh) *oh = op->pool_fused ? op->pool_oh : op->oh;
-    if (ow) *ow = op->pool_fused ? op->pool_ow : op->ow;
+    if (oh) *oh = (op->pool_fused || op->pool2) ? op->pool_oh : op->oh;
+    if (ow) *ow = (op->pool_fused || op->pool2) ? op->pool_ow : op->ow;
 }
 
 int saber_hip_conv2d_set_pooling(saber_hip_conv_t* op, int pool_type, int kh, int kw, int stride_h, int stride_w,
                                  int pad_h, int pad_w, int floor_mode) {
     if (!op) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const saber_hip_conv_desc& d = op->d;
+    // FP32: any implicit-GEMM conv with relu + 2x2 / stride-2 / unpadded max pooling over even output dims (VGG16's five
+    // conv+relu+pool stages): pool-ordered GEMM columns, maximum taken in the epilogue (conv_igemm_impl.h)
+    if (!op->is_i8 && op->algo == ALGO_IGEMM_F32 && pool_type == SABER_HIP_POOL_MAX && kh == 2 && kw == 2 && stride_h == 2 &&
+        stride_w == 2 && pad_h == 0 && pad_w == 0 && d.res_mode == SABER_HIP_RES_NONE && d.act == SABER_HIP_ACT_RELU &&
+        d.out_layout == SABER_HIP_NHWC && !op->pair_k2 && op->oh % 2 == 0 && op->ow % 2 == 0) {
+        op->pool_oh = op->oh / 2;
+        op->pool_ow = op->ow / 2;
+        op->pool2 = 1;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
     const bool fusable = stem_ok(op) && pool_type == SABER_HIP_POOL_MAX && kh == 3 && kw == 3 && stride_h == 2 &&
                          stride_w == 2 && pad_h == 0 && pad_w == 0 && d.res_mode == SABER_HIP_RES_NONE &&
                          (d.out_dtype == SABER_HIP_S8 || d.out_dtype == SABER_HIP_U8);
@@ -389,6 +415,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
     if (op->fc_small) return 10 << 16;
+    if (op->stem) return 7 << 16;
     if (op->img_rb) return op->img_rb | ((op->img_ib | (op->img_nw == 8 ? 0x80 : 0)) << 8) | (9 << 16);
     if (op->halo) return op->tile | (op->ks << 8) | ((op->halo == 4 ? 5 : 6) << 16);
     const int var = op->dma == 0 ? 1 : (op->dma == 1 ? 2 : (op->dma == 2 ? 3 : 4));
@@ -554,6 +581,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.sum_scale = d.sum_scale;
     a.coeff_conv = d.coeff_conv; a.coeff_res = d.coeff_res;
     a.scale_conv = op->out_scale; a.scale_res = d.scale_res;
+    if (op->pool2) { a.pool_oh = op->pool_oh; a.pool_ow = op->pool_ow; }
     a.y2 = y2;
     a.K1 = op->pair_k1; a.K2 = op->pair_k2; a.relu2 = op->pair_relu2; a.out_dtype2 = op->pair_dtype2;
     if (!op->is_i8 && d.res_mode == SABER_HIP_RES_SUM_INPLACE) {
@@ -766,7 +794,7 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
     if (!a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const saber_hip_conv_desc &da = a->d, &db = b->d;
     auto plain = [](const saber_hip_conv* o) {
-        if (!o->weights_set || o->d.res_mode != SABER_HIP_RES_NONE || o->pair_k2 || o->pool_fused) return false;
+        if (!o->weights_set || o->d.res_mode != SABER_HIP_RES_NONE || o->pair_k2 || o->pool_fused || o->pool2) return false;
         if (o->is_i8)
             return o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && !o->pre_quant && !o->pre_pad &&
                    (o->d.out_dtype == SABER_HIP_S8 || o->d.out_dtype == SABER_HIP_U8);
@@ -840,11 +868,10 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
                                    int iters) {
     if (!op || !op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "not a sibling pair");
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    EventPair ev;
+    HIP_TRY(ev.init());
     float best = 1e30f;
-    int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;
+    int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;   // the entry selection stays if nothing runs
     const int ks_list[3] = {1, 2, 4};
     const int dma_list[4] = {0, 1, 2, 4};
     for (int vi = 0; vi < 4; ++vi)
@@ -854,20 +881,18 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
                 if (dma_list[vi] == 4 && t != TILE_32x32) continue;
                 op->tile = t; op->ks = ks_list[ki]; op->dma = dma_list[vi];
                 int rc = saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
-                if (rc) return rc;
-                HIP_TRY(hipEventRecord(e0, s));
-                for (int i = 0; i < iters; ++i) saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
-                HIP_TRY(hipEventRecord(e1, s));
-                HIP_TRY(hipEventSynchronize(e1));
+                if (rc) continue;   // a variant that does not launch is skipped
                 float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (hipEventRecord(ev.e0, s) != hipSuccess) continue;
+                for (int i = 0; i < iters; ++i) rc |= saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
+                if (rc || hipEventRecord(ev.e1, s) != hipSuccess || hipEventSynchronize(ev.e1) != hipSuccess ||
+                    hipEventElapsedTime(&ms, ev.e0, ev.e1) != hipSuccess)
+                    continue;
                 if (ms < best) { best = ms; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
             }
     op->tile = best_tile; op->ks = best_ks; op->dma = best_dma;
     name_algo(op);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return SABER_HIP_OK;
+    return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);   // both outputs hold the selected kernel's result
 }
 
 void saber_hip_conv2d_destroy(saber_hip_conv_t* op) { delete op; }
@@ -1105,7 +1130,7 @@ int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, floa
     HIP_TRY(launch_eltwise_sum_f32(count, a, b, c0, c1, relu, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
-int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode) {
+int saber_hip_pool_out_dim2(int in, int pad, int window, int stride, int floor_mode, int any_pad) {
     int o;  // Pooling<>::compute_output_shape, saber/funcs/pooling.h:92-121
     if (floor_mode) {
         o = (int)((float)(in + 2 * pad - window) / stride) + 1;
@@ -1113,8 +1138,13 @@ int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mo
     } else {
         o = (int)ceilf((float)(in + 2 * pad - window) / stride) + 1;
     }
-    if (pad > 0 && (o - 1) * stride >= in + pad) --o;
+    // the reference applies the clip to BOTH dimensions whenever pooling_padded(), i.e. pad_h || pad_w
+    // (pooling.h:113-120, saber_funcs_param.h:2141), not per dimension
+    if (any_pad && (o - 1) * stride >= in + pad) --o;
     return o;
+}
+int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode) {
+    return saber_hip_pool_out_dim2(in, pad, window, stride, floor_mode, pad > 0);
 }
 int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
                              int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
@@ -1540,6 +1570,7 @@ int saber_hip_net_finalize(saber_hip_net_t* net) {
     net->arena_bytes = off ? off : 256;
     HIP_TRY(hipMalloc((void**)&net->arena, net->arena_bytes));
     HIP_TRY(hipMemset(net->arena, 0, net->arena_bytes));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // the kernels run on non-blocking streams: not ordered after null-stream work
     net->finalized = true;
     return SABER_HIP_OK;
 }
@@ -1559,14 +1590,23 @@ static int net_prepare_lanes(saber_hip_net* net) {
     net->ev_op.assign(nops, nullptr);
     net->has_side = false;
     std::vector<int> w(net->tensor_bytes.size(), -1);
+    std::vector<std::vector<int>> rd(net->tensor_bytes.size());   // ops that read a tensor since its last write
     for (int i = 0; i < nops; ++i) {
         NetOp& o = net->ops[i];
         if (o.lane) net->has_side = true;
         const int ins[3] = {o.in, o.in2, o.out};   // `out` counts as an input: in-place epilogues read it
         for (int t : ins)
-            if (t >= 0 && w[t] >= 0 && net->ops[w[t]].lane != o.lane) net->ops[w[t]].record = true;
-        w[o.out] = i;
-        if (o.out2 >= 0) w[o.out2] = i;
+            if (t >= 0 && w[t] >= 0 && net->ops[w[t]].lane != o.lane) net->ops[w[t]].record = true;   // RAW / WAW
+        const int outs[2] = {o.out, o.out2};
+        for (int t : outs) {
+            if (t < 0) continue;
+            for (int r : rd[t])
+                if (net->ops[r].lane != o.lane) net->ops[r].record = true;   // WAR: a reader on the other lane must finish first
+            rd[t].clear();
+            w[t] = i;
+        }
+        if (o.in >= 0) rd[o.in].push_back(i);
+        if (o.in2 >= 0) rd[o.in2].push_back(i);
     }
     if (net->has_side) {
         HIP_TRY(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
@@ -1595,6 +1635,7 @@ int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
     HIP_TRY(hipEventRecord(net->ev_start, main_s));
     HIP_TRY(hipStreamWaitEvent(net->side, net->ev_start, 0));
     std::fill(net->writer.begin(), net->writer.end(), -1);
+    std::vector<std::vector<int>> readers(net->tensor_bytes.size());
     bool side_dirty = false;
     for (size_t i = 0; i < net->ops.size(); ++i) {
         const NetOp& o = net->ops[i];
@@ -1605,12 +1646,21 @@ int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
             const int wi = net->writer[t];
             if (wi >= 0 && net->ops[wi].lane != o.lane) HIP_TRY(hipStreamWaitEvent(s, net->ev_op[wi], 0));
         }
+        const int outs[2] = {o.out, o.out2};
+        for (int t : outs) {   // write-after-read across lanes: every reader of the old contents has to be done
+            if (t < 0) continue;
+            for (int r : readers[t])
+                if (net->ops[r].lane != o.lane) HIP_TRY(hipStreamWaitEvent(s, net->ev_op[r], 0));
+            readers[t].clear();
+        }
         rc = net_launch(net, o, s);
         if (rc) return rc;
         if (o.record) HIP_TRY(hipEventRecord(net->ev_op[i], s));
         if (o.lane) side_dirty = true;
         net->writer[o.out] = (int)i;
         if (o.out2 >= 0) net->writer[o.out2] = (int)i;
+        if (o.in >= 0) readers[o.in].push_back((int)i);
+        if (o.in2 >= 0) readers[o.in2].push_back((int)i);
     }
     if (side_dirty) {   // join: required before a capture ends, and so that the caller sees one ordered stream
         HIP_TRY(hipEventRecord(net->ev_join, net->side));
@@ -1621,6 +1671,11 @@ int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
 int saber_hip_net_set_lane(saber_hip_net_t* net, int index, int lane) {
     if (index < 0 || index >= (int)net->ops.size() || lane < 0 || lane > 1) return fail(SABER_HIP_INVALID_VALUE, "bad op index / lane");
     if (net->lanes_ready) return fail(SABER_HIP_INVALID_VALUE, "lanes are fixed after the first run");
+    if (lane) {   // both lanes share the arena's single workspace: an op that uses it stays on the main lane
+        const NetOp& o = net->ops[index];
+        const size_t ws = o.kind == OP_CONV && o.conv ? o.conv->ws_bytes : (o.kind == OP_FC && o.fc ? saber_hip_fc_workspace_bytes(o.fc) : 0);
+        if (ws) return fail(SABER_HIP_INVALID_VALUE, "an op that needs the shared workspace cannot run on the side lane");
+    }
     net->ops[index].lane = lane;
     return SABER_HIP_OK;
 }
@@ -1669,6 +1724,36 @@ int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     (void)hipEventDestroy(e1);
     return SABER_HIP_OK;
 }
+// The kernel selection of op `index` in saber_hip_conv2d_get_tile / set_tile encoding (0 for ops without one): lets a caller
+// carry an autotuned selection from one process to the next (bench.py --tune-cache: every profiling pass runs the SAME
+// kernels).
+static saber_hip_conv* net_op_conv(saber_hip_net* net, int index) {
+    if (index < 0 || index >= (int)net->ops.size()) return nullptr;
+    NetOp& o = net->ops[index];
+    if (o.kind == OP_CONV || o.kind == OP_CONV_PAIR) return o.conv;
+    if (o.kind == OP_FC || o.kind == OP_FC_Q) return o.fc ? o.fc->conv : nullptr;
+    return nullptr;
+}
+int saber_hip_net_get_choice(saber_hip_net_t* net, int index) {
+    saber_hip_conv* c = net_op_conv(net, index);
+    return (c && !c->pool_fused && c->algo <= ALGO_IGEMM_F32) ? saber_hip_conv2d_get_tile(c) : 0;
+}
+int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
+    saber_hip_conv* c = net_op_conv(net, index);
+    if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
+    int rc = saber_hip_conv2d_set_tile(c, choice);
+    if (rc) return rc;
+    NetOp& o = net->ops[index];
+    o.name = std::string(o.kind == OP_FC || o.kind == OP_FC_Q ? "fc:" : "conv:") + c->algo_name;
+    if (net->exec) {
+        (void)hipGraphExecDestroy(net->exec);
+        (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
+    return SABER_HIP_OK;
+}
+
 int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters) {
     if (net->exec) {   // a captured graph holds the OLD kernel selections: drop it, the caller captures again
         (void)hipGraphExecDestroy(net->exec);

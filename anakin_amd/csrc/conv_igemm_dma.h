@@ -103,9 +103,8 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
         const int p = pix_base + r;
         x_ok[it] = (r < BNP) && (p < a.M);
         const int pp = x_ok[it] ? p : 0;
-        int n, rem, oh, ow;
-        fast_divmod(pp, ohw, a.inv_ohw, n, rem);
-        fast_divmod(rem, a.OW, a.inv_ow, oh, ow);
+        int n, oh, ow;
+        pixel_decode(a, pp, n, oh, ow);
         x_base[it] = n * a.H * a.W * a.C;
         x_ih0[it] = oh * a.stride_h - a.pad_h;
         x_iw0[it] = ow * a.stride_w - a.pad_w;
@@ -252,7 +251,8 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             int n = 0, sp = 0;
             if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
-            if (a.K2 > 0) epilogue_f32_pair<NV>(a, v, cp, p, kb);
+            if (a.pool_ow) epilogue_f32_pool2<NV>(a, v, cp, p, kb, lane);
+            else if (a.K2 > 0) epilogue_f32_pair<NV>(a, v, cp, p, kb);
             else epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
         } else {
             int v[NV];

@@ -383,6 +383,55 @@ __device__ __forceinline__ void fast_divmod(int p, int d, float inv, int& q, int
     if (r >= d) { ++q; r -= d; }
 }
 
+// GEMM column p -> output pixel (n, oh, ow). Ordinary convs: row-major over (n, oh, ow). With a fused 2x2 / stride-2 max
+// pooling (a.pool_ow != 0, FP32 kernels) the columns are POOL-ORDERED: p = window * 4 + (dy * 2 + dx), windows row-major
+// over (n, oh / 2, ow / 2) - the four pixels of a pooling window are four adjacent MFMA columns = four adjacent lanes of
+// the epilogue, which takes their maximum with two DPP quad permutes and stores the pooled tensor directly.
+__device__ __forceinline__ void pixel_decode(const ConvKArgs& a, int p, int& n, int& oh, int& ow) {
+    if (a.pool_ow) {
+        const int win = p >> 2, sub = p & 3;
+        int rem, py, px;
+        fast_divmod(win, a.pool_oh * a.pool_ow, a.inv_ohw * 4.f, n, rem);     // 1 / (OH*OW / 4), exact scaling
+        fast_divmod(rem, a.pool_ow, a.inv_ow * 2.f, py, px);
+        oh = 2 * py + (sub >> 1);
+        ow = 2 * px + (sub & 1);
+    } else {
+        int rem;
+        fast_divmod(p, a.OH * a.OW, a.inv_ohw, n, rem);
+        fast_divmod(rem, a.OW, a.inv_ow, oh, ow);
+    }
+}
+
+// SaberConv2DPooling, FP32: conv + bias + relu of NV channels of one pixel, then the maximum over the 2x2 window (this
+// lane and its three quad neighbours; relu'd values, so the order of the max cannot matter) and ONE store of the pooled
+// NHWC element by the quad's first lane. Reference structure: sass conv + relu + pooling (sass_funcs.h:366-427),
+// SaberConv2DPooling<X86,AK_FLOAT> (saber_conv_pooling.cpp:13-57: conv into an inner tensor, then pooling).
+template <int NV>
+__device__ __forceinline__ void epilogue_f32_pool2(const ConvKArgs& a, const float (&acc)[NV], const ChanParams<NV>& cp,
+                                                   int p, int kb, int lane) {
+    float o[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        float d = __fadd_rn(acc[r], cp.bias[r]);
+        d = d > 0.f ? d : 0.f;
+        int t = __float_as_int(d);
+        const float m1 = __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        d = fmaxf(d, m1);
+        t = __float_as_int(d);
+        const float m2 = __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+        o[r] = fmaxf(d, m2);
+    }
+    if ((lane & 3) != 0 || p >= a.M || kb >= a.K) return;
+    float* y = (float*)a.y + (size_t)(p >> 2) * a.K + kb;
+    if ((kb + NV <= a.K) && ((a.K & 3) == 0)) {
+#pragma unroll
+        for (int v = 0; v < NV; v += 4) *(float4*)(y + v) = make_float4(o[v], o[v + 1], o[v + 2], o[v + 3]);
+    } else {
+        for (int r = 0; r < NV; ++r)
+            if (kb + r < a.K) y[r] = o[r];
+    }
+}
+
 // physical 16-byte chunk of logical chunk c in LDS row `row`; CPR = chunks per row (4, 8, 16).
 template <int CPR>
 __device__ __forceinline__ int phys_chunk(int row, int c) {
@@ -442,9 +491,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const int p = pix_base + r;
         x_ok[it] = (r < BNP) && (p < a.M);
         const int pp = x_ok[it] ? p : 0;
-        int n, rem, oh, ow;
-        fast_divmod(pp, ohw, a.inv_ohw, n, rem);
-        fast_divmod(rem, a.OW, a.inv_ow, oh, ow);
+        int n, oh, ow;
+        pixel_decode(a, pp, n, oh, ow);
         x_base[it] = n * a.H * a.W * a.C;
         x_ih0[it] = oh * a.stride_h - a.pad_h;
         x_iw0[it] = ow * a.stride_w - a.pad_w;
@@ -599,7 +647,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             int n = 0, sp = 0;
             if (a.out_nchw || a.res_mode == RES_SUM_INPLACE) fast_divmod(p < a.M ? p : 0, ohw, a.inv_ohw, n, sp);
-            if (a.K2 > 0) epilogue_f32_pair<NV>(a, v, cp, p, kb);
+            if (a.pool_ow) epilogue_f32_pool2<NV>(a, v, cp, p, kb, lane);
+            else if (a.K2 > 0) epilogue_f32_pair<NV>(a, v, cp, p, kb);
             else epilogue_f32<NV>(a, v, cp, p, kb, n, sp);
         } else {
             int v[NV];

@@ -32,8 +32,8 @@ SYMBOLS = [
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
-    "saber_hip_pool_out_dim", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
-    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize",
+    "saber_hip_pool_out_dim", "saber_hip_pool_out_dim2", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
+    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_get_choice", "saber_hip_net_set_choice",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
@@ -108,6 +108,8 @@ def load():
     lib.saber_hip_fc_run.argtypes = [P, P, P, P, P]
     lib.saber_hip_fc_destroy.argtypes = [P]
     lib.saber_hip_net_optimize.argtypes = [P, I]
+    lib.saber_hip_net_get_choice.argtypes = [P, I]
+    lib.saber_hip_net_set_choice.argtypes = [P, I, I]
     lib.saber_hip_fc_algo.argtypes = [P]
     lib.saber_hip_fc_algo.restype = C.c_char_p
     lib.saber_hip_fc_set_tile.argtypes = [P, I]
@@ -177,6 +179,19 @@ def check(rc):
         e = SaberHipError("saber_hip status %d: %s" % (rc, load().saber_hip_last_error().decode()))
         e.status = rc
         raise e
+
+
+def source_sha():
+    """Hash of the kernel + host sources that determine what a forward pass launches (csrc/*, workloads.py): profiles
+    record it, bench.py reports a profile's PMC traffic only while it still matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "csrc", "*"))) + [os.path.join(here, "workloads.py")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def require_device():

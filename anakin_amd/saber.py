@@ -146,14 +146,19 @@ class SaberConv2DPooling:
     otherwise the conv runs into an inner tensor and the pooling is a second launch, exactly the structure of
     SaberConv2DPooling<X86,AK_FLOAT> (saber_conv_pooling.cpp:13-57). Same bytes either way."""
 
-    def __init__(self):
-        self.conv = SaberConv2D(True)
+    def __init__(self, int8=True):
+        self.int8 = int8
+        self.conv = SaberConv2D(int8)
         self.fused = False
         self.inner = None
 
     def init(self, in_shape_nchw, conv_param, pool_type, window, stride, pad, in_dtype, out_dtype, in_scale=1.0,
              out_scale=1.0, floor_mode=False, in_layout=None):
-        self.conv.init(in_shape_nchw, conv_param, in_dtype, out_dtype, in_scale, out_scale, in_layout=in_layout)
+        if self.int8:
+            self.conv.init(in_shape_nchw, conv_param, in_dtype, out_dtype, in_scale, out_scale, in_layout=in_layout)
+        else:   # FP32: NHWC in / out inside an op list
+            self.conv.init(in_shape_nchw, conv_param, L.F32, L.F32, in_layout=L.NHWC if in_layout is None else in_layout,
+                           out_layout=L.NHWC)
         self.pool = (pool_type, tuple(window), tuple(stride), tuple(pad), floor_mode)
         n = in_shape_nchw[0]
         ch, cw = self.conv.out_hw
@@ -187,6 +192,10 @@ class SaberConv2DPooling:
         pt, win, st, pd, _ = self.pool
         d = self.conv.desc
         n, ch, cw, k = self.inner.shape
+        if not self.int8:
+            L.check(L.load().saber_hip_pool2d_f32(n, ch, cw, k, self.out_hw[0], self.out_hw[1], win[0], win[1], st[0], st[1],
+                                                  pd[0], pd[1], pt, L.NHWC, _p(self.inner), _p(y), _stream()))
+            return y
         L.check(L.load().saber_hip_pool2d_i8_nhwc(n, ch, cw, k, self.out_hw[0], self.out_hw[1], win[0], win[1], st[0],
                                                   st[1], pd[0], pd[1], pt, d.out_dtype, d.out_dtype, _p(self.inner),
                                                   _p(y), _stream()))
@@ -572,6 +581,17 @@ class Net:
 
     def autotune(self, iters=5):
         L.check(L.load().saber_hip_net_autotune(self.h, _stream(), iters))
+
+    def choices(self):
+        """The kernel selection of every op (saber_hip_conv2d_get_tile encoding, 0 = none)."""
+        lib = L.load()
+        return [int(lib.saber_hip_net_get_choice(self.h, i)) for i in range(self.num_ops())]
+
+    def set_choices(self, choices):
+        lib = L.load()
+        assert len(choices) == self.num_ops()
+        for i, c in enumerate(choices):
+            L.check(lib.saber_hip_net_set_choice(self.h, i, int(c)))
 
     def time_ops(self, iters=20):
         out = (C.c_float * self.num_ops())()

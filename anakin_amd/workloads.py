@@ -318,7 +318,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     return net
 
 
-def build_fp32_net(model, batch, hw=224, pair_siblings=True):
+def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True):
     """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
     does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132)."""
     from . import lib as L
@@ -335,6 +335,12 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
         return alias.get(n, n)
     spec = model["spec"]
     sib = {}
+    fused_away = set()   # pooling ops emitted as part of a SaberConv2DPooling
+    consumers = {}
+    for e in spec:
+        for key in ("src", "a", "b"):
+            if key in e:
+                consumers[e[key]] = consumers.get(e[key], 0) + 1
     produced = []   # (op index, logical edge name the op has just produced): lets a test check every edge right after its op,
                     # before a later in-place residual sum overwrites the buffer
 
@@ -361,6 +367,22 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
                 alias[el["name"]] = T(el["b"])
                 shape[T(el["b"])] = (ho, l["cout"])
                 continue
+            nxt = spec[li + 1] if li + 1 < len(spec) else None
+            if fuse_pool and nxt is not None and nxt["kind"] == "pool" and nxt["src"] == nm and consumers.get(nm) == 1 and \
+                    nxt["type"] == 0 and l["relu"]:
+                # SaberConv2DPooling: conv + relu + max pooling in ONE launch where the library has a fused kernel (VGG16's
+                # 2x2 / stride-2 stages); the conv's own output edge then does not exist
+                cpool = S.SaberConv2DPooling(int8=False).init((B, cin, hin, hin), p, nxt["type"], (nxt["win"],) * 2,
+                                                                (nxt["stride"],) * 2, (nxt["pad"],) * 2, F32, F32)
+                if cpool.fused:
+                    pn, po = nxt["name"], cpool.out_hw[0]
+                    net.add_tensor(pn, (B, po, po, l["cout"]), F32)
+                    shape[pn] = (po, l["cout"])
+                    net.add_conv(cpool.conv, T(l["src"]), pn)
+                    net.keep.append(cpool)
+                    mark(pn)
+                    fused_away.add(pn)
+                    continue
             conv = S.SaberConv2D(False).init((B, cin, hin, hin), p, F32, F32, in_layout=L.NHWC, out_layout=L.NHWC)
             net.add_tensor(nm, (B, ho, ho, l["cout"]), F32)
             shape[nm] = (ho, l["cout"])
@@ -379,6 +401,8 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True):
             net.add_conv(conv, T(l["src"]), nm)
             mark(nm)
         elif kd == "pool":
+            if nm in fused_away:
+                continue
             hin, c = shape[T(l["src"])]
             ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
             net.add_tensor(nm, (B, ho, ho, c), F32)

@@ -120,8 +120,10 @@ void saber_hip_conv2d_destroy(saber_hip_conv_t* op);
  * Pooling<>::compute_output_shape, pooling.h:92-121) and `run` is one kernel; the bytes equal pooling(conv(x)).
  * Returns SABER_HIP_UNIMPL when no fused kernel covers the combination — the caller then dispatches the conv into an
  * inner tensor and the pooling as a second op, as SaberConv2DPooling<X86,AK_FLOAT> does (saber_conv_pooling.cpp:13-57).
- * Fused today: 7x7 / stride-2 conv with <= 4 input channels (the ResNet stem, optionally quantising its f32 input)
- * + 3x3 / stride-2 / pad-0 max pooling, s8 or u8 output. Call before the first run. */
+ * Fused today: (INT8) 7x7 / stride-2 conv with <= 4 input channels (the ResNet stem, optionally quantising its f32 input)
+ * + 3x3 / stride-2 / pad-0 max pooling, s8 or u8 output; (FP32) any relu'd implicit-GEMM conv with NHWC output and even
+ * output dims + 2x2 / stride-2 / pad-0 max pooling (VGG16's conv+relu+pool stages; reference: sass_funcs.h:366-427,
+ * saber_conv_pooling.cpp). Call before the first run. */
 int saber_hip_conv2d_set_pooling(saber_hip_conv_t* op, int pool_type, int kh, int kw, int stride_h, int stride_w,
                                  int pad_h, int pad_w, int floor_mode);
 /* Debug / parity helpers: copy out the quantised weights (OIHW s8) and their scales. */
@@ -221,6 +223,9 @@ int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, floa
                               int relu, float* y, saber_hip_stream_t stream);
 /* Pooling<>::compute_output_shape (pooling.h:69-130) */
 int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode);
+/* The same for one dimension of a pooling whose OTHER dimension may be padded: the reference clips the last window of
+ * both dimensions whenever pad_h || pad_w (pooling.h:113-120); any_pad = (pad_h > 0 || pad_w > 0). */
+int saber_hip_pool_out_dim2(int in, int pad, int window, int stride, int floor_mode, int any_pad);
 /* NHWC s8/u8 -> s8/u8 (max, avg) or f32 (avg) */
 int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int stride_h,
                              int stride_w, int pad_h, int pad_w, int pool_type, int in_dtype, int out_dtype,
@@ -305,6 +310,10 @@ int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream);
 int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us);
 const char* saber_hip_net_op_name(const saber_hip_net_t* net, int index);
 /* RUNTIME strategy over every conv/fc op of the list (on whatever the edge tensors currently hold). */
+/* Kernel selection of op `index` in the saber_hip_conv2d_get_tile / set_tile encoding (0: the op has none). set applies a
+ * selection taken from get (e.g. in an earlier process: every profiling pass can run the same autotuned kernels). */
+int saber_hip_net_get_choice(saber_hip_net_t* net, int index);
+int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice);
 int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters);
 void saber_hip_net_destroy(saber_hip_net_t* net);
 

@@ -18,6 +18,7 @@
 #include "saber/core/tensor.h"
 #include "saber/core/tensor_op.h"
 #include "saber/funcs/conv.h"
+#include "saber/funcs/conv_eltwise.h"
 #include "saber/funcs/timer.h"
 
 #include <cstdio>
@@ -137,6 +138,44 @@ int main() {
         run_and_check(conv, param, L, 2, 14, 14, ctx, true, "Conv<MI355X,AK_INT8> init + operator()");
         run_and_check(conv, param, L, 3, 9, 11, ctx, false, "  same op, new input shape (BaseFunc re-creates)");
         run_and_check(conv, param, L, 3, 9, 11, ctx, false, "  same op, same shape (dispatch only)");
+    }
+    {   // ConvEltwise<MI355X,AK_INT8>: conv + relu'd in-place sum onto the output tensor, s8 bytes added into a u8 output.
+        // The framework hands the ADDED tensor's scale as ConvParam::beta (+ beta_type); the impl derives
+        // sum_scale = beta * (255/127) / out_scale as the x86 impl does (jit_avx512_core_x8s8s32x_conv.cpp:174-189).
+        Layer L(128, 64, 1, 0, 1, true, AK_UINT8, AK_UINT8, 7);
+        const float added_scale = 0.043f;
+        ConvParam<MI355X> cp(1, 0, 0, 1, 1, 1, 1, &L.dw, &L.db, ActivationParam<MI355X>(Active_relu), 1.f, added_scale);
+        cp.beta_type = AK_INT8;
+        EltwiseParam<MI355X> ep(Eltwise_sum, {1.f, 1.f}, ActivationParam<MI355X>(Active_relu));
+        ConvEltwiseParam<MI355X> param(cp, ep);
+        const int N = 2, H = 14, W = 14;
+        std::mt19937 rng(5);
+        Tensor<X86> hx(Shape({N, H, W, L.C}, Layout_NHWC), AK_UINT8), hp(Shape({N, H, W, L.K}, Layout_NHWC), AK_UINT8);
+        const size_t on = (size_t)N * H * W * L.K;
+        for (size_t i = 0; i < (size_t)N * H * W * L.C; ++i) ((uint8_t*)hx.mutable_data())[i] = (uint8_t)(rng() % 256);
+        std::vector<uint8_t> prev(on), want(on);
+        for (auto& v : prev) v = (uint8_t)(rng() % 256);      // s8 bit patterns sitting in the (u8) output tensor
+        memcpy(hp.mutable_data(), prev.data(), on);
+        Tensor<MI355X> dx(hx.valid_shape(), AK_UINT8), dy(hp.valid_shape(), AK_UINT8);
+        dx.set_scale({L.in_scale}); dy.set_scale({L.out_scale});
+        dx.copy_from(hx); dy.copy_from(hp);
+        std::vector<Tensor<MI355X>*> ins{&dx}, outs{&dy};
+        ConvEltwise<MI355X, AK_INT8> op;
+        SaberStatus st = op.init(ins, outs, param, SPECIFY, SABER_IMPL, ctx);
+        if (st == SaberSuccess) st = op(ins, outs, param, ctx);
+        outs[0]->record_event(ctx.get_compute_stream());
+        outs[0]->sync();
+        Tensor<X86> hy(dy.valid_shape(), AK_UINT8);
+        hy.copy_from(dy);
+        orc_residual_t rp = {1, 1, added_scale * (255.f / 127.f) / L.out_scale, 1 /* s8 */, 1.f, 1.f, 1.f, 1.f};
+        memcpy(want.data(), prev.data(), on);
+        orc_conv_i8(N, H, W, L.C, L.K, 1, 1, 0, 0, 1, 1, 1, 1, 1, 2, 2, 1, hx.data(), L.wq.data(), L.bp.data(), L.sc.data(), &rp,
+                    nullptr, want.data());
+        size_t bad = 0;
+        for (size_t i = 0; i < on; ++i) bad += ((const uint8_t*)hy.data())[i] != want[i];
+        ++g_run;
+        if (st != SaberSuccess || bad) { printf("FAIL ConvEltwise<MI355X,AK_INT8> in-place sum: status %d, %zu bytes differ\n", (int)st, bad); ++g_fail; }
+        else printf("ok   ConvEltwise<MI355X,AK_INT8> conv + in-place sum (s8 added into u8, beta -> sum_scale) bit-exact\n");
     }
     {   // SaberTimer<MI355X>: hipEvents around repeated dispatches on the compute stream
         Layer L(256, 256, 3, 1, 1, true, AK_UINT8, AK_UINT8, 99);

@@ -621,6 +621,34 @@ def test_conv_i8_jit_sum_inplace():
         got, conv = run_conv_i8(x, w, None, None, 0.03, 0.04, O.U8, 1, 1, 1, 1, 1,
                                 res_param=(L.RES_SUM_INPLACE, False, sum_scale, (1.0, 1.0), 1.0), y_init=prev)
         assert np.array_equal(got, want), conv.algo()
+    # the bytes already in y need not have the output's dtype (ConvParam::beta_type): s8 added into a u8 output and u8
+    # into an s8 output, every kernel family that can carry the generic epilogue
+    x3 = rng.integers(0, 256, (2, 14, 14, 64)).astype(np.uint8)
+    w3 = (rng.standard_normal((64, 64, 3, 3)) * 0.06).astype(np.float32)
+    b3 = (rng.standard_normal(64) * 0.4).astype(np.float32)
+    ws3 = O.weight_scales(w3)
+    for odt, rdt, relu in ((O.U8, O.S8, 1), (O.S8, O.U8, 0)):
+        prev = (rng.integers(-128, 128, (2, 14, 14, 64)).astype(np.int8) if rdt == O.S8
+                else rng.integers(0, 256, (2, 14, 14, 64)).astype(np.uint8))
+        bp3, sc3 = O.conv_i8_prepare(ws3, b3, 0.02, 0.05, O.U8, odt)
+        rp = O.Residual(O.RES_JIT_SUM, 0, 0.61, rdt, 0, 0, 0, 0)
+        prev_as_out = prev.view(np.uint8 if odt == O.U8 else np.int8)
+        want = O.conv_i8(x3, O.quant_weights(w3, ws3), bp3, sc3, odt, relu, (1, 1), residual=rp, out_init=prev_as_out)
+        for tile in (None, 2 | (1 << 8) | (1 << 16), 1 | (4 << 8) | (3 << 16), 6 << 16, 7 | (1 << 8) | (9 << 16)):
+            N, H, W_, Cc = x3.shape
+            p = S.ConvParam(w3, b3, 1, (1, 1), (1, 1), (1, 1), bool(relu))
+            p.res_mode, p.res_relu, p.sum_scale, p.res_dtype = L.RES_SUM_INPLACE, False, 0.61, rdt
+            conv = S.SaberConv2D(int8=True).init((N, Cc, H, W_), p, O.U8, odt, 0.02, 0.05)
+            if tile is not None:
+                conv.set_tile(tile)
+            y = conv.new_output()
+            y.copy_(dev(prev_as_out))
+            conv.dispatch(dev(x3), y)
+            assert np.array_equal(host(y), want), (conv.algo(), odt, rdt)
+    with pytest.raises(L.SaberHipError):   # an f32 residual under an 8-bit output has no in-place meaning
+        p = S.ConvParam(w3, b3, 1, (1, 1), (1, 1), (1, 1), True)
+        p.res_mode, p.res_dtype = L.RES_SUM_INPLACE, L.F32
+        S.SaberConv2D(int8=True).init((2, 64, 14, 14), p, O.U8, O.U8, 0.02, 0.05)
 
 
 def test_quant_dequant_golden():
@@ -825,6 +853,44 @@ def test_fc_small_batch_kernel(shape, idt):
     else:
         with pytest.raises(L.SaberHipError):
             fc.set_tile(10 << 16)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 12, 12, 32, 3, 1), (1, 64, 28, 20, 48, 3, 1), (3, 8, 6, 10, 20, 1, 0), (1, 4, 16, 16, 64, 3, 1)])
+def test_conv_f32_fused_relu_maxpool2x2(case):
+    """SaberConv2DPooling, FP32: conv + relu + 2x2 / stride-2 max pooling in one launch (pool-ordered GEMM columns, quad
+    maximum in the epilogue) == the same conv followed by the pooling kernel BIT FOR BIT (same float values, a maximum has
+    no rounding), for every tile / stage depth / staging, and within 1e-4 of the oracle's conv -> pool."""
+    N, C, H, W, K, k, pad = case
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)          # NHWC on the device
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    p = S.ConvParam(w, b, 1, (pad, pad), (1, 1), (1, 1), True)
+    want = O.pool_f32_nchw(O.conv_f32_nchw(x.transpose(0, 3, 1, 2), w, b, True, (pad, pad)), (2, 2), (2, 2), (0, 0), 0)
+    two = S.SaberConv2D(False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    y2 = two.new_output()
+    two.dispatch(dev(x), y2)
+    unfused = host(S.pooling_f32(y2, (2, 2), (2, 2), (0, 0), 0, layout=L.NHWC))
+    for var in (1, 2):
+        for tile in range(len(L.TILES)):
+            for ks in (1, 4):
+                cp = S.SaberConv2DPooling(int8=False).init((N, C, H, W), p, 0, (2, 2), (2, 2), (0, 0), L.F32, L.F32)
+                assert cp.fused and cp.out_hw == (H // 2 if pad or k == 1 else (H - 2) // 2, W // 2 if pad or k == 1 else (W - 2) // 2)
+                cp.conv.set_tile(tile | (ks << 8) | (var << 16))
+                y = cp.new_output()
+                cp.dispatch(dev(x), y)
+                got = host(y)
+                assert cp.algo().endswith("+maxpool2x2"), cp.algo()
+                assert np.array_equal(got, unfused), cp.algo()
+    assert np.abs(got.transpose(0, 3, 1, 2) - want).max() <= FP32_RTOL * np.abs(want).max()
+    # no fused kernel for other pooling geometries or un-relu'd convs: the two-launch structure is used
+    cp = S.SaberConv2DPooling(int8=False).init((N, C, H, W), p, 0, (3, 3), (2, 2), (0, 0), L.F32, L.F32)
+    assert not cp.fused
+    y = cp.new_output()
+    cp.dispatch(dev(x), y)
+    assert np.array_equal(host(y), host(S.pooling_f32(y2, (3, 3), (2, 2), (0, 0), 0, layout=L.NHWC)))
+    p0 = S.ConvParam(w, b, 1, (pad, pad), (1, 1), (1, 1), False)
+    assert not S.SaberConv2DPooling(int8=False).init((N, C, H, W), p0, 0, (2, 2), (2, 2), (0, 0), L.F32, L.F32).fused
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])

@@ -106,7 +106,17 @@ def test_vgg16_fp32_full_size_every_edge_to_the_logits():
     """BASELINE.json config 4 (VGG16 FP32) at 224x224, batch 1: all 13 convs, 5 max pools, 3 fc (with the NCHW-flatten
     weight reorder) and the softmax against the oracle's full forward."""
     checked, worst_max, worst_el = _fp32_every_edge("vgg16", 1)
-    assert checked >= 22, checked
+    assert checked >= 17, checked   # 8 conv edges + 5 fused conv+relu+pool stages (their conv edges do not exist) + 3 fc + prob
+    # the five fused SaberConv2DPooling launches write the same bytes as conv followed by pooling
+    model = W.build_model("vgg16")
+    x = W.make_input(1, hw=224)
+    nets = [W.build_fp32_net(model, 1, hw=224, fuse_pool=f) for f in (True, False)]
+    assert nets[1].num_ops() - nets[0].num_ops() == 5
+    for net in nets:
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+    for name in ("pool1", "pool3", "pool5", "fc8"):
+        assert np.array_equal(_h(nets[0].tensor(name)), _h(nets[1].tensor(name))), name
 
 
 def test_resnet101_int8_full_size_every_edge_bit_exact():
