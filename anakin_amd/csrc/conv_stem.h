@@ -216,6 +216,8 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) 
     __shared__ v4i lds_w[WCH];
     __shared__ unsigned lds_x[IR * ICP];
     __shared__ uint2 lds_c[NG * 16 * 8];       // conv tile [pixel][64 channels], bytes in unsigned order
+    SABER_TL_DECL;
+    SABER_TL(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -245,7 +247,9 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) 
     }
     const int iy0 = cy0 * 2 - a.pad_h, ix0 = cx0 * 2 - a.pad_w;
     const unsigned xmask = a.in_u8 ? 0x80808080u : 0u;
+    SABER_TL(1);
     stage_input_patch<F32IN, IR * ICP, ICP>(a, n, iy0, ix0, xmask, tid, lds_x);
+    SABER_TL(2);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = tid + it * 256;
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) 
             for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
     }
 
+    SABER_TL(3);
     // conv epilogue -> LDS bytes in unsigned order (u8 as is, s8 + 128); positions outside the conv image hold 0,
     // the minimum, so a clipped window ignores them
     const bool u8 = a.out_dtype == DT_U8;
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) 
     }
     __syncthreads();
 
+    SABER_TL(4);
     // 3x3 / stride 2 window maxima: one lane per (pooled pixel, 8 channels)
     const int pp = tid >> 3, cg = tid & 7;
     const int ppy = pp / PW, ppx = pp - ppy * PW;
@@ -344,6 +350,8 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) 
         if (kc + 8 <= a.K) *(uint2*)y = o;
         else for (int t = 0; t < a.K - kc; ++t) y[t] = (uint8_t)((t < 4 ? o.x : o.y) >> (8 * (t & 3)));
     }
+    SABER_TL(5);
+    SABER_TL_FLUSH();
 }
 
 static hipError_t launch_conv_stem_pool_inst(int f32_in, const ConvKArgs& a, hipStream_t s) {

@@ -22,6 +22,7 @@ __device__ unsigned long long* saber_tl_buf = nullptr;
 #include "../../anakin_amd/csrc/igemm_m0_e2.hip"
 #include "../../anakin_amd/csrc/igemm_dma_m0_e1.hip"
 #include "../../anakin_amd/csrc/halo_e1.hip"
+#include "../../anakin_amd/csrc/stem_pool.hip"
 namespace saber_mi355x {
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
     static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
@@ -160,6 +161,18 @@ int main() {
         
         const int blocks = ((g.N + g.ib - 1) / g.ib) * ((g.HW + g.rb - 1) / g.rb) * ((g.K + 15) / 16);
         run(P, g.name, blocks, 7, [&] { launch_img_e1(a, g.nw, g.ib, g.rb, P.st); });
+    }
+    for (int nb : {8, 1}) {   // ---- conv1 7x7/2 + pool1 3x3/2 (f32 NCHW image in, u8 NHWC pooled out)
+        // phases: 0 entry, 1 weights requested, 2 input patch staged (loads + quantise + LDS), 3 MFMAs done, 4 conv tile in LDS, 5 stored
+        ConvKArgs a;
+        memset(&a, 0, sizeof a);
+        a.N = nb; a.H = a.W = 224; a.OH = a.OW = 112; a.C = 4; a.K = 64; a.kh = a.kw = 7; a.pad_h = a.pad_w = 3;
+        a.stride_h = a.stride_w = 2; a.dil_h = a.dil_w = 1; a.kw_pad = 8; a.Kg = 7 * 8 * 4; a.Kg_pad = 256; a.Cin = 3; a.qinv = 50.f;
+        a.M = nb * 112 * 112; a.out_dtype = DT_U8; a.relu = 1; a.epi = EPI_I8_CONV; a.pool_oh = a.pool_ow = 56;
+        a.x = dalloc((size_t)nb * 3 * 224 * 224 * 4, 0); a.w = dalloc(128 * 256, -1); a.zero = zero; a.y = dalloc((size_t)nb * 56 * 56 * 64, 0);
+        a.scale = (const float*)dalloc(2048 * 4, 0); a.bias = (const float*)dalloc(2048 * 4, 0);
+        run(P, nb == 8 ? "stem 7x7/2 + maxpool 3x3/2, f32 image in, batch 8" : "stem 7x7/2 + maxpool 3x3/2, batch 1", nb * 98, 6,
+            [&] { launch_conv_stem_pool(1, a, P.st); });
     }
     // ---- the implicit-GEMM / halo kernels on typical ResNet50 layers (batch 8 and batch 1) -----------------------------
     // phases: 0 entry, 1 gather state set up, 2 first stage in LDS (dma: ring prefetch issued), 3 reduction done, 4 stored
