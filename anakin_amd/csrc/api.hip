@@ -218,6 +218,8 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
     if ((d.act != SABER_HIP_ACT_NONE && d.act != SABER_HIP_ACT_RELU) ||
         (d.res_act != SABER_HIP_ACT_NONE && d.res_act != SABER_HIP_ACT_RELU))
         return fail(SABER_HIP_UNIMPL, "only ReLU is fused into the convolution (as in the x86 INT8 path); other activations are separate ops");
+    if (d.act_negative_slope != 0.f && (d.int8_weights || d.act != SABER_HIP_ACT_RELU))
+        return fail(SABER_HIP_UNIMPL, "negative_slope is honoured by the FP32 convolution with Active_relu only (the x86 INT8 conv clamps to 0)");
     const int oh = conv_out(d.h, d.pad_h, d.kh, d.dil_h, d.stride_h);
     const int ow = conv_out(d.w, d.pad_w, d.kw, d.dil_w, d.stride_w);
     if (oh <= 0 || ow <= 0) return fail(SABER_HIP_INVALID_VALUE, "empty output");
@@ -330,7 +332,7 @@ int saber_hip_conv2d_set_pooling(saber_hip_conv_t* op, int pool_type, int kh, in
     // conv+relu+pool stages): pool-ordered GEMM columns, maximum taken in the epilogue (conv_igemm_impl.h)
     if (!op->is_i8 && op->algo == ALGO_IGEMM_F32 && pool_type == SABER_HIP_POOL_MAX && kh == 2 && kw == 2 && stride_h == 2 &&
         stride_w == 2 && pad_h == 0 && pad_w == 0 && d.res_mode == SABER_HIP_RES_NONE && d.act == SABER_HIP_ACT_RELU &&
-        d.out_layout == SABER_HIP_NHWC && !op->pair_k2 && op->oh % 2 == 0 && op->ow % 2 == 0) {
+        d.act_negative_slope == 0.f && d.out_layout == SABER_HIP_NHWC && !op->pair_k2 && op->oh % 2 == 0 && op->ow % 2 == 0) {
         op->pool_oh = op->oh / 2;
         op->pool_ow = op->ow / 2;
         op->pool2 = 1;
@@ -574,6 +576,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.out_dtype = d.out_dtype;
     a.out_nchw = (!op->is_i8 && d.out_layout == SABER_HIP_NCHW) ? 1 : 0;
     a.relu = d.act == SABER_HIP_ACT_RELU;
+    a.neg_slope = d.act_negative_slope;
     a.epi = op->epi;
     a.res_mode = d.res_mode;
     a.res_relu = d.res_act == SABER_HIP_ACT_RELU;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvKArgs a, int
         float d = acc_f;
         if (a.res_mode == RES_SUM_INPLACE) d = __fadd_rn(d, y[o]);
         if (a.bias) d = __fadd_rn(d, a.bias[k]);
-        if (a.relu) d = d > 0.f ? d : 0.f;
+        if (a.relu) d = d > 0.f ? d : (a.neg_slope == 0.f ? 0.f : __fmul_rn(d, a.neg_slope));
         y[o] = d;
     } else {
         // scalar path of epilogue_i8: temporarily present channel k as the only valid one

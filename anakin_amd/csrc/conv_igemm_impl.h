@@ -194,7 +194,7 @@ __device__ __forceinline__ void epilogue_f32(const ConvKArgs& a, const float (&a
             d = __fadd_rn(d, y[o]);
         }
         d = __fadd_rn(d, cp.bias[r]);
-        if (a.relu) d = d > 0.f ? d : 0.f;
+        if (a.relu) d = d > 0.f ? d : (a.neg_slope == 0.f ? 0.f : __fmul_rn(d, a.neg_slope));   // "if (t < 0) t *= slope"
         outf[r] = d;
     }
     if (vec) {
@@ -229,7 +229,7 @@ __device__ __forceinline__ void epilogue_f32_pair(const ConvKArgs& a, const floa
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float d = __fadd_rn(acc[v + t], cp.bias[v + t]);
-            o[t] = relu ? (d > 0.f ? d : 0.f) : d;
+            o[t] = relu ? (d > 0.f ? d : (a.neg_slope == 0.f ? 0.f : __fmul_rn(d, a.neg_slope))) : d;
         }
         *(float4*)(y + v) = make_float4(o[0], o[1], o[2], o[3]);
     }

@@ -73,6 +73,7 @@ struct ConvKArgs {
     int out_dtype;
     int out_nchw;       // f32 outputs only
     int relu;
+    float neg_slope;    // FP32 convs with relu: negative inputs are multiplied by it (0: plain ReLU)
     int epi;
     int res_mode, res_relu, res_dtype;
     float sum_scale, coeff_conv, coeff_res, scale_conv, scale_res;

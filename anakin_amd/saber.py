@@ -47,6 +47,7 @@ class ConvParam:
         self.res_mode = L.RES_NONE
         self.res_relu = False
         self.sum_scale = 1.0
+        self.negative_slope = 0.0     # ActivationParam::negative_slope of an Active_relu (FP32 convs)
         self.res_dtype = None        # RES_SUM_INPLACE: dtype of the bytes already in y (ConvParam.beta_type); None = out dtype
         self.coeff = (1.0, 1.0)
         self.scale_res = 1.0
@@ -83,6 +84,7 @@ class SaberConv2D:
         d.res_mode = param.res_mode
         d.res_act = L.ACT_RELU if param.res_relu else L.ACT_NONE
         d.sum_scale = param.sum_scale
+        d.act_negative_slope = float(getattr(param, "negative_slope", 0.0))
         if getattr(param, "res_dtype", None) is not None:
             d.res_has_dtype, d.res_dtype = 1, int(param.res_dtype)
         d.coeff_conv, d.coeff_res = param.coeff

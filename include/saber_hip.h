@@ -94,6 +94,9 @@ typedef struct {
     float coeff_conv, coeff_res; /* RES_ELTWISE: EltwiseParam.coeff[0], coeff[1] */
     float scale_res;             /* RES_ELTWISE: scale of the residual tensor */
     int int8_weights;            /* 1: INT8 arithmetic (AK_INT8 op), 0: FP32 arithmetic */
+    float act_negative_slope;    /* FP32 convs, act == RELU: ActivationParam::negative_slope, "if (t < 0) t *= slope" (leaky ReLU;
+                                    saber_im2col_conv.cpp:153-207, saber_conv_1x1.cpp:61-64). The x86 INT8 conv ignores it
+                                    (gemm_x8s8s32x_conv.cpp:269-271 clamps to 0): INT8 ops reject a non-zero slope */
     int res_has_dtype;           /* RES_SUM_INPLACE INT8: 1 = res_dtype below is the dtype of the bytes already in y */
     int res_dtype;               /* ... ConvParam.beta_type (s8 or u8; may differ from out_dtype, same element size).
                                     res_has_dtype == 0: the bytes in y have out_dtype */

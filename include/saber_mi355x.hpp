@@ -287,6 +287,7 @@ public:
         d.int8_weights = OpDtype == AK_INT8 ? 1 : 0;
         d.act = (cp.activation_param.has_active && cp.activation_param.active == Active_relu) ? SABER_HIP_ACT_RELU
                                                                                               : SABER_HIP_ACT_NONE;
+        d.act_negative_slope = d.act == SABER_HIP_ACT_RELU ? cp.activation_param.negative_slope : 0.f;
         if (ep.has_eltwise && ep.operation == Eltwise_sum) {
             const bool relu = ep.activation_param.has_active && ep.activation_param.active == Active_relu;
             d.res_act = relu ? SABER_HIP_ACT_RELU : SABER_HIP_ACT_NONE;

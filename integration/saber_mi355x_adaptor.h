@@ -112,6 +112,8 @@ public:
         d.int8_weights = (OpDtype == AK_INT8) ? 1 : 0;
         d.act = (cp.activation_param.has_active && cp.activation_param.active == Active_relu) ? SABER_HIP_ACT_RELU
                                                                                               : SABER_HIP_ACT_NONE;
+        d.act_negative_slope = d.act == SABER_HIP_ACT_RELU ? cp.activation_param.negative_slope : 0.f;
+        if (cp.activation_param.has_active && cp.activation_param.active != Active_relu) return SaberUnImplError;
         if (ep.has_eltwise && ep.operation == Eltwise_sum) {
             // x86 semantics: in-place sum onto the output tensor (saber_conv_eltwise.cpp:40-151; JIT with_sum)
             d.res_mode = SABER_HIP_RES_SUM_INPLACE;

@@ -893,6 +893,30 @@ def test_conv_f32_fused_relu_maxpool2x2(case):
     assert not S.SaberConv2DPooling(int8=False).init((N, C, H, W), p0, 0, (2, 2), (2, 2), (0, 0), L.F32, L.F32).fused
 
 
+def test_conv_f32_leaky_relu():
+    """ActivationParam::negative_slope of an Active_relu on the FP32 conv: "if (t < 0) t *= slope" after the bias
+    (saber_im2col_conv.cpp:153-207, saber_conv_1x1.cpp:61-64). INT8 convs reject it (the x86 INT8 conv clamps to 0)."""
+    rng = np.random.default_rng(71)
+    for (N, C, H, W, K, k, pad, stride) in ((2, 16, 9, 11, 24, 3, 1, 1), (1, 32, 8, 8, 40, 1, 0, 2)):
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        w = (rng.standard_normal((K, C, k, k)) * 0.2).astype(np.float32)
+        b = rng.standard_normal(K).astype(np.float32)
+        lin = O.conv_f32_nchw(x, w, b, False, (pad, pad), (stride, stride))
+        want = np.where(lin < 0, lin * np.float32(0.1), lin).astype(np.float32)
+        for layout in (L.NCHW, L.NHWC):
+            p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (1, 1), True)
+            p.negative_slope = 0.1
+            conv = S.SaberConv2D(False).init((N, C, H, W), p, L.F32, L.F32, in_layout=layout, out_layout=layout)
+            y = conv.new_output()
+            conv.dispatch(dev(x if layout == L.NCHW else np.ascontiguousarray(x.transpose(0, 2, 3, 1))), y)
+            got = host(y) if layout == L.NCHW else host(y).transpose(0, 3, 1, 2)
+            assert np.abs(got - want).max() <= FP32_RTOL * np.abs(want).max() and (got < 0).any()
+    p = S.ConvParam(w, b, 1, (0, 0), (2, 2), (1, 1), True)
+    p.negative_slope = 0.1
+    with pytest.raises(L.SaberHipError):
+        S.SaberConv2D(True).init((1, 32, 8, 8), p, L.S8, L.U8, 0.02, 0.05)
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_f32_vs_oracle(ta, tb):
     rng = np.random.default_rng(51)
