@@ -769,7 +769,7 @@ extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, vo
         // small-image kernel: every feasible (images, rows) slab
         const int rbs[] = {1, 2, 3, 4, 7, 8, 14};
         const int ibs[] = {1, 2, 4};
-        for (int nw = 4; nw <= 8; nw += 4)
+        for (int nw = 4; nw <= 4; nw += 4)
             for (int ib : ibs)
                 for (int rb : rbs) {
                     if (!img_ok(op, nw, ib, rb)) continue;

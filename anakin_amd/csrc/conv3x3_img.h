@@ -31,10 +31,13 @@ constexpr int img_lds_chunks() {
 }
 constexpr int IMG_TAB = 1024;  // upper bound on the halo pixels of a slab
 
-// Measured (scripts/probe/timeline_probe.hip, res4 3x3 at batch 8, 4 waves): prologue 0.9 us, DMA issue 1.0, landing
-// 0.45, the 63 ds_read + xor + MFMA steps of a wave 2.4 (one wave per SIMD is instruction-issue bound: ~80 cycles
-// per step), reduce + epilogue 1.0. Hence NW = 8: two waves per SIMD interleave their dependent chains and every
-// phase is split over twice the waves.
+// Measured with scripts/probe/timeline_probe.hip on res4's 3x3 at batch 8 (per-launch cost in a 40-launch chain; the
+// implicit-GEMM kernel the autotuner used before: 7.5 us): first version (swizzled LDS, one ds_read ahead) 7.3 us =
+// prologue 0.9 + DMA issue 1.0 + landing 0.45 + 63 ds_read/xor/MFMA steps 2.4 + reduce/epilogue 1.0 (+ launch);
+// unswizzled LDS 6.3; LDS reads batched per tap 6.0. Tried and dropped: 8 waves per workgroup (7.9); register
+// staging with the u8 XOR applied once at staging (6.0: what the MFMA loop gains the staging loses); row-linear
+// register staging into a padded, conflict-free [pixel][C+16] image (6.7: the straight-line bound issues 20 loads per
+// lane where 12 are needed).
 template <int EK, int NW, int CW, int NCH, int GPW>
 __global__ __launch_bounds__(64 * NW) void conv3x3_img_kernel(const ImgKArgs ia) {
     const ConvKArgs& a = ia.c;
@@ -85,8 +88,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_img_kernel(const ImgKArgs ia)
     }
     SABER_TL(1);
 
-    // ---- halo -> LDS by DMA: one instruction = 16 halo pixels x 64 B of one channel chunk; lane L lands in physical
-    // 16-byte slot (L & 3) of pixel (L >> 2), so it FETCHES the logical chunk that lives there (source-side swizzle).
+    // ---- halo -> LDS by DMA: one instruction = 16 halo pixels x 64 B of one channel chunk; lane L lands in 16-byte slot
+    // (L & 3) of pixel (L >> 2). The LDS image is NOT swizzled: the MFMA loop of this kernel is bound by instruction issue
+    // (one wave per SIMD, ~12 instructions per MFMA with the swizzle arithmetic), not by LDS bandwidth - a plain
+    // [pixel][64 B] layout makes a fragment address `lane base + wave-uniform tap offset` (one add per fragment instead of
+    // six operations) and the 2..4-way bank conflicts of its ds_read_b128 (8-16 LDS cycles) hide behind the MFMA.
     // Out-of-image halo pixels (zero padding, rows of a partial slab) fetch the zero page.
     {
         const char* xg = (const char*)a.x;
@@ -98,8 +104,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_img_kernel(const ImgKArgs ia)
             const int hy = (int)__umulhi((unsigned)rem, m_hwd), hx = rem - hy * HWd;
             const int iy = r0 - a.pad_h + hy, ix = hx - a.pad_w;
             const bool ok = hp < HP && img < ibv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int q = (0x78 >> (2 * (physq ^ ((hp >> 2) & 3)))) & 3;
-            const char* src0 = xg + (size_t)((((n0 + img) * a.H + iy) * a.W + ix) * C + q * 16);
+            const char* src0 = xg + (size_t)((((n0 + img) * a.H + iy) * a.W + ix) * C + physq * 16);
 #pragma unroll
             for (int cc = 0; cc < NCHUNK; ++cc) {
                 const char* src = ok ? src0 + cc * 64 : zero;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_img_kernel(const ImgKArgs ia)
         p = p < NPX ? p : NPX - 1;                   // lanes beyond the slab read a valid pixel; their results are dropped
         const int img = (int)__umulhi((unsigned)p, m_rowpx), rem = p - img * rowpx;
         const int row = (int)__umulhi((unsigned)rem, m_ow), col = rem - row * a.OW;
-        hp0[j] = (img * (RB + 2) + row) * HWd + col;
+        hp0[j] = ((img * (RB + 2) + row) * HWd + col) * 4 + fq;   // 16-byte slot of (pixel of tap (0,0), k-group fq), chunk 0
     }
     v4i acc[GPW];
 #pragma unroll
@@ -141,16 +146,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_img_kernel(const ImgKArgs ia)
         const int base = (cw * NCH + nc) * HPp;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * HWd + (t % 3);
+            const int toff = (base + (t / 3) * HWd + (t % 3)) * 4;   // wave-uniform slot offset of this (chunk, tap)
             // straight-line over all GPW groups: groups beyond this wave's share (j >= ng) multiply a clamped, valid pixel
             // and are dropped afterwards (a wave-uniform `if (j < ng)` here makes hipcc shuffle every accumulator through
             // the branch: 150 moves per MFMA, measured 17 us for 63 MFMAs)
+            // all GPW fragments of the tap are requested before the first is used: the LDS latency (~64-128 cycles) is paid
+            // once per tap, not once per MFMA (hipcc keeps only one ds_read ahead when they are issued one by one)
+            v4i bf[GPW];
+#pragma unroll
+            for (int j = 0; j < GPW; ++j) bf[j] = lds[hp0[j] + toff];
 #pragma unroll
             for (int j = 0; j < GPW; ++j) {
-                const int hp = hp0[j] + toff;
-                v4i bf = lds[(base + hp) * 4 + swz4(hp, fq)];
-                bf.x ^= xmask; bf.y ^= xmask; bf.z ^= xmask; bf.w ^= xmask;
-                acc[j] = mma_step(wf[nc][t], bf, acc[j]);
+                v4i b = bf[j];
+                b.x ^= xmask; b.y ^= xmask; b.z ^= xmask; b.w ^= xmask;
+                acc[j] = mma_step(wf[nc][t], b, acc[j]);
             }
         }
     }
@@ -199,7 +208,7 @@ struct ImgShape {
 };
 static inline bool img_shape(int C, int OW, int OH, int N, int nw, int ib, int rb, ImgShape* out) {
     if (ib < 1 || rb < 1 || rb > OH || ib > N || OW < 2) return false;   // (OW >= 2: every magic divisor is >= 2)
-    if (nw != 4 && nw != 8) return false;
+    if (nw != 4) return false;   // (an 8-wave variant - two waves per SIMD - was measured slower on every layer: removed)
     int cw, nch, lbytes;
     switch (C) {
     case 64: cw = 1; nch = 1; lbytes = 24 * 1024; break;
@@ -248,10 +257,8 @@ static hipError_t launch_conv3x3_img_inst(const ConvKArgs& a, int nw, int ib, in
     dim3 grid(b.c.npx * b.c.nky), block(64 * nw);
 #define SABER_IMG_CASE(CW_, NCH_)                                                                                        \
     if (sh.cw == CW_ && sh.nch == NCH_) {                                                                                 \
-        if (nw == 4 && sh.gpw == 4) hipLaunchKernelGGL((conv3x3_img_kernel<EK, 4, CW_, NCH_, 4>), grid, block, 0, s, b);        \
-        else if (nw == 4) hipLaunchKernelGGL((conv3x3_img_kernel<EK, 4, CW_, NCH_, 7>), grid, block, 0, s, b);                  \
-        else if (sh.gpw == 2) hipLaunchKernelGGL((conv3x3_img_kernel<EK, 8, CW_, NCH_, 2>), grid, block, 0, s, b);              \
-        else hipLaunchKernelGGL((conv3x3_img_kernel<EK, 8, CW_, NCH_, 4>), grid, block, 0, s, b);                               \
+        if (sh.gpw == 4) hipLaunchKernelGGL((conv3x3_img_kernel<EK, 4, CW_, NCH_, 4>), grid, block, 0, s, b);                   \
+        else hipLaunchKernelGGL((conv3x3_img_kernel<EK, 4, CW_, NCH_, 7>), grid, block, 0, s, b);                               \
         return hipGetLastError();                                                                                         \
     }
     SABER_IMG_CASE(1, 1) SABER_IMG_CASE(2, 1) SABER_IMG_CASE(4, 1) SABER_IMG_CASE(4, 2)

@@ -136,16 +136,11 @@ int main() {
     struct Img { const char* name; int N, HW, C, K, ib, rb, nw; };
     const Img imgs[] = {
         {"img3x3 res4 14x14x256 b8  1img x 7rows w4", 8, 14, 256, 256, 1, 7, 4},
-        {"img3x3 res4 14x14x256 b8  1img x 7rows w8", 8, 14, 256, 256, 1, 7, 8},
-        {"img3x3 res4 14x14x256 b8  1img x 4rows w8", 8, 14, 256, 256, 1, 4, 8},
-        {"img3x3 res5 7x7x512 b8   2img x 7rows w8", 8, 7, 512, 512, 2, 7, 8},
         {"img3x3 res5 7x7x512 b8   1img x 7rows w4", 8, 7, 512, 512, 1, 7, 4},
-        {"img3x3 res5 7x7x512 b8   1img x 7rows w8", 8, 7, 512, 512, 1, 7, 8},
-        {"img3x3 res3 28x28x128 b8 1img x 7rows w8", 8, 28, 128, 128, 1, 7, 8},
-        {"img3x3 res3 28x28x128 b8 1img x 4rows w8", 8, 28, 128, 128, 1, 4, 8},
-        {"img3x3 res2 56x56x64 b8  1img x 2rows w8", 8, 56, 64, 64, 1, 2, 8},
-        {"img3x3 res4 14x14x256 b1  1img x 7rows w8", 1, 14, 256, 256, 1, 7, 8},
-        {"img3x3 res4 14x14x256 b1  1img x 2rows w8", 1, 14, 256, 256, 1, 2, 8},
+        {"img3x3 res5 7x7x512 b8   2img x 7rows w4", 8, 7, 512, 512, 2, 7, 4},
+        {"img3x3 res3 28x28x128 b8 1img x 7rows w4", 8, 28, 128, 128, 1, 7, 4},
+        {"img3x3 res4 14x14x256 b1  1img x 7rows w4", 1, 14, 256, 256, 1, 7, 4},
+        {"img3x3 res4 14x14x256 b1  1img x 2rows w4", 1, 14, 256, 256, 1, 2, 4},
     };
     // phases: 0 entry, 1 weights requested + table built, 2 DMA issued, 3 own DMA landed, 4 everyone's landed, 5 MFMAs done, 6 stored
     for (const Img& g : imgs) {

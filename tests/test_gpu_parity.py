@@ -138,20 +138,17 @@ def test_conv3x3_img_vs_oracle(case, combo):
     wq = O.quant_weights(w, ws)
     bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, odt)
     want = O.conv_i8(x, wq, bp, sc, odt, relu, (pad, pad))
-    ran8 = 0
+    ran = 0
     for ib, rb in slabs:
-        got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, 1, 1, 1,
-                                tile=rb | (ib << 8) | (9 << 16))
-        assert conv.algo().startswith("img3x3") and conv.algo().endswith("_w4"), conv.algo()
-        assert got.dtype == want.dtype and np.array_equal(got, want), (conv.algo(), ib, rb)
-        try:   # the same slab with 8 waves per workgroup (refused when a wave would get more than 4 pixel groups)
+        try:   # a slab beyond the kernel's LDS / row budget is refused by set_tile (the autotuner never offers it)
             got, conv = run_conv_i8(x, w, None, b, in_scale, out_scale, odt, relu, pad, 1, 1, 1,
-                                    tile=rb | ((ib | 0x80) << 8) | (9 << 16))
+                                    tile=rb | (ib << 8) | (9 << 16))
         except L.SaberHipError:
             continue
-        ran8 += 1
-        assert conv.algo().endswith("_w8") and np.array_equal(got, want), (conv.algo(), ib, rb)
-    assert ran8 > 0
+        ran += 1
+        assert conv.algo().startswith("img3x3") and conv.algo().endswith("_w4"), conv.algo()
+        assert got.dtype == want.dtype and np.array_equal(got, want), (conv.algo(), ib, rb)
+    assert ran >= 1, case
 
 
 def test_conv3x3_img_fused_eltwise_and_rejects():
