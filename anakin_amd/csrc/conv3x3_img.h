@@ -176,8 +176,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_img_kernel(const ImgKArgs ia)
         if constexpr (EK == EK_GEN) {
             epilogue_i8<4>(a, v, cp, p, kb);
         } else {
-            if ((kb + 4 <= a.K) && (a.K % 4 == 0)) epilogue_i8_fast<4, EK>(a, v, cp, p, kb);
-            else epilogue_i8<4>(a, v, cp, p, kb);
+            epilogue_i8_fast<4, EK>(a, v, cp, p, kb);   // K % 16 == 0 here (epilogue_kind)
         }
     };
 

@@ -47,7 +47,8 @@ hipError_t launch_stem_e3(int f32_in, const ConvKArgs& a, hipStream_t s);
 static int epilogue_kind(int mode, const ConvKArgs& a) {
     int ek = 3;
     if (mode == 0 && a.K2 > 0) return 4;   // sibling pair (api.hip checked the constraints)
-    if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE) {
+    // the specialised epilogues store whole 4..16-channel lane groups: ragged K takes the generic one
+    if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE && a.K % 16 == 0) {
         if (a.res_mode == RES_ELTWISE) ek = 2;
         else if (a.out_dtype == DT_U8) ek = 1;
         else if (a.out_dtype == DT_S8) ek = 0;

@@ -265,9 +265,9 @@ __global__ __launch_bounds__(256 * WG) void conv_igemm_dma_kernel(const ConvKArg
             } else if constexpr (EK == EK_PAIR) {
                 if (p < a.M) epilogue_i8_pair<NV>(a, v, cp, p, kb);
             } else {
+                // conv_igemm.hip:epilogue_kind sends K % 16 != 0 to EK_GEN, so every lane group here is whole
                 if (p < a.M && kb < a.K) {
-                    if ((kb + NV <= a.K) && (a.K % NV == 0)) epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);
-                    else epilogue_i8<NV>(a, v, cp, p, kb);
+                    epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);
                 }
             }
         }

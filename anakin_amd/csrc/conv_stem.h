@@ -175,8 +175,7 @@ __global__ __launch_bounds__(256) void conv_stem7x7s2_kernel(const ConvKArgs a) 
             epilogue_i8<NV>(a, v, cp, p, kb);
         } else {
             if (kb < a.K) {
-                if ((kb + NV <= a.K) && (a.K % NV == 0)) epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);
-                else epilogue_i8<NV>(a, v, cp, p, kb);
+                epilogue_i8_fast<NV, EK>(a, v, cp, p, kb);   // K % 16 == 0 here (epilogue_kind)
             }
         }
     }
