@@ -122,6 +122,8 @@ struct saber_hip_conv {
     std::vector<int8_t> wq_oihw;
     std::vector<float> w_scale;
     std::vector<float> bias_host;   // the op's f32 bias as handed to set_weights (saber_hip_net_optimize re-creates ops from it)
+    std::vector<float> bias_p_host, scale_host;   // INT8: the device-side bias' / scale / comp arrays (conv1x1 chain repacks them)
+    std::vector<int> comp_host;
     DevBuf<uint8_t> d_w;
     DevBuf<float> d_bias, d_scale;
     DevBuf<int> d_comp;
@@ -129,6 +131,14 @@ struct saber_hip_conv {
     std::string algo_name;
     // sibling pair (saber_hip_conv2d_create_pair): d.k = k1 + k2, rows >= k1 belong to the second conv
     int pair_k1 = 0, pair_k2 = 0, pair_relu2 = 0, pair_dtype2 = 0;
+};
+
+// two 1x1 INT8 convs in one launch (conv1x1_chain.hip); refers to the two ops, owns the repacked stream
+struct saber_hip_chain {
+    saber_hip_conv* a = nullptr;
+    saber_hip_conv* b = nullptr;
+    int c1 = 0, k1 = 0, k2 = 0, tn = 0;
+    DevBuf<uint8_t> d_stream, d_prm1, d_prm2;
 };
 
 struct saber_hip_fc {
@@ -507,6 +517,9 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
         }
         bias_p.resize(K_pad, 0.f);
         scale.resize(K_pad, 0.f);
+        op->bias_p_host = bias_p;
+        op->scale_host = scale;
+        op->comp_host = comp;
         HIP_TRY(op->d_w.upload(wr));
         HIP_TRY(op->d_bias.upload(bias_p));
         HIP_TRY(op->d_scale.upload(scale));
@@ -1185,6 +1198,108 @@ int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hi
     return SABER_HIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// conv1x1 chain: `a` (1x1, fused SaberEltwise epilogue, s8 out) feeding `b` (1x1, s8 / u8 out) in one launch
+// ------------------------------------------------------------------------------------------------
+static bool chain_1x1(const saber_hip_conv* o) {
+    const saber_hip_conv_desc& d = o->d;
+    return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.kh == 1 && d.kw == 1 &&
+           d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && d.group == 1 && !o->pair_k2 &&
+           !o->pool_fused && !o->pool2 && !o->pre_quant && !o->pre_pad && o->c_eff == d.c && d.act_negative_slope == 0.f &&
+           d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC;
+}
+static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::vector<uint8_t>& out) {
+    const int K = o->d.k;
+    out.assign(chunks_pad * 16, 0);
+    for (int k4 = 0; k4 < K / 4; ++k4) {
+        float* f = (float*)(out.data() + (size_t)k4 * 48);
+        int* ip = (int*)(out.data() + (size_t)k4 * 48 + 32);
+        for (int r = 0; r < 4; ++r) {
+            const int k = k4 * 4 + r;
+            f[r] = o->scale_host.empty() ? 1.f : o->scale_host[k];
+            f[4 + r] = (o->has_bias && !o->bias_p_host.empty()) ? o->bias_p_host[k] : 0.f;
+            ip[r] = o->comp_host.empty() ? 0 : o->comp_host[k];
+        }
+    }
+}
+// one conv's weights [K][C] -> per wave, groups of 16*mfg channels, steps ordered [group][k-step][accumulator], each step
+// = 64 lanes x 16 bytes in MFMA A-operand order (row = lane & 15, k-group = lane >> 4); row rho of accumulator mf is
+// channel  base + (rho >> 2) * 4*mfg + mf*4 + (rho & 3)   (conv1x1_chain.hip)
+static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out) {
+    const int kw = K / 4, groups = kw / (16 * mfg), ksn = C / 64;
+    for (int g = 0; g < groups; ++g)
+        for (int ks = 0; ks < ksn; ++ks)
+            for (int mf = 0; mf < mfg; ++mf)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, kq = lane >> 4;
+                    const int ch = wave * kw + g * 16 * mfg + (rho >> 2) * 4 * mfg + mf * 4 + (rho & 3);
+                    const int8_t* src = w + (size_t)ch * C + ks * 64 + kq * 16;
+                    out.insert(out.end(), (const uint8_t*)src, (const uint8_t*)src + 16);
+                }
+}
+int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+    if (!a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!chain_1x1(a) || !chain_1x1(b)) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
+    const saber_hip_conv_desc& da = a->d;
+    const saber_hip_conv_desc& db = b->d;
+    if (da.res_mode != SABER_HIP_RES_ELTWISE || da.out_dtype != SABER_HIP_S8 || (da.res_has_dtype && da.res_dtype != SABER_HIP_S8))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: the first conv must carry the fused eltwise epilogue with s8 residual and output");
+    if (db.res_mode != SABER_HIP_RES_NONE || b->x_dtype != DT_S8 || (db.out_dtype != SABER_HIP_S8 && db.out_dtype != SABER_HIP_U8))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: the second conv must be a plain s8-input conv with an 8-bit output");
+    if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || !conv1x1_chain_ok(da.c, da.k, db.k))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
+    saber_hip_chain* ch = new saber_hip_chain();
+    ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = db.k;
+    ch->tn = conv1x1_chain_tn(da.c, da.n * a->oh * a->ow);
+    const int mfg2 = (db.k / 4) / 16 >= 4 ? 4 : (db.k / 4) / 16;
+    std::vector<uint8_t> stream, p1, p2;
+    stream.reserve((size_t)da.k * da.c + (size_t)db.k * db.c);
+    for (int w = 0; w < 4; ++w) {
+        pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, stream);
+        pack_chain_weights(b->wq_oihw.data(), db.k, db.c, mfg2, w, stream);
+    }
+    pack_chain_params(a, (size_t)da.k / 4 * 3, p1);
+    pack_chain_params(b, ((size_t)db.k / 4 * 3 + 63) / 64 * 64, p2);
+    hipError_t e = ch->d_stream.upload(stream);
+    if (e == hipSuccess) e = ch->d_prm1.upload(p1);
+    if (e == hipSuccess) e = ch->d_prm2.upload(p2);
+    if (e != hipSuccess) {
+        delete ch;
+        return hip_fail(e, "chain: device copies");
+    }
+    *out = ch;
+    return SABER_HIP_OK;
+}
+void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
+int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
+    if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1);
+    if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
+    ch->tn = tn;
+    return SABER_HIP_OK;
+}
+int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* ch) { return ch ? ch->tn : 0; }
+int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void* res, void* y_a, void* y_b,
+                               saber_hip_stream_t stream) {
+    if (!ch || !x || !res || !y_a || !y_b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv* a = ch->a;
+    const saber_hip_conv* b = ch->b;
+    ChainKArgs k;
+    std::memset(&k, 0, sizeof k);
+    k.x = x; k.wstream = ch->d_stream.p; k.res = res; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
+    k.y1 = y_a; k.y2 = y_b;
+    k.M = a->d.n * a->oh * a->ow;
+    k.in_u8 = a->x_dtype == DT_U8;
+    k.relu1 = a->d.act == SABER_HIP_ACT_RELU;
+    k.res_relu = a->d.res_act == SABER_HIP_ACT_RELU;
+    k.coeff_conv = a->d.coeff_conv; k.scale_conv = a->out_scale; k.coeff_res = a->d.coeff_res; k.scale_res = a->d.scale_res;
+    k.relu2 = b->d.act == SABER_HIP_ACT_RELU;
+    k.out_u8_2 = b->d.out_dtype == SABER_HIP_U8;
+    HIP_TRY(launch_conv1x1_chain(k, ch->c1, ch->k1, ch->k2, ch->tn, (hipStream_t)stream));
+    return SABER_HIP_OK;
+}
+
 }  // extern "C"
 
 // ================================================================================================
@@ -1198,6 +1313,11 @@ struct NetOp {
     saber_hip_conv* conv = nullptr;
     saber_hip_fc* fc = nullptr;
     int in = -1, in2 = -1, out = -1, out2 = -1;
+    // conv1x1 chain (saber_hip_net_optimize flag 16): this conv and the NEXT op (a 1x1 conv reading its output) run as one
+    // launch while use_chain is set; the next op carries `skip` and launches nothing
+    saber_hip_chain* chain = nullptr;
+    int chain_out = -1;
+    bool use_chain = false, skip = false;
     int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
     bool record = false;     // an op on the other lane consumes this op's output: record an event after it
     int p[16] = {0};
@@ -1222,13 +1342,17 @@ struct saber_hip_net {
     std::vector<int> writer;           // tensor id -> index of the op that last wrote it (-1: external)
     bool lanes_ready = false, has_side = false;
     std::vector<saber_hip_conv*> owned;   // ops created by saber_hip_net_optimize (destroyed with the net)
+    std::vector<saber_hip_chain*> owned_chains;
 };
 
 static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
     void* ws = net->arena + net->ws_off;
     switch (o.kind) {
-    case OP_CONV: return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
+    case OP_CONV:
+        if (o.skip) return SABER_HIP_OK;      // written by the previous op's chain launch
+        if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
+        return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
     case OP_CONV_PAIR: return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
     case OP_FC: return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
     case OP_QUANT:
@@ -1396,9 +1520,21 @@ int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_i
 //   2  two convs over the same tensor with the same geometry   -> one sibling-pair launch (saber_hip_conv2d_create_pair)
 //   4  conv + max pooling (single consumer)                    -> SaberConv2DPooling where a fused kernel exists
 //   8  global pooling feeding an INT8 fc that quantises on entry -> the pooling also writes the fc's s8 operand
+//  16  1x1 conv with the fused eltwise epilogue + the 1x1 conv that follows it and reads its output (ResNet branch2c + sum
+//      -> next branch2a) -> one conv1x1-chain launch (saber_hip_conv2d_chain_create); both ops stay in the list (the
+//      second one launches nothing while the chain is selected), the autotuner keeps whichever form is faster
 // New ops are re-created from the originals' quantised weights / scales / bias and owned by the net. Call before
 // saber_hip_net_finalize. Returns the number of launches removed, or a negative status.
 // ------------------------------------------------------------------------------------------------
+static void net_name_chain(NetOp& A, NetOp& B) {
+    if (A.use_chain) {
+        A.name = "conv:chain1x1_c" + std::to_string(A.chain->c1) + "_px" + std::to_string(16 * A.chain->tn);
+        B.name = "conv:(in the chain launch)";
+    } else {
+        A.name = std::string("conv:") + A.conv->algo_name;
+        B.name = std::string("conv:") + B.conv->algo_name;
+    }
+}
 static int clone_conv_i8(const saber_hip_conv* src, const saber_hip_conv_desc& d, saber_hip_conv** out) {
     int rc = saber_hip_conv2d_create(&d, out);
     if (rc) return rc;
@@ -1549,6 +1685,24 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
     for (size_t i = 0; i < ops.size(); ++i)
         if (!dead[i]) live.push_back(std::move(ops[i]));
     ops.swap(live);
+    // ---- 16: conv1x1 chains (on the compacted list: the pair must be adjacent) --------------------------------
+    if (flags & 16) {
+        for (size_t i = 0; i + 1 < ops.size(); ++i) {
+            NetOp& A = ops[i];
+            NetOp& B = ops[i + 1];
+            if (A.kind != OP_CONV || B.kind != OP_CONV || !A.conv || !B.conv || A.chain || A.skip || B.chain || A.lane || B.lane)
+                continue;
+            if (A.conv->d.res_mode != SABER_HIP_RES_ELTWISE || B.in != A.out || A.in2 < 0 || B.in2 >= 0) continue;
+            saber_hip_chain* ch = nullptr;
+            if (saber_hip_conv2d_chain_create(A.conv, B.conv, &ch) != SABER_HIP_OK) continue;   // not a chainable shape
+            net->owned_chains.push_back(ch);
+            A.chain = ch;
+            A.chain_out = B.out;
+            A.use_chain = B.skip = ch->c1 <= 256;      // default until the autotuner has timed both forms
+            if (A.use_chain) ++removed;
+            net_name_chain(A, B);
+        }
+    }
     // the shared workspace only has to cover the surviving ops
     net->ws_bytes = 0;
     for (const NetOp& o : ops) {
@@ -1737,17 +1891,31 @@ static saber_hip_conv* net_op_conv(saber_hip_net* net, int index) {
     if (o.kind == OP_FC || o.kind == OP_FC_Q) return o.fc ? o.fc->conv : nullptr;
     return nullptr;
 }
+// bits 0..23: saber_hip_conv2d_get_tile of the op; chain heads add bit 28 (a chain decision is recorded) and the chain's
+// pixel fragments in bits 24..27 (0: run as two launches)
 int saber_hip_net_get_choice(saber_hip_net_t* net, int index) {
     saber_hip_conv* c = net_op_conv(net, index);
-    return (c && !c->pool_fused && c->algo <= ALGO_IGEMM_F32) ? saber_hip_conv2d_get_tile(c) : 0;
+    int choice = (c && !c->pool_fused && c->algo <= ALGO_IGEMM_F32) ? saber_hip_conv2d_get_tile(c) : 0;
+    if (c && net->ops[index].chain) choice |= (1 << 28) | ((net->ops[index].use_chain ? net->ops[index].chain->tn : 0) << 24);
+    return choice;
 }
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     saber_hip_conv* c = net_op_conv(net, index);
     if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
-    int rc = saber_hip_conv2d_set_tile(c, choice);
+    const int chain_bits = choice >> 24;
+    choice &= 0xffffff;
+    int rc = choice ? saber_hip_conv2d_set_tile(c, choice) : SABER_HIP_OK;
     if (rc) return rc;
     NetOp& o = net->ops[index];
     o.name = std::string(o.kind == OP_FC || o.kind == OP_FC_Q ? "fc:" : "conv:") + c->algo_name;
+    if (o.chain && (chain_bits & 16) && index + 1 < (int)net->ops.size()) {
+        const int tn = chain_bits & 15;
+        if (tn && (rc = saber_hip_conv2d_chain_set_tile(o.chain, tn)) != SABER_HIP_OK) return rc;
+        o.use_chain = net->ops[index + 1].skip = tn != 0;
+        net_name_chain(o, net->ops[index + 1]);
+    } else if (o.skip) {
+        o.name = "conv:(in the chain launch)";
+    }
     if (net->exec) {
         (void)hipGraphExecDestroy(net->exec);
         (void)hipGraphDestroy(net->graph);
@@ -1784,13 +1952,57 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         if (rc) return rc;
         o.name = std::string(o.kind == OP_CONV ? "conv:" : "fc:") + c->algo_name;
     }
+    // conv1x1 chains: the two tuned launches against the one chain launch (every pixel-tile size), on the real tensors
+    for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
+        NetOp& A = net->ops[i];
+        NetOp& B = net->ops[i + 1];
+        if (!A.chain) continue;
+        hipStream_t s = (hipStream_t)stream;
+        EventPair ev;
+        HIP_TRY(ev.init());
+        const int n = iters < 20 ? 20 : iters;
+        auto timed = [&](float* ms) -> int {
+            int rc = net_launch(net, A, s) | net_launch(net, B, s);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev.e0, s));
+            for (int it = 0; it < n; ++it) rc |= net_launch(net, A, s) | net_launch(net, B, s);
+            HIP_TRY(hipEventRecord(ev.e1, s));
+            HIP_TRY(hipEventSynchronize(ev.e1));
+            HIP_TRY(hipEventElapsedTime(ms, ev.e0, ev.e1));
+            return rc;
+        };
+        float best = 0.f;
+        int best_tn = 0;             // 0: two launches
+        A.use_chain = B.skip = false;
+        int rc = timed(&best);
+        if (rc) return rc;
+        const int tns[2] = {A.chain->c1 == 64 ? 4 : (A.chain->c1 == 128 ? 2 : 1), A.chain->c1 == 64 ? 2 : (A.chain->c1 == 128 ? 1 : 0)};
+        A.use_chain = B.skip = true;
+        for (int tn : tns) {
+            if (!tn) continue;
+            float ms = 0.f;
+            if (saber_hip_conv2d_chain_set_tile(A.chain, tn) != SABER_HIP_OK || timed(&ms) != SABER_HIP_OK) continue;
+            if (ms < best) { best = ms; best_tn = tn; }
+        }
+        A.use_chain = B.skip = best_tn != 0;
+        if (best_tn) (void)saber_hip_conv2d_chain_set_tile(A.chain, best_tn);
+        net_name_chain(A, B);
+        rc = net_launch(net, A, s) | net_launch(net, B, s);   // both outputs hold the selected form's result
+        if (rc) return rc;
+    }
     return SABER_HIP_OK;
+}
+int saber_hip_net_num_launches(const saber_hip_net_t* net) {
+    int n = 0;
+    for (const NetOp& o : net->ops) n += o.skip ? 0 : 1;
+    return n;
 }
 void saber_hip_net_destroy(saber_hip_net_t* net) {
     if (!net) return;
     if (net->exec) (void)hipGraphExecDestroy(net->exec);
     if (net->graph) (void)hipGraphDestroy(net->graph);
     if (net->arena) (void)hipFree(net->arena);
+    for (saber_hip_chain* c : net->owned_chains) saber_hip_conv2d_chain_destroy(c);
     for (saber_hip_conv* c : net->owned) saber_hip_conv2d_destroy(c);
     for (hipEvent_t e : net->ev_op)
         if (e) (void)hipEventDestroy(e);

@@ -1,0 +1,317 @@
+// anakin_amd/csrc/conv1x1_chain.hip — two back-to-back 1x1 INT8 convolutions in one launch (gfx950).
+//
+// Role: the ResNet bottleneck boundary  branch2c (1x1, C1 -> 4*C1) + SaberEltwise sum + relu  ->  next block's
+// branch2a (1x1, 4*C1 -> C1, relu). Both are per-pixel operators (reference: GemmX8S8S32XConv::dispatch,
+// saber/funcs/impl/x86/gemm_x8s8s32x_conv.cpp:184-257, and SaberEltwise<X86,AK_INT8>, saber_eltwise_int8.cpp), so a
+// workgroup that owns a tile of pixels can run the second conv on the first one's output without leaving the CU:
+// one launch, one read of the tile instead of a write + re-read, and no second launch boundary (2.3-2.7 us each on this
+// part, more than either kernel's arithmetic). Results are the same bits as the two separate launches: the second conv
+// consumes exactly the s8 values the first one stores.
+//
+//   workgroup = NPX = 16*TN pixels x ALL channels of both convs, 4 waves;
+//   wave w owns output channels [w*K1/4, (w+1)*K1/4) of the first conv and [w*K2/4, (w+1)*K2/4) of the second;
+//   weights never touch LDS: the host packs both convs' weights into ONE stream per wave, already in MFMA A-operand
+//   order and in the order the wave consumes them (1 KB = one k-step of 16 channels per "step"), so the inner loop is
+//   `MFMA(ring[r], b, acc); ring[r] = stream[next]` on an R-deep register ring - a flat prefetch that runs across the
+//   boundary between the two convs;
+//   the B operand of the first conv (the pixel tile of x) sits in registers; its epilogue takes the residual tile from
+//   LDS (brought in by LDS-DMA, XOR-swizzled), writes the s8 result over it, and after ONE barrier the same LDS tile is
+//   (a) streamed to y1 with 16-byte coalesced stores and (b) the B operand of the second conv;
+//   the per-channel constants {scale, bias', comp} of both convs are DMA'd into LDS once.
+// Channel <-> MFMA row mapping (chosen by the host packing): in a group of 16*MFG channels handled by MFG accumulators,
+// row rho of accumulator mf is channel  base + (rho >> 2) * 4*MFG + mf*4 + (rho & 3), so a lane (which holds rows
+// 4*fq .. 4*fq+3 of every accumulator) ends up with 4*MFG CONSECUTIVE channels of its pixel: one 16-byte LDS / global
+// access per pixel instead of four 4-byte ones.
+#include "conv_igemm_impl.h"
+
+namespace saber_mi355x {
+
+namespace {
+
+// the fused-eltwise epilogue of epilogue_i8_fast<NV, EK_ELT> (conv_igemm_impl.h) on 4 channels -> 4 packed s8
+__device__ __forceinline__ unsigned chain_elt_pack(const v4i acc, const v4i comp, const v4f bias, const v4f scale,
+                                                   unsigned rs, float lo_s8, float res_lo, const ChainKArgs& a) {
+    float dq[4];
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        v2f d2 = {(float)(acc[r] + comp[r]), (float)(acc[r + 1] + comp[r + 1])};
+        d2 = d2 + v2f{bias[r], bias[r + 1]};
+        d2 = d2 * v2f{scale[r], scale[r + 1]};
+        dq[r] = d2.x;
+        dq[r + 1] = d2.y;
+    }
+    unsigned w = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float q = rintf(dq[t]);
+        q = __builtin_amdgcn_fmed3f(q, lo_s8, 127.f);
+        const float rv = (float)(int)(int8_t)(rs >> (8 * t));
+        float e = __fmul_rn(__fmul_rn(a.coeff_conv, q), a.scale_conv);
+        e = __fadd_rn(e, __fmul_rn(__fmul_rn(a.coeff_res, rv), a.scale_res));
+        e = fmaxf(e, res_lo);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(round_half_away(e) + 128.f, t, w);
+    }
+    return w ^ 0x80808080u;
+}
+
+// the s8 / u8 epilogue of epilogue_i8_pair (run-time output type) on 4 channels
+__device__ __forceinline__ unsigned chain_out_pack(const v4i acc, const v4i comp, const v4f bias, const v4f scale,
+                                                   float lo, float off, unsigned xm) {
+    float dq[4];
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        v2f d2 = {(float)(acc[r] + comp[r]), (float)(acc[r + 1] + comp[r + 1])};
+        d2 = d2 + v2f{bias[r], bias[r + 1]};
+        d2 = d2 * v2f{scale[r], scale[r + 1]};
+        dq[r] = d2.x;
+        dq[r + 1] = d2.y;
+    }
+    unsigned w = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float q = fmaxf(rintf(dq[t]), lo);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(q + off, t, w);
+    }
+    return w ^ xm;
+}
+
+__device__ __forceinline__ void lds_dma16(const void* src, void* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
+
+}  // namespace
+
+// KS1 = C1/64, G1 = K1/256 (64-channel groups per wave, first conv), MFG2 / G2: accumulators per group / groups per wave
+// of the second conv (K2 = 64*G2*MFG2), TN pixel fragments, R ring depth in steps (1 KB per wave each), GU: groups of the
+// first conv per unrolled loop body. R == all steps of the wave: every weight load is issued in the prologue and the
+// ring is never refilled; otherwise R divides GU * (steps per group) and the second conv's group length.
+template <int KS1, int G1, int MFG2, int G2, int TN, int R, int GU>
+__global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) {
+    constexpr int NW = 4;
+    constexpr int KS2 = 4 * G1;                       // K1 / 64
+    constexpr int K1 = 256 * G1, C1 = 64 * KS1, K2 = NW * G2 * 16 * MFG2;
+    constexpr int NPX = 16 * TN;
+    constexpr int SG1 = KS1 * 4, SG2 = KS2 * MFG2;    // steps per channel group
+    constexpr int T1 = G1 * SG1, T2 = G2 * SG2;       // steps per wave
+    constexpr bool FULL = R == T1 + T2;
+    constexpr int NB1 = G1 / GU;
+    constexpr int CPR = K1 / 16;                      // 16-byte chunks per tile row
+    constexpr int P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
+    static_assert(G1 % GU == 0 && (FULL ? (NB1 == 1 && G2 == 1) : ((GU * SG1) % R == 0 && SG2 % R == 0)),
+                  "ring depth must divide the unrolled body lengths");
+    static_assert(CPR >= 16 && P1C % 64 == 0, "tile rows are swizzled on 16 chunks");
+
+    __shared__ v4i tile[NPX * CPR];
+    __shared__ v4i prm1[P1C];
+    __shared__ v4i prm2[P2C];
+    SABER_TL_DECL;
+    SABER_TL(0);
+    asm volatile("" ::"s"(a.x), "s"(a.wstream), "s"(a.res), "s"(a.prm1), "s"(a.prm2), "s"(a.M), "s"(a.in_u8));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int p0 = blockIdx.x * NPX;
+    const int plast = a.M - 1;
+
+    // ---- first conv's B operand: the pixel tile of x, straight into registers ------------------------------------
+    v4i bx[KS1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int p = p0 + j * 16 + frow;
+        p = p < plast ? p : plast;                     // pixels beyond the tensor repeat the last one (never stored)
+        const char* xp = (const char*)a.x + (size_t)p * C1 + fq * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) bx[ks][j] = *(const v4i*)(xp + ks * 64);
+    }
+
+    // ---- residual tile and the per-channel constants -> LDS by DMA -----------------------------------------------
+    // tile[px][chunk ^ (px & 15)]: the epilogue's 16-lane column accesses and the second conv's operand reads hit 16
+    // different bank groups. One instruction moves 64 chunks; lane L of instruction i lands in chunk i*64 + L.
+    // Issued BEFORE the weight ring: vector-memory loads return in order, so by the time the first MFMA has its weights
+    // this wave's DMA has landed (the barrier after the first channel group covers the other waves).
+    {
+        const char* rg = (const char*)a.res;
+        constexpr int NI = NPX * CPR / 64;
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += NW) {
+            const int i = i0 + wave;
+            const int L = i * 64 + lane;
+            const int px = L / CPR, c = (L % CPR) ^ (px & 15);
+            int p = p0 + px;
+            p = p < plast ? p : plast;
+            lds_dma16(rg + (size_t)p * K1 + c * 16, tile + i * 64);
+        }
+        for (int i = wave; i < P1C / 64; i += NW) lds_dma16((const v4i*)a.prm1 + i * 64 + lane, prm1 + i * 64);
+        for (int i = wave; i < P2C / 64; i += NW) lds_dma16((const v4i*)a.prm2 + i * 64 + lane, prm2 + i * 64);
+    }
+    asm volatile("" ::: "memory");                     // keep the ring's loads behind the DMA in program order
+
+    // ---- weight ring: the first R steps of this wave's stream ---------------------------------------------------
+    const v4i* wsb = (const v4i*)a.wstream + (size_t)wave * ((T1 + T2) * 64);
+    v4i ring[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) ring[r] = wsb[r * 64 + lane];
+    wsb += R * 64;                                     // step sb of the current body refills from wsb[sb * 64 + lane]
+
+    const int xmask = a.in_u8 ? (int)0x80808080u : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bx[ks][j].x ^= xmask; bx[ks][j].y ^= xmask; bx[ks][j].z ^= xmask; bx[ks][j].w ^= xmask;
+        }
+    const float lo_s8 = a.relu1 ? 0.f : -128.f;
+    const float res_lo = a.res_relu ? 0.f : -3.0e38f;
+    SABER_TL(1);
+
+    // ================= first conv: groups of 64 channels, steps ordered [ks][mf] ===================================
+#pragma unroll 1
+    for (int body = 0; body < NB1; ++body) {
+#pragma unroll
+        for (int gu = 0; gu < GU; ++gu) {
+            v4i acc[4][TN];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < SG1; ++s) {
+                const int sb = gu * SG1 + s;
+                const int ri = FULL ? sb : sb % R;
+                const int ks = s / 4, mf = s % 4;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[mf][j] = mma_step(ring[ri], bx[ks][j], acc[mf][j]);
+                if (!FULL) ring[ri] = wsb[sb * 64 + lane];    // the stream runs on into the second conv's weights
+            }
+            if (gu == 0 && body == 0) {
+                __builtin_amdgcn_s_barrier();          // every wave's DMA has landed (see above)
+                SABER_TL(2);
+            }
+            // epilogue: lane = 16 consecutive channels cg .. cg+15 of pixels j*16 + frow
+            const int cg = wave * (K1 / NW) + (body * GU + gu) * 64 + fq * 16;
+            const v4i* pp = prm1 + (cg / 4) * 3;
+            v4f sc[4], bi[4];
+            v4i co[4];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                sc[mf] = __builtin_bit_cast(v4f, pp[mf * 3]);
+                bi[mf] = __builtin_bit_cast(v4f, pp[mf * 3 + 1]);
+                co[mf] = pp[mf * 3 + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                v4i* tp = tile + (j * 16 + frow) * CPR + ((cg / 16) ^ frow);
+                const v4i rs = *tp;
+                v4i o;
+                o.x = (int)chain_elt_pack(acc[0][j], co[0], bi[0], sc[0], (unsigned)rs.x, lo_s8, res_lo, a);
+                o.y = (int)chain_elt_pack(acc[1][j], co[1], bi[1], sc[1], (unsigned)rs.y, lo_s8, res_lo, a);
+                o.z = (int)chain_elt_pack(acc[2][j], co[2], bi[2], sc[2], (unsigned)rs.z, lo_s8, res_lo, a);
+                o.w = (int)chain_elt_pack(acc[3][j], co[3], bi[3], sc[3], (unsigned)rs.w, lo_s8, res_lo, a);
+                *tp = o;
+            }
+        }
+        wsb += GU * SG1 * 64;
+    }
+    SABER_TL(3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // the tile now holds the first conv's s8 output, all channels
+
+    // ---- tile -> y1 (coalesced) and -> the second conv's B operand ---------------------------------------------------
+    {
+        char* yg = (char*)a.y1;
+        constexpr int NIT = NPX * CPR / 256;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int L = it * 256 + tid;
+            const int px = L / CPR, c = (L % CPR) ^ (px & 15);
+            const int p = p0 + px;
+            if (p < a.M) *(v4i*)(yg + (size_t)p * K1 + c * 16) = tile[L];
+        }
+    }
+    v4i b2[KS2][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) b2[ks][j] = tile[(j * 16 + frow) * CPR + ((ks * 4 + fq) ^ frow)];
+    SABER_TL(4);
+
+    // ================= second conv =================================================================================
+    const float lo2 = a.relu2 ? 0.f : -3.0e38f;
+    const float off2 = a.out_u8_2 ? 0.f : 128.f;
+    const unsigned xm2 = a.out_u8_2 ? 0u : 0x80808080u;
+#pragma unroll 1
+    for (int g = 0; g < G2; ++g) {
+        v4i acc[MFG2][TN];
+#pragma unroll
+        for (int mf = 0; mf < MFG2; ++mf)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < SG2; ++s) {
+            const int ri = FULL ? T1 + s : s % R;
+            const int ks = s / MFG2, mf = s % MFG2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[mf][j] = mma_step(ring[ri], b2[ks][j], acc[mf][j]);
+            if (!FULL && (s + R < SG2 || g + 1 < G2)) ring[ri] = wsb[s * 64 + lane];   // the stream ends with the last group
+        }
+        wsb += SG2 * 64;
+        const int cg = wave * (K2 / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
+        const v4i* pp = prm2 + (cg / 4) * 3;
+        unsigned o[MFG2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int mf = 0; mf < MFG2; ++mf)
+                o[mf] = chain_out_pack(acc[mf][j], pp[mf * 3 + 2], __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
+                                       __builtin_bit_cast(v4f, pp[mf * 3]), lo2, off2, xm2);
+            const int p = p0 + j * 16 + frow;
+            if (p < a.M) {
+                char* y = (char*)a.y2 + (size_t)p * K2 + cg;
+                if constexpr (MFG2 == 1) *(unsigned*)y = o[0];
+                else if constexpr (MFG2 == 2) *(uint2*)y = make_uint2(o[0], o[1]);
+                else *(uint4*)y = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    SABER_TL(5);
+    SABER_TL_FLUSH();
+}
+
+bool conv1x1_chain_ok(int c1, int k1, int k2) {
+    return (c1 == 64 || c1 == 128 || c1 == 256 || c1 == 512) && k1 == 4 * c1 && k2 == c1;
+}
+
+int conv1x1_chain_tn(int c1, int m) {
+    (void)m;
+    switch (c1) {
+    case 64: return 4;
+    case 128: return 2;
+    case 256: case 512: return 1;
+    default: return 0;
+    }
+}
+
+hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, hipStream_t s) {
+    if (!conv1x1_chain_ok(c1, k1, k2) || a.M <= 0) return hipErrorInvalidValue;
+    const dim3 block(256);
+    const dim3 grid((a.M + 16 * tn - 1) / (16 * tn));
+#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, GU) \
+    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, GU>), grid, block, 0, s, a)
+    // ring depths: measured with scripts/probe/timeline_probe.hip (chain): deeper rings (32 / 64 steps, or the whole
+    // stream in registers) only move the wait into the prologue - the stream is bound by the CU's vector-memory path
+    // (~43 B/clk measured for these 1 KB-per-instruction loads), not by the latency of one round trip
+    switch (c1 * 8 + tn) {
+    case 64 * 8 + 4: SABER_CHAIN(1, 1, 1, 1, 4, 4, 1); break;
+    case 64 * 8 + 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, 1); break;
+    case 128 * 8 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, 1); break;
+    case 128 * 8 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, 1); break;
+    case 256 * 8 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, 1); break;
+    case 512 * 8 + 1: SABER_CHAIN(8, 8, 4, 2, 1, 16, 1); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef SABER_CHAIN
+    return hipGetLastError();
+}
+
+}  // namespace saber_mi355x

@@ -94,6 +94,27 @@ struct ImgKArgs {
 };
 static_assert(offsetof(ConvKArgs, y) == 128, "hot kernel arguments fill exactly the first two 64-byte lines");
 
+// conv1x1_chain_kernel (conv1x1_chain.hip): a 1x1 conv with the fused eltwise epilogue (ResNet branch2c + sum + relu)
+// followed by the next block's 1x1 branch2a conv on the same pixels, one launch.
+struct ChainKArgs {
+    const void* x;        // first conv's input [M][C1], s8 or u8
+    const void* wstream;  // both convs' s8 weights in the order the four waves consume them (api.hip: pack_chain_stream)
+    const void* res;      // residual [M][K1] s8
+    const void* prm1;     // first conv: per 4 channels {scale[4], bias'[4], comp[4]} (48 bytes)
+    const void* prm2;     // second conv, same layout (padded to a multiple of 64 x 16 bytes)
+    void* y1;             // [M][K1] s8: the eltwise output (the next block's shortcut)
+    void* y2;             // [M][K2] s8 / u8: the second conv's output
+    int M, in_u8;
+    int relu1, res_relu;
+    float coeff_conv, scale_conv, coeff_res, scale_res;
+    int relu2, out_u8_2;
+};
+bool conv1x1_chain_ok(int c1, int k1, int k2);
+// number of 16-pixel fragments per workgroup the launcher uses for (c1, m) / 0 if unsupported
+int conv1x1_chain_tn(int c1, int m);
+// bytes of the packed weight stream / its per-wave step geometry
+hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, hipStream_t s);
+
 // hipcc fetches kernel arguments lazily with scalar loads and places each load near its first use; every batch that is
 // issued after an `s_waitcnt lgkmcnt(0)` is one more DEPENDENT round trip (~0.2-0.25 us, measured) before the kernel's
 // first operand load. Naming the hot fields in one empty asm statement makes all of them live at that point, so their

@@ -235,6 +235,34 @@ class SaberConvPair:
             pass
 
 
+class SaberConvChain:
+    """`a` (1x1 conv + fused eltwise, s8) followed by `b` (1x1 conv on a's output) in one launch
+    (saber_hip_conv2d_chain_create): ResNet's `branch2c + sum + relu -> next branch2a`. Both outputs hold the bits of
+    dispatching `a` and then `b`, which is what the reference does (net.cpp:417-509)."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.h = C.c_void_p()
+        L.check(L.load().saber_hip_conv2d_chain_create(a.h, b.h, C.byref(self.h)))
+
+    def dispatch(self, x, res, ya, yb):
+        L.check(L.load().saber_hip_conv2d_chain_run(self.h, _p(x), _p(res), _p(ya), _p(yb), _stream()))
+        return ya, yb
+
+    def set_tile(self, tn):
+        L.check(L.load().saber_hip_conv2d_chain_set_tile(self.h, tn))
+
+    def tile(self):
+        return L.load().saber_hip_conv2d_chain_get_tile(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_conv2d_chain_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SaberFc:
     """Fc<MI355X, AK_FLOAT|AK_INT8> (saber/funcs/fc.h:48-127): out[m,n] = in[m,k] W[n,k]^T + bias."""
 
@@ -555,6 +583,10 @@ class Net:
 
     def num_ops(self):
         return L.load().saber_hip_net_num_ops(self.h)
+
+    def num_launches(self):
+        """kernel launches per forward (ops absorbed into a conv1x1-chain launch do not count)"""
+        return L.load().saber_hip_net_num_launches(self.h)
 
     def op_name(self, i):
         return L.load().saber_hip_net_op_name(self.h, i).decode()

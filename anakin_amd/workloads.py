@@ -176,7 +176,7 @@ def _out_hw(h, k, s, p):
 
 
 def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
-                   cxx_optimize=False):
+                   cxx_optimize=False, chain=None):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
@@ -186,9 +186,14 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     INT8 fc would otherwise compute on entry (same bytes, one launch fewer).
     fuse_pool (default: same as fuse_eltwise): a conv whose only consumer is a max pooling becomes one
     SaberConv2DPooling op where the library has a fused kernel (the stem: conv1 + pool1); the conv's own output
-    edge then does not exist."""
+    edge then does not exist.
+    chain (default: on whenever the eltwise is fused): `branch2c + sum + relu` and the next block's 1x1 `branch2a` run as
+    one conv1x1-chain launch (saber_hip_net_optimize flag 16; both ops stay in the list, the autotuner keeps the faster
+    form). Bytes of both edges unchanged."""
     from . import lib as L
     from . import saber as S
+    if chain is None:
+        chain = bool(fuse_eltwise or cxx_optimize) and not lanes
     if cxx_optimize:
         # the reference op list one to one; the fusions below are then found by the C++ host side
         # (saber_hip_net_optimize), not by this builder
@@ -314,6 +319,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     if cxx_optimize:
         net.unfused_ops = net.num_ops()
         net.removed = net.optimize(15)
+    net.chained = net.optimize(16) if chain else 0
     net.finalize()
     return net
 

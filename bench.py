@@ -187,7 +187,7 @@ def main():
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"value": round(value, 1), "unit": "images/s", "ms_per_step": round(ms_per_step, 4),
-                              "ops": net.num_ops(), "hip_graph": use_graph, "launch_probe": launch_probe}))
+                              "ops": net.num_ops(), "launches": net.num_launches(), "hip_graph": use_graph, "launch_probe": launch_probe}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -207,7 +207,7 @@ def main():
         op_us = net.time_ops(iters=20)          # hipEvents on the launch stream, per op, eager back-to-back
         names = [net.op_name(i) for i in range(net.num_ops())]
         conv_us = sum(t for t, n in zip(op_us, names) if n.startswith("conv:") or n.startswith("fc:"))
-        n_conv = sum(1 for n in names if n.startswith("conv:") or n.startswith("fc:"))
+        n_conv = sum(1 for n in names if (n.startswith("conv:") or n.startswith("fc:")) and "(in the chain launch)" not in n)
         es = 1 if args.precision == "int8" else 4
         alg_bytes = W.algorithmic_bytes_int8(model, B) * es
         alg_ops = 2.0 * W.conv_macs(model["spec"]) * B
@@ -241,7 +241,7 @@ def main():
                 roof["traffic_src_sha"] = tr["src_sha"]
         except (OSError, ValueError, KeyError):
             pass
-        roof.update(kernel="conv_igemm_kernel / conv_igemm_dma_kernel / conv3x3_halo_kernel / conv_stem_pool_kernel (all %d conv/fc launches of one forward)" % n_conv,
+        roof.update(kernel="conv_igemm_kernel / conv_igemm_dma_kernel / conv1x1_chain_kernel / conv3x3_img_kernel / conv_stem_pool_kernel (all %d conv/fc launches of one forward)" % n_conv,
                     launches=n_conv, avg_launch_us=round(conv_region_us / n_conv, 3),
                     avg_launch_us_how="ms_per_step of the timed region x (conv/fc share of the per-op hipEvent times) / launches",
                     per_op_event_sum_us=round(conv_us, 1), conv_share_of_step=round(conv_share, 4),
@@ -348,7 +348,7 @@ def main():
             "data": "synthetic (seeded uniform images, He-init weights with folded BN, MAXABS scales)",
             "config": {"workload": "%s %s post-fusion op list, batch %d per GPU, 224x224" %
                                    (args.model, args.precision, B),
-                       "global_batch": B * n_gpus, "ops": net.num_ops(), "hip_graph": use_graph,
+                       "global_batch": B * n_gpus, "ops": net.num_ops(), "launches": net.num_launches(), "hip_graph": use_graph,
                        "launch_probe": launch_probe,
                        "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus},
             "latency_ms": {"batch": B, "p50": round(p50, 4), "p99": round(p99, 4)},

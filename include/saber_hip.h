@@ -157,6 +157,21 @@ int saber_hip_conv2d_run_pair(saber_hip_conv_t* pair, const void* x, void* y_a, 
 int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* pair, const void* x, void* y_a, void* y_b,
                                    saber_hip_stream_t stream, int iters);
 
+/* 1x1 chain: `a` = 1x1 stride-1 INT8 conv with the fused SaberEltwise epilogue (RES_ELTWISE, s8 residual and output: the
+ * ResNet branch2c + sum + relu) and `b` = the 1x1 stride-1 s8-input conv that reads a's output (the next block's
+ * branch2a) run as ONE launch on shared pixel tiles. Shapes C -> 4C -> C with C in {64, 128, 256, 512}. Both outputs are
+ * written and hold the same bits as  saber_hip_conv2d_run(a) ; saber_hip_conv2d_run(b)  (reference: the two
+ * GemmX8S8S32XConv::dispatch calls + SaberEltwise, gemm_x8s8s32x_conv.cpp:184-257). The chain refers to a and b (they
+ * must outlive it and keep their weights) and owns only the repacked weight stream. */
+typedef struct saber_hip_chain saber_hip_chain_t;
+int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out);
+void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* chain);
+int saber_hip_conv2d_chain_run(saber_hip_chain_t* chain, const void* x, const void* res, void* y_a, void* y_b,
+                               saber_hip_stream_t stream);
+/* pixel fragments (16 pixels each) per workgroup: 4 | 2 for C = 64, 2 | 1 for C = 128, 1 otherwise */
+int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* chain, int tn);
+int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* chain);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Fully connected (SaberFc / VenderFc), FP32 and INT8                                          */
 /* ------------------------------------------------------------------------------------------- */
@@ -289,8 +304,13 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * of the reference's graph optimiser (framework/graph/llvm/fusion/fusion_op_register.cpp:45-175) for this executor.
  * flags: 1 conv + INT8 eltwise -> fused epilogue, 2 sibling convs -> one pair launch, 4 conv + max pooling ->
  * SaberConv2DPooling where a fused kernel exists, 8 global pooling also writes the INT8 fc's quantised operand;
- * 15 = all. Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
+ * 16 a 1x1 conv with the fused eltwise epilogue + the 1x1 conv that reads its output -> one conv1x1-chain launch (both ops
+ * stay in the list; while the chain is selected the second one launches nothing; saber_hip_net_autotune keeps whichever
+ * form is faster); 31 = all. Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0)
+ * or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
+/* kernel launches of one forward pass (ops minus the ones absorbed into a chain launch) */
+int saber_hip_net_num_launches(const saber_hip_net_t* net);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
 /* Lane of an op (graph::Lane, framework/core/net/operator_func.h:103-114; ParallScheduler): 0 = the caller's
  * stream, 1 = the net's side stream. Cross-lane tensor dependencies are ordered with events automatically and

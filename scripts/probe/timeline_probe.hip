@@ -23,6 +23,7 @@ __device__ unsigned long long* saber_tl_buf = nullptr;
 #include "../../anakin_amd/csrc/igemm_dma_m0_e1.hip"
 #include "../../anakin_amd/csrc/halo_e1.hip"
 #include "../../anakin_amd/csrc/stem_pool.hip"
+#include "../../anakin_amd/csrc/conv1x1_chain.hip"
 namespace saber_mi355x {
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
     static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
@@ -111,7 +112,7 @@ static void run(Probe& P, const char* name, int blocks, int nph, F launch) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     Probe P;
     CK(hipStreamCreate(&P.st));
     CK(hipEventCreate(&P.e0));
@@ -124,6 +125,29 @@ int main() {
     void* zero = dalloc(256, 0);
 
     run(P, "empty kernel (256 WGs)", 256, 1, [&] { hipLaunchKernelGGL(null_kernel, dim3(256), dim3(256), 0, P.st, P.out); });
+    if (argc > 1 && !strcmp(argv[1], "chain")) {
+        // conv1x1 chain: phases 0 entry, 1 loads / DMA issued, 2 first group's MFMAs done + DMA barrier, 3 first conv done,
+        // 4 tile stored / second conv's operand in registers, 5 done
+        struct { const char* name; int c, hw, n, tn; } cs[] = {
+            {"chain C=64 56x56 b8 px64", 64, 56, 8, 4}, {"chain C=64 56x56 b8 px32", 64, 56, 8, 2},
+            {"chain C=128 28x28 b8 px32", 128, 28, 8, 2}, {"chain C=128 28x28 b8 px16", 128, 28, 8, 1},
+            {"chain C=256 14x14 b8 px16", 256, 14, 8, 1}, {"chain C=512 7x7 b8 px16", 512, 7, 8, 1},
+            {"chain C=64 56x56 b1 px32", 64, 56, 1, 2}, {"chain C=256 14x14 b1 px16", 256, 14, 1, 1}};
+        for (auto& g : cs) {
+            ChainKArgs a;
+            memset(&a, 0, sizeof a);
+            const int M = g.n * g.hw * g.hw, K1 = 4 * g.c;
+            a.M = M; a.in_u8 = 1; a.relu1 = 0; a.res_relu = 1; a.coeff_conv = 16.f; a.scale_conv = 0.05f; a.coeff_res = 16.f;
+            a.scale_res = 0.04f; a.relu2 = 1; a.out_u8_2 = 1;
+            a.x = dalloc((size_t)M * g.c, -1); a.res = dalloc((size_t)M * K1, -1);
+            a.wstream = dalloc((size_t)2 * K1 * g.c, -1);
+            a.prm1 = dalloc((size_t)K1 * 12, 0); a.prm2 = dalloc((size_t)g.c * 12 + 1024, 0);
+            a.y1 = dalloc((size_t)M * K1, 0); a.y2 = dalloc((size_t)M * g.c, 0);
+            const int blocks = (M + 16 * g.tn - 1) / (16 * g.tn);
+            run(P, g.name, blocks, 6, [&] { launch_conv1x1_chain(a, g.c, K1, g.c, g.tn, P.st); });
+        }
+        return 0;
+    }
     {   // ---- fc1000 of ResNet50, batch 8: phases 0 entry, 1 loads issued, 2 MFMAs done, 3 after the reduce barrier, 4 stored
         ConvKArgs a;
         memset(&a, 0, sizeof a);

@@ -444,6 +444,86 @@ def test_conv_i8_fused_eltwise_equals_two_ops(relu):
     assert np.array_equal(host(e), want)
 
 
+CHAIN_CASES = [
+    # C, N, HW, in dtype of the first conv, out dtype / relu of the second, eltwise relu, pixel fragments (None: default)
+    (64, 2, 56, O.U8, O.U8, 1, 1, None),
+    (64, 1, 13, O.U8, O.U8, 1, 1, 2),      # 169 pixels: ragged last tile
+    (64, 1, 9, O.S8, O.S8, 0, 0, 4),       # s8 in, second conv without relu -> s8, eltwise without relu
+    (128, 2, 28, O.U8, O.U8, 1, 1, None),
+    (128, 1, 11, O.U8, O.S8, 1, 1, 1),
+    (256, 2, 14, O.U8, O.U8, 1, 1, None),
+    (256, 1, 5, O.S8, O.U8, 1, 0, None),   # 25 pixels
+    (512, 2, 7, O.U8, O.U8, 1, 1, None),
+    (512, 1, 3, O.U8, O.S8, 0, 1, None),
+]
+
+
+@pytest.mark.parametrize("case", CHAIN_CASES)
+def test_conv1x1_chain_equals_two_launches_and_oracle(case):
+    """saber_hip_conv2d_chain_run == [conv 1x1 + SaberEltwise sum] then [conv 1x1], bit for bit (both outputs)."""
+    Cc, N, HW, idt, odt2, relu2, res_relu, tn = case
+    rng = np.random.default_rng(1000 + Cc + HW)
+    K1, K2 = 4 * Cc, Cc
+    x = (rng.integers(0, 256, (N, HW, HW, Cc)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, HW, HW, Cc)).astype(np.int8))
+    res = rng.integers(-128, 128, (N, HW, HW, K1)).astype(np.int8)
+    w1 = (rng.standard_normal((K1, Cc, 1, 1)) * np.sqrt(2.0 / Cc)).astype(np.float32)
+    b1 = (rng.standard_normal(K1) * 0.5).astype(np.float32)
+    w2 = (rng.standard_normal((K2, K1, 1, 1)) * np.sqrt(2.0 / K1)).astype(np.float32)
+    b2 = (rng.standard_normal(K2) * 0.5).astype(np.float32)
+    s_in, s_mid, s_res, s_sum, s_out = 0.02, 0.05, 0.043, 0.06, 0.031
+    c = 1.0 / s_sum
+    # oracle
+    ws1 = O.weight_scales(w1)
+    bp1, sc1 = O.conv_i8_prepare(ws1, b1, s_in, s_mid, idt, O.S8)
+    t = O.conv_i8(x, O.quant_weights(w1, ws1), bp1, sc1, O.S8, 0)
+    want1 = O.eltwise_i8(t, res, s_mid, s_res, c, c, bool(res_relu))
+    ws2 = O.weight_scales(w2)
+    bp2, sc2 = O.conv_i8_prepare(ws2, b2, s_sum, s_out, O.S8, odt2)
+    want2 = O.conv_i8(want1, O.quant_weights(w2, ws2), bp2, sc2, odt2, relu2)
+    # device: two launches
+    pa = S.ConvParam(w1, b1, 1, (0, 0), (1, 1), (1, 1), False)
+    pa.res_mode, pa.res_relu, pa.sum_scale, pa.coeff, pa.scale_res = L.RES_ELTWISE, bool(res_relu), 1.0, (c, c), s_res
+    ca = S.SaberConv2D(int8=True).init((N, Cc, HW, HW), pa, idt, O.S8, s_in, s_mid)
+    pb = S.ConvParam(w2, b2, 1, (0, 0), (1, 1), (1, 1), bool(relu2))
+    cb = S.SaberConv2D(int8=True).init((N, K1, HW, HW), pb, O.S8, odt2, s_sum, s_out)
+    y1, y2 = ca.new_output(), cb.new_output()
+    ca.dispatch(dev(x), y1, dev(res))
+    cb.dispatch(y1, y2)
+    assert np.array_equal(host(y1), want1) and np.array_equal(host(y2), want2)
+    # device: one launch
+    chain = S.SaberConvChain(ca, cb)
+    if tn is not None:
+        chain.set_tile(tn)
+    z1, z2 = ca.new_output(), cb.new_output()
+    z1.fill_(77)
+    z2.fill_(77)
+    chain.dispatch(dev(x), dev(res), z1, z2)
+    assert np.array_equal(host(z1), want1), ("y1", chain.tile())
+    assert np.array_equal(host(z2), want2), ("y2", chain.tile())
+
+
+def test_conv1x1_chain_rejects_other_shapes():
+    rng = np.random.default_rng(3)
+    w1 = (rng.standard_normal((128, 32, 1, 1)) * 0.2).astype(np.float32)
+    w2 = (rng.standard_normal((32, 128, 1, 1)) * 0.2).astype(np.float32)
+    pa = S.ConvParam(w1, None, 1, (0, 0), (1, 1), (1, 1), False)
+    pa.res_mode, pa.res_relu, pa.sum_scale, pa.coeff, pa.scale_res = L.RES_ELTWISE, True, 1.0, (20.0, 20.0), 0.05
+    ca = S.SaberConv2D(int8=True).init((1, 32, 8, 8), pa, O.U8, O.S8, 0.02, 0.05)
+    cb = S.SaberConv2D(int8=True).init((1, 128, 8, 8), S.ConvParam(w2, None, 1, (0, 0), (1, 1), (1, 1), True), O.S8, O.U8,
+                                       0.05, 0.03)
+    with pytest.raises(L.SaberHipError):
+        S.SaberConvChain(ca, cb)          # C = 32 has no chain kernel
+    w1 = (rng.standard_normal((256, 64, 1, 1)) * 0.2).astype(np.float32)
+    plain = S.SaberConv2D(int8=True).init((1, 64, 8, 8), S.ConvParam(w1, None, 1, (0, 0), (1, 1), (1, 1), False), O.U8,
+                                          O.S8, 0.02, 0.05)
+    w2 = (rng.standard_normal((64, 256, 1, 1)) * 0.2).astype(np.float32)
+    cb = S.SaberConv2D(int8=True).init((1, 256, 8, 8), S.ConvParam(w2, None, 1, (0, 0), (1, 1), (1, 1), True), O.S8, O.U8,
+                                       0.05, 0.03)
+    with pytest.raises(L.SaberHipError):
+        S.SaberConvChain(plain, cb)       # the first conv has no fused eltwise
+
+
 PAIR_CASES = [
     # N, H, W, C, K1, K2, k, pad, stride
     (2, 14, 14, 64, 256, 64, 1, 0, 1),      # res2a: branch1 + branch2a

@@ -216,6 +216,8 @@ def test_cxx_net_optimize_equals_python_fused_list(setup):
     a = W.build_int8_net(model, dict(scales), 2)                       # fused by workloads.py
     b = W.build_int8_net(model, dict(scales), 2, cxx_optimize=True)    # unfused list + saber_hip_net_optimize
     assert b.unfused_ops == 73 and b.removed == 22 and b.num_ops() == a.num_ops() == 52, (b.unfused_ops, b.removed, b.num_ops())
+    # ... and both lists then get the conv1x1 chains (branch2c + sum -> next branch2a): 12 candidates, the 10 with C <= 256 on
+    assert a.chained == b.chained == 10 and a.num_launches() == b.num_launches() == 42, (a.chained, a.num_launches())
     assert [a.op_name(i) for i in range(52)] == [b.op_name(i) for i in range(52)]
     for net in (a, b):
         net.tensor("data").copy_(torch.from_numpy(x).cuda())
