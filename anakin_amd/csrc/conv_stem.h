@@ -204,7 +204,7 @@ static hipError_t launch_conv_stem_inst(int f32_in, const ConvKArgs& a, hipStrea
 // exact, so the result equals pool(conv(x)) byte for byte; windows are clipped at the image border as
 // SaberPooling does (ceil-mode output shape).
 template <bool F32IN>
-__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const ConvKArgs a) {
+__global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs a) {
     constexpr int PH = 4, PW = 8;
     constexpr int CR = 2 * PH + 1, CC = 2 * PW + 1, NPX = CR * CC;      // 9 x 17 = 153 conv outputs
     constexpr int NG = (NPX + 15) / 16, TN = NG / 2;                    // 10 MFMA pixel groups, 5 per wave column
