@@ -14,7 +14,7 @@ SOURCES = ["conv_igemm.hip", "elementwise.hip", "fc_small.hip", "conv1x1_chain.h
     ["igemm_dma_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 3)]] + \
     ["halo_e%d.hip" % e for e in range(4)] + ["img_e%d.hip" % e for e in (0, 1, 3)] + ["stem_e%d.hip" % e for e in range(4)] + ["stem_pool.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _stale(obj, deps):
@@ -66,7 +66,7 @@ def build_cpp_tests(verbose=False):
         if _stale(out, deps):
             cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-o", out,
                    "-L" + HERE, "-lsaber_mi355x", "-L" + os.path.join(root, "oracle"), "-lsaber_oracle",
-                   "-Wl,-rpath,$ORIGIN/../../anakin_amd", "-Wl,-rpath,$ORIGIN/../../oracle", "-Wno-unused-result"]
+                   "-Wl,-rpath,$ORIGIN/../../anakin_amd", "-Wl,-rpath,$ORIGIN/../../oracle", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

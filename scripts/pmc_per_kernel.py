@@ -7,7 +7,7 @@ import json
 import sqlite3
 import sys
 
-CONV = ("conv_igemm", "conv3x3_halo", "conv3x3_img", "conv_stem", "fc_i8_small")
+CONV = ("conv_igemm", "conv3x3_halo", "conv3x3_img", "conv_stem", "conv1x1_chain", "fc_i8_small")
 path, counter, nlast = sys.argv[1], sys.argv[2], int(sys.argv[3])
 c = sqlite3.connect(path)
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]

@@ -17,7 +17,7 @@ python bench.py --steps 400 --warmup 10 --per-op --tune-cache $OUT/tune.json $EX
 ARGS="--steps 20 --warmup 5 --timed-only --tune-cache $OUT/tune.json $EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
 grep -h '"value"' $OUT/bench_trace.log | head -1 > $OUT/bench_under_trace.json
-NOPS=$(python -c "import json;print(json.load(open('$OUT/bench_under_trace.json'))['ops'])")
+NOPS=$(python -c "import json;d=json.load(open('$OUT/bench_under_trace.json'));print(d.get('launches', d['ops']))")
 DB=$(find $OUT/trace -name '*_results.db' | head -1)
 python scripts/rocprof_summary.py $DB 70 $((NOPS*20)) > $OUT/kernel_trace_summary.txt
 python scripts/trace_sequence.py $DB $NOPS 20 > $OUT/sequence_b8.txt
