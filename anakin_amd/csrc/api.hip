@@ -135,10 +135,11 @@ struct saber_hip_conv {
 
 // two 1x1 INT8 convs in one launch (conv1x1_chain.hip); refers to the two ops, owns the repacked stream
 struct saber_hip_chain {
+    saber_hip_conv* c3 = nullptr;   // the block's 3x3 conv in front of `a` (saber_hip_conv2d_chain_create3), or null
     saber_hip_conv* a = nullptr;
     saber_hip_conv* b = nullptr;
     int c1 = 0, k1 = 0, k2 = 0, tn = 0;
-    DevBuf<uint8_t> d_stream, d_prm1, d_prm2;
+    DevBuf<uint8_t> d_stream, d_prm0, d_prm1, d_prm2;
 };
 
 struct saber_hip_fc {
@@ -1238,7 +1239,22 @@ static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave,
                     out.insert(out.end(), (const uint8_t*)src, (const uint8_t*)src + 16);
                 }
 }
-int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+// the 3x3 conv's weights [K][C][3][3] -> per wave, steps ordered [tap][k-step][accumulator] (conv1x1_chain.hip phase 0)
+static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out) {
+    const int kw = C / 4, mf0 = C / 64, ksn = C / 64;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ks = 0; ks < ksn; ++ks)
+            for (int mf = 0; mf < mf0; ++mf)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, kq = lane >> 4;
+                    const int ch = wave * kw + (rho >> 2) * 4 * mf0 + mf * 4 + (rho & 3);
+                    for (int t = 0; t < 16; ++t) {
+                        const int c = ks * 64 + kq * 16 + t;
+                        out.push_back((uint8_t)w[((size_t)ch * C + c) * 9 + tap]);
+                    }
+                }
+}
+static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out) {
     if (!a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     if (!chain_1x1(a) || !chain_1x1(b)) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
     const saber_hip_conv_desc& da = a->d;
@@ -1249,13 +1265,26 @@ int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, sabe
         return fail(SABER_HIP_INVALID_VALUE, "chain: the second conv must be a plain s8-input conv with an 8-bit output");
     if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || !conv1x1_chain_ok(da.c, da.k, db.k))
         return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
+    if (c3) {
+        const saber_hip_conv_desc& d3 = c3->d;
+        const bool ok = c3->is_i8 && c3->weights_set && c3->algo == ALGO_IGEMM_I8 && c3->epi == EPI_I8_CONV && d3.kh == 3 && d3.kw == 3 &&
+                        d3.stride_h == 1 && d3.stride_w == 1 && d3.pad_h == 1 && d3.pad_w == 1 && d3.dil_h == 1 && d3.dil_w == 1 &&
+                        d3.group == 1 && !c3->pair_k2 && !c3->pool_fused && !c3->pool2 && !c3->pre_quant && !c3->pre_pad &&
+                        c3->c_eff == d3.c && d3.act_negative_slope == 0.f && d3.in_layout == SABER_HIP_NHWC &&
+                        d3.out_layout == SABER_HIP_NHWC && d3.res_mode == SABER_HIP_RES_NONE && d3.c == da.c && d3.k == da.c &&
+                        d3.n == da.n && d3.h == da.h && d3.w == da.w && da.c <= 256 &&
+                        (d3.out_dtype == SABER_HIP_S8 || d3.out_dtype == SABER_HIP_U8) &&
+                        (d3.out_dtype == SABER_HIP_U8) == (a->x_dtype == DT_U8);
+        if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: the head must be the 3x3 stride-1 pad-1 INT8 conv (C -> C, C <= 256) whose 8-bit output the first 1x1 conv reads");
+    }
     saber_hip_chain* ch = new saber_hip_chain();
-    ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = db.k;
+    ch->c3 = c3; ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = db.k;
     ch->tn = conv1x1_chain_tn(da.c, da.n * a->oh * a->ow);
     const int mfg2 = (db.k / 4) / 16 >= 4 ? 4 : (db.k / 4) / 16;
-    std::vector<uint8_t> stream, p1, p2;
-    stream.reserve((size_t)da.k * da.c + (size_t)db.k * db.c);
+    std::vector<uint8_t> stream, p0, p1, p2;
+    stream.reserve((size_t)da.k * da.c + (size_t)db.k * db.c + (c3 ? (size_t)9 * da.c * da.c : 0));
     for (int w = 0; w < 4; ++w) {
+        if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, stream);
         pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, stream);
         pack_chain_weights(b->wq_oihw.data(), db.k, db.c, mfg2, w, stream);
     }
@@ -1264,12 +1293,23 @@ int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, sabe
     hipError_t e = ch->d_stream.upload(stream);
     if (e == hipSuccess) e = ch->d_prm1.upload(p1);
     if (e == hipSuccess) e = ch->d_prm2.upload(p2);
+    if (e == hipSuccess && c3) {
+        pack_chain_params(c3, ((size_t)da.c / 4 * 3 + 63) / 64 * 64, p0);
+        e = ch->d_prm0.upload(p0);
+    }
     if (e != hipSuccess) {
         delete ch;
         return hip_fail(e, "chain: device copies");
     }
     *out = ch;
     return SABER_HIP_OK;
+}
+int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+    return chain_build(nullptr, a, b, out);
+}
+int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+    if (!conv3x3) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    return chain_build(conv3x3, a, b, out);
 }
 void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
@@ -1296,7 +1336,19 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     k.coeff_conv = a->d.coeff_conv; k.scale_conv = a->out_scale; k.coeff_res = a->d.coeff_res; k.scale_res = a->d.scale_res;
     k.relu2 = b->d.act == SABER_HIP_ACT_RELU;
     k.out_u8_2 = b->d.out_dtype == SABER_HIP_U8;
-    HIP_TRY(launch_conv1x1_chain(k, ch->c1, ch->k1, ch->k2, ch->tn, (hipStream_t)stream));
+    if (ch->c3) {   // x is the 3x3 conv's input; tiles of tn rows x 16 columns
+        auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };
+        k.prm0 = ch->d_prm0.p;
+        k.zero = zero_page();
+        k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
+        k.tiles_x = (k.W + 15) / 16;
+        k.tiles_per_img = k.tiles_x * ((k.H + ch->tn - 1) / ch->tn);
+        k.mg_tiles_x = magic(k.tiles_x);
+        k.mg_tpi = magic(k.tiles_per_img);
+        k.in0_u8 = ch->c3->x_dtype == DT_U8;
+        k.relu0 = ch->c3->d.act == SABER_HIP_ACT_RELU;
+    }
+    HIP_TRY(launch_conv1x1_chain(k, ch->c1, ch->k1, ch->k2, ch->tn, ch->c3 ? 1 : 0, (hipStream_t)stream));
     return SABER_HIP_OK;
 }
 
@@ -1318,6 +1370,11 @@ struct NetOp {
     saber_hip_chain* chain = nullptr;
     int chain_out = -1;
     bool use_chain = false, skip = false;
+    // ... with the block's 3x3 conv in front (flag 32): THIS op is that 3x3 conv, the next two are the chain; while use_chain3
+    // is set it launches all three (its own output edge is then not written) and both followers carry `skip`
+    saber_hip_chain* chain3 = nullptr;
+    int chain3_res = -1, chain3_y1 = -1, chain3_y2 = -1;
+    bool use_chain3 = false;
     int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
     bool record = false;     // an op on the other lane consumes this op's output: record an event after it
     int p[16] = {0};
@@ -1351,6 +1408,8 @@ static int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     switch (o.kind) {
     case OP_CONV:
         if (o.skip) return SABER_HIP_OK;      // written by the previous op's chain launch
+        if (o.chain3 && o.use_chain3)
+            return saber_hip_conv2d_chain_run(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), s);
         if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
         return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
     case OP_CONV_PAIR: return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
@@ -1527,13 +1586,35 @@ int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_i
 // saber_hip_net_finalize. Returns the number of launches removed, or a negative status.
 // ------------------------------------------------------------------------------------------------
 static void net_name_chain(NetOp& A, NetOp& B) {
-    if (A.use_chain) {
+    if (A.skip) {
+        A.name = B.name = "conv:(in the chain launch)";
+    } else if (A.use_chain) {
         A.name = "conv:chain1x1_c" + std::to_string(A.chain->c1) + "_px" + std::to_string(16 * A.chain->tn);
         B.name = "conv:(in the chain launch)";
     } else {
         A.name = std::string("conv:") + A.conv->algo_name;
         B.name = std::string("conv:") + B.conv->algo_name;
     }
+}
+// mode of the ops around chain head A = ops[ia]: 0 separate launches, 1 A + B chained, 2 (ops[ia - 1] has chain3) 3x3 + A + B
+static void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
+    NetOp& A = net->ops[ia];
+    NetOp& B = net->ops[ia + 1];
+    NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
+    if (mode == 2 && !H) mode = 1;
+    A.use_chain = mode >= 1;
+    B.skip = mode >= 1;
+    A.skip = mode == 2;
+    if (H) {
+        H->use_chain3 = mode == 2;
+        H->name = mode == 2 ? "conv:conv3x3+chain1x1_c" + std::to_string(H->chain3->c1) + "_" + std::to_string(H->chain3->tn) + "x16"
+                            : std::string("conv:") + H->conv->algo_name;
+    }
+    net_name_chain(A, B);
+}
+static int net_chain_mode(const saber_hip_net* net, int ia) {
+    const NetOp& A = net->ops[ia];
+    return A.skip ? 2 : (A.use_chain ? 1 : 0);
 }
 static int clone_conv_i8(const saber_hip_conv* src, const saber_hip_conv_desc& d, saber_hip_conv** out) {
     int rc = saber_hip_conv2d_create(&d, out);
@@ -1690,7 +1771,8 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
         for (size_t i = 0; i + 1 < ops.size(); ++i) {
             NetOp& A = ops[i];
             NetOp& B = ops[i + 1];
-            if (A.kind != OP_CONV || B.kind != OP_CONV || !A.conv || !B.conv || A.chain || A.skip || B.chain || A.lane || B.lane)
+            if (A.kind != OP_CONV || B.kind != OP_CONV || !A.conv || !B.conv || A.chain || A.skip || B.chain || A.lane || B.lane ||
+                A.chain3 || B.chain3)
                 continue;
             if (A.conv->d.res_mode != SABER_HIP_RES_ELTWISE || B.in != A.out || A.in2 < 0 || B.in2 >= 0) continue;
             saber_hip_chain* ch = nullptr;
@@ -1698,9 +1780,30 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             net->owned_chains.push_back(ch);
             A.chain = ch;
             A.chain_out = B.out;
-            A.use_chain = B.skip = ch->c1 <= 256;      // default until the autotuner has timed both forms
+            net_set_chain_mode(net, (int)i, ch->c1 <= 256 ? 1 : 0);      // default until the autotuner has timed both forms
             if (A.use_chain) ++removed;
-            net_name_chain(A, B);
+        }
+    }
+    // ---- 32: the block's 3x3 conv in front of a chain head, when the head is its only consumer -----------------------
+    if (flags & 32) {
+        for (size_t i = 0; i + 2 < ops.size(); ++i) {
+            NetOp& Hd = ops[i];
+            NetOp& A = ops[i + 1];
+            NetOp& B = ops[i + 2];
+            if (!A.chain || Hd.kind != OP_CONV || !Hd.conv || Hd.chain3 || Hd.chain || Hd.skip || Hd.lane || Hd.in2 >= 0 ||
+                A.in != Hd.out)
+                continue;
+            int readers = 0;
+            for (const NetOp& o : ops) readers += (o.in == Hd.out) + (o.in2 == Hd.out);
+            if (readers != 1) continue;
+            saber_hip_chain* ch = nullptr;
+            if (saber_hip_conv2d_chain_create3(Hd.conv, A.conv, B.conv, &ch) != SABER_HIP_OK) continue;
+            net->owned_chains.push_back(ch);
+            Hd.chain3 = ch;
+            Hd.chain3_res = A.in2; Hd.chain3_y1 = A.out; Hd.chain3_y2 = B.out;
+            const bool was = A.use_chain;
+            net_set_chain_mode(net, (int)i + 1, ch->c1 <= 128 ? 2 : (was ? 1 : 0));
+            if (Hd.use_chain3) removed += was ? 1 : 2;
         }
     }
     // the shared workspace only has to cover the surviving ops
@@ -1897,6 +2000,7 @@ int saber_hip_net_get_choice(saber_hip_net_t* net, int index) {
     saber_hip_conv* c = net_op_conv(net, index);
     int choice = (c && !c->pool_fused && c->algo <= ALGO_IGEMM_F32) ? saber_hip_conv2d_get_tile(c) : 0;
     if (c && net->ops[index].chain) choice |= (1 << 28) | ((net->ops[index].use_chain ? net->ops[index].chain->tn : 0) << 24);
+    if (c && net->ops[index].chain3) choice |= (1 << 29) | ((net->ops[index].use_chain3 ? net->ops[index].chain3->tn : 0) << 24);
     return choice;
 }
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
@@ -1908,11 +2012,15 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     if (rc) return rc;
     NetOp& o = net->ops[index];
     o.name = std::string(o.kind == OP_FC || o.kind == OP_FC_Q ? "fc:" : "conv:") + c->algo_name;
-    if (o.chain && (chain_bits & 16) && index + 1 < (int)net->ops.size()) {
+    // chain decisions: a 3x3 head (bit 29) is restored before its chain head (bit 28, the next op): set_choices runs in op order
+    if (o.chain3 && (chain_bits & 32) && index + 2 < (int)net->ops.size()) {
+        const int tn = chain_bits & 15;
+        if (tn && (rc = saber_hip_conv2d_chain_set_tile(o.chain3, tn)) != SABER_HIP_OK) return rc;
+        net_set_chain_mode(net, index + 1, tn ? 2 : net_chain_mode(net, index + 1) == 2 ? 1 : net_chain_mode(net, index + 1));
+    } else if (o.chain && (chain_bits & 16) && index + 1 < (int)net->ops.size()) {
         const int tn = chain_bits & 15;
         if (tn && (rc = saber_hip_conv2d_chain_set_tile(o.chain, tn)) != SABER_HIP_OK) return rc;
-        o.use_chain = net->ops[index + 1].skip = tn != 0;
-        net_name_chain(o, net->ops[index + 1]);
+        if (net_chain_mode(net, index) != 2) net_set_chain_mode(net, index, tn ? 1 : 0);
     } else if (o.skip) {
         o.name = "conv:(in the chain launch)";
     }
@@ -1952,45 +2060,63 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         if (rc) return rc;
         o.name = std::string(o.kind == OP_CONV ? "conv:" : "fc:") + c->algo_name;
     }
-    // conv1x1 chains: the two tuned launches against the one chain launch (every pixel-tile size), on the real tensors
+    // conv1x1 chains: the tuned separate launches against the chain launch (every pixel-tile size) and, where the block's
+    // 3x3 conv can lead the chain, against that single launch too - on the real tensors
     for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
         NetOp& A = net->ops[i];
-        NetOp& B = net->ops[i + 1];
         if (!A.chain) continue;
+        const int ia = (int)i;
+        NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
+        const int first = H ? ia - 1 : ia;
         hipStream_t s = (hipStream_t)stream;
         EventPair ev;
         HIP_TRY(ev.init());
         const int n = iters < 20 ? 20 : iters;
+        auto run_all = [&]() -> int {
+            int rc = 0;
+            for (int k = first; k <= ia + 1; ++k) rc |= net_launch(net, net->ops[k], s);
+            return rc;
+        };
         auto timed = [&](float* ms) -> int {
-            int rc = net_launch(net, A, s) | net_launch(net, B, s);
+            int rc = run_all();
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ev.e0, s));
-            for (int it = 0; it < n; ++it) rc |= net_launch(net, A, s) | net_launch(net, B, s);
+            for (int it = 0; it < n; ++it) rc |= run_all();
             HIP_TRY(hipEventRecord(ev.e1, s));
             HIP_TRY(hipEventSynchronize(ev.e1));
             HIP_TRY(hipEventElapsedTime(ms, ev.e0, ev.e1));
             return rc;
         };
         float best = 0.f;
-        int best_tn = 0;             // 0: two launches
-        A.use_chain = B.skip = false;
+        int best_mode = 0, best_tn = 0;
+        net_set_chain_mode(net, ia, 0);
         int rc = timed(&best);
         if (rc) return rc;
-        const int tns[2] = {A.chain->c1 == 64 ? 4 : (A.chain->c1 == 128 ? 2 : 1), A.chain->c1 == 64 ? 2 : (A.chain->c1 == 128 ? 1 : 0)};
-        A.use_chain = B.skip = true;
-        for (int tn : tns) {
-            if (!tn) continue;
-            float ms = 0.f;
-            if (saber_hip_conv2d_chain_set_tile(A.chain, tn) != SABER_HIP_OK || timed(&ms) != SABER_HIP_OK) continue;
-            if (ms < best) { best = ms; best_tn = tn; }
+        const int c1 = A.chain->c1;
+        const int tns[2] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 0)};
+        for (int mode = 1; mode <= (H ? 2 : 1); ++mode) {
+            saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
+            for (int tn : tns) {
+                if (!tn) continue;
+                float ms = 0.f;
+                if (saber_hip_conv2d_chain_set_tile(ch, tn) != SABER_HIP_OK) continue;
+                net_set_chain_mode(net, ia, mode);
+                if (timed(&ms) != SABER_HIP_OK) continue;
+                if (ms < best) { best = ms; best_mode = mode; best_tn = tn; }
+            }
         }
-        A.use_chain = B.skip = best_tn != 0;
-        if (best_tn) (void)saber_hip_conv2d_chain_set_tile(A.chain, best_tn);
-        net_name_chain(A, B);
-        rc = net_launch(net, A, s) | net_launch(net, B, s);   // both outputs hold the selected form's result
+        if (best_mode) (void)saber_hip_conv2d_chain_set_tile(best_mode == 2 ? H->chain3 : A.chain, best_tn);
+        net_set_chain_mode(net, ia, best_mode);
+        rc = run_all();   // every written output holds the selected form's result
         if (rc) return rc;
     }
     return SABER_HIP_OK;
+}
+// 1 when tensor `id` is the output edge of a 3x3 conv that currently runs inside a conv3x3 + chain launch (not written)
+int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id) {
+    for (const NetOp& o : net->ops)
+        if (o.chain3 && o.use_chain3 && o.out == id) return 1;
+    return 0;
 }
 int saber_hip_net_num_launches(const saber_hip_net_t* net) {
     int n = 0;

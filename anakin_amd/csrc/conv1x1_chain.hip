@@ -82,55 +82,105 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* dst_wave_base) 
 
 }  // namespace
 
-// KS1 = C1/64, G1 = K1/256 (64-channel groups per wave, first conv), MFG2 / G2: accumulators per group / groups per wave
-// of the second conv (K2 = 64*G2*MFG2), TN pixel fragments, R ring depth in steps (1 KB per wave each), GU: groups of the
-// first conv per unrolled loop body. R == all steps of the wave: every weight load is issued in the prologue and the
-// ring is never refilled; otherwise R divides GU * (steps per group) and the second conv's group length.
-template <int KS1, int G1, int MFG2, int G2, int TN, int R, int GU>
+// KS1 = C1/64, G1 = K1/256 (64-channel groups per wave, first 1x1 conv), MFG2 / G2: accumulators per group / groups per
+// wave of the second 1x1 conv (K2 = 64*G2*MFG2), TN pixel fragments, R ring depth in steps (1 KB per wave each; divides
+// the group lengths of both 1x1 convs).
+// C3: the block's 3x3 conv (C1 -> C1, stride 1, pad 1, the `branch2b` in front of the first 1x1 conv) runs in the same
+// launch as "phase 0": the workgroup's pixels are then a 2-D tile (TN rows x 16 columns) of one image, the input halo
+// (TN+2) x 18 pixels comes into LDS by DMA, the 3x3 conv's weights lead the wave's stream ([tap][k-step][accumulator]),
+// and its 8-bit output tile stays in LDS as the first 1x1 conv's B operand - that edge never reaches memory.
+template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3>
 __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) {
     constexpr int NW = 4;
     constexpr int KS2 = 4 * G1;                       // K1 / 64
     constexpr int K1 = 256 * G1, C1 = 64 * KS1, K2 = NW * G2 * 16 * MFG2;
     constexpr int NPX = 16 * TN;
+    constexpr int MF0 = KS1;                          // 3x3 conv: C1 / 4 channels per wave = KS1 accumulators
+    constexpr int T0 = C3 ? MF0 * 9 * KS1 : 0;        // steps of the 3x3 conv per wave
     constexpr int SG1 = KS1 * 4, SG2 = KS2 * MFG2;    // steps per channel group
     constexpr int T1 = G1 * SG1, T2 = G2 * SG2;       // steps per wave
-    constexpr bool FULL = R == T1 + T2;
-    constexpr int NB1 = G1 / GU;
+    constexpr int OFF = T0 % R;                       // ring slot of the first 1x1 conv's first step
     constexpr int CPR = K1 / 16;                      // 16-byte chunks per tile row
+    constexpr int CH1 = C1 / 16;                      // ... per pixel of the 3x3 conv's input / output
+    constexpr int HW = 18, HP = (TN + 2) * HW;        // halo pixels
+    constexpr int HCH = C3 ? (HP * CH1 + 63) / 64 * 64 : 1;
+    constexpr int P0C = C3 ? (C1 / 4 * 3 + 63) / 64 * 64 : 1;
     constexpr int P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
-    static_assert(G1 % GU == 0 && (FULL ? (NB1 == 1 && G2 == 1) : ((GU * SG1) % R == 0 && SG2 % R == 0)),
-                  "ring depth must divide the unrolled body lengths");
+    static_assert(SG1 % R == 0 && SG2 % R == 0, "ring depth must divide the group lengths");
     static_assert(CPR >= 16 && P1C % 64 == 0, "tile rows are swizzled on 16 chunks");
 
     __shared__ v4i tile[NPX * CPR];
     __shared__ v4i prm1[P1C];
     __shared__ v4i prm2[P2C];
+    __shared__ v4i halo[HCH];
+    __shared__ v4i mid[C3 ? NPX * CH1 : 1];
+    __shared__ v4i prm0[P0C];
     SABER_TL_DECL;
     SABER_TL(0);
     asm volatile("" ::"s"(a.x), "s"(a.wstream), "s"(a.res), "s"(a.prm1), "s"(a.prm2), "s"(a.M), "s"(a.in_u8));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
+    // ---- this workgroup's pixels: a run of NPX pixels, or (C3) rows y0 .. y0+TN-1 x columns x0 .. x0+15 of image n
     const int p0 = blockIdx.x * NPX;
     const int plast = a.M - 1;
+    int n = 0, y0 = 0, x0 = 0;
+    if constexpr (C3) {
+        asm volatile("" ::"s"(a.prm0), "s"(a.zero), "s"(a.H), "s"(a.W), "s"(a.tiles_x), "s"(a.tiles_per_img), "s"(a.mg_tiles_x),
+                     "s"(a.mg_tpi));
+        const int t = blockIdx.x;
+        n = a.mg_tpi ? (int)__umulhi((unsigned)t, a.mg_tpi) : t;
+        const int rem = t - n * a.tiles_per_img;
+        const int ty = a.mg_tiles_x ? (int)__umulhi((unsigned)rem, a.mg_tiles_x) : rem;
+        y0 = ty * TN;
+        x0 = (rem - ty * a.tiles_x) * 16;
+    }
+    auto pix = [&](int px, bool& ok) -> int {          // tile pixel -> index into the [M][channels] tensors (clamped)
+        if constexpr (!C3) {
+            const int p = p0 + px;
+            ok = p < a.M;
+            return p < plast ? p : plast;
+        } else {
+            int y = y0 + (px >> 4), x = x0 + (px & 15);
+            ok = y < a.H && x < a.W;
+            y = y < a.H ? y : a.H - 1;
+            x = x < a.W ? x : a.W - 1;
+            return (n * a.H + y) * a.W + x;
+        }
+    };
 
-    // ---- first conv's B operand: the pixel tile of x, straight into registers ------------------------------------
+    // ---- first 1x1 conv's B operand: the pixel tile of x straight into registers (C3: produced by phase 0 instead)
     v4i bx[KS1][TN];
+    if constexpr (!C3) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int p = p0 + j * 16 + frow;
-        p = p < plast ? p : plast;                     // pixels beyond the tensor repeat the last one (never stored)
-        const char* xp = (const char*)a.x + (size_t)p * C1 + fq * 16;
+        for (int j = 0; j < TN; ++j) {
+            bool ok;
+            const int p = pix(j * 16 + frow, ok);      // pixels beyond the tensor repeat the last one (never stored)
+            const char* xp = (const char*)a.x + (size_t)p * C1 + fq * 16;
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) bx[ks][j] = *(const v4i*)(xp + ks * 64);
+            for (int ks = 0; ks < KS1; ++ks) bx[ks][j] = *(const v4i*)(xp + ks * 64);
+        }
     }
 
-    // ---- residual tile and the per-channel constants -> LDS by DMA -----------------------------------------------
+    // ---- LDS by DMA: (C3) the 3x3 conv's input halo, the residual tile, the per-channel constants ----------------
     // tile[px][chunk ^ (px & 15)]: the epilogue's 16-lane column accesses and the second conv's operand reads hit 16
     // different bank groups. One instruction moves 64 chunks; lane L of instruction i lands in chunk i*64 + L.
     // Issued BEFORE the weight ring: vector-memory loads return in order, so by the time the first MFMA has its weights
-    // this wave's DMA has landed (the barrier after the first channel group covers the other waves).
+    // this wave's DMA has landed.
     {
+        if constexpr (C3) {
+            const char* xg = (const char*)a.x;
+            for (int i = wave; i < HCH / 64; i += NW) {
+                const int L = i * 64 + lane;
+                const int hp = L / CH1, cc = L % CH1;
+                const int hy = hp / HW, hx = hp - hy * HW;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool in = hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // zero padding
+                const char* src = in ? xg + ((size_t)((n * a.H + gy) * a.W + gx) * C1 + cc * 16) : (const char*)a.zero;
+                lds_dma16(src, halo + i * 64);
+            }
+            for (int i = wave; i < P0C / 64; i += NW) lds_dma16((const v4i*)a.prm0 + i * 64 + lane, prm0 + i * 64);
+        }
         const char* rg = (const char*)a.res;
         constexpr int NI = NPX * CPR / 64;
 #pragma unroll
@@ -138,8 +188,8 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             const int i = i0 + wave;
             const int L = i * 64 + lane;
             const int px = L / CPR, c = (L % CPR) ^ (px & 15);
-            int p = p0 + px;
-            p = p < plast ? p : plast;
+            bool ok;
+            const int p = pix(px, ok);
             lds_dma16(rg + (size_t)p * K1 + c * 16, tile + i * 64);
         }
         for (int i = wave; i < P1C / 64; i += NW) lds_dma16((const v4i*)a.prm1 + i * 64 + lane, prm1 + i * 64);
@@ -148,11 +198,62 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     asm volatile("" ::: "memory");                     // keep the ring's loads behind the DMA in program order
 
     // ---- weight ring: the first R steps of this wave's stream ---------------------------------------------------
-    const v4i* wsb = (const v4i*)a.wstream + (size_t)wave * ((T1 + T2) * 64);
+    const v4i* wsb = (const v4i*)a.wstream + (size_t)wave * ((T0 + T1 + T2) * 64);
     v4i ring[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) ring[r] = wsb[r * 64 + lane];
-    wsb += R * 64;                                     // step sb of the current body refills from wsb[sb * 64 + lane]
+    wsb += R * 64;                                     // step s of the current phase / group refills from wsb[s * 64 + lane]
+
+    if constexpr (C3) {
+        // ============= phase 0: the 3x3 conv on the halo, output tile -> LDS ========================================
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R) : "memory");   // everything older than the ring: this wave's DMA
+        __builtin_amdgcn_s_barrier();                              // ... and every other wave's
+        SABER_TL(1);
+        const int xm0 = a.in0_u8 ? (int)0x80808080u : 0;
+        v4i acc[MF0][TN];
+#pragma unroll
+        for (int mf = 0; mf < MF0; ++mf)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+        const v4i* hb = halo + frow * CH1 + fq;
+#pragma unroll
+        for (int s = 0; s < T0; ++s) {                 // steps ordered [tap][k-step][accumulator]
+            const int mf = s % MF0, ks = (s / MF0) % KS1, tap = s / (MF0 * KS1);
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                v4i b = hb[((j + dy) * HW + dx) * CH1 + ks * 4];
+                b.x ^= xm0; b.y ^= xm0; b.z ^= xm0; b.w ^= xm0;
+                acc[mf][j] = mma_step(ring[s % R], b, acc[mf][j]);
+            }
+            ring[s % R] = wsb[s * 64 + lane];
+        }
+        wsb += T0 * 64;
+        // epilogue: lane = 4*MF0 consecutive channels c0.. of pixel j*16 + frow -> mid[px][C1] (bytes)
+        const int c0 = wave * (C1 / NW) + fq * (4 * MF0);
+        const v4i* pp = prm0 + (c0 / 4) * 3;
+        const float lo0 = a.relu0 ? 0.f : -3.0e38f;
+        const float off0 = a.in_u8 ? 0.f : 128.f;      // a.in_u8: dtype of the 3x3 conv's output = first 1x1 conv's input
+        const unsigned xo0 = a.in_u8 ? 0u : 0x80808080u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            unsigned o[MF0];
+#pragma unroll
+            for (int mf = 0; mf < MF0; ++mf)
+                o[mf] = chain_out_pack(acc[mf][j], pp[mf * 3 + 2], __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
+                                       __builtin_bit_cast(v4f, pp[mf * 3]), lo0, off0, xo0);
+            char* mp = (char*)mid + (j * 16 + frow) * C1 + c0;
+            if constexpr (MF0 == 1) *(unsigned*)mp = o[0];
+            else if constexpr (MF0 == 2) *(uint2*)mp = make_uint2(o[0], o[1]);
+            else *(uint4*)mp = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) bx[ks][j] = mid[(j * 16 + frow) * CH1 + ks * 4 + fq];
+    }
 
     const int xmask = a.in_u8 ? (int)0x80808080u : 0;
 #pragma unroll
@@ -163,55 +264,51 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
         }
     const float lo_s8 = a.relu1 ? 0.f : -128.f;
     const float res_lo = a.res_relu ? 0.f : -3.0e38f;
-    SABER_TL(1);
+    if constexpr (!C3) SABER_TL(1);
 
-    // ================= first conv: groups of 64 channels, steps ordered [ks][mf] ===================================
+    // ================= first 1x1 conv: groups of 64 channels, steps ordered [ks][mf] ===============================
 #pragma unroll 1
-    for (int body = 0; body < NB1; ++body) {
+    for (int g = 0; g < G1; ++g) {
+        v4i acc[4][TN];
 #pragma unroll
-        for (int gu = 0; gu < GU; ++gu) {
-            v4i acc[4][TN];
+        for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
+            for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+        for (int s = 0; s < SG1; ++s) {
+            const int ri = (OFF + s) % R;
+            const int ks = s / 4, mf = s % 4;
 #pragma unroll
-            for (int s = 0; s < SG1; ++s) {
-                const int sb = gu * SG1 + s;
-                const int ri = FULL ? sb : sb % R;
-                const int ks = s / 4, mf = s % 4;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[mf][j] = mma_step(ring[ri], bx[ks][j], acc[mf][j]);
-                if (!FULL) ring[ri] = wsb[sb * 64 + lane];    // the stream runs on into the second conv's weights
-            }
-            if (gu == 0 && body == 0) {
-                __builtin_amdgcn_s_barrier();          // every wave's DMA has landed (see above)
-                SABER_TL(2);
-            }
-            // epilogue: lane = 16 consecutive channels cg .. cg+15 of pixels j*16 + frow
-            const int cg = wave * (K1 / NW) + (body * GU + gu) * 64 + fq * 16;
-            const v4i* pp = prm1 + (cg / 4) * 3;
-            v4f sc[4], bi[4];
-            v4i co[4];
-#pragma unroll
-            for (int mf = 0; mf < 4; ++mf) {
-                sc[mf] = __builtin_bit_cast(v4f, pp[mf * 3]);
-                bi[mf] = __builtin_bit_cast(v4f, pp[mf * 3 + 1]);
-                co[mf] = pp[mf * 3 + 2];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                v4i* tp = tile + (j * 16 + frow) * CPR + ((cg / 16) ^ frow);
-                const v4i rs = *tp;
-                v4i o;
-                o.x = (int)chain_elt_pack(acc[0][j], co[0], bi[0], sc[0], (unsigned)rs.x, lo_s8, res_lo, a);
-                o.y = (int)chain_elt_pack(acc[1][j], co[1], bi[1], sc[1], (unsigned)rs.y, lo_s8, res_lo, a);
-                o.z = (int)chain_elt_pack(acc[2][j], co[2], bi[2], sc[2], (unsigned)rs.z, lo_s8, res_lo, a);
-                o.w = (int)chain_elt_pack(acc[3][j], co[3], bi[3], sc[3], (unsigned)rs.w, lo_s8, res_lo, a);
-                *tp = o;
-            }
+            for (int j = 0; j < TN; ++j) acc[mf][j] = mma_step(ring[ri], bx[ks][j], acc[mf][j]);
+            ring[ri] = wsb[s * 64 + lane];             // the stream runs on into the second conv's weights
         }
-        wsb += GU * SG1 * 64;
+        wsb += SG1 * 64;
+        if (!C3 && g == 0) {
+            __builtin_amdgcn_s_barrier();              // every wave's DMA has landed (see above)
+        }
+        if (g == 0) SABER_TL(2);
+        // epilogue: lane = 16 consecutive channels cg .. cg+15 of pixels j*16 + frow
+        const int cg = wave * (K1 / NW) + g * 64 + fq * 16;
+        const v4i* pp = prm1 + (cg / 4) * 3;
+        v4f sc[4], bi[4];
+        v4i co[4];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            sc[mf] = __builtin_bit_cast(v4f, pp[mf * 3]);
+            bi[mf] = __builtin_bit_cast(v4f, pp[mf * 3 + 1]);
+            co[mf] = pp[mf * 3 + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            v4i* tp = tile + (j * 16 + frow) * CPR + ((cg / 16) ^ frow);
+            const v4i rs = *tp;
+            v4i o;
+            o.x = (int)chain_elt_pack(acc[0][j], co[0], bi[0], sc[0], (unsigned)rs.x, lo_s8, res_lo, a);
+            o.y = (int)chain_elt_pack(acc[1][j], co[1], bi[1], sc[1], (unsigned)rs.y, lo_s8, res_lo, a);
+            o.z = (int)chain_elt_pack(acc[2][j], co[2], bi[2], sc[2], (unsigned)rs.z, lo_s8, res_lo, a);
+            o.w = (int)chain_elt_pack(acc[3][j], co[3], bi[3], sc[3], (unsigned)rs.w, lo_s8, res_lo, a);
+            *tp = o;
+        }
     }
     SABER_TL(3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -225,8 +322,9 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
         for (int it = 0; it < NIT; ++it) {
             const int L = it * 256 + tid;
             const int px = L / CPR, c = (L % CPR) ^ (px & 15);
-            const int p = p0 + px;
-            if (p < a.M) *(v4i*)(yg + (size_t)p * K1 + c * 16) = tile[L];
+            bool ok;
+            const int p = pix(px, ok);
+            if (ok) *(v4i*)(yg + (size_t)p * K1 + c * 16) = tile[L];
         }
     }
     v4i b2[KS2][TN];
@@ -236,7 +334,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
         for (int ks = 0; ks < KS2; ++ks) b2[ks][j] = tile[(j * 16 + frow) * CPR + ((ks * 4 + fq) ^ frow)];
     SABER_TL(4);
 
-    // ================= second conv =================================================================================
+    // ================= second 1x1 conv ==============================================================================
     const float lo2 = a.relu2 ? 0.f : -3.0e38f;
     const float off2 = a.out_u8_2 ? 0.f : 128.f;
     const unsigned xm2 = a.out_u8_2 ? 0u : 0x80808080u;
@@ -249,11 +347,11 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < SG2; ++s) {
-            const int ri = FULL ? T1 + s : s % R;
+            const int ri = (OFF + s) % R;
             const int ks = s / MFG2, mf = s % MFG2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[mf][j] = mma_step(ring[ri], b2[ks][j], acc[mf][j]);
-            if (!FULL && (s + R < SG2 || g + 1 < G2)) ring[ri] = wsb[s * 64 + lane];   // the stream ends with the last group
+            if (s + R < SG2 || g + 1 < G2) ring[ri] = wsb[s * 64 + lane];   // the stream ends with the last group
         }
         wsb += SG2 * 64;
         const int cg = wave * (K2 / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
@@ -265,8 +363,9 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             for (int mf = 0; mf < MFG2; ++mf)
                 o[mf] = chain_out_pack(acc[mf][j], pp[mf * 3 + 2], __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
                                        __builtin_bit_cast(v4f, pp[mf * 3]), lo2, off2, xm2);
-            const int p = p0 + j * 16 + frow;
-            if (p < a.M) {
+            bool ok;
+            const int p = pix(j * 16 + frow, ok);
+            if (ok) {
                 char* y = (char*)a.y2 + (size_t)p * K2 + cg;
                 if constexpr (MFG2 == 1) *(unsigned*)y = o[0];
                 else if constexpr (MFG2 == 2) *(uint2*)y = make_uint2(o[0], o[1]);
@@ -292,22 +391,28 @@ int conv1x1_chain_tn(int c1, int m) {
     }
 }
 
-hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, hipStream_t s) {
+// with3x3: a.x is the 3x3 conv's input and the grid is tiles of tn rows x 16 columns (a.H, a.W, a.tiles_* set by api.hip)
+hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, int with3x3, hipStream_t s) {
     if (!conv1x1_chain_ok(c1, k1, k2) || a.M <= 0) return hipErrorInvalidValue;
     const dim3 block(256);
-    const dim3 grid((a.M + 16 * tn - 1) / (16 * tn));
-#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, GU) \
-    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, GU>), grid, block, 0, s, a)
+    const dim3 grid(with3x3 ? a.tiles_per_img * a.N : (a.M + 16 * tn - 1) / (16 * tn));
+#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, C3) \
+    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, C3>), grid, block, 0, s, a)
     // ring depths: measured with scripts/probe/timeline_probe.hip (chain): deeper rings (32 / 64 steps, or the whole
     // stream in registers) only move the wait into the prologue - the stream is bound by the CU's vector-memory path
     // (~43 B/clk measured for these 1 KB-per-instruction loads), not by the latency of one round trip
-    switch (c1 * 8 + tn) {
-    case 64 * 8 + 4: SABER_CHAIN(1, 1, 1, 1, 4, 4, 1); break;
-    case 64 * 8 + 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, 1); break;
-    case 128 * 8 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, 1); break;
-    case 128 * 8 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, 1); break;
-    case 256 * 8 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, 1); break;
-    case 512 * 8 + 1: SABER_CHAIN(8, 8, 4, 2, 1, 16, 1); break;
+    switch (c1 * 16 + tn * 2 + (with3x3 ? 1 : 0)) {
+    case 64 * 16 + 4 * 2: SABER_CHAIN(1, 1, 1, 1, 4, 4, false); break;
+    case 64 * 16 + 2 * 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, false); break;
+    case 128 * 16 + 2 * 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, false); break;
+    case 128 * 16 + 1 * 2: SABER_CHAIN(2, 2, 2, 1, 1, 8, false); break;
+    case 256 * 16 + 1 * 2: SABER_CHAIN(4, 4, 4, 1, 1, 16, false); break;
+    case 512 * 16 + 1 * 2: SABER_CHAIN(8, 8, 4, 2, 1, 16, false); break;
+    case 64 * 16 + 4 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 4, 4, true); break;
+    case 64 * 16 + 2 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 2, 4, true); break;
+    case 128 * 16 + 2 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 2, 8, true); break;
+    case 128 * 16 + 1 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true); break;
+    case 256 * 16 + 1 * 2 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true); break;
     default: return hipErrorInvalidValue;
     }
 #undef SABER_CHAIN

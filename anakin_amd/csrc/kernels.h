@@ -108,12 +108,19 @@ struct ChainKArgs {
     int relu1, res_relu;
     float coeff_conv, scale_conv, coeff_res, scale_res;
     int relu2, out_u8_2;
+    // with the block's 3x3 conv in front (conv1x1_chain_kernel<..., C3 = true>): x is ITS input [N][H][W][C1]
+    const void* prm0;     // the 3x3 conv's {scale, bias', comp}, same layout
+    const void* zero;     // >= 16 zero bytes (padding taps)
+    int N, H, W;
+    int tiles_x, tiles_per_img;        // 16-column tiles per row, tiles per image
+    unsigned mg_tiles_x, mg_tpi;       // ceil(2^32 / d) for the two, 0 when d == 1
+    int in0_u8, relu0;                 // the 3x3 conv's input dtype / relu (its output dtype is in_u8)
 };
 bool conv1x1_chain_ok(int c1, int k1, int k2);
 // number of 16-pixel fragments per workgroup the launcher uses for (c1, m) / 0 if unsupported
 int conv1x1_chain_tn(int c1, int m);
 // bytes of the packed weight stream / its per-wave step geometry
-hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, hipStream_t s);
+hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, int with3x3, hipStream_t s);
 
 // hipcc fetches kernel arguments lazily with scalar loads and places each load near its first use; every batch that is
 // issued after an `s_waitcnt lgkmcnt(0)` is one more DEPENDENT round trip (~0.2-0.25 us, measured) before the kernel's

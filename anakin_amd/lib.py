@@ -26,7 +26,7 @@ SYMBOLS = [
     "saber_hip_conv2d_get_tile", "saber_hip_conv2d_autotune", "saber_hip_conv2d_set_pooling",
     "saber_hip_conv2d_create_pair", "saber_hip_conv2d_run_pair", "saber_hip_conv2d_autotune_pair",
     "saber_hip_net_add_conv_pair",
-    "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
+    "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_create3", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
     "saber_hip_conv2d_chain_set_tile", "saber_hip_conv2d_chain_get_tile",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
     "saber_hip_fc_destroy", "saber_hip_fc_algo", "saber_hip_fc_set_tile", "saber_hip_gemm_f32",
@@ -35,7 +35,7 @@ SYMBOLS = [
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool_out_dim2", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
-    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_get_choice", "saber_hip_net_set_choice",
+    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
@@ -105,6 +105,9 @@ def load():
     lib.saber_hip_conv2d_autotune_pair.argtypes = [P, P, P, P, P, I]
     lib.saber_hip_net_add_conv_pair.argtypes = [P, P, I, I, I]
     lib.saber_hip_conv2d_chain_create.argtypes = [P, P, C.POINTER(P)]
+    lib.saber_hip_conv2d_chain_create3.argtypes = [P, P, P, C.POINTER(P)]
+    lib.saber_hip_net_tensor_unwritten.argtypes = [P, I]
+    lib.saber_hip_net_num_launches.argtypes = [P]
     lib.saber_hip_conv2d_chain_destroy.argtypes = [P]
     lib.saber_hip_conv2d_chain_destroy.restype = None
     lib.saber_hip_conv2d_chain_run.argtypes = [P, P, P, P, P, P]

@@ -240,10 +240,15 @@ class SaberConvChain:
     (saber_hip_conv2d_chain_create): ResNet's `branch2c + sum + relu -> next branch2a`. Both outputs hold the bits of
     dispatching `a` and then `b`, which is what the reference does (net.cpp:417-509)."""
 
-    def __init__(self, a, b):
-        self.a, self.b = a, b
+    def __init__(self, a, b, conv3x3=None):
+        """conv3x3: the block's 3x3 conv in front of `a` joins the launch (saber_hip_conv2d_chain_create3); dispatch() then
+        takes ITS input as x and its own output edge is not written."""
+        self.a, self.b, self.c3 = a, b, conv3x3
         self.h = C.c_void_p()
-        L.check(L.load().saber_hip_conv2d_chain_create(a.h, b.h, C.byref(self.h)))
+        if conv3x3 is None:
+            L.check(L.load().saber_hip_conv2d_chain_create(a.h, b.h, C.byref(self.h)))
+        else:
+            L.check(L.load().saber_hip_conv2d_chain_create3(conv3x3.h, a.h, b.h, C.byref(self.h)))
 
     def dispatch(self, x, res, ya, yb):
         L.check(L.load().saber_hip_conv2d_chain_run(self.h, _p(x), _p(res), _p(ya), _p(yb), _stream()))
@@ -583,6 +588,10 @@ class Net:
 
     def num_ops(self):
         return L.load().saber_hip_net_num_ops(self.h)
+
+    def unwritten(self, name):
+        """True when the named tensor is the output edge of a 3x3 conv that currently runs inside a conv3x3 + chain launch"""
+        return bool(L.load().saber_hip_net_tensor_unwritten(self.h, self.tensors[name][0]))
 
     def num_launches(self):
         """kernel launches per forward (ops absorbed into a conv1x1-chain launch do not count)"""

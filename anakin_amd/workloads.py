@@ -187,13 +187,14 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     fuse_pool (default: same as fuse_eltwise): a conv whose only consumer is a max pooling becomes one
     SaberConv2DPooling op where the library has a fused kernel (the stem: conv1 + pool1); the conv's own output
     edge then does not exist.
-    chain (default: on whenever the eltwise is fused): `branch2c + sum + relu` and the next block's 1x1 `branch2a` run as
-    one conv1x1-chain launch (saber_hip_net_optimize flag 16; both ops stay in the list, the autotuner keeps the faster
-    form). Bytes of both edges unchanged."""
+    chain (default: 2 whenever the eltwise is fused): 1 = `branch2c + sum + relu` and the next block's 1x1 `branch2a` run
+    as one conv1x1-chain launch (saber_hip_net_optimize flag 16; both ops stay in the list, the autotuner keeps the faster
+    form); 2 = the block's 3x3 `branch2b` may lead that launch as well (flag 32; its output edge then stays in LDS:
+    Net.unwritten(name)). Bytes of every written edge unchanged."""
     from . import lib as L
     from . import saber as S
     if chain is None:
-        chain = bool(fuse_eltwise or cxx_optimize) and not lanes
+        chain = 2 if (fuse_eltwise or cxx_optimize) and not lanes else 0
     if cxx_optimize:
         # the reference op list one to one; the fusions below are then found by the C++ host side
         # (saber_hip_net_optimize), not by this builder
@@ -319,7 +320,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     if cxx_optimize:
         net.unfused_ops = net.num_ops()
         net.removed = net.optimize(15)
-    net.chained = net.optimize(16) if chain else 0
+    net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0)) if chain else 0
     net.finalize()
     return net
 

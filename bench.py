@@ -45,6 +45,8 @@ def parse():
                          "applied instead of autotuning when present (profiling passes then all run the same kernels)")
     ap.add_argument("--lanes", action="store_true",
                     help="run the shortcut projections on a side stream (measured SLOWER under hipGraph: 0.464 vs 0.371 ms)")
+    ap.add_argument("--chain", type=int, default=None,
+                    help="INT8 ResNet: 0 no conv1x1 chains, 1 chains, 2 (default) chains that may start with the block's 3x3 conv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -57,7 +59,7 @@ def parse():
 
 def build_net(W, model, scales, batch, args):
     if args.precision == "int8":
-        return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes)
+        return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain)
     return W.build_fp32_net(model, batch)
 
 

@@ -165,6 +165,11 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* pair, const void* x, void* 
  * must outlive it and keep their weights) and owns only the repacked weight stream. */
 typedef struct saber_hip_chain saber_hip_chain_t;
 int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out);
+/* ... led by the block's 3x3 conv (stride 1, pad 1, C -> C with C in {64, 128, 256}, 8-bit output = a's input): three
+ * operators, one launch. saber_hip_conv2d_chain_run then takes the 3x3 conv's INPUT as x; the 3x3 conv's own output edge
+ * is not written (it lives in LDS), y_a / y_b hold the bits of running the three ops one after the other. The pixel
+ * tile is `tn` rows x 16 columns (set_tile: 4 | 2 for C = 64, 2 | 1 for C = 128, 1 for C = 256). */
+int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out);
 void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* chain);
 int saber_hip_conv2d_chain_run(saber_hip_chain_t* chain, const void* x, const void* res, void* y_a, void* y_b,
                                saber_hip_stream_t stream);
@@ -306,11 +311,14 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * SaberConv2DPooling where a fused kernel exists, 8 global pooling also writes the INT8 fc's quantised operand;
  * 16 a 1x1 conv with the fused eltwise epilogue + the 1x1 conv that reads its output -> one conv1x1-chain launch (both ops
  * stay in the list; while the chain is selected the second one launches nothing; saber_hip_net_autotune keeps whichever
- * form is faster); 31 = all. Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0)
- * or a status < 0. */
+ * form is faster); 32 (with 16) the block's 3x3 conv leads that chain launch when the chain head is its only consumer
+ * (its output edge is then not written: saber_hip_net_tensor_unwritten); 63 = all. Bytes of every surviving edge are
+ * unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 /* kernel launches of one forward pass (ops minus the ones absorbed into a chain launch) */
 int saber_hip_net_num_launches(const saber_hip_net_t* net);
+/* 1 when tensor `id` is the output edge of a 3x3 conv currently running inside a conv3x3 + chain launch (never written) */
+int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
 /* Lane of an op (graph::Lane, framework/core/net/operator_func.h:103-114; ParallScheduler): 0 = the caller's
  * stream, 1 = the net's side stream. Cross-lane tensor dependencies are ordered with events automatically and

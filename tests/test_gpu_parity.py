@@ -503,6 +503,71 @@ def test_conv1x1_chain_equals_two_launches_and_oracle(case):
     assert np.array_equal(host(z2), want2), ("y2", chain.tile())
 
 
+CHAIN3_CASES = [
+    # C, N, H, W, dtype into the 3x3, dtype 3x3 -> first 1x1, out dtype / relu of the last conv, eltwise relu, tile rows
+    (64, 2, 56, 56, O.U8, O.U8, O.U8, 1, 1, None),
+    (64, 1, 13, 21, O.U8, O.U8, O.U8, 1, 1, 2),     # ragged rows and columns
+    (64, 1, 7, 9, O.S8, O.S8, O.S8, 0, 0, 4),
+    (128, 2, 28, 28, O.U8, O.U8, O.U8, 1, 1, None),
+    (128, 1, 5, 17, O.U8, O.S8, O.U8, 1, 1, 1),
+    (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, None),
+    (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, None),
+]
+
+
+@pytest.mark.parametrize("case", CHAIN3_CASES)
+def test_conv3x3_chain_equals_three_launches_and_oracle(case):
+    """saber_hip_conv2d_chain_create3: 3x3 conv -> [1x1 conv + SaberEltwise sum] -> 1x1 conv in one launch, bit for bit."""
+    Cc, N, H, Wd, idt, mdt, odt2, relu2, res_relu, tn = case
+    rng = np.random.default_rng(2000 + Cc + H)
+    K1, K2 = 4 * Cc, Cc
+    x = (rng.integers(0, 256, (N, H, Wd, Cc)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, Wd, Cc)).astype(np.int8))
+    res = rng.integers(-128, 128, (N, H, Wd, K1)).astype(np.int8)
+    w0 = (rng.standard_normal((Cc, Cc, 3, 3)) * np.sqrt(2.0 / (9 * Cc))).astype(np.float32)
+    b0 = (rng.standard_normal(Cc) * 0.5).astype(np.float32)
+    w1 = (rng.standard_normal((K1, Cc, 1, 1)) * np.sqrt(2.0 / Cc)).astype(np.float32)
+    b1 = (rng.standard_normal(K1) * 0.5).astype(np.float32)
+    w2 = (rng.standard_normal((K2, K1, 1, 1)) * np.sqrt(2.0 / K1)).astype(np.float32)
+    b2 = (rng.standard_normal(K2) * 0.5).astype(np.float32)
+    s_x, s_in, s_mid, s_res, s_sum, s_out = 0.023, 0.02, 0.05, 0.043, 0.06, 0.031
+    c = 1.0 / s_sum
+    relu0 = mdt == O.U8
+    # oracle
+    ws0 = O.weight_scales(w0)
+    bp0, sc0 = O.conv_i8_prepare(ws0, b0, s_x, s_in, idt, mdt)
+    t0 = O.conv_i8(x, O.quant_weights(w0, ws0), bp0, sc0, mdt, int(relu0), (1, 1))
+    ws1 = O.weight_scales(w1)
+    bp1, sc1 = O.conv_i8_prepare(ws1, b1, s_in, s_mid, mdt, O.S8)
+    t1 = O.conv_i8(t0, O.quant_weights(w1, ws1), bp1, sc1, O.S8, 0)
+    want1 = O.eltwise_i8(t1, res, s_mid, s_res, c, c, bool(res_relu))
+    ws2 = O.weight_scales(w2)
+    bp2, sc2 = O.conv_i8_prepare(ws2, b2, s_sum, s_out, O.S8, odt2)
+    want2 = O.conv_i8(want1, O.quant_weights(w2, ws2), bp2, sc2, odt2, relu2)
+    # device ops
+    c0 = S.SaberConv2D(int8=True).init((N, Cc, H, Wd), S.ConvParam(w0, b0, 1, (1, 1), (1, 1), (1, 1), bool(relu0)), idt, mdt,
+                                       s_x, s_in)
+    pa = S.ConvParam(w1, b1, 1, (0, 0), (1, 1), (1, 1), False)
+    pa.res_mode, pa.res_relu, pa.sum_scale, pa.coeff, pa.scale_res = L.RES_ELTWISE, bool(res_relu), 1.0, (c, c), s_res
+    ca = S.SaberConv2D(int8=True).init((N, Cc, H, Wd), pa, mdt, O.S8, s_in, s_mid)
+    cb = S.SaberConv2D(int8=True).init((N, K1, H, Wd), S.ConvParam(w2, b2, 1, (0, 0), (1, 1), (1, 1), bool(relu2)), O.S8, odt2,
+                                       s_sum, s_out)
+    y0, y1, y2 = c0.new_output(), ca.new_output(), cb.new_output()
+    c0.dispatch(dev(x), y0)
+    ca.dispatch(y0, y1, dev(res))
+    cb.dispatch(y1, y2)
+    assert np.array_equal(host(y0), t0) and np.array_equal(host(y1), want1) and np.array_equal(host(y2), want2)
+    chain = S.SaberConvChain(ca, cb, conv3x3=c0)
+    if tn is not None:
+        chain.set_tile(tn)
+    z1, z2 = ca.new_output(), cb.new_output()
+    z1.fill_(77)
+    z2.fill_(77)
+    chain.dispatch(dev(x), dev(res), z1, z2)
+    assert np.array_equal(host(z1), want1), ("y1", chain.tile())
+    assert np.array_equal(host(z2), want2), ("y2", chain.tile())
+
+
 def test_conv1x1_chain_rejects_other_shapes():
     rng = np.random.default_rng(3)
     w1 = (rng.standard_normal((128, 32, 1, 1)) * 0.2).astype(np.float32)
