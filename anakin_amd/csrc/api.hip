@@ -10,7 +10,10 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -716,6 +719,70 @@ struct EventPair {   // RAII: destroyed on every exit path
         if (e1) (void)hipEventDestroy(e1);
     }
 };
+// Times launches the way they run inside an op list: between repetitions a 64 MB stream through every XCD pushes the
+// operands out of the L2s (the Infinity Cache keeps them), so a kernel that re-reads many weights per workgroup is not
+// flattered by finding them in L2 the way a back-to-back loop of the same launch does (measured: conv3x3 + chain at
+// C = 256 reads 12.9 us back to back, 16 us in the forward pass; the two launches it replaces 13.9 -> 15.3 us).
+struct ColdBench {
+    static constexpr size_t kBytes = (size_t)64 << 20;
+    void* buf = nullptr;
+    std::vector<hipEvent_t> ev;
+    int reps = 0;
+    hipError_t init(int r) {
+        reps = r < 3 ? 3 : (r > 32 ? 32 : r);
+        hipError_t e = hipMalloc(&buf, kBytes + 256);
+        if (e != hipSuccess) return e;
+        e = hipMemset(buf, 1, kBytes + 256);
+        if (e != hipSuccess) return e;
+        ev.assign(2 * (size_t)reps, nullptr);
+        for (hipEvent_t& x : ev)
+            if ((e = hipEventCreate(&x)) != hipSuccess) return e;
+        return hipStreamSynchronize(nullptr);
+    }
+    ~ColdBench() {
+        for (hipEvent_t x : ev)
+            if (x) (void)hipEventDestroy(x);
+        if (buf) (void)hipFree(buf);
+    }
+    // median microseconds of fn() (which enqueues on s and returns a status); < 0 on failure
+    float run(hipStream_t s, const std::function<int()>& fn) {
+        if (fn() != 0) return -1.f;                  // warm-up: code, kernel arguments
+        for (int r = 0; r < reps; ++r) {
+            if (launch_l2_flush(buf, kBytes, (unsigned*)((char*)buf + kBytes), s) != hipSuccess) return -1.f;
+            if (hipEventRecord(ev[2 * r], s) != hipSuccess) return -1.f;
+            if (fn() != 0) return -1.f;
+            if (hipEventRecord(ev[2 * r + 1], s) != hipSuccess) return -1.f;
+        }
+        if (hipEventSynchronize(ev[2 * reps - 1]) != hipSuccess) return -1.f;
+        std::vector<float> t(reps);
+        for (int r = 0; r < reps; ++r)
+            if (hipEventElapsedTime(&t[r], ev[2 * r], ev[2 * r + 1]) != hipSuccess) return -1.f;
+        std::sort(t.begin(), t.end());
+        return t[reps / 2] * 1000.f;
+    }
+};
+
+// One ColdBench per top-level autotune call: nested calls (saber_hip_net_autotune -> saber_hip_conv2d_autotune) share it.
+// SABER_HIP_AUTOTUNE_WARM=1 in the environment restores the back-to-back timing loop (kept for A/B measurements).
+thread_local ColdBench* g_cold = nullptr;
+struct ColdScope {
+    ColdBench local;
+    bool owner = false;
+    hipError_t enter(int reps) {
+        const char* w = std::getenv("SABER_HIP_AUTOTUNE_WARM");
+        if (w && w[0] == '1') return hipSuccess;      // g_cold stays null: callers fall back to the warm loop
+        if (g_cold) return hipSuccess;
+        hipError_t e = local.init(reps);
+        if (e != hipSuccess) return e;
+        g_cold = &local;
+        owner = true;
+        return hipSuccess;
+    }
+    ~ColdScope() {
+        if (owner) g_cold = nullptr;
+    }
+};
+
 }  // namespace
 
 extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
@@ -730,7 +797,18 @@ extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, vo
     float best = 1e30f;
     int err = SABER_HIP_OK;
     // times the op's CURRENT selection; a variant that fails to launch is skipped (its error is kept only if nothing works)
+    ColdScope scope;
+    HIP_TRY(scope.enter(7));
     auto time_current = [&]() {
+        if (g_cold) {   // operands cold in L2, as inside the op list
+            const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run(op, x, y, res, workspace, s); });
+            if (us < 0.f) { err = SABER_HIP_RUNTIME_ERROR; return; }
+            if (us < best) {
+                best = us;
+                best_c = get_choice(op);
+            }
+            return;
+        }
         int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);   // warm-up
         if (rc) { err = rc; return; }
         if (hipEventRecord(ev.e0, s) != hipSuccess) { err = SABER_HIP_RUNTIME_ERROR; return; }
@@ -887,6 +965,8 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
     hipStream_t s = (hipStream_t)stream;
     EventPair ev;
     HIP_TRY(ev.init());
+    ColdScope scope;
+    HIP_TRY(scope.enter(7));
     float best = 1e30f;
     int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;   // the entry selection stays if nothing runs
     const int ks_list[3] = {1, 2, 4};
@@ -897,6 +977,11 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
                 if (dma_list[vi] > 1 && (ks_list[ki] != 4 || t > TILE_64x64)) continue;
                 if (dma_list[vi] == 4 && t != TILE_32x32) continue;
                 op->tile = t; op->ks = ks_list[ki]; op->dma = dma_list[vi];
+                if (g_cold) {
+                    const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s); });
+                    if (us >= 0.f && us < best) { best = us; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
+                    continue;
+                }
                 int rc = saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
                 if (rc) continue;   // a variant that does not launch is skipped
                 float ms = 0;
@@ -2041,6 +2126,8 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         net->graph = nullptr;
     }
     auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
+    ColdScope scope;
+    HIP_TRY(scope.enter(iters < 7 ? 7 : (iters > 15 ? 15 : iters)));
     for (NetOp& o : net->ops) {
         if (o.kind == OP_CONV_PAIR) {
             int rc = saber_hip_conv2d_autotune_pair(o.conv, T(o.in), T(o.out), T(o.out2), stream, iters);
@@ -2069,22 +2156,25 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
         const int first = H ? ia - 1 : ia;
         hipStream_t s = (hipStream_t)stream;
-        EventPair ev;
-        HIP_TRY(ev.init());
-        const int n = iters < 20 ? 20 : iters;
         auto run_all = [&]() -> int {
             int rc = 0;
             for (int k = first; k <= ia + 1; ++k) rc |= net_launch(net, net->ops[k], s);
             return rc;
         };
-        auto timed = [&](float* ms) -> int {
+        auto timed = [&](float* us) -> int {
+            if (g_cold) {
+                *us = g_cold->run(s, run_all);
+                return *us < 0.f ? SABER_HIP_RUNTIME_ERROR : SABER_HIP_OK;
+            }
+            EventPair ev;                 // SABER_HIP_AUTOTUNE_WARM: 20 back-to-back repetitions
+            HIP_TRY(ev.init());
             int rc = run_all();
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ev.e0, s));
-            for (int it = 0; it < n; ++it) rc |= run_all();
+            for (int it = 0; it < 20; ++it) rc |= run_all();
             HIP_TRY(hipEventRecord(ev.e1, s));
             HIP_TRY(hipEventSynchronize(ev.e1));
-            HIP_TRY(hipEventElapsedTime(ms, ev.e0, ev.e1));
+            HIP_TRY(hipEventElapsedTime(us, ev.e0, ev.e1));
             return rc;
         };
         float best = 0.f;

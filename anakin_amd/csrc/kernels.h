@@ -159,6 +159,10 @@ hipError_t launch_conv_stem_pool(int f32_in, const ConvKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 
+// reads `bytes` of device memory through every XCD (autotuning: the timed launch then finds none of its operands in
+// an L2, which is how it runs inside the op list)
+hipError_t launch_l2_flush(const void* buf, size_t bytes, unsigned* sink, hipStream_t s);
+
 // elementwise / layout / pooling / softmax (elementwise.hip)
 hipError_t launch_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
                                         const float* x, void* y, hipStream_t s);
