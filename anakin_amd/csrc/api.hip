@@ -143,6 +143,7 @@ struct saber_hip_chain {
     saber_hip_conv* b = nullptr;
     int c1 = 0, k1 = 0, k2 = 0, tn = 0;
     DevBuf<uint8_t> d_stream, d_prm0, d_prm1, d_prm2;
+    DevBuf<uint8_t> d_stream_split;   // 1x1 chains with C >= 256: [half][wave] streams for the split second conv (tile | 8)
 };
 
 struct saber_hip_fc {
@@ -1312,14 +1313,15 @@ static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::v
 // one conv's weights [K][C] -> per wave, groups of 16*mfg channels, steps ordered [group][k-step][accumulator], each step
 // = 64 lanes x 16 bytes in MFMA A-operand order (row = lane & 15, k-group = lane >> 4); row rho of accumulator mf is
 // channel  base + (rho >> 2) * 4*mfg + mf*4 + (rho & 3)   (conv1x1_chain.hip)
-static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out) {
+static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out, int kbase = 0) {
+    // K: channels of this workgroup's share (rows kbase .. kbase + K - 1 of w)
     const int kw = K / 4, groups = kw / (16 * mfg), ksn = C / 64;
     for (int g = 0; g < groups; ++g)
         for (int ks = 0; ks < ksn; ++ks)
             for (int mf = 0; mf < mfg; ++mf)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int rho = lane & 15, kq = lane >> 4;
-                    const int ch = wave * kw + g * 16 * mfg + (rho >> 2) * 4 * mfg + mf * 4 + (rho & 3);
+                    const int ch = kbase + wave * kw + g * 16 * mfg + (rho >> 2) * 4 * mfg + mf * 4 + (rho & 3);
                     const int8_t* src = w + (size_t)ch * C + ks * 64 + kq * 16;
                     out.insert(out.end(), (const uint8_t*)src, (const uint8_t*)src + 16);
                 }
@@ -1376,6 +1378,17 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
     pack_chain_params(a, (size_t)da.k / 4 * 3, p1);
     pack_chain_params(b, ((size_t)db.k / 4 * 3 + 63) / 64 * 64, p2);
     hipError_t e = ch->d_stream.upload(stream);
+    if (e == hipSuccess && !c3 && da.c >= 256) {
+        std::vector<uint8_t> sp;
+        sp.reserve(2 * (size_t)da.k * da.c + (size_t)db.k * db.c);
+        const int k2w = db.k / 2, mfgw = (k2w / 4) / 16 >= 4 ? 4 : (k2w / 4) / 16;
+        for (int half = 0; half < 2; ++half)
+            for (int w = 0; w < 4; ++w) {
+                pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, sp);
+                pack_chain_weights(b->wq_oihw.data(), k2w, db.c, mfgw, w, sp, half * k2w);
+            }
+        e = ch->d_stream_split.upload(sp);
+    }
     if (e == hipSuccess) e = ch->d_prm1.upload(p1);
     if (e == hipSuccess) e = ch->d_prm2.upload(p2);
     if (e == hipSuccess && c3) {
@@ -1399,7 +1412,8 @@ int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* 
 void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
-    const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1);
+    const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
+                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p);
     if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
     ch->tn = tn;
     return SABER_HIP_OK;
@@ -1412,7 +1426,7 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     const saber_hip_conv* b = ch->b;
     ChainKArgs k;
     std::memset(&k, 0, sizeof k);
-    k.x = x; k.wstream = ch->d_stream.p; k.res = res; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
+    k.x = x; k.wstream = (ch->tn & 8) ? ch->d_stream_split.p : ch->d_stream.p; k.res = res; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
     k.y1 = y_a; k.y2 = y_b;
     k.M = a->d.n * a->oh * a->ow;
     k.in_u8 = a->x_dtype == DT_U8;
@@ -1427,7 +1441,7 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         k.zero = zero_page();
         k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
         k.tiles_x = (k.W + 15) / 16;
-        k.tiles_per_img = k.tiles_x * ((k.H + ch->tn - 1) / ch->tn);
+        k.tiles_per_img = k.tiles_x * ((k.H + (ch->tn & 7) - 1) / (ch->tn & 7));
         k.mg_tiles_x = magic(k.tiles_x);
         k.mg_tpi = magic(k.tiles_per_img);
         k.in0_u8 = ch->c3->x_dtype == DT_U8;
@@ -1674,7 +1688,8 @@ static void net_name_chain(NetOp& A, NetOp& B) {
     if (A.skip) {
         A.name = B.name = "conv:(in the chain launch)";
     } else if (A.use_chain) {
-        A.name = "conv:chain1x1_c" + std::to_string(A.chain->c1) + "_px" + std::to_string(16 * A.chain->tn);
+        A.name = "conv:chain1x1_c" + std::to_string(A.chain->c1) + "_px" + std::to_string(16 * (A.chain->tn & 7)) +
+                 ((A.chain->tn & 8) ? "_split2" : "");
         B.name = "conv:(in the chain launch)";
     } else {
         A.name = std::string("conv:") + A.conv->algo_name;
@@ -2183,7 +2198,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         int rc = timed(&best);
         if (rc) return rc;
         const int c1 = A.chain->c1;
-        const int tns[2] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 0)};
+        const int tns[2] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9)};
         for (int mode = 1; mode <= (H ? 2 : 1); ++mode) {
             saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
             for (int tn : tns) {

@@ -89,11 +89,11 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* dst_wave_base) 
 // launch as "phase 0": the workgroup's pixels are then a 2-D tile (TN rows x 16 columns) of one image, the input halo
 // (TN+2) x 18 pixels comes into LDS by DMA, the 3x3 conv's weights lead the wave's stream ([tap][k-step][accumulator]),
 // and its 8-bit output tile stays in LDS as the first 1x1 conv's B operand - that edge never reaches memory.
-template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3>
+template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP>
 __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) {
     constexpr int NW = 4;
     constexpr int KS2 = 4 * G1;                       // K1 / 64
-    constexpr int K1 = 256 * G1, C1 = 64 * KS1, K2 = NW * G2 * 16 * MFG2;
+    constexpr int K1 = 256 * G1, C1 = 64 * KS1, K2W = NW * G2 * 16 * MFG2, K2 = K2W * SP;   // K2W: this workgroup's share
     constexpr int NPX = 16 * TN;
     constexpr int MF0 = KS1;                          // 3x3 conv: C1 / 4 channels per wave = KS1 accumulators
     constexpr int T0 = C3 ? MF0 * 9 * KS1 : 0;        // steps of the 3x3 conv per wave
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     constexpr int P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
     static_assert(SG1 % R == 0 && SG2 % R == 0, "ring depth must divide the group lengths");
     static_assert(CPR >= 16 && P1C % 64 == 0, "tile rows are swizzled on 16 chunks");
+    static_assert(SP == 1 || (!C3 && (NPX * CPR / 256) % SP == 0), "split second conv: 1x1 chains only");
 
     __shared__ v4i tile[NPX * CPR];
     __shared__ v4i prm1[P1C];
@@ -122,7 +123,10 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
     // ---- this workgroup's pixels: a run of NPX pixels, or (C3) rows y0 .. y0+TN-1 x columns x0 .. x0+15 of image n
-    const int p0 = blockIdx.x * NPX;
+    // SP == 2: two workgroups per pixel tile; both run the first conv, each computes HALF of the second conv's output
+    // channels and stores half of the first conv's tile (a workgroup's time is its weight stream: 1/4 less to pull)
+    const int half = SP == 1 ? 0 : (int)(blockIdx.x % SP);
+    const int p0 = (SP == 1 ? blockIdx.x : blockIdx.x / SP) * NPX;
     const int plast = a.M - 1;
     int n = 0, y0 = 0, x0 = 0;
     if constexpr (C3) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     asm volatile("" ::: "memory");                     // keep the ring's loads behind the DMA in program order
 
     // ---- weight ring: the first R steps of this wave's stream ---------------------------------------------------
-    const v4i* wsb = (const v4i*)a.wstream + (size_t)wave * ((T0 + T1 + T2) * 64);
+    const v4i* wsb = (const v4i*)a.wstream + (size_t)(half * NW + wave) * ((T0 + T1 + T2) * 64);
     v4i ring[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) ring[r] = wsb[r * 64 + lane];
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
         char* yg = (char*)a.y1;
         constexpr int NIT = NPX * CPR / 256;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = half; it < NIT; it += SP) {
             const int L = it * 256 + tid;
             const int px = L / CPR, c = (L % CPR) ^ (px & 15);
             bool ok;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             if (s + R < SG2 || g + 1 < G2) ring[ri] = wsb[s * 64 + lane];   // the stream ends with the last group
         }
         wsb += SG2 * 64;
-        const int cg = wave * (K2 / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
+        const int cg = half * K2W + wave * (K2W / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
         const v4i* pp = prm2 + (cg / 4) * 3;
         unsigned o[MFG2];
 #pragma unroll
@@ -392,27 +396,32 @@ int conv1x1_chain_tn(int c1, int m) {
 }
 
 // with3x3: a.x is the 3x3 conv's input and the grid is tiles of tn rows x 16 columns (a.H, a.W, a.tiles_* set by api.hip)
-hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, int with3x3, hipStream_t s) {
+// tile: pixel fragments per workgroup (1x1 chain: 16-pixel runs; with3x3: rows of a 16-column tile) | 8 when the second
+// conv's output channels are split over two workgroups (wstream then holds [half][wave] streams, api.hip)
+hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tile, int with3x3, hipStream_t s) {
     if (!conv1x1_chain_ok(c1, k1, k2) || a.M <= 0) return hipErrorInvalidValue;
+    const int tn = tile & 7, sp = (tile & 8) ? 2 : 1;
     const dim3 block(256);
-    const dim3 grid(with3x3 ? a.tiles_per_img * a.N : (a.M + 16 * tn - 1) / (16 * tn));
-#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, C3) \
-    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, C3>), grid, block, 0, s, a)
+    const dim3 grid((with3x3 ? a.tiles_per_img * a.N : (a.M + 16 * tn - 1) / (16 * tn)) * sp);
+#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, C3, SP) \
+    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, C3, SP>), grid, block, 0, s, a)
     // ring depths: measured with scripts/probe/timeline_probe.hip (chain): deeper rings (32 / 64 steps, or the whole
     // stream in registers) only move the wait into the prologue - the stream is bound by the CU's vector-memory path
     // (~43 B/clk measured for these 1 KB-per-instruction loads), not by the latency of one round trip
-    switch (c1 * 16 + tn * 2 + (with3x3 ? 1 : 0)) {
-    case 64 * 16 + 4 * 2: SABER_CHAIN(1, 1, 1, 1, 4, 4, false); break;
-    case 64 * 16 + 2 * 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, false); break;
-    case 128 * 16 + 2 * 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, false); break;
-    case 128 * 16 + 1 * 2: SABER_CHAIN(2, 2, 2, 1, 1, 8, false); break;
-    case 256 * 16 + 1 * 2: SABER_CHAIN(4, 4, 4, 1, 1, 16, false); break;
-    case 512 * 16 + 1 * 2: SABER_CHAIN(8, 8, 4, 2, 1, 16, false); break;
-    case 64 * 16 + 4 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 4, 4, true); break;
-    case 64 * 16 + 2 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 2, 4, true); break;
-    case 128 * 16 + 2 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 2, 8, true); break;
-    case 128 * 16 + 1 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true); break;
-    case 256 * 16 + 1 * 2 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true); break;
+    switch (c1 * 32 + tile * 2 + (with3x3 ? 1 : 0)) {
+    case 64 * 32 + 4 * 2: SABER_CHAIN(1, 1, 1, 1, 4, 4, false, 1); break;
+    case 64 * 32 + 2 * 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, false, 1); break;
+    case 128 * 32 + 2 * 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, false, 1); break;
+    case 128 * 32 + 1 * 2: SABER_CHAIN(2, 2, 2, 1, 1, 8, false, 1); break;
+    case 256 * 32 + 1 * 2: SABER_CHAIN(4, 4, 4, 1, 1, 16, false, 1); break;
+    case 256 * 32 + 9 * 2: SABER_CHAIN(4, 4, 2, 1, 1, 16, false, 2); break;     // second conv split over two workgroups
+    case 512 * 32 + 1 * 2: SABER_CHAIN(8, 8, 4, 2, 1, 16, false, 1); break;
+    case 512 * 32 + 9 * 2: SABER_CHAIN(8, 8, 4, 1, 1, 16, false, 2); break;
+    case 64 * 32 + 4 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 4, 4, true, 1); break;
+    case 64 * 32 + 2 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 2, 4, true, 1); break;
+    case 128 * 32 + 2 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1); break;
+    case 128 * 32 + 1 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1); break;
+    case 256 * 32 + 1 * 2 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1); break;
     default: return hipErrorInvalidValue;
     }
 #undef SABER_CHAIN

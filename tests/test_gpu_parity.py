@@ -455,6 +455,9 @@ CHAIN_CASES = [
     (256, 1, 5, O.S8, O.U8, 1, 0, None),   # 25 pixels
     (512, 2, 7, O.U8, O.U8, 1, 1, None),
     (512, 1, 3, O.U8, O.S8, 0, 1, None),
+    (256, 2, 14, O.U8, O.U8, 1, 1, 9),     # second conv split over two workgroups
+    (256, 1, 5, O.S8, O.S8, 0, 0, 9),
+    (512, 2, 7, O.U8, O.U8, 1, 1, 9),
 ]
 
 
