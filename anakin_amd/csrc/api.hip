@@ -1342,15 +1342,20 @@ static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<ui
                 }
 }
 static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out) {
-    if (!a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
-    if (!chain_1x1(a) || !chain_1x1(b)) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
+    // b == nullptr (with c3): conv3x3 + first 1x1 conv only
+    if (!a || !out || (!b && !c3)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!chain_1x1(a) || (b && !chain_1x1(b))) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
     const saber_hip_conv_desc& da = a->d;
-    const saber_hip_conv_desc& db = b->d;
     if (da.res_mode != SABER_HIP_RES_ELTWISE || da.out_dtype != SABER_HIP_S8 || (da.res_has_dtype && da.res_dtype != SABER_HIP_S8))
         return fail(SABER_HIP_INVALID_VALUE, "chain: the first conv must carry the fused eltwise epilogue with s8 residual and output");
-    if (db.res_mode != SABER_HIP_RES_NONE || b->x_dtype != DT_S8 || (db.out_dtype != SABER_HIP_S8 && db.out_dtype != SABER_HIP_U8))
-        return fail(SABER_HIP_INVALID_VALUE, "chain: the second conv must be a plain s8-input conv with an 8-bit output");
-    if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || !conv1x1_chain_ok(da.c, da.k, db.k))
+    if (b) {
+        const saber_hip_conv_desc& db = b->d;
+        if (db.res_mode != SABER_HIP_RES_NONE || b->x_dtype != DT_S8 || (db.out_dtype != SABER_HIP_S8 && db.out_dtype != SABER_HIP_U8))
+            return fail(SABER_HIP_INVALID_VALUE, "chain: the second conv must be a plain s8-input conv with an 8-bit output");
+        if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || db.k != da.c)
+            return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
+    }
+    if (!conv1x1_chain_ok(da.c, da.k, da.c))
         return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
     if (c3) {
         const saber_hip_conv_desc& d3 = c3->d;
@@ -1365,32 +1370,33 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: the head must be the 3x3 stride-1 pad-1 INT8 conv (C -> C, C <= 256) whose 8-bit output the first 1x1 conv reads");
     }
     saber_hip_chain* ch = new saber_hip_chain();
-    ch->c3 = c3; ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = db.k;
+    const int k2 = b ? b->d.k : 0, c2 = b ? b->d.c : 0;
+    ch->c3 = c3; ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = k2;
     ch->tn = conv1x1_chain_tn(da.c, da.n * a->oh * a->ow);
-    const int mfg2 = (db.k / 4) / 16 >= 4 ? 4 : (db.k / 4) / 16;
+    const int mfg2 = (k2 / 4) / 16 >= 4 ? 4 : (k2 / 4) / 16;
     std::vector<uint8_t> stream, p0, p1, p2;
-    stream.reserve((size_t)da.k * da.c + (size_t)db.k * db.c + (c3 ? (size_t)9 * da.c * da.c : 0));
+    stream.reserve((size_t)da.k * da.c + (size_t)k2 * c2 + (c3 ? (size_t)9 * da.c * da.c : 0));
     for (int w = 0; w < 4; ++w) {
         if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, stream);
         pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, stream);
-        pack_chain_weights(b->wq_oihw.data(), db.k, db.c, mfg2, w, stream);
+        if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, mfg2, w, stream);
     }
     pack_chain_params(a, (size_t)da.k / 4 * 3, p1);
-    pack_chain_params(b, ((size_t)db.k / 4 * 3 + 63) / 64 * 64, p2);
+    if (b) pack_chain_params(b, ((size_t)k2 / 4 * 3 + 63) / 64 * 64, p2);
     hipError_t e = ch->d_stream.upload(stream);
     if (e == hipSuccess && !c3 && da.c >= 256) {
         std::vector<uint8_t> sp;
-        sp.reserve(2 * (size_t)da.k * da.c + (size_t)db.k * db.c);
-        const int k2w = db.k / 2, mfgw = (k2w / 4) / 16 >= 4 ? 4 : (k2w / 4) / 16;
+        sp.reserve(2 * (size_t)da.k * da.c + (size_t)k2 * c2);
+        const int k2w = k2 / 2, mfgw = (k2w / 4) / 16 >= 4 ? 4 : (k2w / 4) / 16;
         for (int half = 0; half < 2; ++half)
             for (int w = 0; w < 4; ++w) {
                 pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, sp);
-                pack_chain_weights(b->wq_oihw.data(), k2w, db.c, mfgw, w, sp, half * k2w);
+                pack_chain_weights(b->wq_oihw.data(), k2w, c2, mfgw, w, sp, half * k2w);
             }
         e = ch->d_stream_split.upload(sp);
     }
     if (e == hipSuccess) e = ch->d_prm1.upload(p1);
-    if (e == hipSuccess) e = ch->d_prm2.upload(p2);
+    if (e == hipSuccess && b) e = ch->d_prm2.upload(p2);
     if (e == hipSuccess && c3) {
         pack_chain_params(c3, ((size_t)da.c / 4 * 3 + 63) / 64 * 64, p0);
         e = ch->d_prm0.upload(p0);
@@ -1403,6 +1409,7 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+    if (!b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     return chain_build(nullptr, a, b, out);
 }
 int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
@@ -1413,7 +1420,7 @@ void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
-                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p);
+                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b);
     if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
     ch->tn = tn;
     return SABER_HIP_OK;
@@ -1421,7 +1428,7 @@ int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
 int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* ch) { return ch ? ch->tn : 0; }
 int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void* res, void* y_a, void* y_b,
                                saber_hip_stream_t stream) {
-    if (!ch || !x || !res || !y_a || !y_b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!ch || !x || !res || !y_a || (ch->b && !y_b)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const saber_hip_conv* a = ch->a;
     const saber_hip_conv* b = ch->b;
     ChainKArgs k;
@@ -1433,8 +1440,10 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     k.relu1 = a->d.act == SABER_HIP_ACT_RELU;
     k.res_relu = a->d.res_act == SABER_HIP_ACT_RELU;
     k.coeff_conv = a->d.coeff_conv; k.scale_conv = a->out_scale; k.coeff_res = a->d.coeff_res; k.scale_res = a->d.scale_res;
-    k.relu2 = b->d.act == SABER_HIP_ACT_RELU;
-    k.out_u8_2 = b->d.out_dtype == SABER_HIP_U8;
+    if (b) {
+        k.relu2 = b->d.act == SABER_HIP_ACT_RELU;
+        k.out_u8_2 = b->d.out_dtype == SABER_HIP_U8;
+    }
     if (ch->c3) {   // x is the 3x3 conv's input; tiles of tn rows x 16 columns
         auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };
         k.prm0 = ch->d_prm0.p;
@@ -1696,21 +1705,25 @@ static void net_name_chain(NetOp& A, NetOp& B) {
         B.name = std::string("conv:") + B.conv->algo_name;
     }
 }
-// mode of the ops around chain head A = ops[ia]: 0 separate launches, 1 A + B chained, 2 (ops[ia - 1] has chain3) 3x3 + A + B
+// mode of the ops around A = ops[ia] (a 1x1 conv with the fused eltwise): 0 separate launches, 1 A + B chained (A.chain),
+// 2 the 3x3 conv ops[ia - 1] leads the launch (its chain3; with or without B)
 static void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     NetOp& A = net->ops[ia];
-    NetOp& B = net->ops[ia + 1];
     NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
     if (mode == 2 && !H) mode = 1;
-    A.use_chain = mode >= 1;
-    B.skip = mode >= 1;
+    if (mode == 1 && !A.chain) mode = 0;
+    NetOp* B = A.chain ? &net->ops[ia + 1] : nullptr;
+    A.use_chain = mode == 1 || (mode == 2 && H->chain3->b);
+    if (B) B->skip = mode == 1 || (mode == 2 && H->chain3->b);
     A.skip = mode == 2;
     if (H) {
         H->use_chain3 = mode == 2;
-        H->name = mode == 2 ? "conv:conv3x3+chain1x1_c" + std::to_string(H->chain3->c1) + "_" + std::to_string(H->chain3->tn) + "x16"
+        H->name = mode == 2 ? std::string("conv:conv3x3+") + (H->chain3->b ? "chain1x1_c" : "conv1x1_c") + std::to_string(H->chain3->c1) +
+                                  "_" + std::to_string(H->chain3->tn) + "x16"
                             : std::string("conv:") + H->conv->algo_name;
     }
-    net_name_chain(A, B);
+    if (B) net_name_chain(A, *B);
+    else A.name = A.skip ? "conv:(in the chain launch)" : std::string("conv:") + A.conv->algo_name;
 }
 static int net_chain_mode(const saber_hip_net* net, int ia) {
     const NetOp& A = net->ops[ia];
@@ -1904,6 +1917,24 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             const bool was = A.use_chain;
             net_set_chain_mode(net, (int)i + 1, ch->c1 <= 128 ? 2 : (was ? 1 : 0));
             if (Hd.use_chain3) removed += was ? 1 : 2;
+        }
+        // ... and in front of a fused-eltwise 1x1 conv that heads no chain (the last block of a stage): conv3x3 + conv1x1
+        for (size_t i = 0; i + 1 < ops.size(); ++i) {
+            NetOp& Hd = ops[i];
+            NetOp& A = ops[i + 1];
+            if (A.chain || A.skip || A.kind != OP_CONV || !A.conv || A.conv->d.res_mode != SABER_HIP_RES_ELTWISE || A.in2 < 0 || A.lane ||
+                Hd.kind != OP_CONV || !Hd.conv || Hd.chain3 || Hd.chain || Hd.skip || Hd.lane || Hd.in2 >= 0 || A.in != Hd.out)
+                continue;
+            int readers = 0;
+            for (const NetOp& o : ops) readers += (o.in == Hd.out) + (o.in2 == Hd.out);
+            if (readers != 1) continue;
+            saber_hip_chain* ch = nullptr;
+            if (saber_hip_conv2d_chain_create3(Hd.conv, A.conv, nullptr, &ch) != SABER_HIP_OK) continue;
+            net->owned_chains.push_back(ch);
+            Hd.chain3 = ch;
+            Hd.chain3_res = A.in2; Hd.chain3_y1 = A.out; Hd.chain3_y2 = -1;
+            net_set_chain_mode(net, (int)i + 1, ch->c1 <= 128 ? 2 : 0);
+            if (Hd.use_chain3) ++removed;
         }
     }
     // the shared workspace only has to cover the surviving ops
@@ -2113,7 +2144,7 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     NetOp& o = net->ops[index];
     o.name = std::string(o.kind == OP_FC || o.kind == OP_FC_Q ? "fc:" : "conv:") + c->algo_name;
     // chain decisions: a 3x3 head (bit 29) is restored before its chain head (bit 28, the next op): set_choices runs in op order
-    if (o.chain3 && (chain_bits & 32) && index + 2 < (int)net->ops.size()) {
+    if (o.chain3 && (chain_bits & 32) && index + 1 < (int)net->ops.size()) {
         const int tn = chain_bits & 15;
         if (tn && (rc = saber_hip_conv2d_chain_set_tile(o.chain3, tn)) != SABER_HIP_OK) return rc;
         net_set_chain_mode(net, index + 1, tn ? 2 : net_chain_mode(net, index + 1) == 2 ? 1 : net_chain_mode(net, index + 1));
@@ -2164,16 +2195,17 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     }
     // conv1x1 chains: the tuned separate launches against the chain launch (every pixel-tile size) and, where the block's
     // 3x3 conv can lead the chain, against that single launch too - on the real tensors
-    for (size_t i = 0; i + 1 < net->ops.size(); ++i) {
+    for (size_t i = 0; i < net->ops.size(); ++i) {
         NetOp& A = net->ops[i];
-        if (!A.chain) continue;
         const int ia = (int)i;
         NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
+        if (!A.chain && !H) continue;
         const int first = H ? ia - 1 : ia;
+        const int last = A.chain ? ia + 1 : ia;
         hipStream_t s = (hipStream_t)stream;
         auto run_all = [&]() -> int {
             int rc = 0;
-            for (int k = first; k <= ia + 1; ++k) rc |= net_launch(net, net->ops[k], s);
+            for (int k = first; k <= last; ++k) rc |= net_launch(net, net->ops[k], s);
             return rc;
         };
         auto timed = [&](float* us) -> int {
@@ -2197,9 +2229,9 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         net_set_chain_mode(net, ia, 0);
         int rc = timed(&best);
         if (rc) return rc;
-        const int c1 = A.chain->c1;
+        const int c1 = A.chain ? A.chain->c1 : H->chain3->c1;
         const int tns[2] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9)};
-        for (int mode = 1; mode <= (H ? 2 : 1); ++mode) {
+        for (int mode = A.chain ? 1 : 2; mode <= (H ? 2 : 1); ++mode) {
             saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
             for (int tn : tns) {
                 if (!tn) continue;

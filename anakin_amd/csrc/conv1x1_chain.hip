@@ -89,7 +89,7 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* dst_wave_base) 
 // launch as "phase 0": the workgroup's pixels are then a 2-D tile (TN rows x 16 columns) of one image, the input halo
 // (TN+2) x 18 pixels comes into LDS by DMA, the 3x3 conv's weights lead the wave's stream ([tap][k-step][accumulator]),
 // and its 8-bit output tile stays in LDS as the first 1x1 conv's B operand - that edge never reaches memory.
-template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP>
+template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP, bool HAS2 = true>
 __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) {
     constexpr int NW = 4;
     constexpr int KS2 = 4 * G1;                       // K1 / 64
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     constexpr int MF0 = KS1;                          // 3x3 conv: C1 / 4 channels per wave = KS1 accumulators
     constexpr int T0 = C3 ? MF0 * 9 * KS1 : 0;        // steps of the 3x3 conv per wave
     constexpr int SG1 = KS1 * 4, SG2 = KS2 * MFG2;    // steps per channel group
-    constexpr int T1 = G1 * SG1, T2 = G2 * SG2;       // steps per wave
+    constexpr int T1 = G1 * SG1, T2 = HAS2 ? G2 * SG2 : 0;   // steps per wave (HAS2 = false: no second 1x1 conv)
     constexpr int OFF = T0 % R;                       // ring slot of the first 1x1 conv's first step
     constexpr int CPR = K1 / 16;                      // 16-byte chunks per tile row
     constexpr int CH1 = C1 / 16;                      // ... per pixel of the 3x3 conv's input / output
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             lds_dma16(rg + (size_t)p * K1 + c * 16, tile + i * 64);
         }
         for (int i = wave; i < P1C / 64; i += NW) lds_dma16((const v4i*)a.prm1 + i * 64 + lane, prm1 + i * 64);
-        for (int i = wave; i < P2C / 64; i += NW) lds_dma16((const v4i*)a.prm2 + i * 64 + lane, prm2 + i * 64);
+        if constexpr (HAS2)
+            for (int i = wave; i < P2C / 64; i += NW) lds_dma16((const v4i*)a.prm2 + i * 64 + lane, prm2 + i * 64);
     }
     asm volatile("" ::: "memory");                     // keep the ring's loads behind the DMA in program order
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             const int ks = s / 4, mf = s % 4;
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[mf][j] = mma_step(ring[ri], bx[ks][j], acc[mf][j]);
-            ring[ri] = wsb[s * 64 + lane];             // the stream runs on into the second conv's weights
+            if (HAS2 || s + R < SG1 || g + 1 < G1) ring[ri] = wsb[s * 64 + lane];   // the stream runs on into the second conv's weights
         }
         wsb += SG1 * 64;
         if (!C3 && g == 0) {
@@ -330,6 +331,11 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
             const int p = pix(px, ok);
             if (ok) *(v4i*)(yg + (size_t)p * K1 + c * 16) = tile[L];
         }
+    }
+    if constexpr (!HAS2) {
+        SABER_TL(4);
+        SABER_TL_FLUSH();
+        return;
     }
     v4i b2[KS2][TN];
 #pragma unroll
@@ -399,15 +405,27 @@ int conv1x1_chain_tn(int c1, int m) {
 // tile: pixel fragments per workgroup (1x1 chain: 16-pixel runs; with3x3: rows of a 16-column tile) | 8 when the second
 // conv's output channels are split over two workgroups (wstream then holds [half][wave] streams, api.hip)
 hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tile, int with3x3, hipStream_t s) {
-    if (!conv1x1_chain_ok(c1, k1, k2) || a.M <= 0) return hipErrorInvalidValue;
+    const bool has2 = k2 != 0;          // k2 == 0: conv3x3 + first 1x1 conv only (with3x3 required)
+    if (!conv1x1_chain_ok(c1, k1, has2 ? k2 : c1) || a.M <= 0 || (!has2 && !with3x3)) return hipErrorInvalidValue;
     const int tn = tile & 7, sp = (tile & 8) ? 2 : 1;
     const dim3 block(256);
     const dim3 grid((with3x3 ? a.tiles_per_img * a.N : (a.M + 16 * tn - 1) / (16 * tn)) * sp);
-#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, C3, SP) \
-    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, C3, SP>), grid, block, 0, s, a)
+#define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, C3, SP, ...) \
+    hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, C3, SP, ##__VA_ARGS__>), grid, block, 0, s, a)
     // ring depths: measured with scripts/probe/timeline_probe.hip (chain): deeper rings (32 / 64 steps, or the whole
     // stream in registers) only move the wait into the prologue - the stream is bound by the CU's vector-memory path
     // (~43 B/clk measured for these 1 KB-per-instruction loads), not by the latency of one round trip
+    if (!has2) {
+        switch (c1 * 32 + tile) {
+        case 64 * 32 + 4: SABER_CHAIN(1, 1, 1, 1, 4, 4, true, 1, false); break;
+        case 64 * 32 + 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, true, 1, false); break;
+        case 128 * 32 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1, false); break;
+        case 128 * 32 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1, false); break;
+        case 256 * 32 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1, false); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (c1 * 32 + tile * 2 + (with3x3 ? 1 : 0)) {
     case 64 * 32 + 4 * 2: SABER_CHAIN(1, 1, 1, 1, 4, 4, false, 1); break;
     case 64 * 32 + 2 * 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, false, 1); break;

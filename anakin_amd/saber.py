@@ -247,10 +247,10 @@ class SaberConvChain:
         self.h = C.c_void_p()
         if conv3x3 is None:
             L.check(L.load().saber_hip_conv2d_chain_create(a.h, b.h, C.byref(self.h)))
-        else:
-            L.check(L.load().saber_hip_conv2d_chain_create3(conv3x3.h, a.h, b.h, C.byref(self.h)))
+        else:   # b may be None: conv3x3 + `a` only
+            L.check(L.load().saber_hip_conv2d_chain_create3(conv3x3.h, a.h, None if b is None else b.h, C.byref(self.h)))
 
-    def dispatch(self, x, res, ya, yb):
+    def dispatch(self, x, res, ya, yb=None):
         L.check(L.load().saber_hip_conv2d_chain_run(self.h, _p(x), _p(res), _p(ya), _p(yb), _stream()))
         return ya, yb
 

@@ -569,6 +569,13 @@ def test_conv3x3_chain_equals_three_launches_and_oracle(case):
     chain.dispatch(dev(x), dev(res), z1, z2)
     assert np.array_equal(host(z1), want1), ("y1", chain.tile())
     assert np.array_equal(host(z2), want2), ("y2", chain.tile())
+    # conv3x3 + first 1x1 conv only (the last block of a stage: no 1x1 conv follows on the same pixels)
+    double = S.SaberConvChain(ca, None, conv3x3=c0)
+    if tn is not None:
+        double.set_tile(tn)
+    z1.fill_(55)
+    double.dispatch(dev(x), dev(res), z1)
+    assert np.array_equal(host(z1), want1), ("double y1", double.tile())
 
 
 def test_conv1x1_chain_rejects_other_shapes():

@@ -40,7 +40,7 @@ def test_resnet50_int8_every_edge_bit_exact(setup, fuse):
     net.run()
     checked = 0
     unwritten = [n for n in net.tensors if net.unwritten(n)]
-    assert len(unwritten) == (5 if fuse == "chain3" else 0), unwritten
+    assert len(unwritten) == (7 if fuse == "chain3" else 0), unwritten
     for name in net.tensors:
         if name in unwritten:
             checked += 1
@@ -228,7 +228,8 @@ def test_cxx_net_optimize_equals_python_fused_list(setup):
     assert b.unfused_ops == 73 and b.removed == 22 and b.num_ops() == a.num_ops() == 52, (b.unfused_ops, b.removed, b.num_ops())
     # ... and both lists then get the conv1x1 chains (branch2c + sum -> next branch2a): 12 candidates, the 10 with C <= 256 on
     # and where the chain head is the only reader of the block's 3x3 conv that conv leads the launch (5 with C <= 128 on)
-    assert a.chained == b.chained == 15 and a.num_launches() == b.num_launches() == 37, (a.chained, a.num_launches())
+    # (+ conv3x3 + conv1x1 in the last blocks of res2 / res3, whose 1x1 conv heads no chain)
+    assert a.chained == b.chained == 17 and a.num_launches() == b.num_launches() == 35, (a.chained, a.num_launches())
     assert [a.op_name(i) for i in range(52)] == [b.op_name(i) for i in range(52)]
     for net in (a, b):
         net.tensor("data").copy_(torch.from_numpy(x).cuda())
