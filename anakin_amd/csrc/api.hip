@@ -766,6 +766,27 @@ struct ColdBench {
 // One ColdBench per top-level autotune call: nested calls (saber_hip_net_autotune -> saber_hip_conv2d_autotune) share it.
 // SABER_HIP_AUTOTUNE_WARM=1 in the environment restores the back-to-back timing loop (kept for A/B measurements).
 thread_local ColdBench* g_cold = nullptr;
+// Kernel reuse across the ops of one net: the FIRST launch of a given kernel function in a forward pass pays for its cold
+// code (0.3-0.6 us on most boxes of the pool, 3-9 us on some: profiles/r02/slow_box/ - repeats of the same function
+// later in the pass run at full speed), so among candidates within g_reuse_tol of the fastest the tuner prefers a
+// function another op of the net already uses. Set by saber_hip_net_autotune for the duration of its run.
+thread_local std::vector<unsigned long long>* g_used_kernels = nullptr;
+constexpr float g_reuse_tol = 0.03f;
+unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice& c) {
+    const saber_hip_conv_desc& d = op->d;
+    int ek = 3;   // conv_igemm.hip: epilogue_kind
+    if (op->pair_k2) ek = 4;
+    else if (op->algo != ALGO_IGEMM_F32 && op->epi == EPI_I8_CONV && d.res_mode != SABER_HIP_RES_SUM_INPLACE && d.k % 16 == 0)
+        ek = d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : (d.out_dtype == SABER_HIP_U8 ? 1 : (d.out_dtype == SABER_HIP_S8 ? 0 : 3));
+    unsigned long long k = (unsigned long long)op->algo | ((unsigned long long)ek << 4);
+    if (c.fc_small) return k | (1ull << 8) | ((unsigned long long)((op->c_eff + 255) / 256) << 16);
+    if (c.stem) return k | (2ull << 8);
+    if (c.img_rb)   // <EK, NW, CW, NCH, GPW>: channel count and pixel groups per wave
+        return k | (3ull << 8) | ((unsigned long long)op->c_eff << 16) |
+               ((unsigned long long)((c.img_ib * c.img_rb * op->ow + 15) / 16) << 32);
+    if (c.halo) return k | (4ull << 8) | ((unsigned long long)c.halo << 16) | ((unsigned long long)(op->c_eff % 128 == 0) << 24);
+    return k | (5ull << 8) | ((unsigned long long)c.tile << 16) | ((unsigned long long)c.ks << 24) | ((unsigned long long)c.dma << 32);
+}
 struct ColdScope {
     ColdBench local;
     bool owner = false;
@@ -800,10 +821,12 @@ extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, vo
     // times the op's CURRENT selection; a variant that fails to launch is skipped (its error is kept only if nothing works)
     ColdScope scope;
     HIP_TRY(scope.enter(7));
+    std::vector<std::pair<float, ConvChoice>> cands;
     auto time_current = [&]() {
         if (g_cold) {   // operands cold in L2, as inside the op list
             const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run(op, x, y, res, workspace, s); });
             if (us < 0.f) { err = SABER_HIP_RUNTIME_ERROR; return; }
+            cands.emplace_back(us, get_choice(op));
             if (us < best) {
                 best = us;
                 best_c = get_choice(op);
@@ -876,6 +899,17 @@ extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, vo
         set_choice(op, entry);
         name_algo(op);
         return err ? err : fail(SABER_HIP_RUNTIME_ERROR, "autotune: no variant ran");
+    }
+    if (g_used_kernels) {   // prefer a kernel function the net already uses when it is within g_reuse_tol of the fastest
+        float reuse_best = best * (1.f + g_reuse_tol);
+        for (const auto& cd : cands) {
+            const unsigned long long key = kernel_key(op, cd.second);
+            if (cd.first <= reuse_best && std::find(g_used_kernels->begin(), g_used_kernels->end(), key) != g_used_kernels->end()) {
+                reuse_best = cd.first;
+                best_c = cd.second;
+            }
+        }
+        g_used_kernels->push_back(kernel_key(op, best_c));
     }
     set_choice(op, best_c);
     name_algo(op);
@@ -968,6 +1002,7 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
     HIP_TRY(ev.init());
     ColdScope scope;
     HIP_TRY(scope.enter(7));
+    std::vector<std::pair<float, ConvChoice>> pcands;
     float best = 1e30f;
     int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;   // the entry selection stays if nothing runs
     const int ks_list[3] = {1, 2, 4};
@@ -980,6 +1015,7 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
                 op->tile = t; op->ks = ks_list[ki]; op->dma = dma_list[vi];
                 if (g_cold) {
                     const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s); });
+                    if (us >= 0.f) pcands.emplace_back(us, get_choice(op));
                     if (us >= 0.f && us < best) { best = us; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
                     continue;
                 }
@@ -994,6 +1030,17 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
                 if (ms < best) { best = ms; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
             }
     op->tile = best_tile; op->ks = best_ks; op->dma = best_dma;
+    if (g_used_kernels && best < 1e30f) {   // kernel reuse across the net's sibling pairs (see kernel_key)
+        float reuse_best = best * (1.f + g_reuse_tol);
+        for (const auto& cd : pcands) {
+            const unsigned long long key = kernel_key(op, cd.second);
+            if (cd.first <= reuse_best && std::find(g_used_kernels->begin(), g_used_kernels->end(), key) != g_used_kernels->end()) {
+                reuse_best = cd.first;
+                op->tile = cd.second.tile; op->ks = cd.second.ks; op->dma = cd.second.dma;
+            }
+        }
+        g_used_kernels->push_back(kernel_key(op, get_choice(op)));
+    }
     name_algo(op);
     return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);   // both outputs hold the selected kernel's result
 }
@@ -2174,6 +2221,11 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
     ColdScope scope;
     HIP_TRY(scope.enter(iters < 7 ? 7 : (iters > 15 ? 15 : iters)));
+    std::vector<unsigned long long> used_kernels;
+    struct UsedScope {
+        UsedScope(std::vector<unsigned long long>* v) { g_used_kernels = g_cold ? v : nullptr; }
+        ~UsedScope() { g_used_kernels = nullptr; }
+    } used_scope(&used_kernels);
     for (NetOp& o : net->ops) {
         if (o.kind == OP_CONV_PAIR) {
             int rc = saber_hip_conv2d_autotune_pair(o.conv, T(o.in), T(o.out), T(o.out2), stream, iters);
