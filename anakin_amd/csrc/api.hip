@@ -2198,10 +2198,9 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     } else if (o.chain && (chain_bits & 16) && index + 1 < (int)net->ops.size()) {
         const int tn = chain_bits & 15;
         if (tn && (rc = saber_hip_conv2d_chain_set_tile(o.chain, tn)) != SABER_HIP_OK) return rc;
-        if (net_chain_mode(net, index) != 2) net_set_chain_mode(net, index, tn ? 1 : 0);
-    } else if (o.skip) {
-        o.name = "conv:(in the chain launch)";
+        net_set_chain_mode(net, index, net_chain_mode(net, index) == 2 ? 2 : (tn ? 1 : 0));   // (also restores the names)
     }
+    if (o.skip) o.name = "conv:(in the chain launch)";
     if (net->exec) {
         (void)hipGraphExecDestroy(net->exec);
         (void)hipGraphDestroy(net->graph);

@@ -247,3 +247,25 @@ def test_cxx_net_optimize_equals_python_fused_list(setup):
                 assert np.array_equal(ga, ref[name].reshape(ga.shape)), name
             checked += 1
     assert checked >= 39, checked
+
+
+def test_autotuned_selection_round_trips_through_choices(setup):
+    """Net.choices() / set_choices() (the bench's --tune-cache) carry the whole autotuned selection - kernel variant per op
+    AND the chain decisions (separate launches / conv1x1 chain / chain led by the 3x3 conv, with their tile sizes) - into a
+    freshly built net: same op names, same launch count, bit-identical logits."""
+    model, x, scales, ref = setup
+    a = W.build_int8_net(model, dict(scales), 2)
+    a.tensor("data").copy_(torch.from_numpy(x).cuda())
+    a.run()
+    a.autotune(iters=3)
+    a.run()
+    torch.cuda.synchronize()
+    b = W.build_int8_net(model, dict(scales), 2)
+    b.set_choices(a.choices())
+    assert [a.op_name(i) for i in range(a.num_ops())] == [b.op_name(i) for i in range(b.num_ops())]
+    assert a.num_launches() == b.num_launches()
+    b.tensor("data").copy_(torch.from_numpy(x).cuda())
+    b.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(_h(a.tensor("fc1000")), _h(b.tensor("fc1000")))
+    assert np.array_equal(_h(b.tensor("fc1000")), ref["fc1000"].reshape(2, -1))
