@@ -128,7 +128,10 @@ int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "chain")) {
         // conv1x1 chain: phases 0 entry, 1 loads / DMA issued, 2 first group's MFMAs done + DMA barrier, 3 first conv done,
         // 4 tile stored / second conv's operand in registers, 5 done
-        struct { const char* name; int c, hw, n, tn; } cs[] = {
+        struct { const char* name; int c, hw, n, tn, w3; } cs[] = {
+            {"conv3x3+chain C=64 56x56 b8 2x16", 64, 56, 8, 2, 1}, {"conv3x3+chain C=128 28x28 b8 1x16", 128, 28, 8, 1, 1},
+            {"conv3x3+conv1x1 C=64 56x56 b8 2x16", 64, 56, 8, 2, 2}, {"chain C=256 14x14 b8 px16 split2", 256, 14, 8, 9, 0},
+            {"conv3x3+chain C=64 56x56 b1 2x16", 64, 56, 1, 2, 1},
             {"chain C=64 56x56 b8 px64", 64, 56, 8, 4}, {"chain C=64 56x56 b8 px32", 64, 56, 8, 2},
             {"chain C=128 28x28 b8 px32", 128, 28, 8, 2}, {"chain C=128 28x28 b8 px16", 128, 28, 8, 1},
             {"chain C=256 14x14 b8 px16", 256, 14, 8, 1}, {"chain C=512 7x7 b8 px16", 512, 7, 8, 1},
@@ -143,8 +146,17 @@ int main(int argc, char** argv) {
             a.wstream = dalloc((size_t)2 * K1 * g.c, -1);
             a.prm1 = dalloc((size_t)K1 * 12, 0); a.prm2 = dalloc((size_t)g.c * 12 + 1024, 0);
             a.y1 = dalloc((size_t)M * K1, 0); a.y2 = dalloc((size_t)M * g.c, 0);
-            const int blocks = (M + 16 * g.tn - 1) / (16 * g.tn);
-            run(P, g.name, blocks, 6, [&] { launch_conv1x1_chain(a, g.c, K1, g.c, g.tn, P.st); });
+            a.wstream = dalloc((size_t)4 * K1 * g.c + (size_t)9 * g.c * g.c + 65536, -1);
+            const int tn = g.tn & 7;
+            int blocks = ((M + 16 * tn - 1) / (16 * tn)) * ((g.tn & 8) ? 2 : 1);
+            if (g.w3) {
+                auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };
+                a.prm0 = dalloc((size_t)g.c * 12 + 1024, 0); a.zero = zero; a.N = g.n; a.H = a.W = g.hw;
+                a.tiles_x = (g.hw + 15) / 16; a.tiles_per_img = a.tiles_x * ((g.hw + tn - 1) / tn);
+                a.mg_tiles_x = magic(a.tiles_x); a.mg_tpi = magic(a.tiles_per_img); a.in0_u8 = 1; a.relu0 = 1;
+                blocks = a.tiles_per_img * g.n;
+            }
+            run(P, g.name, blocks, 6, [&] { launch_conv1x1_chain(a, g.c, K1, g.w3 == 2 ? 0 : g.c, g.tn, g.w3 ? 1 : 0, P.st); });
         }
         return 0;
     }
