@@ -144,6 +144,8 @@ struct saber_hip_chain {
     int c1 = 0, k1 = 0, k2 = 0, tn = 0;
     DevBuf<uint8_t> d_stream, d_prm0, d_prm1, d_prm2;
     DevBuf<uint8_t> d_stream_split;   // 1x1 chains with C >= 256: [half][wave] streams for the split second conv (tile | 8)
+    DevBuf<uint8_t> d_stream_split8;  // C == 256: the same for 8 waves per workgroup (tile 11)
+    DevBuf<uint8_t> d_stream_w8;      // C == 128: the whole stream for 8 waves per workgroup (tile | 4)
 };
 
 struct saber_hip_fc {
@@ -1360,9 +1362,10 @@ static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::v
 // one conv's weights [K][C] -> per wave, groups of 16*mfg channels, steps ordered [group][k-step][accumulator], each step
 // = 64 lanes x 16 bytes in MFMA A-operand order (row = lane & 15, k-group = lane >> 4); row rho of accumulator mf is
 // channel  base + (rho >> 2) * 4*mfg + mf*4 + (rho & 3)   (conv1x1_chain.hip)
-static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out, int kbase = 0) {
-    // K: channels of this workgroup's share (rows kbase .. kbase + K - 1 of w)
-    const int kw = K / 4, groups = kw / (16 * mfg), ksn = C / 64;
+static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out, int kbase = 0,
+                               int nw = 4) {
+    // K: channels of this workgroup's share (rows kbase .. kbase + K - 1 of w), nw waves
+    const int kw = K / nw, groups = kw / (16 * mfg), ksn = C / 64;
     for (int g = 0; g < groups; ++g)
         for (int ks = 0; ks < ksn; ++ks)
             for (int mf = 0; mf < mfg; ++mf)
@@ -1374,8 +1377,8 @@ static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave,
                 }
 }
 // the 3x3 conv's weights [K][C][3][3] -> per wave, steps ordered [tap][k-step][accumulator] (conv1x1_chain.hip phase 0)
-static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out) {
-    const int kw = C / 4, mf0 = C / 64, ksn = C / 64;
+static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out, int nw = 4) {
+    const int kw = C / nw, mf0 = kw / 16, ksn = C / 64;
     for (int tap = 0; tap < 9; ++tap)
         for (int ks = 0; ks < ksn; ++ks)
             for (int mf = 0; mf < mf0; ++mf)
@@ -1441,6 +1444,26 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
                 pack_chain_weights(b->wq_oihw.data(), k2w, c2, mfgw, w, sp, half * k2w);
             }
         e = ch->d_stream_split.upload(sp);
+        if (e == hipSuccess && da.c == 256) {   // 8 waves: 128 first-conv channels (2 groups) and 16 second-conv channels per wave
+            std::vector<uint8_t> s8;
+            s8.reserve(sp.size());
+            for (int half = 0; half < 2; ++half)
+                for (int w = 0; w < 8; ++w) {
+                    pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, s8, 0, 8);
+                    pack_chain_weights(b->wq_oihw.data(), k2w, c2, 1, w, s8, half * k2w, 8);
+                }
+            e = ch->d_stream_split8.upload(s8);
+        }
+    }
+    if (e == hipSuccess && da.c == 128) {   // 8 waves: 16 channels of the 3x3 / 64 of the first / 16 of the second 1x1 conv per wave
+        std::vector<uint8_t> s8;
+        s8.reserve(stream.size());
+        for (int w = 0; w < 8; ++w) {
+            if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, s8, 8);
+            pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, s8, 0, 8);
+            if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, 1, w, s8, 0, 8);
+        }
+        e = ch->d_stream_w8.upload(s8);
     }
     if (e == hipSuccess) e = ch->d_prm1.upload(p1);
     if (e == hipSuccess && b) e = ch->d_prm2.upload(p2);
@@ -1467,7 +1490,8 @@ void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
-                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b);
+                    (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) ||
+                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b);
     if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
     ch->tn = tn;
     return SABER_HIP_OK;
@@ -1480,7 +1504,9 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     const saber_hip_conv* b = ch->b;
     ChainKArgs k;
     std::memset(&k, 0, sizeof k);
-    k.x = x; k.wstream = (ch->tn & 8) ? ch->d_stream_split.p : ch->d_stream.p; k.res = res; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
+    k.x = x; k.res = res;
+    k.wstream = ch->tn == 11 ? ch->d_stream_split8.p : ((ch->tn & 8) ? ch->d_stream_split.p : ch->d_stream.p);
+    if (ch->c1 == 128 && (ch->tn & 4)) k.wstream = ch->d_stream_w8.p; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
     k.y1 = y_a; k.y2 = y_b;
     k.M = a->d.n * a->oh * a->ow;
     k.in_u8 = a->x_dtype == DT_U8;
@@ -1497,7 +1523,8 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         k.zero = zero_page();
         k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
         k.tiles_x = (k.W + 15) / 16;
-        k.tiles_per_img = k.tiles_x * ((k.H + (ch->tn & 7) - 1) / (ch->tn & 7));
+        const int rows = ch->c1 == 128 ? ch->tn & 3 : ch->tn & 7;    // tile rows (C = 128: bit 2 of the code = 8 waves)
+        k.tiles_per_img = k.tiles_x * ((k.H + rows - 1) / rows);
         k.mg_tiles_x = magic(k.tiles_x);
         k.mg_tpi = magic(k.tiles_per_img);
         k.in0_u8 = ch->c3->x_dtype == DT_U8;
@@ -1744,8 +1771,10 @@ static void net_name_chain(NetOp& A, NetOp& B) {
     if (A.skip) {
         A.name = B.name = "conv:(in the chain launch)";
     } else if (A.use_chain) {
-        A.name = "conv:chain1x1_c" + std::to_string(A.chain->c1) + "_px" + std::to_string(16 * (A.chain->tn & 7)) +
-                 ((A.chain->tn & 8) ? "_split2" : "");
+        const int t = A.chain->tn, c = A.chain->c1;
+        const bool w8 = t == 11 || (c == 128 && (t & 4));
+        A.name = "conv:chain1x1_c" + std::to_string(c) + "_px" + std::to_string(t == 11 ? 16 : 16 * (c == 128 ? t & 3 : t & 7)) +
+                 ((t & 8) ? "_split2" : "") + (w8 ? "_w8" : "");
         B.name = "conv:(in the chain launch)";
     } else {
         A.name = std::string("conv:") + A.conv->algo_name;
@@ -1766,7 +1795,8 @@ static void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     if (H) {
         H->use_chain3 = mode == 2;
         H->name = mode == 2 ? std::string("conv:conv3x3+") + (H->chain3->b ? "chain1x1_c" : "conv1x1_c") + std::to_string(H->chain3->c1) +
-                                  "_" + std::to_string(H->chain3->tn) + "x16"
+                                  "_" + std::to_string(H->chain3->c1 == 128 ? H->chain3->tn & 3 : H->chain3->tn) + "x16" +
+                                  (H->chain3->c1 == 128 && (H->chain3->tn & 4) ? "_w8" : "")
                             : std::string("conv:") + H->conv->algo_name;
     }
     if (B) net_name_chain(A, *B);
@@ -2360,7 +2390,8 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         int rc = timed(&best);
         if (rc) return rc;
         const int c1 = A.chain ? A.chain->c1 : H->chain3->c1;
-        const int tns[2] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9)};
+        const int tns[4] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9), c1 == 256 ? 11 : (c1 == 128 ? 6 : 0),
+                            c1 == 128 ? 5 : 0};
         for (int mode = A.chain ? 1 : 2; mode <= (H ? 2 : 1); ++mode) {
             saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
             for (int tn : tns) {

@@ -89,13 +89,16 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* dst_wave_base) 
 // launch as "phase 0": the workgroup's pixels are then a 2-D tile (TN rows x 16 columns) of one image, the input halo
 // (TN+2) x 18 pixels comes into LDS by DMA, the 3x3 conv's weights lead the wave's stream ([tap][k-step][accumulator]),
 // and its 8-bit output tile stays in LDS as the first 1x1 conv's B operand - that edge never reaches memory.
-template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP, bool HAS2 = true>
-__global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) {
-    constexpr int NW = 4;
-    constexpr int KS2 = 4 * G1;                       // K1 / 64
-    constexpr int K1 = 256 * G1, C1 = 64 * KS1, K2W = NW * G2 * 16 * MFG2, K2 = K2W * SP;   // K2W: this workgroup's share
+// NW: waves per workgroup (4, or 8 = two per SIMD: one wave's epilogue arithmetic overlaps the other's weight stream; G1 /
+// G2 count the channel groups PER WAVE, so K1 = 64 * NW * G1)
+template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP, bool HAS2 = true, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs a) {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int KS2 = NW * G1;                      // K1 / 64
+    constexpr int K1 = 64 * NW * G1, C1 = 64 * KS1, K2W = NW * G2 * 16 * MFG2, K2 = K2W * SP;   // K2W: this workgroup's share
     constexpr int NPX = 16 * TN;
-    constexpr int MF0 = KS1;                          // 3x3 conv: C1 / 4 channels per wave = KS1 accumulators
+    constexpr int MF0 = C3 ? C1 / (16 * NW) : 1;      // 3x3 conv: C1 / NW channels per wave = MF0 accumulators
+    static_assert(!C3 || C1 % (16 * NW) == 0, "3x3 conv: at least 16 channels per wave");
     constexpr int T0 = C3 ? MF0 * 9 * KS1 : 0;        // steps of the 3x3 conv per wave
     constexpr int SG1 = KS1 * 4, SG2 = KS2 * MFG2;    // steps per channel group
     constexpr int T1 = G1 * SG1, T2 = HAS2 ? G2 * SG2 : 0;   // steps per wave (HAS2 = false: no second 1x1 conv)
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     constexpr int P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
     static_assert(SG1 % R == 0 && SG2 % R == 0, "ring depth must divide the group lengths");
     static_assert(CPR >= 16 && P1C % 64 == 0, "tile rows are swizzled on 16 chunks");
-    static_assert(SP == 1 || (!C3 && (NPX * CPR / 256) % SP == 0), "split second conv: 1x1 chains only");
+    static_assert(SP == 1 || (!C3 && (NPX * CPR / (64 * NW)) % SP == 0), "split second conv: 1x1 chains only");
 
     __shared__ v4i tile[NPX * CPR];
     __shared__ v4i prm1[P1C];
@@ -322,10 +325,10 @@ __global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainKArgs a) 
     // ---- tile -> y1 (coalesced) and -> the second conv's B operand ---------------------------------------------------
     {
         char* yg = (char*)a.y1;
-        constexpr int NIT = NPX * CPR / 256;
+        constexpr int NIT = NPX * CPR / (64 * NW);
 #pragma unroll
         for (int it = half; it < NIT; it += SP) {
-            const int L = it * 256 + tid;
+            const int L = it * (64 * NW) + tid;
             const int px = L / CPR, c = (L % CPR) ^ (px & 15);
             bool ok;
             const int p = pix(px, ok);
@@ -407,8 +410,11 @@ int conv1x1_chain_tn(int c1, int m) {
 hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tile, int with3x3, hipStream_t s) {
     const bool has2 = k2 != 0;          // k2 == 0: conv3x3 + first 1x1 conv only (with3x3 required)
     if (!conv1x1_chain_ok(c1, k1, has2 ? k2 : c1) || a.M <= 0 || (!has2 && !with3x3)) return hipErrorInvalidValue;
-    const int tn = tile & 7, sp = (tile & 8) ? 2 : 1;
-    const dim3 block(256);
+    // C >= 256 codes: 1 = one fragment, 9 = second conv split over two workgroups, 11 = split + 8 waves per workgroup
+    // C = 128 codes: 2 | 1 fragments, + 4 = 8 waves per workgroup
+    const bool w8 = (c1 >= 256 && (tile & 7) == 3) || (c1 == 128 && (tile & 4));
+    const int tn = c1 == 128 ? tile & 3 : (w8 ? 1 : tile & 7), sp = (tile & 8) ? 2 : 1;
+    const dim3 block(w8 ? 512 : 256);
     const dim3 grid((with3x3 ? a.tiles_per_img * a.N : (a.M + 16 * tn - 1) / (16 * tn)) * sp);
 #define SABER_CHAIN(KS1, G1, MFG2, G2, TN, R, C3, SP, ...) \
     hipLaunchKernelGGL((conv1x1_chain_kernel<KS1, G1, MFG2, G2, TN, R, C3, SP, ##__VA_ARGS__>), grid, block, 0, s, a)
@@ -422,6 +428,8 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
         case 128 * 32 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1, false); break;
         case 128 * 32 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1, false); break;
         case 256 * 32 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1, false); break;
+        case 128 * 32 + 6: SABER_CHAIN(2, 1, 1, 1, 2, 8, true, 1, false, 8); break;
+        case 128 * 32 + 5: SABER_CHAIN(2, 1, 1, 1, 1, 8, true, 1, false, 8); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -433,6 +441,7 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
     case 128 * 32 + 1 * 2: SABER_CHAIN(2, 2, 2, 1, 1, 8, false, 1); break;
     case 256 * 32 + 1 * 2: SABER_CHAIN(4, 4, 4, 1, 1, 16, false, 1); break;
     case 256 * 32 + 9 * 2: SABER_CHAIN(4, 4, 2, 1, 1, 16, false, 2); break;     // second conv split over two workgroups
+    case 256 * 32 + 11 * 2: SABER_CHAIN(4, 2, 1, 1, 1, 16, false, 2, true, 8); break;   // ... and 8 waves
     case 512 * 32 + 1 * 2: SABER_CHAIN(8, 8, 4, 2, 1, 16, false, 1); break;
     case 512 * 32 + 9 * 2: SABER_CHAIN(8, 8, 4, 1, 1, 16, false, 2); break;
     case 64 * 32 + 4 * 2 + 1: SABER_CHAIN(1, 1, 1, 1, 4, 4, true, 1); break;
@@ -440,6 +449,10 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
     case 128 * 32 + 2 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1); break;
     case 128 * 32 + 1 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1); break;
     case 256 * 32 + 1 * 2 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1); break;
+    case 128 * 32 + 6 * 2: SABER_CHAIN(2, 1, 1, 1, 2, 8, false, 1, true, 8); break;      // 8 waves
+    case 128 * 32 + 5 * 2: SABER_CHAIN(2, 1, 1, 1, 1, 8, false, 1, true, 8); break;
+    case 128 * 32 + 6 * 2 + 1: SABER_CHAIN(2, 1, 1, 1, 2, 8, true, 1, true, 8); break;
+    case 128 * 32 + 5 * 2 + 1: SABER_CHAIN(2, 1, 1, 1, 1, 8, true, 1, true, 8); break;
     default: return hipErrorInvalidValue;
     }
 #undef SABER_CHAIN

@@ -174,7 +174,8 @@ void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* chain);
 int saber_hip_conv2d_chain_run(saber_hip_chain_t* chain, const void* x, const void* res, void* y_a, void* y_b,
                                saber_hip_stream_t stream);
 /* pixel fragments (16 pixels each) per workgroup: 4 | 2 for C = 64, 2 | 1 for C = 128, 1 otherwise; C >= 256 also takes
- * 9 = 1 fragment with the second conv's output channels split over two workgroups (both run the first conv) */
+ * 9 = 1 fragment with the second conv's output channels split over two workgroups (both run the first conv);
+ * C = 256 also 11 = the same with 8 waves per workgroup; C = 128 also 6 | 5 = 2 | 1 fragments with 8 waves */
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* chain, int tn);
 int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* chain);
 

@@ -458,6 +458,10 @@ CHAIN_CASES = [
     (256, 2, 14, O.U8, O.U8, 1, 1, 9),     # second conv split over two workgroups
     (256, 1, 5, O.S8, O.S8, 0, 0, 9),
     (512, 2, 7, O.U8, O.U8, 1, 1, 9),
+    (256, 2, 14, O.U8, O.U8, 1, 1, 11),    # split + 8 waves per workgroup
+    (256, 1, 5, O.S8, O.S8, 0, 0, 11),
+    (128, 2, 28, O.U8, O.U8, 1, 1, 6),     # 8 waves per workgroup
+    (128, 1, 11, O.U8, O.S8, 1, 1, 5),
 ]
 
 
@@ -515,6 +519,8 @@ CHAIN3_CASES = [
     (128, 1, 5, 17, O.U8, O.S8, O.U8, 1, 1, 1),
     (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, None),
     (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, None),
+    (128, 2, 28, 28, O.U8, O.U8, O.U8, 1, 1, 5),    # 8 waves per workgroup
+    (128, 1, 5, 17, O.U8, O.S8, O.U8, 1, 1, 6),
 ]
 
 
