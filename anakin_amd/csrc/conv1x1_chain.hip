@@ -105,8 +105,12 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
     constexpr int OFF = T0 % R;                       // ring slot of the first 1x1 conv's first step
     constexpr int CPR = K1 / 16;                      // 16-byte chunks per tile row
     constexpr int CH1 = C1 / 16;                      // ... per pixel of the 3x3 conv's input / output
+    // LDS pixel pitch of the halo and of the 3x3 conv's output tile: one chunk of padding per pixel makes the 16 lanes of a
+    // fragment column (consecutive pixels, same chunk) hit 16 different 16-byte bank groups (pitch odd in chunks); with the
+    // natural pitch (4 / 8 / 16 chunks) they collide 4- / 8- / 16-way (SQ_LDS_BANK_CONFLICT: 58 % of the LDS cycles at C = 128)
+    constexpr int PCH = CH1 + 1;
     constexpr int HW = 18, HP = (TN + 2) * HW;        // halo pixels
-    constexpr int HCH = C3 ? (HP * CH1 + 63) / 64 * 64 : 1;
+    constexpr int HCH = C3 ? (HP * PCH + 63) / 64 * 64 : 1;
     constexpr int P0C = C3 ? (C1 / 4 * 3 + 63) / 64 * 64 : 1;
     constexpr int P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
     static_assert(SG1 % R == 0 && SG2 % R == 0, "ring depth must divide the group lengths");
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
     __shared__ v4i prm1[P1C];
     __shared__ v4i prm2[P2C];
     __shared__ v4i halo[HCH];
-    __shared__ v4i mid[C3 ? NPX * CH1 : 1];
+    __shared__ v4i mid[C3 ? NPX * PCH : 1];
     __shared__ v4i prm0[P0C];
     SABER_TL_DECL;
     SABER_TL(0);
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             const char* xg = (const char*)a.x;
             for (int i = wave; i < HCH / 64; i += NW) {
                 const int L = i * 64 + lane;
-                const int hp = L / CH1, cc = L % CH1;
+                const int hp = L / PCH, cc = L - hp * PCH;            // cc == CH1: the padding chunk (fetches zeros)
                 const int hy = hp / HW, hx = hp - hy * HW;
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                const bool in = hp < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // zero padding
+                const bool in = hp < HP && cc < CH1 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // zero padding
                 const char* src = in ? xg + ((size_t)((n * a.H + gy) * a.W + gx) * C1 + cc * 16) : (const char*)a.zero;
                 lds_dma16(src, halo + i * 64);
             }
@@ -223,14 +227,14 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
         for (int mf = 0; mf < MF0; ++mf)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
-        const v4i* hb = halo + frow * CH1 + fq;
+        const v4i* hb = halo + frow * PCH + fq;
 #pragma unroll
         for (int s = 0; s < T0; ++s) {                 // steps ordered [tap][k-step][accumulator]
             const int mf = s % MF0, ks = (s / MF0) % KS1, tap = s / (MF0 * KS1);
             const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                v4i b = hb[((j + dy) * HW + dx) * CH1 + ks * 4];
+                v4i b = hb[((j + dy) * HW + dx) * PCH + ks * 4];
                 b.x ^= xm0; b.y ^= xm0; b.z ^= xm0; b.w ^= xm0;
                 acc[mf][j] = mma_step(ring[s % R], b, acc[mf][j]);
             }
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             for (int mf = 0; mf < MF0; ++mf)
                 o[mf] = chain_out_pack(acc[mf][j], pp[mf * 3 + 2], __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
                                        __builtin_bit_cast(v4f, pp[mf * 3]), lo0, off0, xo0);
-            char* mp = (char*)mid + (j * 16 + frow) * C1 + c0;
+            char* mp = (char*)mid + (j * 16 + frow) * (PCH * 16) + c0;
             if constexpr (MF0 == 1) *(unsigned*)mp = o[0];
             else if constexpr (MF0 == 2) *(uint2*)mp = make_uint2(o[0], o[1]);
             else *(uint4*)mp = make_uint4(o[0], o[1], o[2], o[3]);
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) bx[ks][j] = mid[(j * 16 + frow) * CH1 + ks * 4 + fq];
+            for (int ks = 0; ks < KS1; ++ks) bx[ks][j] = mid[(j * 16 + frow) * PCH + ks * 4 + fq];
     }
 
     const int xmask = a.in_u8 ? (int)0x80808080u : 0;
