@@ -5,6 +5,7 @@
 #   kernel_trace_summary.txt, sequence_b8.txt   rocprofv3 --kernel-trace of 20 timed steps
 #   fetch_per_kernel.txt, write_per_kernel.txt  PMC passes (separate runs, kernel-trace only) with per-dispatch bytes
 #   mfma_util.txt                derived MfmaUtil per kernel, time-weighted
+#   inst_mix_per_launch.txt, lds_per_launch.txt   wave-instruction counts (VALU / MFMA / LDS / VMEM) and LDS bank-conflict cycles per launch
 #   traffic.json                 HBM bytes per launch (FETCH doubled per the gfx950 correction) + the source hash bench.py checks
 set -u
 TAG=${1:-r02}; shift
@@ -28,6 +29,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc MfmaUtil -d $OUT/pmc_mfma -o m -- python bench.py $ARGS --no-graph > $OUT/bench_mfma.log 2>&1
 python scripts/pmc_kernel_avg.py $(find $OUT/pmc_mfma -name '*_results.db' | head -1) MfmaUtil $NOPS > $OUT/mfma_util.txt
+# instruction mix and LDS conflicts per launch (two more PMC passes; SQ counters are summed over the chip)
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc_inst -o i -- python bench.py $ARGS --no-graph > $OUT/bench_inst.log 2>&1
+python scripts/pmc_mix.py $(find $OUT/pmc_inst -name '*_results.db' | head -1) $NOPS > $OUT/inst_mix_per_launch.txt
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_lds -o l -- python bench.py $ARGS --no-graph > $OUT/bench_lds.log 2>&1
+python scripts/pmc_mix.py $(find $OUT/pmc_lds -name '*_results.db' | head -1) $NOPS > $OUT/lds_per_launch.txt
+rm -rf $OUT/pmc_inst $OUT/pmc_lds
 python scripts/make_traffic_json.py $OUT
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
 head -3 $OUT/sequence_b8.txt; tail -1 $OUT/mfma_util.txt; cat $OUT/traffic.json | head -20
