@@ -40,16 +40,27 @@ __device__ __forceinline__ unsigned chain_elt_pack(const v4i acc, const v4i comp
         dq[r] = d2.x;
         dq[r + 1] = d2.y;
     }
+    // the eltwise on PAIRS of values with packed f32 multiplies / adds (IEEE per component, no contraction: the bits of the
+    // scalar sequence, ~3 VALU instructions fewer per output)
     unsigned w = 0;
+    const v2f cc = {a.coeff_conv, a.coeff_conv}, sc2 = {a.scale_conv, a.scale_conv};
+    const v2f cr = {a.coeff_res, a.coeff_res}, sr2 = {a.scale_res, a.scale_res};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float q = rintf(dq[t]);
-        q = __builtin_amdgcn_fmed3f(q, lo_s8, 127.f);
-        const float rv = (float)(int)(int8_t)(rs >> (8 * t));
-        float e = __fmul_rn(__fmul_rn(a.coeff_conv, q), a.scale_conv);
-        e = __fadd_rn(e, __fmul_rn(__fmul_rn(a.coeff_res, rv), a.scale_res));
-        e = fmaxf(e, res_lo);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(round_half_away(e) + 128.f, t, w);
+    for (int t = 0; t < 4; t += 2) {
+        v2f q = {__builtin_amdgcn_fmed3f(rintf(dq[t]), lo_s8, 127.f), __builtin_amdgcn_fmed3f(rintf(dq[t + 1]), lo_s8, 127.f)};
+        v2f rv = {(float)(int)(int8_t)(rs >> (8 * t)), (float)(int)(int8_t)(rs >> (8 * t + 8))};
+        v2f e = (cc * q) * sc2;
+        e = e + (cr * rv) * sr2;
+        e.x = fmaxf(e.x, res_lo);
+        e.y = fmaxf(e.y, res_lo);
+        // round_half_away(e) + 128: trunc(e + copysign(0.49999997, e)) + 128
+        v2f h = {copysignf(0x1.fffffep-2f, e.x), copysignf(0x1.fffffep-2f, e.y)};
+        v2f r = e + h;
+        r.x = truncf(r.x);
+        r.y = truncf(r.y);
+        r = r + v2f{128.f, 128.f};
+        w = __builtin_amdgcn_cvt_pk_u8_f32(r.x, t, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(r.y, t + 1, w);
     }
     return w ^ 0x80808080u;
 }
@@ -67,10 +78,17 @@ __device__ __forceinline__ unsigned chain_out_pack(const v4i acc, const v4i comp
         dq[r + 1] = d2.y;
     }
     unsigned w = 0;
+    if (xm == 0u) {   // u8: the saturating convert clamps at 0 itself (the relu, if any, is implied) - no max, no offset
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float q = fmaxf(rintf(dq[t]), lo);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(q + off, t, w);
+        for (int t = 0; t < 4; ++t) w = __builtin_amdgcn_cvt_pk_u8_f32(rintf(dq[t]), t, w);
+        return w;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t += 2) {
+        v2f q = {fmaxf(rintf(dq[t]), lo), fmaxf(rintf(dq[t + 1]), lo)};
+        q = q + v2f{off, off};
+        w = __builtin_amdgcn_cvt_pk_u8_f32(q.x, t, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(q.y, t + 1, w);
     }
     return w ^ xm;
 }
@@ -222,11 +240,14 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
         __builtin_amdgcn_s_barrier();                              // ... and every other wave's
         SABER_TL(1);
         const int xm0 = a.in0_u8 ? (int)0x80808080u : 0;
+        // accumulators start at the per-channel compensation (exact integer sum, any order): one add per output saved
+        const int c0 = wave * (C1 / NW) + fq * (4 * MF0);
+        const v4i* pp = prm0 + (c0 / 4) * 3;
         v4i acc[MF0][TN];
 #pragma unroll
         for (int mf = 0; mf < MF0; ++mf)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+            for (int j = 0; j < TN; ++j) acc[mf][j] = pp[mf * 3 + 2];
         const v4i* hb = halo + frow * PCH + fq;
 #pragma unroll
         for (int s = 0; s < T0; ++s) {                 // steps ordered [tap][k-step][accumulator]
@@ -242,8 +263,6 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
         }
         wsb += T0 * 64;
         // epilogue: lane = 4*MF0 consecutive channels c0.. of pixel j*16 + frow -> mid[px][C1] (bytes)
-        const int c0 = wave * (C1 / NW) + fq * (4 * MF0);
-        const v4i* pp = prm0 + (c0 / 4) * 3;
         const float lo0 = a.relu0 ? 0.f : -3.0e38f;
         const float off0 = a.in_u8 ? 0.f : 128.f;      // a.in_u8: dtype of the 3x3 conv's output = first 1x1 conv's input
         const unsigned xo0 = a.in_u8 ? 0u : 0x80808080u;
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             unsigned o[MF0];
 #pragma unroll
             for (int mf = 0; mf < MF0; ++mf)
-                o[mf] = chain_out_pack(acc[mf][j], pp[mf * 3 + 2], __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
+                o[mf] = chain_out_pack(acc[mf][j], v4i{0, 0, 0, 0}, __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
                                        __builtin_bit_cast(v4f, pp[mf * 3]), lo0, off0, xo0);
             char* mp = (char*)mid + (j * 16 + frow) * (PCH * 16) + c0;
             if constexpr (MF0 == 1) *(unsigned*)mp = o[0];
@@ -282,10 +301,15 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
 #pragma unroll 1
     for (int g = 0; g < G1; ++g) {
         v4i acc[4][TN];
+        const int cg = wave * (K1 / NW) + g * 64 + fq * 16;   // lane = 16 consecutive channels cg .. cg+15 of pixels j*16 + frow
+        const v4i* pp = prm1 + (cg / 4) * 3;
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (C3) acc[mf][j] = pp[mf * 3 + 2];   // constants are in LDS since the barrier before phase 0
+                else acc[mf][j] = v4i{0, 0, 0, 0};               // (1x1 chain: their DMA is still in flight; added in the epilogue)
+            }
 #pragma unroll
         for (int s = 0; s < SG1; ++s) {
             const int ri = (OFF + s) % R;
@@ -299,16 +323,15 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             __builtin_amdgcn_s_barrier();              // every wave's DMA has landed (see above)
         }
         if (g == 0) SABER_TL(2);
-        // epilogue: lane = 16 consecutive channels cg .. cg+15 of pixels j*16 + frow
-        const int cg = wave * (K1 / NW) + g * 64 + fq * 16;
-        const v4i* pp = prm1 + (cg / 4) * 3;
+        // epilogue
         v4f sc[4], bi[4];
         v4i co[4];
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             sc[mf] = __builtin_bit_cast(v4f, pp[mf * 3]);
             bi[mf] = __builtin_bit_cast(v4f, pp[mf * 3 + 1]);
-            co[mf] = pp[mf * 3 + 2];
+            if constexpr (C3) co[mf] = v4i{0, 0, 0, 0};
+            else co[mf] = pp[mf * 3 + 2];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -358,10 +381,12 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
 #pragma unroll 1
     for (int g = 0; g < G2; ++g) {
         v4i acc[MFG2][TN];
+        const int cg = half * K2W + wave * (K2W / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
+        const v4i* pp = prm2 + (cg / 4) * 3;
 #pragma unroll
         for (int mf = 0; mf < MFG2; ++mf)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[mf][j] = v4i{0, 0, 0, 0};
+            for (int j = 0; j < TN; ++j) acc[mf][j] = pp[mf * 3 + 2];   // start at the compensation (see phase 0)
 #pragma unroll
         for (int s = 0; s < SG2; ++s) {
             const int ri = (OFF + s) % R;
@@ -371,14 +396,12 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             if (s + R < SG2 || g + 1 < G2) ring[ri] = wsb[s * 64 + lane];   // the stream ends with the last group
         }
         wsb += SG2 * 64;
-        const int cg = half * K2W + wave * (K2W / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
-        const v4i* pp = prm2 + (cg / 4) * 3;
         unsigned o[MFG2];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int mf = 0; mf < MFG2; ++mf)
-                o[mf] = chain_out_pack(acc[mf][j], pp[mf * 3 + 2], __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
+                o[mf] = chain_out_pack(acc[mf][j], v4i{0, 0, 0, 0}, __builtin_bit_cast(v4f, pp[mf * 3 + 1]),
                                        __builtin_bit_cast(v4f, pp[mf * 3]), lo2, off2, xm2);
             bool ok;
             const int p = pix(j * 16 + frow, ok);
