@@ -311,12 +311,21 @@ __global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs 
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 unsigned w = 0;
+                float dq[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float d = (float)(acc[v][j][t] + cp.comp[v * 4 + t]);
-                    d = __fadd_rn(d, cp.bias[v * 4 + t]);
-                    d = __fmul_rn(d, cp.scale[v * 4 + t]);
-                    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaxf(rintf(d), lo_clamp) + off, t, w);
+                for (int t = 0; t < 4; t += 2) {   // packed f32 add / mul on channel pairs (IEEE per component: same bits)
+                    v2f d2 = {(float)(acc[v][j][t] + cp.comp[v * 4 + t]), (float)(acc[v][j][t + 1] + cp.comp[v * 4 + t + 1])};
+                    d2 = d2 + v2f{cp.bias[v * 4 + t], cp.bias[v * 4 + t + 1]};
+                    d2 = d2 * v2f{cp.scale[v * 4 + t], cp.scale[v * 4 + t + 1]};
+                    dq[t] = d2.x;
+                    dq[t + 1] = d2.y;
+                }
+                if (u8) {   // the saturating convert clamps at 0 itself: no max, no offset
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w = __builtin_amdgcn_cvt_pk_u8_f32(rintf(dq[t]), t, w);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w = __builtin_amdgcn_cvt_pk_u8_f32(fmaxf(rintf(dq[t]), lo_clamp) + off, t, w);
                 }
                 pk[v] = w;
             }
