@@ -278,6 +278,45 @@ def main():
             b1 = dict(p50_ms=round(l1[len(l1) // 2], 4), mean_ms=round(statistics.mean(l1), 4),
                       images_per_s=round(1000.0 / statistics.mean(l1), 1))
 
+        # ---------------- serving throughput: several independent batches in flight (extra, NOT `value`) ----------
+        # The forward pass is a chain of 35 dependent launches that leaves most CUs idle most of the time; a server with
+        # more than one request queue (the reference's Worker runs one Net per thread, framework/core/worker.h) fills them
+        # with another batch. Two / three op lists with the same kernel selection, each a hipGraph on its own stream.
+        multi = None
+        if not args.no_b1 and world == 1 and args.precision == "int8":
+            multi = {}
+            extra, streams = [], []
+            for i in range(2):
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    ne = build_net(W, model, scales, B, args)
+                    ne.set_choices(net.choices())
+                    ne.tensor("data").copy_(torch.from_numpy(W.make_input(B, seed=11 + i)).cuda())
+                    ne.run()
+                    ne.capture()
+                extra.append(ne)
+                streams.append(st)
+            torch.cuda.synchronize()
+            net.capture()      # (again: the launch-mode probe may have kept or dropped its graph)
+            for k in (2, 3):
+                group = [(net, torch.cuda.current_stream())] + list(zip(extra[:k - 1], streams[:k - 1]))
+
+                def round_():
+                    for n_, s_ in group:
+                        with torch.cuda.stream(s_):
+                            n_.replay()
+                for _ in range(20):
+                    round_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    round_()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 200
+                multi["streams_%d" % k] = {"images_per_s": round(k * B / dt, 1), "ms_per_round": round(dt * 1e3, 4),
+                                           "batches_in_flight": k, "batch": B}
+            multi["note"] = "independent batch-%d forward passes in flight on separate streams; each batch's latency is ms_per_round" % B
+
         # ---------------- CPU baseline on this host, bounded sample, rank 0 only -----------------------------
         # "reference": the ResNet50 INT8 op list through the REFERENCE'S OWN x86 objects compiled into oracle/_ref
         # (GemmX8S8S32XConv + MKL cblas_gemm_s8u8s32, SaberEltwise, PackedMKLInt8Gemm; oracle/net_oracle.RefNet), batch 1,
@@ -355,6 +394,7 @@ def main():
                        "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus},
             "latency_ms": {"batch": B, "p50": round(p50, 4), "p99": round(p99, 4)},
             "batch1": b1,
+            "multi_stream": multi,
             "roofline": roof,
             "cpu_baseline": cpu,
         }

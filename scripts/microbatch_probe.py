@@ -1,4 +1,5 @@
-"""Probe: batch 8 as k concurrent micro-batch op lists on k streams (each its own hipGraph)."""
+"""Probe: batch 8 as k concurrent micro-batch op lists on k streams (each its own hipGraph); with `python
+scripts/microbatch_probe.py streams` instead: k independent batch-8 op lists in flight on k streams (serving throughput)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,8 +7,9 @@ from anakin_amd import workloads as W
 
 model = W.build_model("resnet50")
 scales = W.calibrate(model, W.make_input(2))
-for k in (1, 2, 4):
-    b = 8 // k
+STREAMS = len(sys.argv) > 1 and sys.argv[1] == "streams"
+for k in ((1, 2, 3) if STREAMS else (1, 2, 4)):
+    b = 8 if STREAMS else 8 // k
     nets, streams = [], []
     for i in range(k):
         s = torch.cuda.Stream()
@@ -28,4 +30,5 @@ for k in (1, 2, 4):
     for _ in range(n): step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print("micro-batches=%d x batch %d: %.4f ms per 8 images -> %.0f images/s" % (k, b, dt * 1e3, 8 / dt))
+    imgs = k * b
+    print("%s=%d x batch %d: %.4f ms per %d images -> %.0f images/s" % ("streams" if STREAMS else "micro-batches", k, b, dt * 1e3, imgs, imgs / dt))
