@@ -327,55 +327,59 @@ def main():
         # "port": the same list through the plain-C restatement oracle/saber_oracle.c (OpenMP), kept beside it.
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.precision == "int8":
-            from oracle import net_oracle as NO
-            from oracle import oracle as ORC
-            ncpu = os.cpu_count() or 1
-            xs = W.make_input(1)
-            port = {}
-            prep = NO.prepare_int8(model)           # weight quantisation is init-time work, not timed
-            for cores in sorted({min(8, ncpu), min(ncpu, 32)}):
-                NO.set_threads(cores)
-                NO.run_int8(model, dict(scales), xs, prep=prep)
-                t1 = time.perf_counter()
-                n_img = 0
-                while time.perf_counter() - t1 < args.cpu_seconds * 0.2:
+            try:
+                from oracle import net_oracle as NO
+                from oracle import oracle as ORC
+                ncpu = os.cpu_count() or 1
+                xs = W.make_input(1)
+                port = {}
+                prep = NO.prepare_int8(model)           # weight quantisation is init-time work, not timed
+                for cores in sorted({min(8, ncpu), min(ncpu, 32)}):
+                    NO.set_threads(cores)
                     NO.run_int8(model, dict(scales), xs, prep=prep)
-                    n_img += 1
-                port[cores] = round(n_img / (time.perf_counter() - t1), 3)
-            if ORC.ref_available():
-                rn = NO.RefNet(model, dict(scales), 1)
-                rn.run(xs)
-                NO.ref_set_threads(min(8, ncpu))
-                one = rn.time_ms(2, 3)
-                iters = max(5, min(200, int(args.cpu_seconds * 0.5 * 1000.0 / max(one, 1e-3))))
-                ms8 = rn.time_ms(10, iters)
-                # a second point at more threads, bounded: MKL oversubscribes badly on these small GEMMs (256 threads on a
-                # 256-core host: 10 s per image), so at most 32 threads and at most ~3 s of it
-                more = min(ncpu, 32)
-                more_ips = None
-                if more > 8:
-                    NO.ref_set_threads(more)
-                    one = rn.time_ms(1, 1)
-                    if one < 500.0:
-                        more_ips = round(1000.0 / rn.time_ms(1, max(2, min(30, int(3000.0 / one)))), 3)
+                    t1 = time.perf_counter()
+                    n_img = 0
+                    while time.perf_counter() - t1 < args.cpu_seconds * 0.2:
+                        NO.run_int8(model, dict(scales), xs, prep=prep)
+                        n_img += 1
+                    port[cores] = round(n_img / (time.perf_counter() - t1), 3)
+                if ORC.ref_available():
+                    rn = NO.RefNet(model, dict(scales), 1)
+                    rn.run(xs)
                     NO.ref_set_threads(min(8, ncpu))
-                cpu = dict(value=round(1000.0 / ms8, 3), unit="images/s", cores=min(8, ncpu), kind="reference",
-                           ms_per_image=round(ms8, 3),
-                           sample="ResNet50 INT8 batch 1, 224x224, unfused reference op list (53 conv + 16 eltwise + pool + "
-                                  "gpool + fc), %d timed forwards after 10 warm-up, through the reference's own x86 Saber "
-                                  "objects compiled unmodified into oracle/_ref (GemmX8S8S32XConv + MKL cblas_gemm_s8u8s32, "
-                                  "SaberEltwise, PackedMKLInt8Gemm), MKL/OpenMP threads = %d of %d host cores; this is the "
-                                  "reference's GEMM path - its JIT-VNNI path needs xbyak and is not buildable here "
-                                  "(README.md:92 quotes 3.21 ms/image for it on 8 Xeon-6271 threads)" % (iters, min(8, ncpu), ncpu),
-                           more_threads={"cores": more, "images_per_s": more_ips},
-                           port={"kind": "port", "what": "oracle/saber_oracle.c (plain-C restatement, OpenMP)",
-                                 "images_per_s_by_cores": port})
-            else:
-                cores = max(port)
-                cpu = dict(value=port[cores], unit="images/s", cores=cores, kind="port",
-                           sample="ResNet50 INT8 forward (batch 1, 224x224, unfused reference op list) through "
-                                  "oracle/saber_oracle.c, OpenMP over %d host threads (oracle/_ref not present)" % cores,
-                           port={"images_per_s_by_cores": port})
+                    one = rn.time_ms(2, 3)
+                    iters = max(5, min(200, int(args.cpu_seconds * 0.5 * 1000.0 / max(one, 1e-3))))
+                    ms8 = rn.time_ms(10, iters)
+                    # a second point at more threads, bounded: MKL oversubscribes badly on these small GEMMs (256 threads on a
+                    # 256-core host: 10 s per image), so at most 32 threads and at most ~3 s of it
+                    more = min(ncpu, 32)
+                    more_ips = None
+                    if more > 8:
+                        NO.ref_set_threads(more)
+                        one = rn.time_ms(1, 1)
+                        if one < 500.0:
+                            more_ips = round(1000.0 / rn.time_ms(1, max(2, min(30, int(3000.0 / one)))), 3)
+                        NO.ref_set_threads(min(8, ncpu))
+                    cpu = dict(value=round(1000.0 / ms8, 3), unit="images/s", cores=min(8, ncpu), kind="reference",
+                               ms_per_image=round(ms8, 3),
+                               sample="ResNet50 INT8 batch 1, 224x224, unfused reference op list (53 conv + 16 eltwise + pool + "
+                                      "gpool + fc), %d timed forwards after 10 warm-up, through the reference's own x86 Saber "
+                                      "objects compiled unmodified into oracle/_ref (GemmX8S8S32XConv + MKL cblas_gemm_s8u8s32, "
+                                      "SaberEltwise, PackedMKLInt8Gemm), MKL/OpenMP threads = %d of %d host cores; this is the "
+                                      "reference's GEMM path - its JIT-VNNI path needs xbyak and is not buildable here "
+                                      "(README.md:92 quotes 3.21 ms/image for it on 8 Xeon-6271 threads)" % (iters, min(8, ncpu), ncpu),
+                               more_threads={"cores": more, "images_per_s": more_ips},
+                               port={"kind": "port", "what": "oracle/saber_oracle.c (plain-C restatement, OpenMP)",
+                                     "images_per_s_by_cores": port})
+                else:
+                    cores = max(port)
+                    cpu = dict(value=port[cores], unit="images/s", cores=cores, kind="port",
+                               sample="ResNet50 INT8 forward (batch 1, 224x224, unfused reference op list) through "
+                                      "oracle/saber_oracle.c, OpenMP over %d host threads (oracle/_ref not present)" % cores,
+                               port={"images_per_s_by_cores": port})
+            except Exception as e:   # noqa: BLE001 - a broken checker must not cost the measured line; it is reported instead
+                cpu = {"error": "%s: %s" % (type(e).__name__, e), "value": None, "unit": "images/s", "cores": 0, "kind": "none",
+                       "sample": "cpu baseline failed to run on this host"}
 
         out = {
             # BASELINE.json's metric: value = images/s at batch 8 per GPU; the p50 latencies at batch 8 and batch 1 are
