@@ -915,6 +915,13 @@ def test_pooling_f32_vs_oracle():
             want = O.pool_f32_nchw(xc, win, st, pad, pt).transpose(0, 2, 3, 1)
             got = host(S.pooling_f32(dev(xh), win, st, pad, pt, layout=L.NHWC))
             assert np.array_equal(got, want), (c, win, st, pad, pt)
+    # NHWC global pooling (ResNet pool5, <= 64 pixels): the all-loads-in-flight kernel keeps the reference's summation order
+    for (c, hh, ww, pt) in ((256, 7, 7, 1), (6, 5, 8, 2), (32, 3, 3, 0), (8, 8, 8, 1)):
+        xc = rng.standard_normal((3, c, hh, ww)).astype(np.float32)
+        xh = np.ascontiguousarray(xc.transpose(0, 2, 3, 1))
+        want = O.pool_f32_nchw(xc, None, None, None, pt, global_pool=True).transpose(0, 2, 3, 1)
+        got = host(S.pooling_f32(dev(xh), None, None, None, pt, global_pooling=True, layout=L.NHWC))
+        assert np.array_equal(got, want), (c, hh, ww, pt)
 
 
 def test_pooling_f32_from_i8_equals_dequant_then_pool():
