@@ -214,7 +214,7 @@ static void name_algo(saber_hip_conv* op) {
     char buf[64];
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
-    else if (op->fc_small) snprintf(buf, sizeof buf, "fc_i8_small_16xk4");
+    else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
@@ -679,6 +679,10 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
         else HIP_TRY(launch_conv_igemm(1, op->tile, op->ks, a, s));
         break;
     case ALGO_IGEMM_F32:
+        if (op->fc_small) {
+            HIP_TRY(launch_fc_f32_small(a, s));
+            break;
+        }
         HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
         break;
     case ALGO_DIRECT_I8:
@@ -708,6 +712,10 @@ void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small;
 }
 bool fc_small_ok(const saber_hip_conv* op) {
+    if (op->algo == ALGO_IGEMM_F32)   // FP32 fc: a 1x1 "conv" on a [m, 1, 1, k] NHWC tensor, plain f32 epilogue, no residual
+        return op->epi == EPI_F32 && op->d.h == 1 && op->d.w == 1 && op->d.kh == 1 && op->d.kw == 1 && !op->pre_transpose &&
+               op->d.out_layout == SABER_HIP_NHWC && op->d.res_mode == SABER_HIP_RES_NONE && !op->pair_k2 && !op->pool2 &&
+               fc_f32_small_ok(op->d.n, op->c_eff, op->Kg_pad);
     return op->algo == ALGO_IGEMM_I8 && (op->epi == EPI_I8_FC_S8 || op->epi == EPI_I8_FC_U8) && op->d.h == 1 && op->d.w == 1 &&
            fc_i8_small_ok(op->d.n, op->c_eff, op->Kg_pad);
 }
@@ -1089,6 +1097,9 @@ int saber_hip_fc_create(const saber_hip_fc_desc* desc, saber_hip_fc_t** out) {
             fc->conv->fc_small = 1;
             name_algo(fc->conv);
         }
+    } else if (fc_small_ok(fc->conv)) {   // FP32: likewise
+        fc->conv->fc_small = 1;
+        name_algo(fc->conv);
     }
     *out = fc;
     return SABER_HIP_OK;

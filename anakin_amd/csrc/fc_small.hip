@@ -77,6 +77,64 @@ __global__ __launch_bounds__(256) void fc_i8_small_kernel(const ConvKArgs a) {
     SABER_TL_FLUSH();
 }
 
+// FP32 fc (VenderFc<X86,AK_FLOAT>, vender_fc.cpp:154-212: out = in W^T + bias) at <= 16 batch rows: the same shape of
+// kernel on v_mfma_f32_16x16x4_f32 - 16 outputs per workgroup, the 4 waves split the reduction, weight and activation chunks
+// (16 floats per row per step) go straight into MFMA operand registers sixteen steps at a time, partial sums meet in LDS.
+// ResNet50's fc (8 x 2048 -> 1000, an 8 MB weight stream): 15.4 us through the implicit-GEMM kernel's 32 workgroups.
+__global__ __launch_bounds__(256) void fc_f32_small_kernel(const ConvKArgs a, int ksw) {
+    __shared__ v4f redf[3][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int m = frow < a.M ? frow : a.M - 1;
+    const int k0 = wave * ksw * 16 + fq * 4;                 // this lane's first reduction index
+    const float* wp = (const float*)a.w + (size_t)(n0 + frow) * a.Kg_pad + k0;
+    const float* xp = (const float*)a.x + (size_t)m * a.C + k0;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ksw; s0 += 16) {
+        v4i wf[16], xf[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bool in = s0 + s < ksw && k0 + (s0 + s) * 16 < a.C;      // the activation row is C floats; weights are zero padded
+            wf[s] = in ? *(const v4i*)(wp + (s0 + s) * 16) : v4i{0, 0, 0, 0};
+            xf[s] = in ? *(const v4i*)(xp + (s0 + s) * 16) : v4i{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = mma_step(wf[s], xf[s], acc);
+    }
+    if (wave > 0) redf[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+    acc += redf[0][lane];
+    acc += redf[1][lane];
+    acc += redf[2][lane];
+    const int kb = n0 + fq * 4;
+    if (frow >= a.M || kb >= a.K) return;
+    float out[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float d = acc[r];
+        if (a.bias && kb + r < a.K) d = __fadd_rn(d, a.bias[kb + r]);
+        if (a.relu) d = d > 0.f ? d : (a.neg_slope == 0.f ? 0.f : __fmul_rn(d, a.neg_slope));
+        out[r] = d;
+    }
+    float* y = (float*)a.y + (size_t)frow * a.K + kb;
+    if (kb + 4 <= a.K && (a.K & 3) == 0) {
+        *(float4*)y = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (int r = 0; r < 4; ++r)
+            if (kb + r < a.K) y[r] = out[r];
+    }
+}
+bool fc_f32_small_ok(int m, int c, int kg_pad) { return m >= 1 && m <= 16 && c % 4 == 0 && c <= 65536 && kg_pad >= (c + 63) / 64 * 64; }
+hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s) {
+    if (!fc_f32_small_ok(a.M, a.C, a.Kg_pad)) return hipErrorInvalidValue;
+    const int ksw = (a.C + 63) / 64;       // 16-float k-steps per wave
+    hipLaunchKernelGGL(fc_f32_small_kernel, dim3((a.K + 15) / 16), dim3(256), 0, s, a, ksw);
+    return hipGetLastError();
+}
+
 // a.M = batch rows (<= 16), a.C = reduction length (multiple of 16), a.K = outputs, a.Kg_pad = weight row pitch
 bool fc_i8_small_ok(int m, int c, int kg_pad) { return m >= 1 && m <= 16 && c % 16 == 0 && c <= 4 * 16 * 64 && kg_pad >= ((c + 255) / 256) * 256; }
 

@@ -152,6 +152,9 @@ bool conv3x3_img_feasible(int C, int OW, int OH, int N, int nw, int ib, int rb);
 // into MFMA registers (fc_small.hip). a.M rows, a.C reduction, a.K outputs, FC epilogues only.
 hipError_t launch_fc_i8_small(const ConvKArgs& a, hipStream_t s);
 bool fc_i8_small_ok(int m, int c, int kg_pad);
+// the FP32 counterpart (EPI_F32 epilogue: + bias, optional relu), any a.C % 4 == 0
+hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s);
+bool fc_f32_small_ok(int m, int c, int kg_pad);
 // ResNet stem (7x7 stride 2, <= 4 channels) with the input patch in LDS; f32_in: fuse the quantise-on-entry
 hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s);
 // ... followed by the 3x3 / stride-2 / pad-0 max pooling in the same kernel (s8 / u8 outputs only)

@@ -991,6 +991,17 @@ def test_fc_vs_oracle():
     assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * np.abs(want).max()
     fc = S.SaberFc(False).init(M, N, K, np.ascontiguousarray(w.T), b, L.F32, w_is_kn=True)
     assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * np.abs(want).max()
+    assert fc.algo().startswith("fc_f32_small")
+    # ragged FP32 shapes through the small-batch kernel (k not a multiple of the 64-float wave stride, n not of 16 / 4)
+    for (m2, n2, k2) in ((1, 10, 36), (16, 1000, 2048), (5, 33, 100), (3, 7, 4096)):
+        w2 = (rng.standard_normal((n2, k2)) * 0.05).astype(np.float32)
+        b2 = rng.standard_normal(n2).astype(np.float32)
+        x2 = rng.standard_normal((m2, k2)).astype(np.float32)
+        fc2 = S.SaberFc(False).init(m2, n2, k2, w2, b2, L.F32)
+        y2 = torch.empty((m2, n2), dtype=torch.float32, device="cuda")
+        want2 = O.fc_f32(x2, w2, b2)
+        assert fc2.algo().startswith("fc_f32_small"), fc2.algo()
+        assert np.abs(host(fc2.dispatch(dev(x2), y2)) - want2).max() <= FP32_RTOL * np.abs(want2).max(), (m2, n2, k2)
 
 
 @pytest.mark.parametrize("shape", [(1, 1000, 2048), (16, 1000, 2048), (5, 24, 4096), (3, 1000, 528), (8, 50, 16),
