@@ -1293,6 +1293,11 @@ int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, floa
     HIP_TRY(launch_eltwise_sum_f32(count, a, b, c0, c1, relu, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
+int saber_hip_relu_f32(size_t count, const float* x, float* y, saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_relu_f32(count, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
 int saber_hip_pool_out_dim2(int in, int pad, int window, int stride, int floor_mode, int any_pad) {
     int o;  // Pooling<>::compute_output_shape, saber/funcs/pooling.h:92-121
     if (floor_mode) {

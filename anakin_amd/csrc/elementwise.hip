@@ -287,6 +287,22 @@ hipError_t launch_eltwise_sum_f32(size_t count, const float* a, const float* b, 
     return hipGetLastError();
 }
 
+// ---- standalone ReLU (SaberActivation<X86,AK_FLOAT>, Active_relu: saber_activation.cpp:136-154) ---------------
+__global__ __launch_bounds__(256) void relu_f32_kernel(size_t count, const float* __restrict__ x, float* __restrict__ y) {
+    const size_t vec = count >> 2;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < vec; gid += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)x)[gid];
+        ((float4*)y)[gid] = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f,
+                                        v.w > 0.f ? v.w : 0.f);
+    }
+    for (size_t i = (vec << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+        y[i] = x[i] > 0.f ? x[i] : 0.f;
+}
+hipError_t launch_relu_f32(size_t count, const float* x, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(relu_f32_kernel, dim3(grid_for((count + 3) / 4)), dim3(256), 0, s, count, x, y);
+    return hipGetLastError();
+}
+
 // ---- 8-bit NHWC pooling -----------------------------------------------------------------------
 // One lane per (output pixel, 4-channel dword). JIT semantics: int32 window sum, (float)sum * idivider,
 // round-to-nearest-even, saturate; max by signed/unsigned compare.

@@ -33,7 +33,7 @@ SYMBOLS = [
     "saber_hip_gemm_i8_create", "saber_hip_gemm_i8_workspace_bytes", "saber_hip_gemm_i8_run", "saber_hip_gemm_i8_destroy",
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
-    "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32",
+    "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32", "saber_hip_relu_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool_out_dim2", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
     "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
@@ -149,6 +149,7 @@ def load():
     lib.saber_hip_net_add_pool_f32_from_i8_q.argtypes = [P] + [I] * 14 + [F, I, I, F, I]
     lib.saber_hip_net_add_fc_q.argtypes = [P, P, I, I]
     lib.saber_hip_softmax_f32.argtypes = [I, I, P, P, P]
+    lib.saber_hip_relu_f32.argtypes = [Z, P, P, P]
     lib.saber_hip_net_create.argtypes = [C.POINTER(P)]
     lib.saber_hip_net_add_tensor.argtypes = [P, Z]
     lib.saber_hip_net_add_conv.argtypes = [P, P, I, I, I]

@@ -83,12 +83,94 @@ def conv_macs(spec, hw=224):
             total += l["cin"] * l["cout"] * l["k"] ** 2 * o * o
         elif l["kind"] == "pool":
             s = sizes[l["src"]]
-            sizes[l["name"]] = int(np.ceil((s + 2 * l["pad"] - l["win"]) / l["stride"])) + 1
+            rnd = np.floor if l.get("floor") else np.ceil
+            sizes[l["name"]] = int(rnd((s + 2 * l["pad"] - l["win"]) / l["stride"])) + 1
         elif l["kind"] == "eltwise":
             sizes[l["name"]] = sizes[l["a"]]
         elif l["kind"] == "fc":
             total += l["cin"] * l["cout"]
     return total
+
+
+# --------------------------------------------------------------------------------------------- the reference's own graph
+def framework_spec(spec, precision="int8"):
+    """The layer list as the REFERENCE'S optimiser and edge rules leave it (checked op for op against the reference's own
+    Graph::Optimize + Net::init by tests/test_net_oplist.py and integration/test_net_mi355x.cpp):
+
+    * graph_strategy::apply_stride_up (framework/graph/llvm/optimizer/optimize_strategy.h:41-47,196-287; applied for every
+      target, graph.cpp:405): the stride of 1x1 convolutions that all read the same eltwise is pushed UP through it — the
+      producing `branch2c` (1x1) hands it on to the 3x3 `branch2b`, which becomes stride 2, and the other eltwise input gets a
+      1x1 / stride-s max pooling (floor mode) named `<its Split node>_pool`. Values at the kept pixels are unchanged.
+    * INT8 edge dtypes (CalibratorParser::get_dtype, framework/core/net/calibrator_parse.cpp:82-128 with the node dtypes of
+      AutoLayoutConfigHelper::auto_config_node_dtype, auto_layout_config.cpp:105-131): conv+relu -> u8, everything else s8 —
+      EXCEPT a convolution with 1 or 3 input channels, whose output dtype follows its CONSUMER (conv1 -> pool1: s8).
+    * The tail runs 8-bit: an int8 -> fp32 edge would be f32, which SaberEltwise<AK_INT8> cannot write
+      (saber_eltwise.cpp:85-95), so pool5 is an INT8 average pooling (s8 -> s8, scale inherited,
+      saber_pooling.cpp:571-582) and the fc reads s8 (vender_fc.cpp:254-262 -> PackedMKLInt8Gemm).
+    FP32: only the stride-up applies (conv + eltwise stay separate entries here; the FP32 executor fuses them)."""
+    out = [dict(l) for l in spec]
+    by = {l["name"]: l for l in out}
+    readers = {}
+    for l in out:
+        for key in ("src", "a", "b"):
+            if key in l:
+                readers.setdefault(l[key], []).append(l)
+
+    def conv1x1(l, stride=None):
+        return l["kind"] == "conv" and l["k"] == 1 and (stride is None or l["stride"] == stride)
+
+    def push_up(conv):            # _stride_up: a strided 1x1 conv hands its stride to a conv-like producer
+        s = conv["stride"]
+        if conv["k"] != 1 or s <= 1:
+            return
+        src = by.get(conv["src"])
+        if src is not None and src["kind"] == "conv" and len(readers[src["name"]]) == 1:
+            src["stride"] *= s
+            conv["stride"] = 1
+            push_up(src)
+
+    inserted = []
+    for e in [l for l in out if l["kind"] == "eltwise"]:
+        rd = readers.get(e["name"], [])
+        if len(rd) < 2 or not all(conv1x1(r) for r in rd) or len({r["stride"] for r in rd}) != 1 or rd[0]["stride"] <= 1:
+            continue
+        s = rd[0]["stride"]
+        for r in rd:
+            r["stride"] = 1
+        for key in ("a", "b"):    # _stride_up_like_concat: every input of the eltwise
+            src = by[e[key]]
+            if src["kind"] == "conv" and len(readers[src["name"]]) == 1:
+                src["stride"] *= s
+                push_up(src)
+            else:                 # not a conv (a Split behind the previous block): 1x1 / stride-s max pooling
+                pn = src["name"] + "_outsplit_pool"
+                pool = dict(kind="pool", name=pn, src=src["name"], win=1, stride=s, pad=0, type=0, floor=True)
+                inserted.append((e["name"], pool))
+                e[key] = pn
+    for before, pool in inserted:
+        # the reference schedules it anywhere between its producer and the eltwise; here: right before the block's first conv
+        blk = next(i for i, l in enumerate(out) if l["kind"] == "conv" and l.get("eltwise") == before) - 2
+        out.insert(max(blk, 0), pool)
+        by[pool["name"]] = pool
+    if precision == "int8":
+        for l in out:
+            if l["kind"] == "conv":
+                l["odt"] = U8 if l["relu"] else S8
+                if l["cin"] in (1, 3):      # calibrator_parse.cpp:104-113: the consumer decides
+                    nxt = readers.get(l["name"], [])
+                    relu_conv = bool(nxt) and all(r["kind"] == "conv" and r["relu"] for r in nxt)
+                    l["odt"] = U8 if relu_conv else S8
+            elif l["kind"] == "gpool":
+                l["int8"] = True
+    return out
+
+
+def framework_model(model, precision="int8"):
+    """`model` with the layer list rewritten by framework_spec (weights are shared, not copied)."""
+    m = dict(model)
+    m["spec"] = framework_spec(model["spec"], precision)
+    m["framework"] = True
+    return m
 
 
 # --------------------------------------------------------------------------------------------- weights
@@ -110,7 +192,7 @@ def fold_bn(w, bias, bn_scale, eps, mean, var, scale_w, scale_b):
 def build_model(name="resnet50", seed=42):
     """Seeded weights: conv ~ N(0, sqrt(2/(C*k*k))), BN gamma U(.5,1.5), beta/mean U(-.1,.1), var U(.5,1.5)."""
     spec = {"resnet50": lambda: resnet_spec(50), "resnet101": lambda: resnet_spec(101), "vgg16": vgg16_spec}[name]()
-    params = {}
+    params, raw = {}, {}          # raw: the BatchNorm / Scale blobs before folding (what a model file holds)
     for idx, l in enumerate(spec):
         rng = np.random.default_rng(seed + idx)
         if l["kind"] == "conv":
@@ -125,11 +207,12 @@ def build_model(name="resnet50", seed=42):
                 mean = rng.uniform(-0.1, 0.1, k).astype(np.float32)
                 var = rng.uniform(0.5, 1.5, k).astype(np.float32)
                 params[l["name"]] = fold_bn(w, None, 1.0, 1e-5, mean, var, gamma, beta)
+                raw[l["name"]] = dict(w=w, mean=mean, var=var, gamma=gamma, beta=beta)
         elif l["kind"] == "fc":
             w = (rng.standard_normal((l["cout"], l["cin"])) * np.sqrt(1.0 / l["cin"])).astype(np.float32)
             b = rng.uniform(-0.1, 0.1, l["cout"]).astype(np.float32)
             params[l["name"]] = (w, b)
-    return dict(name=name, spec=spec, params=params)
+    return dict(name=name, spec=spec, params=params, raw=raw)
 
 
 def make_input(batch, seed=1234, hw=224):
@@ -153,7 +236,7 @@ def calibrate(model, x):
                 if l["relu"]:
                     y = torch.relu(y)
             elif kd == "pool":
-                y = Fn.max_pool2d(t[l["src"]], l["win"], l["stride"], l["pad"], ceil_mode=True)
+                y = Fn.max_pool2d(t[l["src"]], l["win"], l["stride"], l["pad"], ceil_mode=not l.get("floor", False))
             elif kd == "eltwise":
                 y = torch.relu(t[l["a"]] + t[l["b"]])
             elif kd == "gpool":
@@ -228,7 +311,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             hin, cin = shape[l["src"]]
             ho = _out_hw(hin, l["k"], l["stride"], l["pad"])
             w, b = model["params"][nm]
-            odt = U8 if l["relu"] else S8
+            odt = l.get("odt", U8 if l["relu"] else S8)   # framework_spec: conv1's output dtype follows its consumer
             p = S.ConvParam(w, b, 1, (l["pad"],) * 2, (l["stride"],) * 2, (1, 1), l["relu"])
             shape[nm], dtype[nm] = (ho, l["cout"]), odt
             if fuse_eltwise and "eltwise" in l:
@@ -270,7 +353,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
                 net.set_lane(idx, 1)   # the shortcut projection is independent of branch2a/2b: side lane
         elif kd == "pool":
             hin, c = shape[l["src"]]
-            ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
+            ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"], l.get("floor", False))
             shape[nm], dtype[nm] = (ho, c), dtype[l["src"]]
             scales[nm] = scales[l["src"]]   # SaberPooling<X86,AK_INT8>::init: output scale := input scale
             net.add_tensor(nm, (B, ho, ho, c), dtype[nm])
@@ -291,6 +374,13 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             else:
                 net.add_eltwise_i8(B * ho * ho * c, scales[l["a"]], scales[l["b"]], coeff, coeff, l["relu"], l["a"],
                                    l["b"], nm)
+        elif kd == "gpool" and l.get("int8"):
+            # INT8 global average pooling (framework_spec): s8 NHWC -> s8 [B,1,1,c], scale inherited
+            hin, c = shape[l["src"]]
+            shape[nm], dtype[nm] = (1, c), dtype[l["src"]]
+            scales[nm] = scales[l["src"]]
+            net.add_tensor(nm, (B, 1, 1, c), dtype[nm])
+            net.add_pool_i8(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]], dtype[nm], l["src"], nm)
         elif kd == "gpool":
             # FP32 pooling op fed an s8 NHWC edge: dequantise on entry (saber_pooling.cpp:399-402), then avg
             hin, c = shape[l["src"]]
@@ -308,7 +398,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             shape[nm], dtype[nm] = (1, c), F32
         elif kd == "fc":
             w, b = model["params"][nm]
-            fc = S.SaberFc(True).init(B, l["cout"], l["cin"], w, b, F32, scales[l["src"]])
+            fc = S.SaberFc(True).init(B, l["cout"], l["cin"], w, b, dtype.get(l["src"], F32), scales[l["src"]])
             net.add_tensor(nm, (B, l["cout"]), F32)
             if l["src"] in quantised:
                 net.add_fc_q(fc, quantised[l["src"]], nm)
@@ -464,7 +554,8 @@ def algorithmic_bytes_int8(model, batch, hw=224):
             wts += cin * l["cout"] * l["k"] ** 2
         elif l["kind"] == "pool":
             hin, c = sizes[l["src"]]
-            sizes[l["name"]] = (int(np.ceil((hin + 2 * l["pad"] - l["win"]) / l["stride"])) + 1, c)
+            rnd = np.floor if l.get("floor") else np.ceil
+            sizes[l["name"]] = (int(rnd((hin + 2 * l["pad"] - l["win"]) / l["stride"])) + 1, c)
         elif l["kind"] == "eltwise":
             sizes[l["name"]] = sizes[l["a"]]
         elif l["kind"] == "fc":

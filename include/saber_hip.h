@@ -246,6 +246,9 @@ int saber_hip_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, flo
                              float coeff_a, float coeff_b, int relu, int8_t* y, saber_hip_stream_t stream);
 int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, float coeff_a, float coeff_b,
                               int relu, float* y, saber_hip_stream_t stream);
+/* standalone ReLU op (framework/operators/relu.cpp -> Activation<T,D>, Active_relu; saber_activation.cpp:136-154):
+ * y = x > 0 ? x : 0 over `count` f32 elements; x == y (in place) is allowed */
+int saber_hip_relu_f32(size_t count, const float* x, float* y, saber_hip_stream_t stream);
 /* Pooling<>::compute_output_shape (pooling.h:69-130) */
 int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode);
 /* The same for one dimension of a pooling whose OTHER dimension may be padded: the reference clips the last window of

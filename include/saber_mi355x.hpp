@@ -304,7 +304,9 @@ public:
                     d.res_has_dtype = 1;
                     d.res_dtype = to_hip_dtype(cp.beta_type);
                 } else {
-                    if (cp.beta != 1.f) return SaberUnImplError;   // FP32: out = act(conv + bias + 1 * out)
+                    // FP32: out = act(conv + bias + 1 * out); the x86 impl adds the output whenever the eltwise is present
+                    // (saber_conv_1x1.cpp:42-46), ConvParam::beta is only meaningful for INT8
+                    if (ep.coeff.size() >= 2 && (ep.coeff[0] != 1.f || ep.coeff[1] != 1.f)) return SaberUnImplError;
                     d.sum_scale = 1.f;
                 }
             }

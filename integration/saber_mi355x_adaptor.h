@@ -125,7 +125,10 @@ public:
                 d.res_has_dtype = 1;
                 d.res_dtype = mi355x_dtype(cp.beta_type);   // the bytes in y may be s8 under a u8 output and vice versa
             } else {
-                if (cp.beta != 1.f) return SaberUnImplError;   // FP32: out = act(conv + bias + 1 * out)
+                // FP32: out = act(conv + bias + 1 * out). The x86 impl adds the output whenever the eltwise is present
+                // (saber_conv_1x1.cpp:42-46 `_add_output = 1.f`; saber_conv_eltwise.cpp:139-143 SaberEltwise with the
+                // eltwise's coefficients) — ConvParam::beta is only meaningful for INT8. Coefficients other than (1, 1): no.
+                if (ep.coeff.size() >= 2 && (ep.coeff[0] != 1.f || ep.coeff[1] != 1.f)) return SaberUnImplError;
                 d.sum_scale = 1.f;
             }
         }
@@ -152,6 +155,9 @@ public:
     virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs,
                                  std::vector<Tensor<TargetType>*>& outputs,
                                  ConvEltwiseParam<TargetType>& param) {
+        // BaseFunc::init ORs the impls' statuses into SaberSuccess (= -1, base.h:126-128), so a failed create() is not
+        // reported there: refuse here instead of running without an operator
+        if (!_op) return SaberNotInitialized;
         saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
         void* ws = saber_hip_conv2d_workspace_bytes(_op) ? _ws.mutable_data() : nullptr;
         return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), nullptr, ws, stream));
@@ -236,6 +242,7 @@ public:
     }
     virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
                                  ConvPoolingParam<TargetType>& param) {
+        if (!_op) return SaberNotInitialized;
         saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
         if (_fused)
             return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), nullptr, _ws, stream));
@@ -299,6 +306,7 @@ public:
     }
     virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs,
                                  std::vector<Tensor<TargetType>*>& outputs, FcParam<TargetType>& param) {
+        if (!_op) return SaberNotInitialized;
         saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
         return mi355x_status(saber_hip_fc_run(_op, inputs[0]->data(), (float*)outputs[0]->mutable_data(), _ws, stream));
     }
@@ -307,6 +315,167 @@ private:
     saber_hip_fc_t* _op;
     void* _ws;
     Tensor<TargetType> _wst;
+};
+
+// Pooling<MI355X, OpDtype> (saber/funcs/pooling.h:69-130; x86: saber_pooling.cpp:312-654).
+//   AK_INT8 op : s8/u8 NHWC in -> s8/u8 NHWC out, the output inherits the input's scale (SaberPooling<X86,AK_INT8>::init).
+//   AK_FLOAT op: f32 in (NCHW or NHWC) -> f32 out of the same layout; an 8-bit NHWC input is dequantised on entry and the
+//                result is f32 NCHW (saber_pooling.cpp:399-402).
+template <typename TargetType, DataType OpDtype>
+class SaberPoolingMI355X : public ImplBase<TargetType, OpDtype, PoolingParam<TargetType> > {
+public:
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                             PoolingParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        if (OpDtype == AK_INT8) outputs[0]->set_scale(inputs[0]->get_scale());
+        return create(inputs, outputs, param, ctx);
+    }
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                               PoolingParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        const DataType it = inputs[0]->get_dtype(), ot = outputs[0]->get_dtype();
+        const bool in8 = it == AK_INT8 || it == AK_UINT8, out8 = ot == AK_INT8 || ot == AK_UINT8;
+        if (OpDtype == AK_INT8) {
+            if (!in8 || !out8 || inputs[0]->get_layout() != Layout_NHWC || outputs[0]->get_layout() != Layout_NHWC)
+                return SaberUnImplError;
+        } else {
+            if (ot != AK_FLOAT) return SaberUnImplError;
+            if (in8 && inputs[0]->get_layout() != Layout_NHWC) return SaberUnImplError;
+            if (!in8 && (it != AK_FLOAT || inputs[0]->get_layout() != outputs[0]->get_layout())) return SaberUnImplError;
+        }
+        _type = param.pooling_type == Pooling_max ? SABER_HIP_POOL_MAX
+                : (param.pooling_type == Pooling_average_include_padding ? SABER_HIP_POOL_AVG_INCL
+                                                                         : SABER_HIP_POOL_AVG_EXCL);
+        return SaberSuccess;
+    }
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                                 PoolingParam<TargetType>& p) {
+        saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
+        Tensor<TargetType>* in = inputs[0];
+        Tensor<TargetType>* out = outputs[0];
+        const int n = in->num(), c = in->channel(), h = in->height(), w = in->width(), oh = out->height(), ow = out->width();
+        const DataType it = in->get_dtype();
+        if (OpDtype == AK_INT8)
+            return mi355x_status(saber_hip_pool2d_i8_nhwc(n, h, w, c, oh, ow, p.window_h, p.window_w, p.stride_h, p.stride_w,
+                                                          p.pad_h, p.pad_w, _type, mi355x_dtype(it),
+                                                          mi355x_dtype(out->get_dtype()), in->data(), out->mutable_data(),
+                                                          stream));
+        if (it == AK_INT8 || it == AK_UINT8)
+            return mi355x_status(saber_hip_pool2d_f32_from_i8(n, h, w, c, oh, ow, p.window_h, p.window_w, p.stride_h,
+                                                              p.stride_w, p.pad_h, p.pad_w, _type, mi355x_dtype(it),
+                                                              in->get_scale().size() ? in->get_scale()[0] : 1.f, in->data(),
+                                                              (float*)out->mutable_data(), stream));
+        return mi355x_status(saber_hip_pool2d_f32(n, h, w, c, oh, ow, p.window_h, p.window_w, p.stride_h, p.stride_w, p.pad_h,
+                                                  p.pad_w, _type, mi355x_layout(in->get_layout()), (const float*)in->data(),
+                                                  (float*)out->mutable_data(), stream));
+    }
+
+private:
+    int _type;
+};
+
+// Eltwise<MI355X, OpDtype> (saber/funcs/eltwise.h; x86: saber_eltwise.cpp:40-113): the two-input sum (+ relu) of a residual
+// block. AK_INT8: s8 NHWC inputs and output, `saturate(roundf(relu(c0*q0*s0 + c1*q1*s1)))` — the output scale is not
+// applied by the reference (saber_eltwise.cpp:85), callers fold it into the coefficients.
+template <typename TargetType, DataType OpDtype>
+class SaberEltwiseMI355X : public ImplBase<TargetType, OpDtype, EltwiseParam<TargetType> > {
+public:
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                             EltwiseParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        return create(inputs, outputs, param, ctx);
+    }
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                               EltwiseParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        if (param.operation != Eltwise_sum || inputs.size() != 2 || param.coeff.size() < 2) return SaberUnImplError;
+        const ActivationParam<TargetType>& ap = param.activation_param;
+        if (param.has_eltwise && ap.has_active && ap.active != Active_relu) return SaberUnImplError;
+        const DataType want = OpDtype == AK_INT8 ? AK_INT8 : AK_FLOAT;
+        for (size_t i = 0; i < inputs.size(); ++i) {
+            if (inputs[i]->get_dtype() != want) return SaberUnImplError;
+            if (OpDtype == AK_INT8 && (inputs[i]->get_layout() != Layout_NHWC || inputs[i]->get_scale().empty()))
+                return SaberUnImplError;
+            if (inputs[i]->get_layout() != inputs[0]->get_layout()) return SaberUnImplError;
+        }
+        if (outputs[0]->get_dtype() != want || outputs[0]->get_layout() != inputs[0]->get_layout()) return SaberUnImplError;
+        return SaberSuccess;
+    }
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                                 EltwiseParam<TargetType>& param) {
+        saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
+        const int relu = (param.has_eltwise && param.activation_param.has_active &&
+                          param.activation_param.active == Active_relu) ? 1 : 0;
+        const size_t count = (size_t)inputs[0]->valid_size();
+        if (OpDtype == AK_INT8)
+            return mi355x_status(saber_hip_eltwise_sum_i8(count, (const int8_t*)inputs[0]->data(),
+                                                          (const int8_t*)inputs[1]->data(), inputs[0]->get_scale()[0],
+                                                          inputs[1]->get_scale()[0], param.coeff[0], param.coeff[1], relu,
+                                                          (int8_t*)outputs[0]->mutable_data(), stream));
+        return mi355x_status(saber_hip_eltwise_sum_f32(count, (const float*)inputs[0]->data(), (const float*)inputs[1]->data(),
+                                                       param.coeff[0], param.coeff[1], relu,
+                                                       (float*)outputs[0]->mutable_data(), stream));
+    }
+};
+
+// Softmax<MI355X, AK_FLOAT> (saber/funcs/softmax.h; x86: saber_softmax.cpp) over `axis` when everything after it is 1
+// (the classifier head: [n, classes, 1, 1], axis 1)
+template <typename TargetType, DataType OpDtype>
+class SaberSoftmaxMI355X : public ImplBase<TargetType, OpDtype, SoftmaxParam<TargetType> > {
+public:
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                             SoftmaxParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        return create(inputs, outputs, param, ctx);
+    }
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                               SoftmaxParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        if (OpDtype != AK_FLOAT || inputs[0]->get_dtype() != AK_FLOAT || outputs[0]->get_dtype() != AK_FLOAT)
+            return SaberUnImplError;
+        _rows = inputs[0]->count_valid(0, param.axis);
+        _cols = inputs[0]->valid_shape()[param.axis];
+        if (inputs[0]->count_valid(param.axis + 1, inputs[0]->dims()) != 1) return SaberUnImplError;
+        return SaberSuccess;
+    }
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                                 SoftmaxParam<TargetType>& param) {
+        return mi355x_status(saber_hip_softmax_f32(_rows, _cols, (const float*)inputs[0]->data(),
+                                                   (float*)outputs[0]->mutable_data(),
+                                                   (saber_hip_stream_t)this->_ctx->get_compute_stream()));
+    }
+
+private:
+    int _rows, _cols;
+};
+
+// Activation<MI355X, AK_FLOAT>, Active_relu (the standalone ReLU operator, framework/operators/relu.cpp; x86:
+// saber_activation.cpp:136-154). Every other activation type: SaberUnImplError.
+template <typename TargetType, DataType OpDtype>
+class SaberActivationMI355X : public ImplBase<TargetType, OpDtype, ActivationParam<TargetType> > {
+public:
+    virtual SaberStatus init(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                             ActivationParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        return create(inputs, outputs, param, ctx);
+    }
+    virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                               ActivationParam<TargetType>& param, Context<TargetType>& ctx) {
+        this->_ctx = &ctx;
+        if (OpDtype != AK_FLOAT || param.active != Active_relu || param.negative_slope != 0.f) return SaberUnImplError;
+        if (inputs[0]->get_dtype() != AK_FLOAT || outputs[0]->get_dtype() != AK_FLOAT) return SaberUnImplError;
+        return SaberSuccess;
+    }
+    virtual SaberStatus dispatch(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
+                                 ActivationParam<TargetType>& param) {
+        saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
+        for (size_t i = 0; i < inputs.size(); ++i) {
+            int rc = saber_hip_relu_f32((size_t)inputs[i]->valid_size(), (const float*)inputs[i]->data(),
+                                        (float*)outputs[i]->mutable_data(), stream);
+            if (rc) return mi355x_status(rc);
+        }
+        return SaberSuccess;
+    }
 };
 
 // Gemm<MI355X, SABER_IMPL, float, float> (saber/funcs/gemm.h:27-66): raw row-major pointers

@@ -41,19 +41,25 @@ def run_int8(model, scales, x, keep=True, prep=None):
                 in_dt = S8
             else:
                 in_dt = dt[l["src"]]
-            odt = U8 if l["relu"] else S8
+            odt = l.get("odt", U8 if l["relu"] else S8)   # workloads.framework_spec: conv1's output follows its consumer
             ws, wq = prep[nm]
             bp, sc = O.conv_i8_prepare(ws, b, scales[l["src"]], scales[nm], in_dt, odt)
             t[nm] = O.conv_i8(src, wq, bp, sc, odt, l["relu"], (l["pad"],) * 2, (l["stride"],) * 2)
             dt[nm] = odt
         elif kd == "pool":
-            t[nm] = O.pool_i8_nhwc(t[l["src"]], (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"])
+            t[nm] = O.pool_i8_nhwc(t[l["src"]], (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"],
+                                   floor_mode=l.get("floor", False))
             dt[nm] = dt[l["src"]]
             scales[nm] = scales[l["src"]]
         elif kd == "eltwise":
             c = np.float32(1.0 / scales[nm])
             t[nm] = O.eltwise_i8(t[l["a"]], t[l["b"]], scales[l["a"]], scales[l["b"]], c, c, l["relu"])
             dt[nm] = S8
+        elif kd == "gpool" and l.get("int8"):
+            # INT8 global average pooling, s8 -> s8, the output inherits the input's scale (saber_pooling.cpp:571-582)
+            t[nm] = O.pool_i8_nhwc(t[l["src"]], None, None, None, 1, global_pool=True)
+            dt[nm] = dt[l["src"]]
+            scales[nm] = scales[l["src"]]
         elif kd == "gpool":
             deq = O.dequant_nhwc_to_nchw(t[l["src"]], scales[l["src"]])
             t[nm] = O.pool_f32_nchw(deq, None, None, None, 1, global_pool=True)
@@ -62,7 +68,8 @@ def run_int8(model, scales, x, keep=True, prep=None):
             w, b = model["params"][nm]
             ws, wq = prep[nm]
             xin = t[l["src"]].reshape(t[l["src"]].shape[0], -1)
-            xq = O.quant_flat_s8(xin, scales[l["src"]])
+            # f32 input: quantised on entry; s8 input: used as it is (vender_fc.cpp:254-262, mkl_packed_int8_gemm.cpp:52-57)
+            xq = xin if dt[l["src"]] == S8 else O.quant_flat_s8(xin, scales[l["src"]])
             t[nm] = O.fc_i8(xq, wq, ws, scales[l["src"]], b)
             dt[nm] = F32
         elif kd == "softmax":
@@ -80,7 +87,8 @@ def run_fp32(model, x):
             w, b = model["params"][nm]
             t[nm] = O.conv_f32_nchw(t[l["src"]], w, b, l["relu"], (l["pad"],) * 2, (l["stride"],) * 2)
         elif kd == "pool":
-            t[nm] = O.pool_f32_nchw(t[l["src"]], (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"])
+            t[nm] = O.pool_f32_nchw(t[l["src"]], (l["win"],) * 2, (l["stride"],) * 2, (l["pad"],) * 2, l["type"],
+                                    floor_mode=l.get("floor", False))
         elif kd == "eltwise":
             t[nm] = O.eltwise_f32(t[l["a"]], t[l["b"]], 1.0, 1.0, l["relu"])
         elif kd == "gpool":

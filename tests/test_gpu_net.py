@@ -1,0 +1,110 @@
+"""SURVEY §8 row f-4 on the GPU: the reference's OWN Graph -> Optimize() -> Net<MI355X>::init -> prediction() with the
+MI355X Saber target underneath (integration/test_net_mi355x.cpp, built by integration/build_mi355x_test.sh).
+
+For each network the binary builds the graph from ORIGINAL operators (Convolution + BatchNorm + Scale + ReLU, ...), lets the
+reference's optimiser fuse / stride-up / schedule / alias it, runs Net::prediction() and then the same executors once more
+op by op, dumping every output edge while it is fresh (the memory planner reuses the buffers). Checked here:
+  * INT8 ResNet50 @224: every edge and the logits BIT-IDENTICAL to the CPU oracle running workloads.framework_spec — the list
+    tests/test_net_oplist.py proves equal to the reference optimiser's; softmax within 1e-4 of its maximum;
+  * Net::prediction()'s own output (buffers aliased, no intermediate syncs) == the op-by-op pass;
+  * FP32 ResNet50 (Conv / ConvEltwise<MI355X,AK_FLOAT>, Pooling, Fc under BaseFunc) and VGG16 (ConvRelu, ReLU, 3 x Dense):
+    logits and every edge within 1e-4 (both criteria of tests/test_gpu_resnet.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "integration", "_build", "test_net_mi355x.bin")
+
+from anakin_amd import workloads as W          # noqa: E402
+from integration import net_model as NM        # noqa: E402
+from oracle import net_oracle as NO            # noqa: E402
+
+NP = {"s8": np.int8, "u8": np.uint8, "f32": np.float32}
+
+
+def run_net(tmp_path, name, precision, batch, iters=0):
+    assert os.path.exists(BIN), "integration/_build/test_net_mi355x.bin is missing: run __graft_entry__.build()"
+    model = W.build_model(name)
+    x = W.make_input(batch)
+    scales = W.calibrate(model, x) if precision == "int8" else {}
+    d = str(tmp_path)
+    mt, wb = NM.write_model(model, scales, batch, d, precision)
+    x.tofile(os.path.join(d, "input.bin"))
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    cmd = [BIN, mt, wb, os.path.join(d, "input.bin"), d] + ([str(iters)] if iters else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "net ok" in r.stdout
+    return model, x, scales, NM.parse_oplist(os.path.join(d, "oplist.txt")), d
+
+
+def load(d, op, j, edge):
+    a = np.fromfile(os.path.join(d, "step_%d_%d.bin" % (op["index"], j)), NP[edge["dtype"]])
+    return a.reshape(edge["shape"])
+
+
+def test_net_mi355x_resnet50_int8_every_edge_bit_exact(tmp_path):
+    batch = 2
+    model, x, scales, ops, d = run_net(tmp_path, "resnet50", "int8", batch, iters=50)
+    fm = W.framework_model(model, "int8")
+    ref = NO.run_int8(fm, dict(scales), x)
+    checked = 0
+    for o in ops:
+        if o["type"] in ("Input", "Output", "Split"):
+            continue
+        got, want = load(d, o, 0, o["outs"][0]), ref[o["name"]]
+        if o["type"] == "Softmax":
+            assert np.abs(got.reshape(batch, -1) - want.reshape(batch, -1)).max() <= 1e-4 * want.max()
+        else:
+            assert got.dtype == want.dtype, (o["name"], got.dtype, want.dtype)
+            assert np.array_equal(got.reshape(want.shape), want), o["name"]       # 8-bit edges and the f32 logits: exact
+        checked += 1
+    assert checked == 76
+    # the untouched Net::prediction() (all buffers aliased by the reference's memory planner) gives the same output
+    prob = np.fromfile(os.path.join(d, "out_prob_out.bin"), np.float32)
+    last = [o for o in ops if o["type"] == "Softmax"][0]
+    assert np.array_equal(prob, load(d, last, 0, last["outs"][0]).ravel())
+    t = open(os.path.join(d, "timing.txt")).read().split()
+    ms = float(t[t.index("ms_per_prediction") + 1])
+    print("Net<MI355X,INT8>::prediction, reference op list (76 compute ops), batch %d: %.4f ms" % (batch, ms))
+    assert 0 < ms < 50
+
+
+def _fp32_check(got, want, name):
+    want = want.reshape(got.shape)
+    dd = np.abs(got - want)
+    e_max = float(dd.max() / np.abs(want).max())
+    e_el = float((dd / (np.abs(want) + np.abs(want).mean())).max())
+    assert e_max <= 1e-4 and e_el <= 1e-4, (name, e_max, e_el)
+
+
+@pytest.mark.parametrize("name", ["resnet50", "vgg16"])
+def test_net_mi355x_fp32_every_edge(tmp_path, name):
+    """Net<MI355X, FP32>: NCHW f32 edges, Conv / ConvEltwise (in-place residual sum on the shortcut's buffer, the Gather node
+    behind it is a placeholder) / ConvRelu / Pooling / Dense / ReLU / Softmax <MI355X, AK_FLOAT> under the reference's BaseFunc."""
+    model, x, _, ops, d = run_net(tmp_path, name, "fp32", 1)
+    fm = W.framework_model(model, "fp32")
+    ref = NO.run_fp32(fm, x)
+    spec = {l["name"]: l for l in fm["spec"]}
+    checked = 0
+    for o in ops:
+        if o["type"] in ("Input", "Output", "Split", "Gather"):
+            continue
+        nm = o["name"]
+        if o["type"] == "ConvEltwise":            # the fused op carries the conv's name; its result is the eltwise's
+            nm = spec[nm]["eltwise"]
+        if o["type"] == "ReLU":                   # Dense + ReLU: the oracle's fc entry already holds the relu'd values
+            nm = nm[:-len("_relu")]
+        elif o["type"] == "Dense" and spec[nm].get("relu"):
+            continue                              # pre-activation value: not an oracle edge
+        _fp32_check(load(d, o, 0, o["outs"][0]), ref[nm], nm)
+        checked += 1
+    assert checked >= (56 if name == "resnet50" else 20), checked
+    prob = np.fromfile(os.path.join(d, "out_prob_out.bin"), np.float32)
+    _fp32_check(prob, ref["prob"], "prob (Net::prediction)")

@@ -1,0 +1,135 @@
+"""The op list of `anakin_amd.workloads.framework_spec` IS what the reference's own optimiser emits.
+
+`integration/_build/test_net_mi355x.bin` is the reference's framework — Graph / fusion pass / stride-up / schedulers /
+memory planner / Net, compiled unmodified against the MI355X target (integration/apply_mi355x_target.py) — driven with the
+network as ORIGINAL operators (Convolution + BatchNorm + Scale + ReLU ...). Here it runs `dry` on the malloc-backed mock HIP
+runtime (integration/mock_hip): Graph::Optimize() and Net<MI355X>::init() execute for real (they are host code), nothing
+is computed. The dumped op list — operator types after fusion, producers, and every edge's dtype / layout / shape / scale —
+must equal the Python list op for op; the GPU tier (tests/test_gpu_net.py) then checks the bytes.
+
+The binaries are built by integration/build_mi355x_test.sh where /root/reference exists and travel with the repo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from anakin_amd import workloads as W          # noqa: E402
+from integration import net_model as NM        # noqa: E402
+
+BIN = os.path.join(ROOT, "integration", "_build", "test_net_mi355x.bin")
+MOCK = os.path.join(ROOT, "integration", "_build", "libmock_hip.so")
+pytestmark = pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(MOCK)),
+                                reason="integration/_build not built (needs /root/reference at build time)")
+
+DT = {W.F32: "f32", W.S8: "s8", W.U8: "u8"}
+
+
+def dry_run(tmp_path, name, precision, batch=1):
+    model = W.build_model(name)
+    x = W.make_input(batch)
+    scales = W.calibrate(model, x) if precision == "int8" else {}
+    d = str(tmp_path)
+    mt, wb = NM.write_model(model, scales, batch, d, precision)
+    x.tofile(os.path.join(d, "input.bin"))
+    env = dict(os.environ, LD_PRELOAD=MOCK)
+    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "dry"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return model, scales, NM.parse_oplist(os.path.join(d, "oplist.txt"))
+
+
+def resolve_producers(ops):
+    """name of the COMPUTE op (or Input) behind every input of every op, looking through Split / Gather nodes."""
+    by = {o["name"]: o for o in ops}
+
+    def real(node):
+        o = by[node]
+        return real(o["ins"][0]["edge_bottom"]) if o["type"] == "Split" else node
+    for o in ops:
+        for e in o["ins"] + o["outs"]:
+            # edge name = <bottom>_<top>; node names contain '_' themselves, so match against the known nodes
+            cands = [n for n in by if e["edge"].startswith(n + "_") and e["edge"][len(n) + 1:] in by]
+            assert cands, e["edge"]
+            e["edge_bottom"] = max(cands, key=len)
+    return {o["name"]: [real(e["edge_bottom"]) for e in o["ins"]] for o in ops}
+
+
+def expected_type(l, raw):
+    if l["kind"] == "conv":
+        bn = l["name"] in raw
+        return {(True, True): "ConvBatchnormScaleRelu", (True, False): "ConvBatchnormScale", (False, True): "ConvRelu",
+                (False, False): "Convolution"}[(bn, bool(l["relu"]))]
+    return {"pool": "Pooling", "gpool": "Pooling", "eltwise": "EltwiseRelu", "fc": "Dense", "softmax": "Softmax"}[l["kind"]]
+
+
+def test_resnet50_int8_op_list_is_the_reference_optimisers(tmp_path):
+    model, scales, ops = dry_run(tmp_path, "resnet50", "int8")
+    prod = resolve_producers(ops)
+    compute = [o for o in ops if o["type"] not in ("Input", "Output", "Split")]
+    spec = W.framework_spec(model["spec"], "int8")
+    assert len(compute) == len(spec) == 76          # 53 conv + 16 eltwise + pool1 + 3 stride-up poolings + pool5 + fc + softmax
+    by = {o["name"]: o for o in compute}
+    assert sorted(by) == sorted(l["name"] for l in spec)          # name for name
+    # both orders are schedules of the same DAG: every op of the reference's order runs after its producers
+    pos = {o["name"]: i for i, o in enumerate(ops)}
+    shape, dt, sc = {"data": (224, 3)}, {"data": W.F32}, dict(scales)
+    for l in spec:
+        o = by[l["name"]]
+        assert o["type"] == expected_type(l, model["raw"]), l["name"]
+        srcs = [l[k] for k in ("src", "a", "b") if k in l]
+        assert sorted(prod[o["name"]]) == sorted(srcs), (l["name"], prod[o["name"]], srcs)
+        assert all(pos[s] < pos[o["name"]] for s in srcs)
+        out = o["outs"][0]
+        if l["kind"] == "conv":
+            hin, _ = shape[l["src"]]
+            ho = (hin + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+            shape[l["name"]], dt[l["name"]] = (ho, l["cout"]), l["odt"]
+            assert o["prec"] == ("uint8" if l["relu"] else "int8")      # auto_config_node_dtype
+        elif l["kind"] == "pool":
+            hin, c = shape[l["src"]]
+            rnd = np.floor if l.get("floor") else np.ceil
+            shape[l["name"]], dt[l["name"]] = (int(rnd((hin + 2 * l["pad"] - l["win"]) / l["stride"])) + 1, c), dt[l["src"]]
+            sc[l["name"]] = sc[l["src"]]
+        elif l["kind"] == "gpool":
+            assert l["int8"]
+            shape[l["name"]], dt[l["name"]] = (1, shape[l["src"]][1]), dt[l["src"]]
+            sc[l["name"]] = sc[l["src"]]
+        elif l["kind"] == "eltwise":
+            shape[l["name"]], dt[l["name"]] = shape[l["a"]], W.S8
+        elif l["kind"] in ("fc", "softmax"):
+            shape[l["name"]], dt[l["name"]] = (1, 1000), W.F32
+        hw, c = shape[l["name"]]
+        assert out["dtype"] == DT[dt[l["name"]]], (l["name"], out)
+        if dt[l["name"]] == W.F32:
+            assert out["layout"] == "nchw" and out["shape"] == [1, c, hw, hw], (l["name"], out)
+        else:
+            assert out["layout"] == "nhwc" and out["shape"] == [1, hw, hw, c], (l["name"], out)
+            if l["kind"] not in ("pool", "gpool"):    # a pooling's output scale is overwritten at init (inherits its input's)
+                assert abs(out["scale"] - sc[l["name"]]) <= 1e-6 * sc[l["name"]], (l["name"], out["scale"], sc[l["name"]])
+        for e, s in zip(o["ins"], srcs if l["kind"] != "eltwise" else [l["a"], l["b"]]):
+            if l["kind"] != "eltwise":
+                assert e["dtype"] == DT[dt[s]], (l["name"], e)
+    # the three stride-2 3x3 convolutions and their shortcut poolings (graph_strategy::apply_stride_up)
+    s2 = [l["name"] for l in spec if l["kind"] == "conv" and l["k"] == 3 and l["stride"] == 2]
+    assert s2 == ["res2c_branch2b", "res3d_branch2b", "res4f_branch2b"]
+    assert [l["name"] for l in spec if l.get("floor")] == ["res2b_outsplit_pool", "res3c_outsplit_pool", "res4e_outsplit_pool"]
+    # the memory planner aliases edge buffers (MemoryScheduler): far fewer distinct buffers than edges
+    ptrs = {e["ptr"] for o in compute for e in o["outs"]}
+    assert len(ptrs) <= 8, len(ptrs)
+
+
+def test_resnet50_fp32_and_vgg16_pass_the_reference_optimiser(tmp_path):
+    _, _, ops = dry_run(tmp_path / "r50", "resnet50", "fp32")
+    kinds = [o["type"] for o in ops]
+    # FP32: the conv+eltwise fusion scheduler is ON (graph.cpp:423-436): 16 ConvEltwise + their Gather placeholders
+    assert kinds.count("ConvEltwise") == 16 and kinds.count("Gather") == 16
+    assert kinds.count("ConvBatchnormScaleRelu") == 33 and kinds.count("ConvBatchnormScale") == 4
+    assert kinds.count("Pooling") == 5 and kinds.count("Dense") == 1 and kinds.count("Softmax") == 1
+    assert all(e["dtype"] == "f32" and e["layout"] == "nchw" for o in ops for e in o["outs"])
+    _, _, ops = dry_run(tmp_path / "vgg", "vgg16", "fp32")
+    kinds = [o["type"] for o in ops]
+    assert kinds.count("ConvRelu") == 13 and kinds.count("Pooling") == 5 and kinds.count("Dense") == 3
+    assert kinds.count("ReLU") == 2 and kinds.count("Softmax") == 1
