@@ -294,6 +294,13 @@ int saber_hip_conv2d_create(const saber_hip_conv_desc* desc, saber_hip_conv_t** 
             delete op;
             return fail(SABER_HIP_INVALID_VALUE, "RES_ELTWISE produces s8 (SaberEltwise<X86,AK_INT8>)");
         }
+        if (d.res_stride > 1) {
+            if (d.res_mode != SABER_HIP_RES_ELTWISE || op->algo == ALGO_DIRECT_I8 ||
+                (d.res_h - 1) / d.res_stride + 1 != oh || (d.res_w - 1) / d.res_stride + 1 != ow) {
+                delete op;
+                return fail(SABER_HIP_INVALID_VALUE, "res_stride: RES_ELTWISE on the implicit-GEMM path with (res_h - 1) / s + 1 == oh, (res_w - 1) / s + 1 == ow");
+            }
+        }
     } else {
         if (d.in_dtype != SABER_HIP_F32 || d.out_dtype != SABER_HIP_F32) {
             delete op;
@@ -605,6 +612,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.coeff_conv = d.coeff_conv; a.coeff_res = d.coeff_res;
     a.scale_conv = op->out_scale; a.scale_res = d.scale_res;
     if (op->pool2) { a.pool_oh = op->pool_oh; a.pool_ow = op->pool_ow; }
+    if (d.res_stride > 1) { a.res_sub = d.res_stride; a.res_H = d.res_h; a.res_W = d.res_w; }
     a.y2 = y2;
     a.K1 = op->pair_k1; a.K2 = op->pair_k2; a.relu2 = op->pair_relu2; a.out_dtype2 = op->pair_dtype2;
     if (!op->is_i8 && d.res_mode == SABER_HIP_RES_SUM_INPLACE) {
@@ -1359,7 +1367,7 @@ static bool chain_1x1(const saber_hip_conv* o) {
     return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.kh == 1 && d.kw == 1 &&
            d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && d.group == 1 && !o->pair_k2 &&
            !o->pool_fused && !o->pool2 && !o->pre_quant && !o->pre_pad && o->c_eff == d.c && d.act_negative_slope == 0.f &&
-           d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC;
+           d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC && d.res_stride <= 1;
 }
 static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::vector<uint8_t>& out) {
     const int K = o->d.k;
@@ -1888,6 +1896,42 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
                 ++removed;
                 break;
             }
+        }
+    }
+    // ---- 64: a shortcut's 1x1 / stride-s max pooling read by a fused eltwise epilogue only -> folded into that read ----
+    // (the pooling graph_strategy::apply_stride_up inserts, optimize_strategy.h:213-248: one element per window, so the op is
+    // a spatial subsampling; the conv then reads the pooling's SOURCE at (oy * s, ox * s): saber_hip_conv_desc::res_stride)
+    if (flags & 64) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (dead[i] || ops[i].kind != OP_POOL_I8) continue;
+            NetOp& q = ops[i];   // p[] = n,h,w,c,oh,ow,kh,kw,sh,sw,ph,pw,type,in_dtype,out_dtype
+            if (q.p[6] != 1 || q.p[7] != 1 || q.p[8] != q.p[9] || q.p[8] < 2 || q.p[10] || q.p[11] || q.p[12] != SABER_HIP_POOL_MAX ||
+                q.p[13] != SABER_HIP_S8 || q.p[14] != SABER_HIP_S8 || (q.p[1] - 1) / q.p[8] + 1 != q.p[4] ||
+                (q.p[2] - 1) / q.p[8] + 1 != q.p[5] || consumers(q.out) != 1)
+                continue;
+            int c = -1;
+            for (size_t j = i + 1; j < ops.size() && c < 0; ++j) {
+                if (dead[j]) continue;
+                if (ops[j].out == q.in || ops[j].out2 == q.in) break;            // the pooling's source is rewritten first
+                if (ops[j].in2 == q.out && ops[j].kind == OP_CONV && ops[j].conv && !ops[j].chain && !ops[j].chain3 &&
+                    ops[j].conv->d.res_mode == SABER_HIP_RES_ELTWISE && ops[j].conv->d.res_stride <= 1 && ops[j].lane == q.lane)
+                    c = (int)j;
+                else if (ops[j].in == q.out || ops[j].in2 == q.out) break;       // some other reader
+            }
+            if (c < 0) continue;
+            const saber_hip_conv* src = ops[c].conv;
+            if (src->oh != q.p[4] || src->ow != q.p[5] || src->d.k != q.p[3] || src->d.n != q.p[0]) continue;
+            saber_hip_conv_desc d = src->d;
+            d.res_stride = q.p[8]; d.res_h = q.p[1]; d.res_w = q.p[2];
+            saber_hip_conv* fused = nullptr;
+            if (clone_conv_i8(src, d, &fused) != SABER_HIP_OK) continue;       // (the direct fallback kernel cannot: keep the op)
+            net->owned.push_back(fused);
+            ops[c].conv = fused;
+            ops[c].in2 = q.in;
+            ops[c].name = std::string("conv:") + fused->algo_name + "+res/" + std::to_string(q.p[8]);
+            dead[i] = 1;
+            net->tensor_bytes[q.out] = 0;
+            ++removed;
         }
     }
     // ---- 4: conv + max pooling ----------------------------------------------------------------------------------
@@ -2428,6 +2472,8 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
 }
 // 1 when tensor `id` is the output edge of a 3x3 conv that currently runs inside a conv3x3 + chain launch (not written)
 int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id) {
+    if (id < 0 || id >= (int)net->tensor_bytes.size()) return 0;
+    if (net->tensor_bytes[id] == 0) return 1;      // the edge was removed by saber_hip_net_optimize (it has no storage)
     for (const NetOp& o : net->ops)
         if (o.chain3 && o.use_chain3 && o.out == id) return 1;
     return 0;

@@ -94,6 +94,22 @@ __device__ __forceinline__ void load_chan_params(const ConvKArgs& a, int kb, Cha
     }
 }
 
+// Pixel of the residual tensor that output pixel p adds (RES_ELTWISE): p itself, or — when the executor folded a
+// 1x1 / stride-s shortcut pooling into this read (ConvKArgs::res_sub) — pixel (n, oy * s, ox * s) of the pooling's source.
+__device__ __forceinline__ size_t residual_pixel(const ConvKArgs& a, int p) {
+    if (a.res_sub <= 1) return (size_t)p;
+    const int ohw = a.OH * a.OW;
+    int n = (int)((float)p * a.inv_ohw);            // exact p / ohw for p < 2^24 (one fix-up step), as fast_divmod
+    int sp = p - n * ohw;
+    if (sp < 0) { --n; sp += ohw; }
+    if (sp >= ohw) { ++n; sp -= ohw; }
+    int oy = (int)((float)sp * a.inv_ow);
+    int ox = sp - oy * a.OW;
+    if (ox < 0) { --oy; ox += a.OW; }
+    if (ox >= a.OW) { ++oy; ox -= a.OW; }
+    return ((size_t)n * a.res_H + (size_t)oy * a.res_sub) * a.res_W + (size_t)ox * a.res_sub;
+}
+
 template <int NV>
 __device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, const int (&acc)[NV], const ChanParams<NV>& cp,
                                             int p, int kb) {
@@ -108,12 +124,13 @@ __device__ __forceinline__ void epilogue_i8(const ConvKArgs& a, const int (&acc)
     if (a.epi == EPI_I8_CONV && a.res_mode != RES_NONE) {
         const void* src = a.res_mode == RES_ELTWISE ? a.res : (const void*)a.y;
         const int rdt = a.res_mode == RES_ELTWISE ? DT_S8 : a.res_dtype;
+        const size_t ro = a.res_mode == RES_ELTWISE ? residual_pixel(a, p) * a.K + kb : o;
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             if (kb + r >= a.K) { resv[r] = 0; continue; }
-            if (rdt == DT_F32) resv[r] = __float_as_int(((const float*)src)[o + r]);
-            else if (rdt == DT_U8) resv[r] = (int)((const uint8_t*)src)[o + r];
-            else resv[r] = (int)((const int8_t*)src)[o + r];
+            if (rdt == DT_F32) resv[r] = __float_as_int(((const float*)src)[ro + r]);
+            else if (rdt == DT_U8) resv[r] = (int)((const uint8_t*)src)[ro + r];
+            else resv[r] = (int)((const int8_t*)src)[ro + r];
         }
     }
 #pragma unroll
@@ -256,7 +273,7 @@ __device__ __forceinline__ float round_half_away(float t) {
 // NV residual bytes (the fused eltwise's second operand) of pixel p, channels kb..kb+NV-1: one vector load
 template <int NV>
 __device__ __forceinline__ void load_residual(const ConvKArgs& a, int p, int kb, unsigned (&rs)[NV / 4]) {
-    const uint8_t* src = (const uint8_t*)a.res + (size_t)p * a.K + kb;
+    const uint8_t* src = (const uint8_t*)a.res + residual_pixel(a, p) * a.K + kb;
     if constexpr (NV == 4) rs[0] = *(const unsigned*)src;
     else if constexpr (NV == 8) { const uint2 t = *(const uint2*)src; rs[0] = t.x; rs[1] = t.y; }
     else { const uint4 t = *(const uint4*)src; rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }

@@ -416,10 +416,61 @@ __global__ __launch_bounds__(256) void maxpool_i8_nhwc_vec16_kernel(int n, int h
         y[(((size_t)img * oh + oy) * ow + ox) * cg + g] = o;
     }
 }
+// INT8 global average pooling (the tail of the graph the reference's optimiser emits: pool5 as an AK_INT8 op, 7x7 -> 1x1):
+// a workgroup owns 128 channels of one image; 8 pixel groups x 32 channel quads sum their share of the h*w pixels in
+// int32 (exact, order independent), the partials meet in LDS and 32 lanes finish with the JIT kernel's arithmetic
+// ((float)sum * (1 / count), round to nearest even, saturate). All of a lane's loads are independent: the generic
+// kernel above walks the 49 pixels of a window serially in one lane (13.9 us at batch 8; this: one latency).
+__global__ __launch_bounds__(256) void gpool_i8_nhwc_kernel(int hw, int c, float idiv, int in_u8, int out_dtype,
+                                                            const uint8_t* __restrict__ x, void* __restrict__ y) {
+    __shared__ int part[8][32][4];
+    const int img = blockIdx.y, cq = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int ch = blockIdx.x * 128 + cq * 4;
+    int sum[4] = {0, 0, 0, 0};
+    if (ch < c) {
+        const uint8_t* base = x + (size_t)img * hw * c + ch;
+        for (int px = pg; px < hw; px += 8) {
+            const unsigned v = *(const unsigned*)(base + (size_t)px * c);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int b = (v >> (8 * t)) & 0xff;
+                sum[t] += in_u8 ? b : (int)(int8_t)b;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) part[pg][cq][t] = sum[t];
+    __syncthreads();
+    if (pg == 0 && ch < c) {
+        int q[4];
+        float f[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int tot = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += part[g][cq][t];
+            f[t] = __fmul_rn((float)tot, idiv);
+            q[t] = out_dtype == DT_U8 ? q_sat_u8(rintf(f[t])) : q_sat_s8(rintf(f[t]));
+        }
+        const size_t o = (size_t)img * c + ch;
+        if (out_dtype == DT_F32) {
+            *(float4*)((float*)y + o) = make_float4(f[0], f[1], f[2], f[3]);
+        } else {
+            *(unsigned*)((uint8_t*)y + o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) |
+                                            ((unsigned)(q[3] & 0xff) << 24);
+        }
+    }
+}
+
 hipError_t launch_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw,
                                  int ph, int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
                                  hipStream_t s) {
     if (type == 0 && out_dtype == DT_F32) return hipErrorInvalidValue;  // as the reference (pooling kernel :425)
+    if (type != 0 && oh == 1 && ow == 1 && kh == h && kw == w && ph == 0 && pw == 0 && (c & 3) == 0 && n <= 65535) {
+        hipLaunchKernelGGL(gpool_i8_nhwc_kernel, dim3((c + 127) / 128, n), dim3(256), 0, s, h * w, c,
+                           1.0f / (float)(kh * kw), in_dtype == DT_U8, out_dtype, (const uint8_t*)x, y);
+        return hipGetLastError();
+    }
     if (type == 0 && (c & 15) == 0 && in_dtype == out_dtype) {
         hipLaunchKernelGGL(maxpool_i8_nhwc_vec16_kernel, dim3(grid_for((size_t)n * oh * ow * (c >> 4))), dim3(256), 0, s,
                            n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, in_dtype == DT_U8, (const uint4*)x, (uint4*)y);

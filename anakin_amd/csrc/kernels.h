@@ -82,6 +82,10 @@ struct ConvKArgs {
     void* y2;
     int K1, K2, relu2, out_dtype2;
     int pool_oh, pool_ow;   // fused 3x3 / stride-2 max pooling (conv_stem_pool_kernel): pooled output dims
+    // RES_ELTWISE with a spatially subsampled residual: res is [N][res_H][res_W][K] and output pixel (n, oy, ox) adds
+    // res[n][oy * res_sub][ox * res_sub] - a 1x1 / stride-s max pooling (one element per window: the identity on it)
+    // folded into the read. res_sub <= 1: res is [M][K].
+    int res_sub, res_H, res_W;
 };
 
 // conv3x3_img_kernel takes the common block plus its slab geometry (kept out of ConvKArgs: every byte of kernel

@@ -52,7 +52,8 @@ class ConvDesc(C.Structure):
                  "group", "in_dtype", "out_dtype", "in_layout", "out_layout", "act", "res_mode", "res_act")] + \
                [("sum_scale", C.c_float), ("coeff_conv", C.c_float), ("coeff_res", C.c_float),
                 ("scale_res", C.c_float), ("int8_weights", C.c_int), ("act_negative_slope", C.c_float),
-                ("res_has_dtype", C.c_int), ("res_dtype", C.c_int)]
+                ("res_has_dtype", C.c_int), ("res_dtype", C.c_int), ("res_stride", C.c_int), ("res_h", C.c_int),
+                ("res_w", C.c_int)]
 
 
 class FcDesc(C.Structure):

@@ -51,6 +51,8 @@ class ConvParam:
         self.res_dtype = None        # RES_SUM_INPLACE: dtype of the bytes already in y (ConvParam.beta_type); None = out dtype
         self.coeff = (1.0, 1.0)
         self.scale_res = 1.0
+        self.res_stride = 0           # RES_ELTWISE: (stride, res_h, res_w) of a 1x1 / stride-s shortcut pooling folded into the
+        self.res_hw = (0, 0)          # residual read (saber_hip_conv_desc::res_stride)
 
 
 class SaberConv2D:
@@ -90,6 +92,8 @@ class SaberConv2D:
         d.coeff_conv, d.coeff_res = param.coeff
         d.scale_res = param.scale_res
         d.int8_weights = 1 if self.int8 else 0
+        if getattr(param, "res_stride", 0) > 1:
+            d.res_stride, (d.res_h, d.res_w) = int(param.res_stride), param.res_hw
         self.desc = d
         L.check(lib.saber_hip_conv2d_create(C.byref(d), C.byref(self.h)))
         w_np = np.ascontiguousarray(param.weight)

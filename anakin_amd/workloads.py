@@ -259,7 +259,7 @@ def _out_hw(h, k, s, p):
 
 
 def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
-                   cxx_optimize=False, chain=None):
+                   cxx_optimize=False, chain=None, absorb_pool=True):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
@@ -410,6 +410,8 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     if cxx_optimize:
         net.unfused_ops = net.num_ops()
         net.removed = net.optimize(15)
+    # a stride-up shortcut pooling (framework_spec) read only by a fused eltwise epilogue is folded into that read
+    net.absorbed = net.optimize(64) if (fuse_eltwise or cxx_optimize) and absorb_pool else 0
     net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0)) if chain else 0
     net.finalize()
     return net

@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet101", "vgg16"])
     ap.add_argument("--precision", default="int8", choices=["int8", "fp32"])
+    ap.add_argument("--graph", default="framework", choices=["framework", "caffe"],
+                    help="INT8: 'framework' = the op list the reference's own optimiser + edge rules emit (workloads.framework_spec: "
+                         "stride-up, conv1 -> s8, INT8 tail; what Net<MI355X> runs), 'caffe' = the round-1/2 list (plain Caffe topology)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-fuse", action="store_true", help="keep the 16 eltwise ops separate (reference op list)")
     ap.add_argument("--no-autotune", action="store_true")
@@ -129,6 +132,8 @@ def main():
 
     B = args.batch
     model = W.build_model(args.model)
+    if args.precision == "int8" and args.graph == "framework":
+        model = W.framework_model(model, "int8")
     x = W.make_input(B, seed=1234 + rank)
     scales = W.calibrate(model, W.make_input(2)) if args.precision == "int8" else {}
     net = build_net(W, model, scales, B, args)

@@ -100,6 +100,11 @@ typedef struct {
     int res_has_dtype;           /* RES_SUM_INPLACE INT8: 1 = res_dtype below is the dtype of the bytes already in y */
     int res_dtype;               /* ... ConvParam.beta_type (s8 or u8; may differ from out_dtype, same element size).
                                     res_has_dtype == 0: the bytes in y have out_dtype */
+    int res_stride;              /* RES_ELTWISE: > 1 = the residual tensor is [n, res_h, res_w, k] and output pixel (oy, ox) adds
+                                    res[oy * res_stride][ox * res_stride] — the 1x1 / stride-s max pooling that the reference's
+                                    graph_strategy::apply_stride_up puts on a shortcut (optimize_strategy.h:213-248; one element
+                                    per window, floor mode) folded into the epilogue's read. 0 / 1: res is [n, oh, ow, k] */
+    int res_h, res_w;            /* ... the pooling's input dims: (res_h - 1) / res_stride + 1 == oh, likewise res_w */
 } saber_hip_conv_desc;
 
 typedef struct saber_hip_conv saber_hip_conv_t;
@@ -317,12 +322,15 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * 16 a 1x1 conv with the fused eltwise epilogue + the 1x1 conv that reads its output -> one conv1x1-chain launch (both ops
  * stay in the list; while the chain is selected the second one launches nothing; saber_hip_net_autotune keeps whichever
  * form is faster); 32 (with 16) the block's 3x3 conv leads that chain launch when the chain head is its only consumer
- * (its output edge is then not written: saber_hip_net_tensor_unwritten); 63 = all. Bytes of every surviving edge are
+ * (its output edge is then not written: saber_hip_net_tensor_unwritten); 64 a 1x1 / stride-s max pooling (the shortcut
+ * pooling the reference's stride-up pass inserts) whose only reader is a fused eltwise epilogue -> folded into that read
+ * (saber_hip_conv_desc::res_stride; the pooled edge no longer exists); 127 = all. Bytes of every surviving edge are
  * unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 /* kernel launches of one forward pass (ops minus the ones absorbed into a chain launch) */
 int saber_hip_net_num_launches(const saber_hip_net_t* net);
-/* 1 when tensor `id` is the output edge of a 3x3 conv currently running inside a conv3x3 + chain launch (never written) */
+/* 1 when tensor `id` is never written: the output edge of a 3x3 conv currently running inside a conv3x3 + chain launch, or an
+ * edge saber_hip_net_optimize removed (a fused conv's own output, an absorbed pooling's output: it has no storage) */
 int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id);
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id);
 /* Lane of an op (graph::Lane, framework/core/net/operator_func.h:103-114; ParallScheduler): 0 = the caller's

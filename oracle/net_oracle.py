@@ -119,6 +119,7 @@ class RefNet:
         R.ref_net_eltwise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
         R.ref_net_maxpool.argtypes = [C.c_void_p] + [C.c_int] * 5
         R.ref_net_gpool_fc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float]
+        R.ref_net_avgpool_fc_s8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         R.ref_net_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         R.ref_net_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         R.ref_net_time_ms.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -140,7 +141,7 @@ class RefNet:
                 cin, hin = self.shape[l["src"]]
                 ho = (hin + 2 * l["pad"] - l["k"]) // l["stride"] + 1
                 w, b = model["params"][nm]
-                tensor(nm, l["cout"], ho, U8 if l["relu"] else S8, scales[nm])
+                tensor(nm, l["cout"], ho, l.get("odt", U8 if l["relu"] else S8), scales[nm])
                 w = np.ascontiguousarray(w, np.float32)
                 b = np.ascontiguousarray(b, np.float32)
                 self.keep += [w, b]
@@ -149,7 +150,7 @@ class RefNet:
                 assert rc == 0, (nm, rc)
             elif kd == "pool":
                 c, hin = self.shape[l["src"]]
-                ho = O.pool_out_dim(hin, l["pad"], l["win"], l["stride"])
+                ho = O.pool_out_dim(hin, l["pad"], l["win"], l["stride"], l.get("floor", False))
                 scales[nm] = scales[l["src"]]
                 tensor(nm, c, ho, self.dt[l["src"]], scales[nm])
                 assert l["type"] == 0
@@ -168,8 +169,14 @@ class RefNet:
                 self.keep += [w, b]
                 self.n_out = nxt["cout"]
                 self.ids[nxt["name"]] = R.ref_net_tensor(self.h, B, self.n_out, 1, 1, F32, 1.0)
-                rc = R.ref_net_gpool_fc(self.h, self.ids[l["src"]], self.ids[nxt["name"]], self.n_out, w.ctypes.data,
-                                        b.ctypes.data, float(scales[nm]))
+                if l.get("int8"):       # workloads.framework_spec: INT8 average pooling, the fc reads its s8 result
+                    c, _ = self.shape[l["src"]]
+                    tensor(nm, c, 1, S8, scales[l["src"]])
+                    rc = R.ref_net_avgpool_fc_s8(self.h, self.ids[l["src"]], self.ids[nm], self.ids[nxt["name"]], self.n_out,
+                                                 w.ctypes.data, b.ctypes.data)
+                else:
+                    rc = R.ref_net_gpool_fc(self.h, self.ids[l["src"]], self.ids[nxt["name"]], self.n_out, w.ctypes.data,
+                                            b.ctypes.data, float(scales[nm]))
                 assert rc == 0
                 self.out_name = nxt["name"]
             # fc handled with gpool; softmax is not part of the timed reference list (a 1000-element row)

@@ -379,7 +379,7 @@ int ref_gemm_s8s8s32(int trans_a, int trans_b, int m, int n, int k, const int8_t
 
 namespace {
 struct RefOp {
-    int kind;   // 0 conv, 1 eltwise, 2 maxpool, 3 gpool+fc
+    int kind;   // 0 conv, 1 eltwise, 2 maxpool, 3 gpool (f32) + fc, 4 INT8 global average pooling + fc on its s8 result
     int in = -1, in2 = -1, out = -1;
     // conv
     std::unique_ptr<GemmX8S8S32XConv> conv;
@@ -502,6 +502,39 @@ int ref_net_gpool_fc(void* h, int in_id, int out_id, int n, const float* w_nk, c
     return 0;
 }
 
+// The tail of the graph the reference's optimiser + edge rules produce (workloads.framework_spec): INT8 global average
+// pooling s8 NHWC [m, hh, ww, k] -> s8 [m, 1, 1, k] keeping the input's scale (SaberPooling<X86,AK_INT8>::init,
+// saber_pooling.cpp:571-582; the kernel is an xbyak JIT: restated here with its arithmetic — int32 window sum x (1/count),
+// round to nearest even, saturate; kernel/jit_avx512_core_8bit_pooling_kernel.cpp) and the INT8 fc on that s8 tensor.
+// VenderFc<X86,AK_INT8> routes an s8 input to PackedMKLInt8Gemm (vender_fc.cpp:254-262), whose dispatch has no
+// (s8 in, f32 out) branch — it ends in LOG(FATAL) "not support" (mkl_packed_int8_gemm.cpp:46-96): the reference cannot
+// run this edge combination although its own edge rules produce it. The contract pinned here is that operator's
+// (f32 in, f32 out) branch fed the DEQUANTISED tensor q * in_scale: its quantise-on-entry
+// (scale_fp32_int8: saturate(roundf(x * 1/in_scale))) returns exactly q for every s8 q, so the GEMM, the per-channel
+// scale and the bias add that follow are the reference's own code on the same integers.
+int ref_net_avgpool_fc_s8(void* h, int in_id, int pooled_id, int out_id, int n, const float* w_nk, const float* bias) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 4; op->in = in_id; op->in2 = pooled_id; op->out = out_id;
+    Shape s = net->t[in_id]->valid_shape();   // NHWC
+    const int m = s[0], k = s[3];
+    op->m = m; op->n = n; op->k = k;
+    const float in_scale = net->t[in_id]->get_scale()[0];
+    net->t[pooled_id]->set_scale({in_scale});
+    Tensor<X86> wt(Shape({1, 1, n, k}, Layout_NCHW), AK_FLOAT);
+    memcpy(wt.mutable_data(), w_nk, sizeof(float) * (size_t)n * k);
+    op->fc.reset(new PackedMKLInt8Gemm());
+    if (op->fc->init(false, true, m, n, k, wt, in_scale) != SaberSuccess) return -1;
+    op->pooled.reset(new Tensor<X86>(Shape({m, k, 1, 1}, Layout_NCHW), AK_FLOAT));
+    op->pooled->set_scale({in_scale});
+    if (bias) {
+        op->fb.reset(new Tensor<X86>(Shape({1, n, 1, 1}, Layout_NCHW), AK_FLOAT));
+        memcpy(op->fb->mutable_data(), bias, sizeof(float) * n);
+    }
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
 static int ref_net_forward(RefNet* net) {
     for (auto& up : net->ops) {
         RefOp* op = up.get();
@@ -547,6 +580,25 @@ static int ref_net_forward(RefNet* net) {
                             dst[(((size_t)n * OH + oy) * OW + ox) * Cc + c] = (uint8_t)best;
                         }
                     }
+        } else if (op->kind == 4) {
+            Tensor<X86>* ti = net->t[op->in].get();
+            Tensor<X86>* tp = net->t[op->in2].get();
+            Shape si = ti->valid_shape();
+            const int hw = si[1] * si[2], k = si[3];
+            const int8_t* src = (const int8_t*)ti->data();
+            int8_t* dst = (int8_t*)tp->mutable_data();
+            const float idiv = 1.0f / (float)hw;
+            for (int mi = 0; mi < op->m; ++mi)
+                for (int c = 0; c < k; ++c) {
+                    int32_t acc = 0;
+                    for (int j = 0; j < hw; ++j) acc += src[((size_t)mi * hw + j) * k + c];
+                    float f = nearbyintf((float)acc * idiv);
+                    dst[(size_t)mi * k + c] = (int8_t)(f > 127.f ? 127.f : (f < -128.f ? -128.f : f));
+                }
+            float* deq = (float*)op->pooled->mutable_data();
+            const float in_scale = tp->get_scale()[0];
+            for (int i = 0; i < op->m * k; ++i) deq[i] = (float)dst[i] * in_scale;
+            if (op->fc->dispatch(1.f, 0.f, op->m, *op->pooled, *net->t[op->out], op->fb.get()) != SaberSuccess) return 4;
         } else {
             reorder_nhwc_nchw(*net->t[op->in], *op->deq);
             const float* d = (const float*)op->deq->data();

@@ -1133,3 +1133,64 @@ def test_softmax_vs_oracle():
     got = host(S.softmax(dev(x)))
     want = O.softmax_f32(x)
     assert np.abs(got - want).max() <= FP32_RTOL * want.max() and np.allclose(got.sum(1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("geo", [(2, 56, 64, 256, 2), (3, 28, 128, 512, 2), (8, 14, 256, 1024, 2), (2, 15, 64, 128, 2), (1, 30, 32, 64, 3)])
+def test_conv_i8_fused_eltwise_with_subsampled_residual(geo):
+    """saber_hip_conv_desc::res_stride: the 1x1 / stride-s shortcut pooling of the reference's stride-up pass folded into
+    the fused eltwise epilogue's residual read == max-pooling the shortcut first (oracle: pool_i8 floor mode, then
+    conv(->s8) + SaberEltwise), every implicit-GEMM variant the op offers."""
+    n, ho, c, k, s = geo
+    rng = np.random.default_rng(5 + ho + c)
+    hs = ho * s - (1 if ho % 2 else 0)            # (hs - 1) // s + 1 == ho for both an exact and a ragged source size
+    x = rng.integers(0, 256, (n, ho, ho, c)).astype(np.uint8)
+    res_full = rng.integers(-128, 128, (n, hs, hs, k)).astype(np.int8)
+    w = (rng.standard_normal((k, c, 1, 1)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(k) * 0.2).astype(np.float32)
+    in_scale, conv_scale, res_scale, out_scale = 0.02, 0.11, 0.09, 0.13
+    coeff = 1.0 / out_scale
+    pooled = O.pool_i8_nhwc(res_full, (1, 1), (s, s), (0, 0), 0, floor_mode=True)
+    assert pooled.shape == (n, ho, ho, k)
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, conv_scale, O.U8, O.S8)
+    y = O.conv_i8(x, O.quant_weights(w, ws), bp, sc, O.S8, 0, (0, 0))
+    want = O.eltwise_i8(y, pooled, conv_scale, res_scale, coeff, coeff, True)
+    p = S.ConvParam(w, b, 1, (0, 0), (1, 1), (1, 1), False)
+    p.res_mode, p.res_relu, p.coeff, p.scale_res = L.RES_ELTWISE, True, (coeff, coeff), res_scale
+    p.res_stride, p.res_hw = s, (hs, hs)
+    conv = S.SaberConv2D(True).init((n, c, ho, ho), p, L.U8, L.S8, in_scale, conv_scale)
+    variants = [None] + [tile | (ks << 8) | (var << 16) for var, ks, tiles in
+                         ((1, 1, range(len(L.TILES))), (2, 1, range(len(L.TILES))), (3, 4, (0, 1, 2)), (4, 4, (0,))) for tile in tiles]
+    for t in variants:      # every implicit-GEMM tile / staging variant (register-staged, LDS-DMA ring, wave groups)
+        if t is not None:
+            conv.set_tile(t)
+        out = conv.new_output()
+        conv.dispatch(dev(x), out, res=dev(res_full))
+        assert np.array_equal(host(out), want), (geo, conv.algo())
+    # ragged channel counts take the generic epilogue
+    k2 = 72
+    w2, b2 = w[:k2], b[:k2]
+    ws2 = O.weight_scales(w2)
+    bp2, sc2 = O.conv_i8_prepare(ws2, b2, in_scale, conv_scale, O.U8, O.S8)
+    want2 = O.eltwise_i8(O.conv_i8(x, O.quant_weights(w2, ws2), bp2, sc2, O.S8, 0, (0, 0)), np.ascontiguousarray(pooled[..., :k2]),
+                         conv_scale, res_scale, coeff, coeff, True)
+    p2 = S.ConvParam(w2, b2, 1, (0, 0), (1, 1), (1, 1), False)
+    p2.res_mode, p2.res_relu, p2.coeff, p2.scale_res = L.RES_ELTWISE, True, (coeff, coeff), res_scale
+    p2.res_stride, p2.res_hw = s, (hs, hs)
+    conv2 = S.SaberConv2D(True).init((n, c, ho, ho), p2, L.U8, L.S8, in_scale, conv_scale)
+    out2 = conv2.new_output()
+    conv2.dispatch(dev(x), out2, res=dev(np.ascontiguousarray(res_full[..., :k2])))
+    assert np.array_equal(host(out2), want2), conv2.algo()
+
+
+@pytest.mark.parametrize("shape", [(8, 7, 7, 2048), (3, 14, 14, 200), (1, 5, 9, 132), (2, 7, 7, 64)])
+@pytest.mark.parametrize("dt", [O.S8, O.U8])
+def test_global_average_pooling_i8_kernel(shape, dt):
+    """The INT8 global average pooling of the graph's tail (gpool_i8_nhwc_kernel): s8 / u8 / f32 outputs, channel counts that
+    are not a multiple of its 128-channel workgroup."""
+    rng = np.random.default_rng(shape[1] * 7 + shape[3])
+    x = rng.integers(0, 256, shape).astype(np.uint8) if dt == O.U8 else rng.integers(-128, 128, shape).astype(np.int8)
+    for od in (None, L.F32):
+        got = host(S.pooling_i8(dev(x), None, None, None, 1, out_dtype=od, global_pooling=True))
+        want = O.pool_i8_nhwc(x, None, None, None, 1, out_dtype=None if od is None else O.F32, global_pool=True)
+        assert np.array_equal(got, want), (shape, dt, od)

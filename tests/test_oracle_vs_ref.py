@@ -254,3 +254,27 @@ def test_resnet50_int8_op_list_through_reference_objects():
     assert len(edges) >= 70
     for nm in edges:
         assert np.array_equal(rn.read(nm), ref[nm]), nm
+
+
+def test_resnet50_int8_FRAMEWORK_op_list_through_reference_objects():
+    """The same pin for the list the reference's own optimiser + edge rules emit (workloads.framework_spec, proved equal to
+    Graph::Optimize + Net::init by tests/test_net_oplist.py): three stride-2 3x3 convolutions with 1x1 / stride-2 max
+    poolings on their shortcuts (apply_stride_up), conv1 writing s8 (its consumer's dtype), INT8 global average pooling and
+    the fc on its s8 result — 76 operators through GemmX8S8S32XConv (incl. <int8_t,int8_t> with relu for conv1),
+    SaberEltwise<X86,AK_INT8> and PackedMKLInt8Gemm (s8 input): every edge and the logits equal the restated oracle's."""
+    from anakin_amd import workloads as W
+    from oracle import net_oracle as NO
+    model = W.framework_model(W.build_model("resnet50"), "int8")
+    assert len(model["spec"]) == 76
+    xs = W.make_input(1)
+    scales = {k: v * 1.25 for k, v in W.calibrate(model, W.make_input(2)).items()}
+    rn = NO.RefNet(model, scales, 1)
+    y = rn.run(xs)
+    ref = NO.run_int8(model, dict(scales), xs)
+    assert np.array_equal(y, ref["fc1000"].reshape(y.shape))
+    edges = [nm for nm in rn.shape if nm != "data" and nm in ref]
+    assert len(edges) >= 74
+    for nm in edges:
+        assert np.array_equal(rn.read(nm).reshape(ref[nm].shape), ref[nm]), nm
+    assert ref["conv1"].dtype == np.int8 and ref["conv1"].min() >= 0          # relu'd, stored as s8
+    assert ref["res2c"].shape == (1, 28, 28, 256)                              # stride-up: the block already runs at 28 x 28
