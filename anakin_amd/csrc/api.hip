@@ -1879,6 +1879,12 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
                 if (net->tensor_bytes[tc] != net->tensor_bytes[e.out] || e.count != net->tensor_bytes[tc]) continue;
                 const int pr = producer(tr, (int)i);
                 if (pr >= p) continue;   // the residual must exist when the conv runs (external tensors: pr == -1)
+                // the fused conv writes e.out at the CONV's position: no live op in (p, i) may read or write that tensor,
+                // and it must not alias the residual (in-place eltwise)
+                bool clash = e.out == tr;
+                for (int j = p + 1; j < (int)i && !clash; ++j)
+                    if (!dead[j]) clash = ops[j].in == e.out || ops[j].in2 == e.out || ops[j].out == e.out || ops[j].out2 == e.out;
+                if (clash) continue;
                 saber_hip_conv_desc d = src->d;
                 d.res_mode = SABER_HIP_RES_ELTWISE;
                 d.res_act = e.p[0] ? SABER_HIP_ACT_RELU : SABER_HIP_ACT_NONE;
@@ -1972,6 +1978,12 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
                 if (dead[j]) continue;
                 if (ops[j].out == ops[i].in || ops[j].out2 == ops[i].in) break;   // the shared input is rewritten: stop
                 if (!plain_i8_conv(ops[j]) || ops[j].in != ops[i].in) continue;
+                {   // op j's output is written at position i instead: nothing in [i, j) may touch that tensor
+                    bool clash = false;
+                    for (size_t m = i; m < j && !clash; ++m)
+                        if (!dead[m]) clash = ops[m].in == ops[j].out || ops[m].in2 == ops[j].out || ops[m].out == ops[j].out || ops[m].out2 == ops[j].out;
+                    if (clash) continue;
+                }
                 saber_hip_conv* pair = nullptr;
                 bool swapped = false;
                 if (saber_hip_conv2d_create_pair(ops[i].conv, ops[j].conv, &pair) != SABER_HIP_OK) {
@@ -2016,6 +2028,14 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
     for (size_t i = 0; i < ops.size(); ++i)
         if (!dead[i]) live.push_back(std::move(ops[i]));
     ops.swap(live);
+    // A chain launch reads and writes the tensors of SEVERAL ops (chain3_res / chain_out / chain3_y1 / chain3_y2), while the
+    // cross-lane event ordering of saber_hip_net_run only follows the launching op's own in / in2 / out / out2: in a
+    // two-lane net a chained launch could read a residual produced on the other lane before its event. The two executor
+    // options are therefore exclusive: no chains once any op sits on the side lane (and saber_hip_net_set_lane refuses
+    // a lane change once chains exist).
+    bool two_lanes = false;
+    for (const NetOp& o : ops) two_lanes |= o.lane != 0;
+    if (two_lanes) flags &= ~(16 | 32);
     // ---- 16: conv1x1 chains (on the compacted list: the pair must be adjacent) --------------------------------
     if (flags & 16) {
         for (size_t i = 0; i + 1 < ops.size(); ++i) {
@@ -2199,6 +2219,9 @@ int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
 int saber_hip_net_set_lane(saber_hip_net_t* net, int index, int lane) {
     if (index < 0 || index >= (int)net->ops.size() || lane < 0 || lane > 1) return fail(SABER_HIP_INVALID_VALUE, "bad op index / lane");
     if (net->lanes_ready) return fail(SABER_HIP_INVALID_VALUE, "lanes are fixed after the first run");
+    for (const NetOp& o : net->ops)
+        if (lane && (o.chain || o.chain3))
+            return fail(SABER_HIP_INVALID_VALUE, "the net has conv1x1 chain launches: lanes must be assigned before saber_hip_net_optimize (a chain launch spans several ops' tensors)");
     if (lane) {   // both lanes share the arena's single workspace: an op that uses it stays on the main lane
         const NetOp& o = net->ops[index];
         const size_t ws = o.kind == OP_CONV && o.conv ? o.conv->ws_bytes : (o.kind == OP_FC && o.fc ? saber_hip_fc_workspace_bytes(o.fc) : 0);
@@ -2230,6 +2253,86 @@ int saber_hip_net_capture(saber_hip_net_t* net, saber_hip_stream_t stream) {
 int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream) {
     if (!net->exec) return fail(SABER_HIP_INVALID_VALUE, "net not captured");
     HIP_TRY(hipGraphLaunch(net->exec, (hipStream_t)stream));
+    return SABER_HIP_OK;
+}
+// Algorithmic work of ONE launch of op `index` (every tensor touched once — input, output, residual — plus the
+// weights once; MACs x 2), summed over the operators the launch covers (a chain head reports its followers' work too, the
+// followers report 0). Streaming ops: bytes only.
+static void conv_work(const saber_hip_conv* c, double& bytes, double& flops) {
+    const saber_hip_conv_desc& d = c->d;
+    const double esz_in = d.in_dtype == SABER_HIP_F32 ? 4 : 1, esz_out = d.out_dtype == SABER_HIP_F32 ? 4 : 1;
+    const double esz_w = c->is_i8 ? 1 : 4;
+    const double in_el = (double)d.n * d.h * d.w * d.c;
+    const int oh = c->oh, ow = c->ow;
+    // a sibling pair carries k = k1 + k2 output channels; a fused pooling writes the pooled tensor
+    const double out_el = (double)d.n * ((c->pool_fused || c->pool2) ? c->pool_oh * c->pool_ow : oh * ow) * d.k;
+    bytes += in_el * esz_in + out_el * esz_out + (double)d.k * (d.c / d.group) * d.kh * d.kw * esz_w;
+    if (d.res_mode != SABER_HIP_RES_NONE) bytes += (double)d.n * oh * ow * d.k * esz_out;
+    flops += 2.0 * d.n * oh * ow * (double)d.k * (d.c / d.group) * d.kh * d.kw;
+}
+int saber_hip_net_op_work(const saber_hip_net_t* net, int index, double* bytes, double* flops) {
+    if (!net || index < 0 || index >= (int)net->ops.size() || !bytes || !flops) return fail(SABER_HIP_INVALID_VALUE, "bad argument");
+    *bytes = 0; *flops = 0;
+    const NetOp& o = net->ops[index];
+    auto tb = [&](int t) { return t >= 0 ? (double)net->tensor_bytes[t] : 0.0; };
+    switch (o.kind) {
+    case OP_CONV:
+        if (o.skip) return SABER_HIP_OK;
+        conv_work(o.conv, *bytes, *flops);
+        if (o.chain3 && o.use_chain3) {
+            for (int j = index + 1; j < (int)net->ops.size() && net->ops[j].skip; ++j) conv_work(net->ops[j].conv, *bytes, *flops);
+        } else if (o.chain && o.use_chain) {
+            if (index + 1 < (int)net->ops.size() && net->ops[index + 1].skip) conv_work(net->ops[index + 1].conv, *bytes, *flops);
+        }
+        return SABER_HIP_OK;
+    case OP_CONV_PAIR: conv_work(o.conv, *bytes, *flops); return SABER_HIP_OK;
+    case OP_FC:
+    case OP_FC_Q: {
+        const saber_hip_fc_desc& d = o.fc->d;
+        const double esz = d.int8_weights ? 1 : 4;
+        *bytes = (double)d.m * d.k * (o.kind == OP_FC_Q || d.in_dtype != SABER_HIP_F32 ? 1 : 4) + (double)d.m * d.n * 4 + (double)d.n * d.k * esz;
+        *flops = 2.0 * d.m * d.n * d.k;
+        return SABER_HIP_OK;
+    }
+    default: *bytes = tb(o.in) + tb(o.in2) + tb(o.out) + tb(o.out2); return SABER_HIP_OK;
+    }
+}
+// Per-op time INSIDE a forward pass: one event after every launch of an eager pass, averaged over `iters` passes
+// (out_us[i] = event[i] - event[i-1]; skipped ops report 0). Unlike saber_hip_net_time_ops (each op repeated back to back,
+// operands warm) this is the op in its place in the pipeline, boundary included; the events themselves add to the pass, so
+// use the SHARES and scale them to the untimed step time.
+int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {
+    if (!net || !net->finalized || iters <= 0 || !out_us) return fail(SABER_HIP_INVALID_VALUE, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = net->ops.size();
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters + 1; ++it) {      // the first pass warms up and is dropped
+        HIP_TRY(hipEventRecord(ev[0], s));
+        size_t last = 0;                          // index (into ev) of the newest recorded event
+        std::vector<size_t> prev(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const NetOp& o = net->ops[i];
+            int rc = net_launch(net, o, s);
+            if (rc) return rc;
+            prev[i] = last;
+            if (o.kind == OP_CONV && o.skip) continue;     // launches nothing: no event (a marker packet costs ~2.5 us itself)
+            HIP_TRY(hipEventRecord(ev[i + 1], s));
+            last = i + 1;
+        }
+        HIP_TRY(hipEventSynchronize(ev[last]));
+        if (!it) continue;
+        for (size_t i = 0; i < n; ++i) {
+            const NetOp& o = net->ops[i];
+            if (o.kind == OP_CONV && o.skip) continue;
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[prev[i]], ev[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) out_us[i] = (float)(acc[i] * 1000.0 / iters);
+    for (auto& e : ev) (void)hipEventDestroy(e);
     return SABER_HIP_OK;
 }
 int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {

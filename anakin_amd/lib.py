@@ -41,7 +41,7 @@ SYMBOLS = [
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
     "saber_hip_net_add_pool_f32_from_i8", "saber_hip_net_add_softmax", "saber_hip_net_set_lane", "saber_hip_net_finalize", "saber_hip_net_tensor_ptr",
     "saber_hip_net_arena_bytes", "saber_hip_net_num_ops", "saber_hip_net_run", "saber_hip_net_run_op",
-    "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_op_name",
+    "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_time_pass", "saber_hip_net_op_work", "saber_hip_net_op_name",
     "saber_hip_net_autotune", "saber_hip_net_destroy",
 ]
 
@@ -176,6 +176,8 @@ def load():
     lib.saber_hip_net_capture.argtypes = [P, P]
     lib.saber_hip_net_replay.argtypes = [P, P]
     lib.saber_hip_net_time_ops.argtypes = [P, P, I, P]
+    lib.saber_hip_net_time_pass.argtypes = [P, P, I, P]
+    lib.saber_hip_net_op_work.argtypes = [P, I, P, P]
     lib.saber_hip_net_op_name.argtypes = [P, I]
     lib.saber_hip_net_op_name.restype = C.c_char_p
     lib.saber_hip_net_autotune.argtypes = [P, P, I]

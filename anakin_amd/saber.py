@@ -645,6 +645,18 @@ class Net:
         L.check(L.load().saber_hip_net_time_ops(self.h, _stream(), iters, out))
         return list(out)
 
+    def time_pass(self, iters=20):
+        """Per-op microseconds INSIDE a forward pass (one event after every launch; saber_hip_net_time_pass)."""
+        out = (C.c_float * self.num_ops())()
+        L.check(L.load().saber_hip_net_time_pass(self.h, _stream(), iters, out))
+        return list(out)
+
+    def op_work(self, index):
+        """(algorithmic bytes, flops) of one launch of op `index` (saber_hip_net_op_work)."""
+        b, f = C.c_double(), C.c_double()
+        L.check(L.load().saber_hip_net_op_work(self.h, int(index), C.byref(b), C.byref(f)))
+        return b.value, f.value
+
     def arena_bytes(self):
         return L.load().saber_hip_net_arena_bytes(self.h)
 

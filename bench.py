@@ -1,16 +1,21 @@
 #!/usr/bin/env python
 """bench.py — ResNet50 INT8 inference throughput on MI355X through the C-ABI HIP Saber target.
 
-A "step" is ONE forward pass of the post-fusion ResNet50 INT8 op list (53 conv-like ops, 2 pools,
-16 residual adds fused bit-exactly into the branch2c epilogues, global pool, FC, softmax) over one
-batch of synthetic images already resident in HBM. Protocol mirrors the reference's (README.md:44,
-benchmark/CNN/run.sh): warm-up, then K timed iterations; images/s = batch * K / time.
+A "step" is ONE forward pass of the ResNet50 INT8 op list over one batch of synthetic images already resident in HBM.
+The list is the one the REFERENCE'S OWN optimiser and edge rules emit for the Caffe ResNet50 graph
+(anakin_amd.workloads.framework_spec, proved equal to Graph::Optimize + Net<MI355X>::init by tests/test_net_oplist.py:
+76 operators = 53 conv-like + 16 eltwise + 5 pooling + fc + softmax), re-fused by this executor into fewer launches with
+bit-identical results on every surviving edge (fused eltwise epilogues, sibling pairs, conv+pooling, conv1x1 chains, the
+stride-up shortcut poolings folded into a residual read). The unfused 76-op list is timed beside it
+(`reference_op_list`). Protocol mirrors the reference's (README.md:44, benchmark/CNN/run.sh): warm-up, then K timed
+iterations; images/s = batch * K / time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the batch is sharded as independent
-per-GPU sub-batches (weak scaling, no data-path collective) and the per-rank logits are
-all-gathered over RCCL each step (the only exchange the path has).
+N > 1: one rank per GPU under torch.distributed.run — started by the driver, or by this script itself when it is called
+plainly with --gpus N (it re-executes under torch.distributed.run on 127.0.0.1). The batch is sharded as independent
+per-GPU sub-batches (weak scaling, no data-path collective) and the per-rank logits are all-gathered over RCCL each step
+(the only exchange the path has).
 """
 import argparse
 import json
@@ -50,6 +55,8 @@ def parse():
                     help="run the shortcut projections on a side stream (measured SLOWER under hipGraph: 0.464 vs 0.371 ms)")
     ap.add_argument("--chain", type=int, default=None,
                     help="INT8 ResNet: 0 no conv1x1 chains, 1 chains, 2 (default) chains that may start with the block's 3x3 conv")
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="N > 1: all-gather the per-step logits once per this many steps (each step's logits are kept in a ring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -99,8 +106,22 @@ def pick_launch_mode(net, steps=60, gather=None, flush=None):
     return use_graph, {"graph_ms": round(t["graph"], 4), "eager_ms": round(t["eager"], 4)}
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` called plainly: become N ranks (torch.distributed.run, one node, 127.0.0.1)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)          # does not return
     import torch
     import torch.distributed as dist
     from anakin_amd import lib as L
@@ -125,6 +146,9 @@ def main():
         torch.cuda.set_device(0)
     L.require_device()   # no fallback: the HIP library and a gfx950 device are mandatory
     n_gpus = world
+    if n_gpus != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d "
+                         "(or call `python bench.py --gpus %d` plainly and let it spawn the ranks)" % (args.gpus, world, args.gpus, args.gpus))
 
     # all launches go to one non-default stream (graph capture/replay, event timing)
     stream = torch.cuda.Stream()
@@ -140,7 +164,9 @@ def main():
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     torch.cuda.synchronize()
-    cache_key = "%s_%s_b%d" % (args.model, args.precision, B)
+    # a cached selection is only valid for the sources and executor options it was tuned on
+    cache_key = "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_%s" % (args.model, args.precision, args.graph, B, int(not args.no_fuse),
+                                                           int(args.lanes), args.chain, L.source_sha())
     cache = {}
     if args.tune_cache and os.path.exists(args.tune_cache):
         cache = json.load(open(args.tune_cache))
@@ -159,14 +185,22 @@ def main():
 
     logits = net.tensor("prob")
     gather = gather_flush = None
-    if world > 1:
-        # the path's only exchange: the per-rank logits over RCCL, double-buffered and asynchronous (step i's
-        # all-gather runs on RCCL's stream while step i+1 computes; every gather completes inside the timed region)
-        ag = shard.AsyncLogitGather(logits, world)
+    gather_host_us = None
+    if world > 1 and os.environ.get("BENCH_NO_GATHER") != "1":   # (BENCH_NO_GATHER=1: diagnostic, isolates what the exchange costs)
+        # the path's only exchange: the per-rank logits over RCCL. Every step's logits go into a device ring (one small async
+        # copy per step); once per --gather-every steps the ring is all-gathered in one asynchronous collective that overlaps
+        # the following steps; every gather completes inside the timed region (gather_flush = finish)
+        ag = shard.BatchedLogitGather(logits, world, every=args.gather_every)
 
         def gather():
             ag.step(logits)
-        gather_flush = ag.flush
+        gather_flush = ag.finish
+        t_g = time.perf_counter()
+        for _ in range(50):
+            gather()
+        gather_host_us = (time.perf_counter() - t_g) * 1e6 / 50     # host time of one asynchronous gather call
+        gather_flush()
+        torch.cuda.synchronize()
 
     if use_graph:
         use_graph, launch_probe = pick_launch_mode(net, gather=gather, flush=gather_flush)
@@ -210,55 +244,73 @@ def main():
         lat = sorted(a.elapsed_time(b) for a, b in ev)
         p50, p99 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(len(lat) * 0.99))]
 
-        # ---------------- roofline of the dominant kernel family (implicit-GEMM conv) ---------------
-        op_us = net.time_ops(iters=20)          # hipEvents on the launch stream, per op, eager back-to-back
+        # ---------------- roofline: every kernel function of the pass, and the dominant one ---------------
+        # Per-op durations measured LIVE, in the pipeline: one hipEvent after every launch of an eager pass on the launch
+        # stream (saber_hip_net_time_pass, 30 passes); their shares are scaled to the step time of the timed region (the
+        # events lengthen a pass). Algorithmic bytes / ops per launch come from the executor itself
+        # (saber_hip_net_op_work: SURVEY §8d — input + output + residual activations once, weights once; 2 x MACs — summed
+        # over the operators a chain / pair launch covers). The rocprofv3 kernel trace of the same command sits in profiles/.
+        pass_us = net.time_pass(iters=30)
+        op_us = net.time_ops(iters=20)          # for reference: each op repeated back to back (operands warm)
         names = [net.op_name(i) for i in range(net.num_ops())]
-        conv_us = sum(t for t, n in zip(op_us, names) if n.startswith("conv:") or n.startswith("fc:"))
-        n_conv = sum(1 for n in names if (n.startswith("conv:") or n.startswith("fc:")) and "(in the chain launch)" not in n)
-        es = 1 if args.precision == "int8" else 4
-        alg_bytes = W.algorithmic_bytes_int8(model, B) * es
-        alg_ops = 2.0 * W.conv_macs(model["spec"]) * B
-        # Average launch duration of the conv/fc kernels IN THE TIMED REGION: the step time of the timed region (the number the
-        # driver can check against its own clock; it contains every kernel boundary) apportioned to the conv/fc launches by
-        # their share of the per-op hipEvent times. The isolated per-op sum itself is kept beside it: it re-runs one op 20
-        # times back to back (operands warm in L2 / Infinity Cache, short kernels bounded by the host's launch rate), so it
-        # is not the in-pipeline duration. A rocprofv3 kernel trace of the same command sits in profiles/ (traced runs are
-        # ~10 % slower: profiles/README.md has the reconciliation).
-        conv_share = conv_us / max(sum(op_us), 1e-9)
-        conv_region_us = ms_per_step * 1e3 * conv_share
-        achieved_gbs = alg_bytes / (conv_region_us * 1e-6) / 1e9
-        achieved_tops = alg_ops / (conv_region_us * 1e-6) / 1e12
+        scale_to_step = ms_per_step * 1e3 / max(sum(pass_us), 1e-9)
         peak_ops = MFMA_I8_PEAK_TOPS if args.precision == "int8" else MFMA_F32_PEAK_TFLOPS
-        t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), alg_ops / (peak_ops * 1e12)
-        bound = "hbm" if t_hbm >= t_mfma else "mfma"
-        if bound == "hbm":
-            roof = dict(bound="hbm", achieved=round(achieved_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved_gbs / HBM_PEAK_GBS, 4), traffic=None)
+        kern = {}
+        for i, (nm, t) in enumerate(zip(names, pass_us)):
+            if "(in the chain launch)" in nm:
+                continue
+            by, fl = net.op_work(i)
+            k = kern.setdefault(nm, dict(kernel=nm, launches=0, us=0.0, bytes=0.0, flops=0.0))
+            k["launches"] += 1
+            k["us"] += t * scale_to_step
+            k["bytes"] += by
+            k["flops"] += fl
+        per_kernel = []
+        for k in kern.values():
+            gbs = k["bytes"] / (k["us"] * 1e-6) / 1e9
+            tops = k["flops"] / (k["us"] * 1e-6) / 1e12
+            per_kernel.append(dict(kernel=k["kernel"], launches=k["launches"], avg_us=round(k["us"] / k["launches"], 3),
+                                   total_us=round(k["us"], 2), bytes_per_launch=int(k["bytes"] / k["launches"]),
+                                   gops_per_launch=round(k["flops"] / k["launches"] / 1e9, 4), gbs=round(gbs, 1),
+                                   hbm_frac=round(gbs / HBM_PEAK_GBS, 4), mfma_frac=round(tops / peak_ops, 4)))
+        per_kernel.sort(key=lambda r: -r["total_us"])
+        convs = [r for r in per_kernel if r["kernel"].startswith(("conv:", "fc:"))]
+        dom = convs[0]                           # the kernel function with the largest share of the step
+        conv_us_step = sum(r["total_us"] for r in convs)
+        alg_bytes = sum(r["bytes_per_launch"] * r["launches"] for r in convs)
+        alg_ops = sum(r["gops_per_launch"] * r["launches"] for r in convs) * 1e9
+        n_conv = sum(r["launches"] for r in convs)
+        t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = dom["gops_per_launch"] * 1e9 / (peak_ops * 1e12)
+        if t_hbm >= t_mfma:
+            roof = dict(bound="hbm", achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["hbm_frac"], traffic=None)
         else:
-            roof = dict(bound="mfma", achieved=round(achieved_tops, 2), peak=peak_ops, unit="TFLOP/s",
-                        frac=round(achieved_tops / peak_ops, 4), traffic=None)
-        # HBM traffic from the committed PMC passes (profiles/r02/traffic.json: per launch, FETCH_SIZE doubled per the gfx950
-        # correction) - only while the sources it was measured on are unchanged (src_sha) and the workload is the same;
-        # otherwise null: a stale counter is worse than none.
+            roof = dict(bound="mfma", achieved=round(dom["mfma_frac"] * peak_ops, 2), peak=peak_ops, unit="TFLOP/s",
+                        frac=dom["mfma_frac"], traffic=None)
+        # HBM traffic of that kernel from the committed PMC passes (profiles/r03/traffic.json: per launch, FETCH_SIZE doubled per
+        # the gfx950 correction) - only while the sources it was measured on are unchanged (src_sha): a stale counter is worse than none
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))
-            if tr.get("batch") == B and args.precision == "int8" and args.model == "resnet50" and tr.get("src_sha") == L.source_sha():
-                roof["traffic"] = tr["hbm_bytes_per_launch"]
-                roof["traffic_unit"] = "bytes per launch (algorithmic_bytes_per_launch is the figure to compare with)"
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic.json")))
+            if tr.get("batch") == B and tr.get("graph") == args.graph and args.precision == "int8" and args.model == "resnet50" \
+                    and tr.get("src_sha") == L.source_sha():
+                roof["traffic"] = tr.get("per_kernel", {}).get(dom["kernel"])
+                roof["traffic_all_conv"] = tr.get("hbm_bytes_per_forward")
                 roof["traffic_src_sha"] = tr["src_sha"]
         except (OSError, ValueError, KeyError):
             pass
-        roof.update(kernel="conv_igemm_kernel / conv_igemm_dma_kernel / conv1x1_chain_kernel / conv3x3_img_kernel / conv_stem_pool_kernel (all %d conv/fc launches of one forward)" % n_conv,
-                    launches=n_conv, avg_launch_us=round(conv_region_us / n_conv, 3),
-                    avg_launch_us_how="ms_per_step of the timed region x (conv/fc share of the per-op hipEvent times) / launches",
-                    per_op_event_sum_us=round(conv_us, 1), conv_share_of_step=round(conv_share, 4),
-                    algorithmic_bytes_per_launch=int(alg_bytes / n_conv),
+        all_gbs = alg_bytes / (conv_us_step * 1e-6) / 1e9
+        roof.update(kernel=dom["kernel"], launches=dom["launches"], avg_launch_us=dom["avg_us"],
+                    algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_gops_per_launch=dom["gops_per_launch"],
+                    how="dominant kernel function of the pass by total time; avg_launch_us = its share of an event-per-launch eager "
+                        "pass (saber_hip_net_time_pass, hipEvents on the launch stream) scaled to ms_per_step of the timed region",
+                    frac_all_conv=round(all_gbs / HBM_PEAK_GBS, 4), achieved_all_conv_gbs=round(all_gbs, 1),
+                    mfma_frac_all_conv=round(alg_ops / (conv_us_step * 1e-6) / 1e12 / peak_ops, 4),
+                    conv_fc_launches=n_conv, conv_fc_us_of_step=round(conv_us_step, 1),
                     algorithmic_bytes_per_forward=int(alg_bytes), algorithmic_ops_per_forward=int(alg_ops),
-                    mfma_frac=round(achieved_tops / peak_ops, 4), hbm_frac=round(achieved_gbs / HBM_PEAK_GBS, 4),
-                    sum_all_op_us=round(sum(op_us), 1))
+                    back_to_back_op_sum_us=round(sum(op_us), 1), per_kernel=per_kernel)
         if args.per_op:
-            for i, (n, t) in enumerate(zip(names, op_us)):   # execution order
-                print("%3d %8.2f us  %s" % (i, t, n), file=sys.stderr)
+            for i, (n, t, t2) in enumerate(zip(names, pass_us, op_us)):   # execution order: in-pass (scaled) | back-to-back
+                print("%3d %8.2f us %8.2f us  %s" % (i, t * scale_to_step, t2, n), file=sys.stderr)
 
         # ---------------- batch-1 latency leg (the metric quotes p50 @ batch 1 and 8) ---------------
         b1 = None
@@ -325,6 +377,75 @@ def main():
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
                 multi = {"error": "%s: %s" % (type(e).__name__, e)}
 
+        # ---------------- the reference op list, unfused: what an unchanged Net dispatches (76 operators) ---------------
+        # (a) the same C++ executor on the list with ONE op per reference operator (no executor-level fusion at all);
+        # (b) when the integration binary is present: the reference's own Net<MI355X>::prediction() loop on the same network
+        #     (integration/test_net_mi355x.cpp: Graph(AddOp) -> Optimize() -> Net::init -> prediction, hipEvents through
+        #     SaberTimer<MI355X>) - the reference's executor is host-bound at these kernel durations (BaseFunc::operator()
+        #     re-checks shapes and records an event per output edge), that time is ITS cost, not the kernels'.
+        ref_list = None
+        if not args.no_b1 and world == 1 and args.precision == "int8" and args.graph == "framework":
+            try:
+                rn = W.build_int8_net(model, dict(scales), B, fuse_eltwise=False, chain=0, pair_siblings=False, fuse_tail=False,
+                                      fuse_pool=False)
+                rn.tensor("data").copy_(torch.from_numpy(x).cuda())
+                rn.run()
+                if not args.no_autotune:
+                    rn.autotune(iters=10)
+                rn.capture()
+                g_ref, probe_ref = pick_launch_mode(rn, steps=40)
+                timed_steps(rn, 10, g_ref)
+                t0 = time.perf_counter()
+                timed_steps(rn, 200, g_ref)
+                ms_ref = (time.perf_counter() - t0) * 1e3 / 200
+                ref_list = dict(ops=rn.num_ops(), launches=rn.num_launches(), ms_per_step=round(ms_ref, 4),
+                                images_per_s=round(B * 1000.0 / ms_ref, 1), hip_graph=g_ref,
+                                what="workloads.framework_spec one op per reference operator (the list Graph::Optimize + "
+                                     "Net<MI355X>::init produce, tests/test_net_oplist.py), through saber_hip_net_run")
+                del rn
+                exe = os.path.join(ROOT, "integration", "_build", "test_net_mi355x.bin")
+                if os.path.exists(exe) and args.model == "resnet50":
+                    import subprocess
+                    import tempfile
+                    from integration import net_model as NM
+                    with tempfile.TemporaryDirectory() as td:
+                        base = W.build_model(args.model)
+                        mt, wb = NM.write_model(base, dict(scales), B, td, "int8")
+                        x.tofile(os.path.join(td, "input.bin"))
+                        r = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, "200"], capture_output=True,
+                                           text=True, timeout=300)
+                        if r.returncode == 0:
+                            tt = open(os.path.join(td, "timing.txt")).read().split()
+                            ref_list["net_prediction"] = dict(
+                                ms_per_step=round(float(tt[tt.index("ms_per_prediction") + 1]), 4), exec_funcs=int(tt[1]),
+                                what="the reference's own Net<MI355X, INT8>::prediction() (framework/core/net/net.cpp:417-509) "
+                                     "on the graph its optimiser produced, MI355X Saber target underneath")
+            except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
+                ref_list = {"error": "%s: %s" % (type(e).__name__, e)}
+
+        # ---------------- Gemm<MI355X, float, float> (saber_hip_gemm_f32), timed once: SURVEY §8 row a-8 ---------------
+        gemm = None
+        if not args.no_b1 and world == 1:
+            try:
+                from anakin_amd import saber as S
+                gm = gn = gk = 2048
+                ga = torch.randn(gm, gk, device="cuda")
+                gb = torch.randn(gk, gn, device="cuda")
+                gc = torch.empty(gm, gn, device="cuda")
+                for _ in range(3):
+                    S.gemm(False, False, gm, gn, gk, 1.0, ga, gb, 0.0, gc)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    S.gemm(False, False, gm, gn, gk, 1.0, ga, gb, 0.0, gc)
+                e1.record()
+                torch.cuda.synchronize()
+                g_us = e0.elapsed_time(e1) * 1e3 / 20
+                gemm = dict(m=gm, n=gn, k=gk, us=round(g_us, 2), tflops=round(2.0 * gm * gn * gk / (g_us * 1e-6) / 1e12, 2),
+                            mfma_f32_frac=round(2.0 * gm * gn * gk / (g_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
+            except Exception as e:   # noqa: BLE001
+                gemm = {"error": "%s: %s" % (type(e).__name__, e)}
+
         # ---------------- CPU baseline on this host, bounded sample, rank 0 only -----------------------------
         # "reference": the ResNet50 INT8 op list through the REFERENCE'S OWN x86 objects compiled into oracle/_ref
         # (GemmX8S8S32XConv + MKL cblas_gemm_s8u8s32, SaberEltwise, PackedMKLInt8Gemm; oracle/net_oracle.RefNet), batch 1,
@@ -367,12 +488,15 @@ def main():
                         NO.ref_set_threads(min(8, ncpu))
                     cpu = dict(value=round(1000.0 / ms8, 3), unit="images/s", cores=min(8, ncpu), kind="reference",
                                ms_per_image=round(ms8, 3),
-                               sample="ResNet50 INT8 batch 1, 224x224, unfused reference op list (53 conv + 16 eltwise + pool + "
-                                      "gpool + fc), %d timed forwards after 10 warm-up, through the reference's own x86 Saber "
+                               sample="ResNet50 INT8 batch 1, 224x224, unfused reference op list (%s), %d timed forwards "
+                                      "after 10 warm-up, through the reference's own x86 Saber "
                                       "objects compiled unmodified into oracle/_ref (GemmX8S8S32XConv + MKL cblas_gemm_s8u8s32, "
                                       "SaberEltwise, PackedMKLInt8Gemm), MKL/OpenMP threads = %d of %d host cores; this is the "
                                       "reference's GEMM path - its JIT-VNNI path needs xbyak and is not buildable here "
-                                      "(README.md:92 quotes 3.21 ms/image for it on 8 Xeon-6271 threads)" % (iters, min(8, ncpu), ncpu),
+                                      "(README.md:92 quotes 3.21 ms/image for it on 8 Xeon-6271 threads)" % (
+                                   "the 76 operators the reference's optimiser emits: 53 conv + 16 eltwise + 5 pooling + fc"
+                                   if args.graph == "framework" else "Caffe topology: 53 conv + 16 eltwise + pool + gpool + fc",
+                                   iters, min(8, ncpu), ncpu),
                                more_threads={"cores": more, "images_per_s": more_ips},
                                port={"kind": "port", "what": "oracle/saber_oracle.c (plain-C restatement, OpenMP)",
                                      "images_per_s_by_cores": port})
@@ -399,14 +523,27 @@ def main():
             "dtype_detail": "s8/u8 x s8 -> s32 (MFMA i8), f32 requantisation epilogue" if args.precision == "int8"
             else "f32 (v_mfma_f32_16x16x4_f32)",
             "data": "synthetic (seeded uniform images, He-init weights with folded BN, MAXABS scales)",
-            "config": {"workload": "%s %s post-fusion op list, batch %d per GPU, 224x224" %
-                                   (args.model, args.precision, B),
+            "config": {"workload": "%s %s, batch %d per GPU, 224x224: %s" %
+                                   (args.model, args.precision, B,
+                                    "the op list the reference's own optimiser emits (76 operators), re-fused by the executor"
+                                    if (args.precision == "int8" and args.graph == "framework") else "post-fusion op list (Caffe topology)"),
+                       "graph": args.graph if args.precision == "int8" else "caffe",
                        "global_batch": B * n_gpus, "ops": net.num_ops(), "launches": net.num_launches(), "hip_graph": use_graph,
                        "launch_probe": launch_probe,
-                       "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus},
+                       "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus,
+                       "rccl_ranks": world if world > 1 else 0,
+                       "gather": None if (world == 1 or gather is None) else {"every_steps": args.gather_every, "backend": dist.get_backend(),
+                                                          "host_us_per_step": round(gather_host_us, 1),
+                                                          "what": "every step's logits -> device ring (async copy); one asynchronous "
+                                                                  "all-gather of the ring per every_steps steps, all inside the timed region"}},
+            "parity_scope": "every edge bit-exact vs the CPU oracle at batch 2 (tests/test_gpu_resnet.py, test_gpu_net.py through the "
+                            "reference's Net); batch 8 by batch invariance (image i of a batch-8 run == the same image alone) + the "
+                            "oracle's logits for the images it ran",
             "latency_ms": {"batch": B, "p50": round(p50, 4), "p99": round(p99, 4)},
             "batch1": b1,
+            "reference_op_list": ref_list,
             "multi_stream": multi,
+            "gemm_f32": gemm,
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -352,6 +352,13 @@ int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream);
 /* Per-op device time in microseconds measured with hipEvents on `stream` (iters launches each,
  * eager). out_us has saber_hip_net_num_ops() entries. */
 int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us);
+/* The same inside a forward pass: one event after every launch of an eager pass, out_us[i] = event[i] - event[i-1] averaged
+ * over `iters` passes (the op in its place in the pipeline, kernel boundary included; ops absorbed into a chain launch: 0).
+ * The events lengthen the pass: use the shares, scaled to an untimed step. */
+int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us);
+/* Algorithmic work of one launch of op `index` (input + output + residual activations once, weights once;
+ * 2 x MACs), summed over the operators the launch covers (chain / pair launches). */
+int saber_hip_net_op_work(const saber_hip_net_t* net, int index, double* bytes, double* flops);
 const char* saber_hip_net_op_name(const saber_hip_net_t* net, int index);
 /* RUNTIME strategy over every conv/fc op of the list (on whatever the edge tensors currently hold). */
 /* Kernel selection of op `index` in the saber_hip_conv2d_get_tile / set_tile encoding (0: the op has none). set applies a

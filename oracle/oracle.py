@@ -448,6 +448,21 @@ def ref_conv_basic_check_int8(x, wq, bias_i32, scale, relu, pad=(0, 0), stride=(
     return out
 
 
+def ref_conv_basic_check_int8_sum(x, wq, scale, relu, prev, sum_scale, pad=(0, 0), stride=(1, 1)):
+    """conv_basic_check_int8 with its Eltwise_sum post-op: `prev` (s8 NHWC, the bytes already in the output) is summed in."""
+    x = np.ascontiguousarray(x)
+    wq = np.ascontiguousarray(wq, np.int8)
+    N, H, W, Cc = x.shape
+    K, _, kh, kw = wq.shape
+    out = np.ascontiguousarray(prev, np.int8).copy()
+    scale = np.ascontiguousarray(scale, np.float32)
+    ref().ref_conv_basic_check_int8_sum.argtypes = [C.c_int] * 15 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                                     C.c_float, C.c_void_p]
+    ref().ref_conv_basic_check_int8_sum(N, H, W, Cc, K, kh, kw, pad[0], pad[1], stride[0], stride[1], 1, 1, 1, code_of(x),
+                                        _ptr(x), _ptr(wq), None, int(relu), _ptr(scale), float(sum_scale), _ptr(out))
+    return out
+
+
 def ref_pool_basic_check_int8(x, oh, ow, win, stride, pad, ptype):
     x = np.ascontiguousarray(x)
     N, H, W, Cc = x.shape

@@ -262,6 +262,26 @@ int ref_conv_basic_check_int8(int N, int H, int W, int C, int K, int kh, int kw,
     return 0;
 }
 
+// The same helper with its Eltwise_sum post-op (conv_func_helper.h:127-130,172-174): `out` arrives holding the bytes to add
+// (the residual branch's output: the op sums in place) and leaves holding saturate(rne(relu(acc * scale + prev * sum_scale))).
+int ref_conv_basic_check_int8_sum(int N, int H, int W, int C, int K, int kh, int kw, int pad_h, int pad_w,
+                                  int stride_h, int stride_w, int dil_h, int dil_w, int group,
+                                  int in_dtype, const void* x, const int8_t* w, const int* bias,
+                                  int with_relu, const float* scale, float sum_scale, int8_t* out) {
+    int OH = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+    int OW = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+    Tensor<X86> tin(Shape({N, H, W, C}, Layout_NHWC), to_dtype(in_dtype));
+    Tensor<X86> tout(Shape({N, OH, OW, K}, Layout_NHWC), AK_INT8);
+    memcpy(tin.mutable_data(), x, (size_t)N * H * W * C);
+    memcpy(tout.mutable_data(), out, (size_t)N * OH * OW * K);
+    std::vector<float> sc(scale, scale + K);
+    EltwiseParam<X86> ep(Eltwise_sum, {1.f, sum_scale});
+    conv_basic_check_int8<X86>(tin, tout, (const char*)w, bias, group, kw, kh, stride_w, stride_h,
+                               dil_w, dil_h, pad_w, pad_h, bias != nullptr, with_relu != 0, sc, &ep);
+    memcpy(out, tout.data(), (size_t)N * OH * OW * K);
+    return 0;
+}
+
 // pooling_type: 0 max, 1 avg include padding, 2 avg exclude padding
 int ref_pool_basic_check_int8(int N, int H, int W, int C, int OH, int OW, int kh, int kw, int stride_h,
                               int stride_w, int pad_h, int pad_w, int pooling_type, int dtype,

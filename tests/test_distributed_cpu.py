@@ -53,10 +53,24 @@ def _worker(rank, world, port, global_batch, ret):
             seen.append(ag.latest().numpy().copy())
     ag.flush()
     seen.append(ag.latest().numpy().copy())
+    # the bench's batched gather: 7 steps with every=3 -> two full rings + a remainder of one, every step's logits arrive
+    bg = shard.BatchedLogitGather(local, world, every=3)
+    got = []
+    for step in range(7):
+        bg.step(local + 10 * step)
+        if bg.pending is None and bg.gathers and bg.i % 3 == 0:
+            pass
+        if bg.i % 3 == 0:
+            bg.flush()
+            got.append(bg.latest().numpy().copy())
+    bg.finish()
+    got.append(bg.latest().numpy().copy())
     if rank == 0:
         ret["logits"] = full.numpy().copy()
         ret["t"] = t
         ret["async"] = seen
+        ret["batched"] = got
+        ret["gathers"] = bg.gathers
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,3 +92,11 @@ def test_two_rank_gloo_matches_single_process():
     assert np.array_equal(ret["logits"], want)     # batch sharding changes nothing, bit for bit
     assert ret["t"] == 1.5                          # max over ranks
     assert len(ret["async"]) == 3 and all(np.array_equal(a, want + i) for i, a in enumerate(ret["async"]))
+    # batched gather: [world, count, local batch, classes]; step k's logits of rank r sit at [r, k % 3]
+    assert ret["gathers"] == 3 and [g.shape[1] for g in ret["batched"]] == [3, 3, 1]
+    half = gb // world
+    for gi, g in enumerate(ret["batched"]):
+        for k in range(g.shape[1]):
+            step = gi * 3 + k
+            assert np.array_equal(np.concatenate([g[r, k] for r in range(world)], 0), want + 10 * step), (gi, k)
+    assert half * world == gb

@@ -27,3 +27,40 @@ def test_bench_two_ranks_share_one_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
     assert out["value"] > 0 and abs(out["value"] - 16 * 1000.0 / out["ms_per_step"]) < 0.02 * out["value"]
     assert out["config"]["parallelism"] == "batch-shard x2"
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_spawns_its_own_ranks_and_the_gather_is_cheap():
+    """`python bench.py --gpus 2` called PLAINLY (no torchrun): the script re-executes itself under torch.distributed.run,
+    shards the batch over two ranks (here sharing the one GPU of the test box, logits through gloo), asserts n_gpus == --gpus
+    and prints one line. What the exchange costs is isolated by running the same two ranks once more WITHOUT it
+    (BENCH_NO_GATHER=1): two PROCESSES time-slicing one GPU are slow for reasons that have nothing to do with the path (no
+    concurrent contexts), so the criterion is gather-on <= 1.15 x gather-off, and the host time of one gather call is reported."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "60", "--warmup", "5", "--no-cpu-baseline", "--no-b1"]
+
+    def run(extra_env, gpus):
+        e = dict(env, **extra_env)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + (["--gpus", str(gpus)] if gpus > 1 else []) + common,
+                           capture_output=True, text=True, env=e, cwd=ROOT, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+    o1 = run({}, 1)
+    share = dict(BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    o2 = run(share, 2)
+    o2n = run(dict(share, BENCH_NO_GATHER="1"), 2)
+    assert o2["n_gpus"] == 2 and o2["config"]["rccl_ranks"] == 2 and o2["config"]["global_batch"] == 16
+    assert o2["config"]["gather"]["every_steps"] == 16 and o2["config"]["gather"]["host_us_per_step"] > 0
+    assert o2n["config"]["gather"] is None
+    print("1 rank: %.4f ms/step; 2 ranks sharing the GPU: %.4f ms/step with the logits gather, %.4f without (x%.3f); "
+          "gather host time %.1f us per step" % (o1["ms_per_step"], o2["ms_per_step"], o2n["ms_per_step"],
+                                                  o2["ms_per_step"] / o2n["ms_per_step"], o2["config"]["gather"]["host_us_per_step"]))
+    assert o2["ms_per_step"] <= 1.15 * o2n["ms_per_step"], (o2["ms_per_step"], o2n["ms_per_step"])
+    # a wrong world size is refused instead of silently running one rank
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline", "--no-b1"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=600)
+    assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE is 1" in (bad.stdout + bad.stderr)

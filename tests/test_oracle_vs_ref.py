@@ -278,3 +278,50 @@ def test_resnet50_int8_FRAMEWORK_op_list_through_reference_objects():
         assert np.array_equal(rn.read(nm).reshape(ref[nm].shape), ref[nm]), nm
     assert ref["conv1"].dtype == np.int8 and ref["conv1"].min() >= 0          # relu'd, stored as s8
     assert ref["res2c"].shape == (1, 28, 28, 256)                              # stride-up: the block already runs at 28 x 28
+
+
+@pytest.mark.parametrize("sum_scale", [1.0, 0.5, 2.0, 0.37])
+def test_conv_i8_with_sum_matches_reference_integer_test_oracle(sum_scale):
+    """The INT8 conv + in-place sum post-op (the JIT `with_sum`, kernel/jit_avx512_core_x8s8s32x_conv_kernel.cpp:156-177 —
+    xbyak, not buildable here) pinned with reference CODE that is: conv_basic_check_int8's Eltwise_sum branch
+    (test/saber/conv_func_helper.h:127-130,168-186), compiled into oracle/_ref. Same structure — acc * scale, + prev *
+    sum_scale, relu, round to nearest even, saturate — with |acc| < 2^24 so that the helper's float accumulation is exact.
+    For sum_scale in {1, 1/2, 2} (prev * sum_scale exact) the two must agree BIT FOR BIT. For a general factor the JIT fuses
+    the multiply-add (vfmadd231ps: one rounding, restated with fmaf) where the helper rounds twice: the results may differ
+    by one unit where the sum lands within an ulp of a rounding boundary — at most 1, on under 0.1 % of the outputs."""
+    rng = np.random.default_rng(21)
+    x = rng.integers(-128, 128, (2, 9, 9, 32)).astype(np.int8)
+    wq = rng.integers(-127, 128, (16, 32, 3, 3)).astype(np.int8)
+    scale = (rng.random(16) * 1e-3 + 1e-4).astype(np.float32)
+    prev = rng.integers(-128, 128, (2, 9, 9, 16)).astype(np.int8)
+    rp = O.Residual(O.RES_JIT_SUM, 0, sum_scale, O.S8, 0, 0, 0, 0)
+    got = O.conv_i8(x, wq, None, scale, O.S8, True, (1, 1), residual=rp, out_init=prev.copy())
+    want = O.ref_conv_basic_check_int8_sum(x, wq, scale, True, prev, sum_scale, (1, 1))
+    if sum_scale in (1.0, 0.5, 2.0):
+        assert np.array_equal(got, want)
+    else:
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, (d.max(), (d != 0).mean())
+    assert (got > 0).any() and (got == 0).any()      # the relu and the sum both matter in this sample
+
+
+def test_int8_average_pooling_contract_is_the_jit_kernels():
+    """INT8 average pooling: the x86 implementation is an xbyak JIT kernel (kernel/jit_avx512_core_8bit_pooling_kernel.cpp,
+    not buildable here) that multiplies the int32 window sum by a precomputed 1/count and rounds to nearest even; the
+    reference's test helper pool_basic_check_int8 (conv_func_helper.h:29-100, compiled into oracle/_ref) DIVIDES. The pinned
+    contract is the kernel's (`(float)sum * (1.f / count)`): it equals the helper wherever count is a power of two (1/count
+    exact) and differs by at most one unit elsewhere, only where sum / count sits within an ulp of a .5 boundary. Both facts
+    are tested; the deviation is a documented choice, not an unknown."""
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 128, (2, 16, 16, 32)).astype(np.int8)
+    for win, stride in (((2, 2), (2, 2)), ((4, 4), (4, 4)), ((8, 8), (8, 8))):      # count 4 / 16 / 64: exact reciprocals
+        oh = O.pool_out_dim(16, 0, win[0], stride[0])
+        assert np.array_equal(O.pool_i8_nhwc(x, win, stride, (0, 0), 1), O.ref_pool_basic_check_int8(x, oh, oh, win, stride, (0, 0), 1))
+    x7 = rng.integers(0, 128, (4, 7, 7, 256)).astype(np.int8)                          # count 49 (ResNet's pool5)
+    got = O.pool_i8_nhwc(x7, (7, 7), (7, 7), (0, 0), 1).astype(np.int32)
+    want = O.ref_pool_basic_check_int8(x7, 1, 1, (7, 7), (7, 7), (0, 0), 1).astype(np.int32)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.02
+    # and the kernel's formula, restated independently in numpy float32
+    s = x7.astype(np.int32).sum((1, 2), keepdims=True)
+    f = (s.astype(np.float32) * np.float32(1.0 / 49.0)).astype(np.float32)
+    assert np.array_equal(got, np.clip(np.rint(f), -128, 127).astype(np.int32))
