@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsaber_mi355x.so")
 SOURCES = ["conv_igemm.hip", "elementwise.hip", "fc_small.hip", "conv1x1_chain.hip", "api.hip"] + \
-    ["igemm_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1), (1, 2), (1, 3), (2, 3)]] + \
+    ["igemm_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1), (1, 2), (1, 3), (2, 3), (3, 3)]] + \
     ["igemm_dma_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 3)]] + \
     ["halo_e%d.hip" % e for e in range(4)] + ["img_e%d.hip" % e for e in (0, 1, 3)] + ["stem_e%d.hip" % e for e in range(4)] + ["stem_pool.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -109,6 +109,8 @@ struct saber_hip_conv {
     int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
+    int b3 = 0;              // FP32: 1 = the implicit GEMM runs on the bf16 matrix cores (three bf16 operand planes, conv_igemm_impl.h
+                             // MODE 3): needs c_eff % 8 == 0 and the pre-split weight planes d_w3
     int img_ib = 0, img_rb = 0, img_nw = 4;   // img_rb > 0: small-image 3x3 kernel (conv3x3_img.h): images / output rows
                                               // per workgroup slab, waves per workgroup (4 or 8)
     int epi = EPI_I8_CONV;
@@ -128,6 +130,7 @@ struct saber_hip_conv {
     std::vector<float> bias_p_host, scale_host;   // INT8: the device-side bias' / scale / comp arrays (conv1x1 chain repacks them)
     std::vector<int> comp_host;
     DevBuf<uint8_t> d_w;
+    DevBuf<uint8_t> d_w3;    // FP32 convs: the repacked weights split into three bf16 planes [3][K_pad][Kg_pad] (b3 variant)
     DevBuf<float> d_bias, d_scale;
     DevBuf<int> d_comp;
     bool has_bias = false, has_comp = false;
@@ -195,7 +198,7 @@ static bool halo_ok(const saber_hip_conv* op) {
            d.pad_w <= 1;
 }
 
-namespace { bool fc_small_ok(const saber_hip_conv* op); }
+namespace { bool fc_small_ok(const saber_hip_conv* op); bool b3_ok(const saber_hip_conv* op); }
 
 static bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb) {
     return halo_ok(op) && !op->pair_k2 && conv3x3_img_feasible(op->c_eff, op->ow, op->oh, op->d.n, nw, ib, rb);
@@ -207,6 +210,12 @@ static bool stem_ok(const saber_hip_conv* op) {
            d.stride_w == 2 && d.dil_h == 1 && d.dil_w == 1 && d.group == 1;
 }
 
+// STATIC default of the bf16-plane FP32 kernel: on for MFMA-bound layers (a 3x3 or larger filter over >= 64 channels and
+// >= 3136 output pixels), where the six bf16 MFMAs per slab beat the eight f32 ones (profiles/r03_*_fp32/; the latency-bound
+// 1x1 and small-image layers do not gain); the RUNTIME strategy (saber_hip_conv2d_autotune) times both anyway.
+static bool f32_static_b3(const saber_hip_conv* op) {
+    return op->d.kh * op->d.kw > 1 && op->c_eff >= 64 && (long)op->d.n * op->oh * op->ow >= 3136;
+}
 static void name_algo(saber_hip_conv* op) {
     static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
     int bmk = 0, bnp = 0;
@@ -218,7 +227,7 @@ static void name_algo(saber_hip_conv* op) {
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
-        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s", an[op->algo], bmk, bnp, op->ks,
+        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s", op->b3 ? "igemm_f32_bf16x3" : an[op->algo], bmk, bnp, op->ks,
                  op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")),
                  op->pool2 ? "+maxpool2x2" : "");
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
@@ -399,6 +408,14 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         name_algo(op);
         return SABER_HIP_OK;
     }
+    if (var == 11) {   // FP32 implicit GEMM on three bf16 planes (register-staged, one 32-deep slab per stage)
+        if (!b3_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 variant: FP32 implicit-GEMM conv with C % 8 == 0 (not a sibling pair, not an fc)");
+        if (tile < 0 || tile >= TILE_COUNT) return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
+        if (!(ks == 0 || ks == 1 || (ks == 2 && tile != TILE_128x128))) return fail(SABER_HIP_INVALID_VALUE, "bf16x3: stage depth 1, or 2 below 128x128");
+        op->b3 = 1; op->dma = 0; op->ks = ks ? ks : 1; op->tile = tile; op->fc_small = 0;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
     if (var == 10) {   // small-batch fc kernel
         if (!fc_small_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "small-batch fc kernel: INT8 fc with <= 16 rows and k <= 4096");
         op->fc_small = 1;
@@ -423,6 +440,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         return SABER_HIP_OK;
     }
     if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
+        op->b3 = 0;
         op->halo = 0;
         op->stem = 0;
         op->img_ib = op->img_rb = 0;
@@ -441,6 +459,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
     if (op->fc_small) return 10 << 16;
+    if (op->b3) return op->tile | (op->ks << 8) | (11 << 16);
     if (op->stem) return 7 << 16;
     if (op->img_rb) return op->img_rb | ((op->img_ib | (op->img_nw == 8 ? 0x80 : 0)) << 8) | (9 << 16);
     if (op->halo) return op->tile | (op->ks << 8) | ((op->halo == 4 ? 5 : 6) << 16);
@@ -562,6 +581,38 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
         }
         std::vector<uint8_t> raw((const uint8_t*)wr.data(), (const uint8_t*)wr.data() + wr.size() * sizeof(float));
         HIP_TRY(op->d_w.upload(raw));
+        // the same matrix as three bf16 planes (w = h + m + l exactly: 3 x 8 mantissa bits) for the bf16-MFMA variant; spatial
+        // convolutions only (an fc streams its weights once: 6 bytes per weight instead of 4 would only slow it down)
+        if (op->algo == ALGO_IGEMM_F32 && op->c_eff % 8 == 0 && (long)d.h * d.w > 1 && !getenv("SABER_HIP_NO_BF16X3")) {
+            auto rne = [](float x) {
+                uint32_t u;
+                std::memcpy(&u, &x, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                return (uint16_t)(u >> 16);
+            };
+            auto bf = [](uint16_t h) {
+                const uint32_t u = (uint32_t)h << 16;
+                float f;
+                std::memcpy(&f, &u, 4);
+                return f;
+            };
+            const size_t n = wr.size();
+            std::vector<uint8_t> planes(n * 6);
+            uint16_t* pl = (uint16_t*)planes.data();
+            for (size_t i = 0; i < n; ++i) {
+                const uint16_t h = rne(wr[i]);
+                const float r1 = wr[i] - bf(h);
+                const uint16_t m = rne(r1);
+                const float r2 = r1 - bf(m);
+                pl[i] = h; pl[n + i] = m; pl[2 * n + i] = rne(r2);
+            }
+            HIP_TRY(op->d_w3.upload(planes));
+            // STATIC choice (BaseFunc STATIC strategy): SABER_HIP_F32_BF16X3=1 makes the bf16-plane kernel the default of every
+            // eligible FP32 convolution (0 keeps the f32-MFMA kernels); unset: see f32_static_b3()
+            const char* e = getenv("SABER_HIP_F32_BF16X3");
+            const bool want = e ? (e[0] == '1') : f32_static_b3(op);
+            if (want && !op->pair_k2) { op->b3 = 1; op->ks = 1; op->dma = 0; name_algo(op); }
+        }
         std::vector<float> b(K_pad, 0.f);
         if (bias) std::memcpy(b.data(), bias, sizeof(float) * K);
         HIP_TRY(op->d_bias.upload(b));
@@ -595,7 +646,11 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     a.stride_h = d.stride_h; a.stride_w = d.stride_w; a.dil_h = d.dil_h; a.dil_w = d.dil_w;
     a.M = d.n * op->oh * op->ow;
     a.Kg = op->Kg; a.Kg_pad = op->Kg_pad; a.kw_pad = op->kw_pad;
-    const int estage = (op->algo == ALGO_IGEMM_F32 ? 16 : 64) * op->ks * (op->dma > 1 ? op->dma : 1);   // elements per stage
+    const int estage = op->b3 ? 32 * op->ks : (op->algo == ALGO_IGEMM_F32 ? 16 : 64) * op->ks * (op->dma > 1 ? op->dma : 1);   // elements per stage
+    if (op->b3) {
+        a.w = op->d_w3.p;
+        a.w_plane_chunks = (int)((size_t)round_up(d.k, 128) * op->Kg_pad / 8);
+    }
     a.steps = (op->Kg + estage - 1) / estage;
     a.inv_ohw = 1.0f / (float)(op->oh * op->ow);
     a.inv_ow = 1.0f / (float)op->ow;
@@ -691,7 +746,8 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
             HIP_TRY(launch_fc_f32_small(a, s));
             break;
         }
-        HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
+        if (op->b3) HIP_TRY(launch_conv_igemm(3, op->tile, op->ks, a, s));
+        else HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
         break;
     case ALGO_DIRECT_I8:
         a.comp = nullptr;
@@ -710,14 +766,17 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
 namespace {
 // one selection of kernel variant for an op (what the autotuner saves / restores)
 struct ConvChoice {
-    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small;
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3;
 };
 ConvChoice get_choice(const saber_hip_conv* op) {
-    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small};
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3};
 }
 void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
-    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3;
+}
+bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
+    return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr && !op->pair_k2;
 }
 bool fc_small_ok(const saber_hip_conv* op) {
     if (op->algo == ALGO_IGEMM_F32)   // FP32 fc: a 1x1 "conv" on a [m, 1, 1, k] NHWC tensor, plain f32 epilogue, no residual
@@ -803,7 +862,7 @@ unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice& c) {
         return k | (3ull << 8) | ((unsigned long long)op->c_eff << 16) |
                ((unsigned long long)((c.img_ib * c.img_rb * op->ow + 15) / 16) << 32);
     if (c.halo) return k | (4ull << 8) | ((unsigned long long)c.halo << 16) | ((unsigned long long)(op->c_eff % 128 == 0) << 24);
-    return k | (5ull << 8) | ((unsigned long long)c.tile << 16) | ((unsigned long long)c.ks << 24) | ((unsigned long long)c.dma << 32);
+    return k | ((c.b3 ? 6ull : 5ull) << 8) | ((unsigned long long)c.tile << 16) | ((unsigned long long)c.ks << 24) | ((unsigned long long)c.dma << 32);
 }
 struct ColdScope {
     ColdBench local;
@@ -866,7 +925,7 @@ extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, vo
             best_c = get_choice(op);
         }
     };
-    ConvChoice c = {op->tile, op->ks, 0, 0, 0, 0, 0, 4, 0};
+    ConvChoice c = {op->tile, op->ks, 0, 0, 0, 0, 0, 4, 0, 0};
     if (op->fc_small && fc_small_ok(op)) return SABER_HIP_OK;   // small-batch fc: one launch at the latency floor, nothing to tune
     const int ks_list[3] = {1, 2, 4};
     const int dma_list[4] = {0, 1, 2, 4};
@@ -878,6 +937,14 @@ extern "C" int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, vo
                 if (dma_list[vi] == 4 && t != TILE_32x32) continue;
                 c.tile = t; c.ks = ks_list[ki]; c.dma = dma_list[vi];
                 set_choice(op, c);
+                time_current();
+            }
+    if (b3_ok(op))      // FP32 on the bf16 matrix cores: every tile
+        for (int kd = 1; kd <= 2; ++kd)
+            for (int t = 0; t < TILE_COUNT; ++t) {
+                if (kd == 2 && t == TILE_128x128) continue;
+                ConvChoice cb = {t, kd, 0, 0, 0, 0, 0, 4, 0, 1};
+                set_choice(op, cb);
                 time_current();
             }
     c = best_c;

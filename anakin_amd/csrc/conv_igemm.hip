@@ -24,7 +24,7 @@ void tile_dims(int tile, int* bm_k, int* bn_pix) {
 }
 
 #define DECL(m, e) hipError_t launch_igemm_m##m##_e##e(int tile, int ks, const ConvKArgs& a, hipStream_t s);
-DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(0, 4) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3)
+DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(0, 4) DECL(1, 0) DECL(1, 1) DECL(1, 2) DECL(1, 3) DECL(2, 3) DECL(3, 3)
 #undef DECL
 #define DECL(m, e) hipError_t launch_igemm_dma_m##m##_e##e(int tile, int ks, int wg, const ConvKArgs& a, hipStream_t s);
 DECL(0, 0) DECL(0, 1) DECL(0, 2) DECL(0, 3) DECL(0, 4) DECL(2, 3)
@@ -48,7 +48,7 @@ static int epilogue_kind(int mode, const ConvKArgs& a) {
     int ek = 3;
     if (mode == 0 && a.K2 > 0) return 4;   // sibling pair (api.hip checked the constraints)
     // the specialised epilogues store whole 4..16-channel lane groups: ragged K takes the generic one
-    if (mode != 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE && a.K % 16 == 0) {
+    if (mode < 2 && a.epi == EPI_I8_CONV && a.res_mode != RES_SUM_INPLACE && a.K % 16 == 0) {
         if (a.res_mode == RES_ELTWISE) ek = 2;
         else if (a.out_dtype == DT_U8) ek = 1;
         else if (a.out_dtype == DT_S8) ek = 0;
@@ -107,6 +107,7 @@ hipError_t launch_conv_igemm(int mode, int tile, int ks, const ConvKArgs& a, hip
     case 10: return launch_igemm_m1_e2(tile, ks, a, s);
     case 11: return launch_igemm_m1_e3(tile, ks, a, s);
     case 19: return launch_igemm_m2_e3(tile, ks, a, s);
+    case 27: return launch_igemm_m3_e3(tile, ks, a, s);
     default: return hipErrorInvalidValue;
     }
 }

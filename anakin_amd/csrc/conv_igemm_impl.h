@@ -68,6 +68,34 @@ __device__ __forceinline__ v4f mma_step(v4i a, v4i b, v4f c) {
     return c;
 }
 
+// FP32 on the bf16 matrix cores (MODE 3): x = h + m + l with h, m, l bf16 — three 8-bit mantissas cover the 24 of an f32
+// exactly — and a . b ~= hh + hm + mh + hl + lh + mm (the dropped ml / lm / ll products are <= 2^-32 relative), six
+// v_mfma_f32_16x16x32_bf16 per 32-deep slab accumulated in f32 against eight v_mfma_f32_16x16x4_f32: the bf16 pipe runs
+// 16x the f32 MFMA rate, so 16 / 6 = 2.7x at best (measured in the inner loop: 2.1 - 2.3x, scripts/probe/bf16_split_probe.hip,
+// with a dot-product error of 1.1e-6 over K = 2304, the f32 MFMA's own being 1.5e-6).
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f mma_step3(const v4i (&a)[3], const v4i (&b)[3], v4f c) {
+#define SABER_MF(x, y) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, x), __builtin_bit_cast(v8bf, y), c, 0, 0, 0)
+    SABER_MF(a[2], b[0]); SABER_MF(a[0], b[2]); SABER_MF(a[1], b[1]);      // small terms first
+    SABER_MF(a[1], b[0]); SABER_MF(a[0], b[1]); SABER_MF(a[0], b[0]);
+#undef SABER_MF
+    return c;
+}
+// two f32 -> packed (hi, mid, lo) bf16 pairs; every subtraction is exact, the conversions round to nearest even
+// (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const v2f x = {x0, x1};
+    const v2bf hb = __builtin_convertvector(x, v2bf);
+    const v2f r1 = x - __builtin_convertvector(hb, v2f);
+    const v2bf mb = __builtin_convertvector(r1, v2bf);
+    const v2f r2 = r1 - __builtin_convertvector(mb, v2f);
+    const v2bf lb = __builtin_convertvector(r2, v2bf);
+    h = __builtin_bit_cast(unsigned, hb);
+    m = __builtin_bit_cast(unsigned, mb);
+    l = __builtin_bit_cast(unsigned, lb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue of one lane: NV = TM*4 CONSECUTIVE output channels (kb .. kb+NV-1) of one output pixel p.
 // The weight rows of a block tile are permuted so that MFMA tile tm / D-row i holds channel
@@ -466,9 +494,12 @@ __device__ __forceinline__ int phys_chunk(int row, int c) {
 // ---------------------------------------------------------------------------------------------
 template <int MODE, int TM, int TN, int KS, int EK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
-    constexpr bool F32 = (MODE == 2);
+    constexpr bool B3 = (MODE == 3);     // f32 tensors, three bf16 operand planes (see mma_step3)
+    constexpr bool F32 = (MODE == 2) || B3;
     constexpr bool C4 = (MODE == 1);
-    constexpr int ES = F32 ? 4 : 1;      // bytes per element
+    constexpr int ES = B3 ? 2 : (F32 ? 4 : 1);   // bytes per element in LDS / in the repacked weights
+    constexpr int XS = F32 ? 4 : 1;      // bytes per activation element in memory
+    constexpr int NP = B3 ? 3 : 1;       // operand planes
     constexpr int EC = 16 / ES;          // elements per 16-byte chunk
     constexpr int CPR = 4 * KS;          // chunks per row per stage
     constexpr int ESTAGE = CPR * EC;     // elements per stage
@@ -482,7 +513,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr bool X_FULL = BNP % RPP == 0;
     using acc_t = typename std::conditional<F32, v4f, v4i>::type;
 
-    __shared__ v4i lds[2][(BMK + BNP) * CPR];
+    __shared__ v4i lds[2][NP][(BMK + BNP) * CPR];
     SABER_TL_DECL;
     SABER_TL(0);
     pin_hot_args(a);
@@ -528,16 +559,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         cur_j = tap - cur_i * a.kw;
     }
 
-    v4i xv[XIT], wv[WIT];
+    v4i xv[XIT][B3 ? 2 : 1], wv[NP][WIT];     // B3: an activation chunk is 8 f32 = two 16-byte loads, split at store time
     const v4i* w16 = (const v4i*)a.w;
     const int w_row_chunks = a.Kg_pad / EC;
 
     auto load_stage = [&](int s) {
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int r = lr + it * RPP;
-            if (W_FULL || r < BMK) wv[it] = w16[(size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
-        }
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int r = lr + it * RPP;
+                if (W_FULL || r < BMK)
+                    wv[pl][it] = w16[(size_t)pl * a.w_plane_chunks + (size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
+            }
         const bool tap_ok = cur_i < a.kh;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -556,13 +590,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 // stage body is one basic block and its address arithmetic can be scheduled between the MFMAs
                 const int iw = x_iw0[it] + cur_j * a.dil_w;
                 const bool ok = row_ok && iw >= 0 && iw < a.W;
-                const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * ES;
-                v = *(const v4i*)(ok ? xp : (const char*)a.zero);
+                const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * XS;
+                xp = ok ? xp : (const char*)a.zero;
+                v = *(const v4i*)xp;
+                if constexpr (B3) xv[it][1] = *(const v4i*)(xp + 16);
             }
             if (!F32 && a.in_u8) {
                 v.x ^= 0x80808080; v.y ^= 0x80808080; v.z ^= 0x80808080; v.w ^= 0x80808080;
             }
-            xv[it] = v;
+            xv[it][0] = v;
         }
         // advance the cursor by one stage
         if (C4) {
@@ -586,13 +622,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 // permuted LDS row so that MFMA tile (wm, tm) reads 16 consecutive rows (conflict-free)
                 const int rr = r % (TM * 16), wmr = r / (TM * 16);
                 const int lrow = (wmr * TM + ((rr >> 2) % TM)) * 16 + (rr / (TM * 4)) * 4 + (rr & 3);
-                lds[buf][lrow * CPR + phys_chunk<CPR>(lrow, lq)] = wv[it];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) lds[buf][pl][lrow * CPR + phys_chunk<CPR>(lrow, lq)] = wv[pl][it];
             }
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int r = lr + it * RPP;
-            if (X_FULL || r < BNP) lds[buf][(BMK + r) * CPR + phys_chunk<CPR>(r, lq)] = xv[it];
+            if (X_FULL || r < BNP) {
+                const int li = (BMK + r) * CPR + phys_chunk<CPR>(r, lq);
+                if constexpr (B3) {
+                    const v4f f0 = __builtin_bit_cast(v4f, xv[it][0]), f1 = __builtin_bit_cast(v4f, xv[it][1]);
+                    unsigned h[4], m[4], l[4];
+                    split3_pair(f0.x, f0.y, h[0], m[0], l[0]);
+                    split3_pair(f0.z, f0.w, h[1], m[1], l[1]);
+                    split3_pair(f1.x, f1.y, h[2], m[2], l[2]);
+                    split3_pair(f1.z, f1.w, h[3], m[3], l[3]);
+                    lds[buf][0][li] = v4i{(int)h[0], (int)h[1], (int)h[2], (int)h[3]};
+                    lds[buf][1][li] = v4i{(int)m[0], (int)m[1], (int)m[2], (int)m[3]};
+                    lds[buf][2][li] = v4i{(int)l[0], (int)l[1], (int)l[2], (int)l[3]};
+                } else {
+                    lds[buf][0][li] = xv[it][0];
+                }
+            }
         }
     };
 
@@ -636,16 +688,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         if (s + 1 < a.steps) load_stage(s + 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            v4i af[TM], bf[TN];
+            v4i af[TM][NP], bf[TN][NP];
             // phys_chunk(row, ks*4 + fq) == phys_chunk(row, fq) ^ (ks*4): the k-step only touches chunk bits 2..3
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = lds[buf][a_idx[i] ^ (ks << 2)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = lds[buf][b_idx[j] ^ (ks << 2)];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i], bf[j], acc[i][j]);
+                for (int pl = 0; pl < NP; ++pl) af[i][pl] = lds[buf][pl][a_idx[i] ^ (ks << 2)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) bf[j][pl] = lds[buf][pl][b_idx[j] ^ (ks << 2)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (B3) acc[i][j] = mma_step3(af[i], bf[j], acc[i][j]);
+                    else acc[i][j] = mma_step(af[i][0], bf[j][0], acc[i][j]);
+                }
         }
         if (s + 1 < a.steps) store_stage(buf ^ 1);
         __syncthreads();
@@ -698,7 +757,7 @@ static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
     b.nky = (a.K + bmk - 1) / bmk;
     b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     if (MODE != 1) {   // gather-cursor increments of one stage (4*KS chunks of 16 bytes)
-        const int estage = 4 * KS * (MODE == 2 ? 4 : 16);
+        const int estage = 4 * KS * (MODE == 2 ? 4 : (MODE == 3 ? 8 : 16));
         const int taps = estage / a.C;
         b.adv_c = estage - taps * a.C;
         b.adv_i = taps / a.kw;
@@ -721,6 +780,31 @@ static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
 // One translation unit per (MODE, EK) instantiates its 18 (tile, stage-depth) kernels through this.
 template <int MODE, int EK>
 static hipError_t launch_igemm_inst(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
+    if constexpr (MODE == 3) {   // three operand planes: one 32-deep slab per stage is already 96 KB of LDS at 128 x 128
+        if (ks == 1) return launch_mode<MODE, 1, EK>(tile, a, s);
+        if (ks != 2 || tile == TILE_128x128) return hipErrorInvalidValue;     // two slabs per stage: up to 144 KB (128 x 64)
+        int bmk, bnp;
+        tile_dims(tile, &bmk, &bnp);
+        ConvKArgs b = a;
+        b.npx = (a.M + bnp - 1) / bnp;
+        b.nky = (a.K + bmk - 1) / bmk;
+        b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
+        const int estage = 4 * 2 * 8;
+        const int taps = estage / a.C;
+        b.adv_c = estage - taps * a.C;
+        b.adv_i = taps / a.kw;
+        b.adv_j = taps - b.adv_i * a.kw;
+        dim3 grid(b.npx * b.nky), block(256);
+        switch (tile) {
+        case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, 2, EK>), grid, block, 0, s, b); break;
+        case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1, 2, EK>), grid, block, 0, s, b); break;
+        case TILE_64x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, 2, EK>), grid, block, 0, s, b); break;
+        case TILE_128x64: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 2, 2, EK>), grid, block, 0, s, b); break;
+        case TILE_64x128: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4, 2, EK>), grid, block, 0, s, b); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    } else
     switch (ks) {
     case 1: return launch_mode<MODE, 1, EK>(tile, a, s);
     case 2: return launch_mode<MODE, 2, EK>(tile, a, s);

@@ -86,6 +86,7 @@ struct ConvKArgs {
     // res[n][oy * res_sub][ox * res_sub] - a 1x1 / stride-s max pooling (one element per window: the identity on it)
     // folded into the read. res_sub <= 1: res is [M][K].
     int res_sub, res_H, res_W;
+    int w_plane_chunks;     // MODE 3 (FP32 on three bf16 planes): 16-byte chunks between the weight planes (K_pad * Kg_pad / 8)
 };
 
 // conv3x3_img_kernel takes the common block plus its slab geometry (kept out of ConvKArgs: every byte of kernel

@@ -128,6 +128,10 @@ class SaberConv2D:
     def set_tile(self, tile):
         L.check(L.load().saber_hip_conv2d_set_tile(self.h, tile))
 
+    def tile_id(self):
+        """The current block tile (low byte of saber_hip_conv2d_get_tile)."""
+        return L.load().saber_hip_conv2d_get_tile(self.h) & 0xff
+
     def autotune(self, x, y, res=None, iters=5):
         L.check(L.load().saber_hip_conv2d_autotune(self.h, _p(x), _p(y), _p(res), _p(self.ws), _stream(), iters))
 

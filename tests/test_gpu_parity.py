@@ -1194,3 +1194,67 @@ def test_global_average_pooling_i8_kernel(shape, dt):
         got = host(S.pooling_i8(dev(x), None, None, None, 1, out_dtype=od, global_pooling=True))
         want = O.pool_i8_nhwc(x, None, None, None, 1, out_dtype=None if od is None else O.F32, global_pool=True)
         assert np.array_equal(got, want), (shape, dt, od)
+
+
+# ---- FP32 convolution on the bf16 matrix cores: x = h + m + l (three bf16 planes), six products, f32 accumulate ---------
+@pytest.mark.parametrize("tile", range(len(L.TILES)))
+def test_conv_f32_bf16x3_every_tile_golden(tile):
+    """The reference-made golden FP32 3x3 convolution through the bf16-plane variant (set_tile variant 11), every tile:
+    within the same 1e-4 as the f32-MFMA kernels (BASELINE.json: FP32 'within 1e-4 rel')."""
+    g = load("conv_f32_3x3")
+    N, C, H, W, K, k, pad, stride = [int(v) for v in g["spec"]]
+    if C % 8:
+        pytest.skip("bf16x3 needs C % 8 == 0")
+    p = S.ConvParam(g["w"], g["bias"], 1, (pad, pad), (stride, stride), (1, 1), True)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32)
+    conv.set_tile(tile | (1 << 8) | (11 << 16))
+    assert "bf16x3" in conv.algo()
+    y = conv.new_output()
+    conv.dispatch(dev(g["x"]), y)
+    err = np.abs(host(y) - g["y"]).max() / np.abs(g["y"]).max()
+    assert err <= FP32_RTOL, (conv.algo(), err)
+
+
+F32_B3_SWEEP = [
+    # N, H, W, C, K, k, pad, stride, dil, layout ("nhwc" | "nchw")
+    (2, 28, 28, 64, 64, 3, 1, 1, 1, "nhwc"),     # VGG-like 3x3
+    (1, 14, 14, 256, 512, 3, 1, 1, 1, "nhwc"),
+    (3, 9, 9, 16, 20, 1, 0, 1, 1, "nhwc"),       # ragged K, tiny C (K-steps straddle... one slab = 32 > C: taps mix)
+    (1, 7, 7, 48, 34, 3, 1, 1, 1, "nhwc"),       # K % 4 != 0, C = 48 (a 32-deep slab straddles taps)
+    (2, 13, 11, 32, 64, 3, 1, 2, 1, "nhwc"),     # ragged spatial, stride 2
+    (1, 10, 10, 16, 16, 3, 2, 1, 2, "nhwc"),     # dilation 2
+    (1, 5, 5, 64, 32, 5, 2, 1, 1, "nchw"),       # NCHW in / out (transposed into the workspace)
+    (2, 56, 56, 64, 256, 1, 0, 1, 1, "nhwc"),    # ResNet 1x1
+]
+
+
+@pytest.mark.parametrize("case", F32_B3_SWEEP)
+def test_conv_f32_bf16x3_sweep_vs_oracle(case):
+    """Shapes sweep of the bf16-plane FP32 convolution against the oracle's naive f32 convolution (conv_basic_check order):
+    max-norm AND element-wise criteria of the network tests, and against the f32-MFMA kernel of the same op (both are
+    rounding-level approximations of the exact sum: they must agree far inside the tolerance)."""
+    N, H, W, C, K, k, pad, stride, dil, layout = case
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    x = (rng.random((N, C, H, W)) * 3.0).astype(np.float32)                                  # relu'd activations
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, True, (pad, pad), (stride, stride), (dil, dil))
+    p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (dil, dil), True)
+    lay = L.NCHW if layout == "nchw" else L.NHWC
+    xin = x if layout == "nchw" else np.ascontiguousarray(x.transpose(0, 2, 3, 1))
+    outs = {}
+    for variant in ("f32", "bf16x3"):
+        conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=lay, out_layout=lay)
+        if variant == "bf16x3":
+            conv.set_tile(conv.tile_id() | (1 << 8) | (11 << 16))
+            assert "bf16x3" in conv.algo()
+        y = conv.new_output()
+        conv.dispatch(dev(xin), y)
+        got = host(y)
+        outs[variant] = got if layout == "nchw" else got.transpose(0, 3, 1, 2)
+    for variant, got in outs.items():
+        d = np.abs(got - want)
+        e_max = float(d.max() / np.abs(want).max())
+        e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+        assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (variant, case, e_max, e_el)
+    assert np.abs(outs["f32"] - outs["bf16x3"]).max() <= 2e-5 * np.abs(want).max()

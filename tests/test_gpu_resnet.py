@@ -102,6 +102,17 @@ def _fp32_every_edge(model_name, batch):
     return checked, worst_max, worst_el
 
 
+@pytest.mark.parametrize("b3", ["0", "1"])
+def test_fp32_networks_every_edge_with_and_without_the_bf16_plane_kernels(b3, monkeypatch):
+    """The same every-edge FP32 criteria with the STATIC choice forced to the f32-MFMA kernels (SABER_HIP_F32_BF16X3=0) and to
+    the bf16-plane kernels for every eligible convolution (=1): ResNet50 batch 1 and VGG16 batch 1 at 224 x 224."""
+    monkeypatch.setenv("SABER_HIP_F32_BF16X3", b3)
+    for name, floor in (("resnet50", 56), ("vgg16", 17)):
+        checked, worst_max, worst_el = _fp32_every_edge(name, 1)
+        assert checked >= floor, (name, checked)
+        print("%s FP32, bf16x3=%s: %d edges, worst max-norm %.2e, worst element-wise %.2e" % (name, b3, checked, worst_max, worst_el))
+
+
 def test_resnet50_fp32_batch2_full_size_every_edge():
     """BASELINE.json config 2 at its stated size (224x224), batch 2: 53 convs (16 with the fused in-place residual sum),
     2 pools, fc, softmax - every edge within 1e-4."""
