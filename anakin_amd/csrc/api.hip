@@ -1429,12 +1429,12 @@ int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hi
 // ------------------------------------------------------------------------------------------------
 // conv1x1 chain: `a` (1x1, fused SaberEltwise epilogue, s8 out) feeding `b` (1x1, s8 / u8 out) in one launch
 // ------------------------------------------------------------------------------------------------
-static bool chain_1x1(const saber_hip_conv* o) {
+static bool chain_1x1(const saber_hip_conv* o, bool sub_res_ok = false) {
     const saber_hip_conv_desc& d = o->d;
     return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.kh == 1 && d.kw == 1 &&
            d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && d.group == 1 && !o->pair_k2 &&
            !o->pool_fused && !o->pool2 && !o->pre_quant && !o->pre_pad && o->c_eff == d.c && d.act_negative_slope == 0.f &&
-           d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC && d.res_stride <= 1;
+           d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC && (d.res_stride <= 1 || sub_res_ok);
 }
 static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::vector<uint8_t>& out) {
     const int K = o->d.k;
@@ -1485,7 +1485,11 @@ static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<ui
 static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out) {
     // b == nullptr (with c3): conv3x3 + first 1x1 conv only
     if (!a || !out || (!b && !c3)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
-    if (!chain_1x1(a) || (b && !chain_1x1(b))) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
+    // a sub-sampled shortcut (saber_hip_conv_desc::res_stride) is read by the conv3x3 + conv1x1 form with a strided head only
+    const bool strided = c3 && !b && c3->d.stride_h == 2 && c3->d.stride_w == 2;
+    if (!chain_1x1(a, strided) || (b && !chain_1x1(b))) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
+    if (strided != (a->d.res_stride > 1) || (strided && a->d.res_stride != 2))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: a stride-2 head goes with a shortcut sub-sampled by 2 (and only with one)");
     const saber_hip_conv_desc& da = a->d;
     if (da.res_mode != SABER_HIP_RES_ELTWISE || da.out_dtype != SABER_HIP_S8 || (da.res_has_dtype && da.res_dtype != SABER_HIP_S8))
         return fail(SABER_HIP_INVALID_VALUE, "chain: the first conv must carry the fused eltwise epilogue with s8 residual and output");
@@ -1501,14 +1505,14 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
     if (c3) {
         const saber_hip_conv_desc& d3 = c3->d;
         const bool ok = c3->is_i8 && c3->weights_set && c3->algo == ALGO_IGEMM_I8 && c3->epi == EPI_I8_CONV && d3.kh == 3 && d3.kw == 3 &&
-                        d3.stride_h == 1 && d3.stride_w == 1 && d3.pad_h == 1 && d3.pad_w == 1 && d3.dil_h == 1 && d3.dil_w == 1 &&
+                        d3.stride_h == (strided ? 2 : 1) && d3.stride_w == d3.stride_h && d3.pad_h == 1 && d3.pad_w == 1 && d3.dil_h == 1 && d3.dil_w == 1 &&
                         d3.group == 1 && !c3->pair_k2 && !c3->pool_fused && !c3->pool2 && !c3->pre_quant && !c3->pre_pad &&
                         c3->c_eff == d3.c && d3.act_negative_slope == 0.f && d3.in_layout == SABER_HIP_NHWC &&
                         d3.out_layout == SABER_HIP_NHWC && d3.res_mode == SABER_HIP_RES_NONE && d3.c == da.c && d3.k == da.c &&
-                        d3.n == da.n && d3.h == da.h && d3.w == da.w && da.c <= 256 &&
+                        d3.n == da.n && c3->oh == da.h && c3->ow == da.w && da.c <= 256 &&
                         (d3.out_dtype == SABER_HIP_S8 || d3.out_dtype == SABER_HIP_U8) &&
                         (d3.out_dtype == SABER_HIP_U8) == (a->x_dtype == DT_U8);
-        if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: the head must be the 3x3 stride-1 pad-1 INT8 conv (C -> C, C <= 256) whose 8-bit output the first 1x1 conv reads");
+        if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: the head must be the 3x3 pad-1 INT8 conv (C -> C, C <= 256; stride 1, or 2 in front of a lone 1x1 conv) whose 8-bit output the first 1x1 conv reads");
     }
     saber_hip_chain* ch = new saber_hip_chain();
     const int k2 = b ? b->d.k : 0, c2 = b ? b->d.c : 0;
@@ -1620,6 +1624,9 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         k.mg_tpi = magic(k.tiles_per_img);
         k.in0_u8 = ch->c3->x_dtype == DT_U8;
         k.relu0 = ch->c3->d.act == SABER_HIP_ACT_RELU;
+        k.s0 = ch->c3->d.stride_h;
+        k.H0 = ch->c3->d.h; k.W0 = ch->c3->d.w;
+        if (a->d.res_stride > 1) { k.res_sub = a->d.res_stride; k.res_H = a->d.res_h; k.res_W = a->d.res_w; }
     }
     HIP_TRY(launch_conv1x1_chain(k, ch->c1, ch->k1, ch->k2, ch->tn, ch->c3 ? 1 : 0, (hipStream_t)stream));
     return SABER_HIP_OK;

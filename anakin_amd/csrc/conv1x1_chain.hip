@@ -109,9 +109,14 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* dst_wave_base) 
 // and its 8-bit output tile stays in LDS as the first 1x1 conv's B operand - that edge never reaches memory.
 // NW: waves per workgroup (4, or 8 = two per SIMD: one wave's epilogue arithmetic overlaps the other's weight stream; G1 /
 // G2 count the channel groups PER WAVE, so K1 = 64 * NW * G1)
-template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP, bool HAS2 = true, int NW = 4>
+// S0: stride of the leading 3x3 conv (1, or 2 = the form the reference's stride-up pass leaves in the last block of a stage:
+// 3x3 / stride 2, then 1x1 + eltwise whose shortcut is the previous block's output sub-sampled by the same stride — the
+// absorbed `<split>_pool`, ChainKArgs::res_sub). The halo is then (2 TN + 1) x 33 input pixels and tap (dy, dx) of output
+// pixel (j, col) sits at halo pixel (2 j + dy, 2 col + dx).
+template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP, bool HAS2 = true, int NW = 4, int S0 = 1>
 __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs a) {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(S0 == 1 || (C3 && !HAS2 && S0 == 2), "a strided head exists for conv3x3 + conv1x1 only");
     constexpr int KS2 = NW * G1;                      // K1 / 64
     constexpr int K1 = 64 * NW * G1, C1 = 64 * KS1, K2W = NW * G2 * 16 * MFG2, K2 = K2W * SP;   // K2W: this workgroup's share
     constexpr int NPX = 16 * TN;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
     // fragment column (consecutive pixels, same chunk) hit 16 different 16-byte bank groups (pitch odd in chunks); with the
     // natural pitch (4 / 8 / 16 chunks) they collide 4- / 8- / 16-way (SQ_LDS_BANK_CONFLICT: 58 % of the LDS cycles at C = 128)
     constexpr int PCH = CH1 + 1;
-    constexpr int HW = 18, HP = (TN + 2) * HW;        // halo pixels
+    constexpr int HW = 16 * S0 + 3 - S0, HP = ((TN - 1) * S0 + 3) * HW;        // halo: 18 x (TN + 2) pixels at stride 1, 33 x (2 TN + 1) at 2
     constexpr int HCH = C3 ? (HP * PCH + 63) / 64 * 64 : 1;
     constexpr int P0C = C3 ? (C1 / 4 * 3 + 63) / 64 * 64 : 1;
     constexpr int P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
@@ -203,9 +208,10 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
                 const int L = i * 64 + lane;
                 const int hp = L / PCH, cc = L - hp * PCH;            // cc == CH1: the padding chunk (fetches zeros)
                 const int hy = hp / HW, hx = hp - hy * HW;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                const bool in = hp < HP && cc < CH1 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // zero padding
-                const char* src = in ? xg + ((size_t)((n * a.H + gy) * a.W + gx) * C1 + cc * 16) : (const char*)a.zero;
+                const int gy = y0 * S0 - 1 + hy, gx = x0 * S0 - 1 + hx;
+                const int H0 = S0 == 1 ? a.H : a.H0, W0 = S0 == 1 ? a.W : a.W0;     // the 3x3 conv's INPUT dims
+                const bool in = hp < HP && cc < CH1 && (unsigned)gy < (unsigned)H0 && (unsigned)gx < (unsigned)W0;   // zero padding
+                const char* src = in ? xg + ((size_t)((n * H0 + gy) * W0 + gx) * C1 + cc * 16) : (const char*)a.zero;
                 lds_dma16(src, halo + i * 64);
             }
             for (int i = wave; i < P0C / 64; i += NW) lds_dma16((const v4i*)a.prm0 + i * 64 + lane, prm0 + i * 64);
@@ -218,7 +224,11 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             const int L = i * 64 + lane;
             const int px = L / CPR, c = (L % CPR) ^ (px & 15);
             bool ok;
-            const int p = pix(px, ok);
+            int p = pix(px, ok);
+            if constexpr (S0 > 1) {      // the shortcut is [N][res_H][res_W][K1]: pixel (y * res_sub, x * res_sub) of it
+                const int yy = min(y0 + (px >> 4), a.H - 1), xx = min(x0 + (px & 15), a.W - 1);
+                p = (n * a.res_H + yy * a.res_sub) * a.res_W + xx * a.res_sub;
+            }
             lds_dma16(rg + (size_t)p * K1 + c * 16, tile + i * 64);
         }
         for (int i = wave; i < P1C / 64; i += NW) lds_dma16((const v4i*)a.prm1 + i * 64 + lane, prm1 + i * 64);
@@ -248,14 +258,14 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
         for (int mf = 0; mf < MF0; ++mf)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[mf][j] = pp[mf * 3 + 2];
-        const v4i* hb = halo + frow * PCH + fq;
+        const v4i* hb = halo + (frow * S0) * PCH + fq;
 #pragma unroll
         for (int s = 0; s < T0; ++s) {                 // steps ordered [tap][k-step][accumulator]
             const int mf = s % MF0, ks = (s / MF0) % KS1, tap = s / (MF0 * KS1);
             const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                v4i b = hb[((j + dy) * HW + dx) * PCH + ks * 4];
+                v4i b = hb[((j * S0 + dy) * HW + dx) * PCH + ks * 4];
                 b.x ^= xm0; b.y ^= xm0; b.z ^= xm0; b.w ^= xm0;
                 acc[mf][j] = mma_step(ring[s % R], b, acc[mf][j]);
             }
@@ -448,6 +458,19 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
     // ring depths: measured with scripts/probe/timeline_probe.hip (chain): deeper rings (32 / 64 steps, or the whole
     // stream in registers) only move the wait into the prologue - the stream is bound by the CU's vector-memory path
     // (~43 B/clk measured for these 1 KB-per-instruction loads), not by the latency of one round trip
+    if (!has2 && a.s0 == 2) {      // strided head (the last block of a stage after the reference's stride-up)
+        switch (c1 * 32 + tile) {
+        case 64 * 32 + 4: SABER_CHAIN(1, 1, 1, 1, 4, 4, true, 1, false, 4, 2); break;
+        case 64 * 32 + 2: SABER_CHAIN(1, 1, 1, 1, 2, 4, true, 1, false, 4, 2); break;
+        case 128 * 32 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1, false, 4, 2); break;
+        case 128 * 32 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1, false, 4, 2); break;
+        case 256 * 32 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1, false, 4, 2); break;
+        case 128 * 32 + 6: SABER_CHAIN(2, 1, 1, 1, 2, 8, true, 1, false, 8, 2); break;
+        case 128 * 32 + 5: SABER_CHAIN(2, 1, 1, 1, 1, 8, true, 1, false, 8, 2); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (!has2) {
         switch (c1 * 32 + tile) {
         case 64 * 32 + 4: SABER_CHAIN(1, 1, 1, 1, 4, 4, true, 1, false); break;

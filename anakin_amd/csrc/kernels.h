@@ -120,6 +120,8 @@ struct ChainKArgs {
     int tiles_x, tiles_per_img;        // 16-column tiles per row, tiles per image
     unsigned mg_tiles_x, mg_tpi;       // ceil(2^32 / d) for the two, 0 when d == 1
     int in0_u8, relu0;                 // the 3x3 conv's input dtype / relu (its output dtype is in_u8)
+    int s0, H0, W0;                    // stride of the leading 3x3 conv (1 | 2) and, for 2, its input dims (H, W are the output's)
+    int res_sub, res_H, res_W;         // s0 == 2: the shortcut is [N][res_H][res_W][K1], read at (y * res_sub, x * res_sub)
 };
 bool conv1x1_chain_ok(int c1, int k1, int k2);
 // number of 16-pixel fragments per workgroup the launcher uses for (c1, m) / 0 if unsupported

@@ -1258,3 +1258,70 @@ def test_conv_f32_bf16x3_sweep_vs_oracle(case):
         e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
         assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (variant, case, e_max, e_el)
     assert np.abs(outs["f32"] - outs["bf16x3"]).max() <= 2e-5 * np.abs(want).max()
+
+
+STRIDED_HEAD_CASES = [
+    # C, N, Hin, Win, 3x3 input dtype, mid dtype, eltwise relu, tile code (None: default)
+    (64, 2, 56, 56, O.U8, O.U8, 1, None),        # res2c after the reference's stride-up: 56 -> 28
+    (64, 1, 27, 41, O.U8, O.U8, 1, 2),           # odd input dims: ragged output rows / columns, odd shortcut dims
+    (128, 2, 28, 28, O.U8, O.U8, 1, None),       # res3d
+    (128, 1, 11, 35, O.S8, O.S8, 0, 1),
+    (128, 2, 28, 28, O.U8, O.U8, 1, 6),          # 8 waves per workgroup
+    (256, 2, 14, 14, O.U8, O.U8, 1, None),       # res4f
+    (256, 1, 9, 7, O.U8, O.S8, 1, None),
+]
+
+
+@pytest.mark.parametrize("case", STRIDED_HEAD_CASES)
+def test_strided_conv3x3_conv1x1_chain_with_subsampled_shortcut(case):
+    """The last block of a stage as the reference's stride-up leaves it: 3x3 / stride 2 (C -> C), then 1x1 (C -> 4C) + eltwise
+    whose shortcut is the previous block's output sub-sampled by 2 (the absorbed 1x1 / stride-2 pooling, res_stride) — ONE
+    launch (saber_hip_conv2d_chain_create3 with a stride-2 head and no second 1x1 conv), the bits of pooling + the two convs."""
+    Cc, N, H, Wd, idt, mdt, res_relu, tn = case
+    rng = np.random.default_rng(3100 + Cc + H)
+    K1 = 4 * Cc
+    x = (rng.integers(0, 256, (N, H, Wd, Cc)).astype(np.uint8) if idt == O.U8
+         else rng.integers(-128, 128, (N, H, Wd, Cc)).astype(np.int8))
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (Wd + 2 - 3) // 2 + 1
+    Hs, Ws = 2 * Ho - (1 if H % 2 else 0), 2 * Wo - (1 if Wd % 2 else 0)        # shortcut dims with (Hs - 1) // 2 + 1 == Ho
+    assert (Hs - 1) // 2 + 1 == Ho and (Ws - 1) // 2 + 1 == Wo
+    res_full = rng.integers(-128, 128, (N, Hs, Ws, K1)).astype(np.int8)
+    w0 = (rng.standard_normal((Cc, Cc, 3, 3)) * np.sqrt(2.0 / (9 * Cc))).astype(np.float32)
+    b0 = (rng.standard_normal(Cc) * 0.5).astype(np.float32)
+    w1 = (rng.standard_normal((K1, Cc, 1, 1)) * np.sqrt(2.0 / Cc)).astype(np.float32)
+    b1 = (rng.standard_normal(K1) * 0.5).astype(np.float32)
+    s_x, s_in, s_mid, s_res, s_sum = 0.023, 0.02, 0.05, 0.043, 0.06
+    c = 1.0 / s_sum
+    relu0 = mdt == O.U8
+    ws0 = O.weight_scales(w0)
+    bp0, sc0 = O.conv_i8_prepare(ws0, b0, s_x, s_in, idt, mdt)
+    t0 = O.conv_i8(x, O.quant_weights(w0, ws0), bp0, sc0, mdt, int(relu0), (1, 1), (2, 2))
+    assert t0.shape == (N, Ho, Wo, Cc)
+    ws1 = O.weight_scales(w1)
+    bp1, sc1 = O.conv_i8_prepare(ws1, b1, s_in, s_mid, mdt, O.S8)
+    t1 = O.conv_i8(t0, O.quant_weights(w1, ws1), bp1, sc1, O.S8, 0)
+    pooled = O.pool_i8_nhwc(res_full, (1, 1), (2, 2), (0, 0), 0, floor_mode=True)
+    want = O.eltwise_i8(t1, pooled, s_mid, s_res, c, c, bool(res_relu))
+    c0 = S.SaberConv2D(int8=True).init((N, Cc, H, Wd), S.ConvParam(w0, b0, 1, (1, 1), (2, 2), (1, 1), bool(relu0)), idt, mdt,
+                                       s_x, s_in)
+    pa = S.ConvParam(w1, b1, 1, (0, 0), (1, 1), (1, 1), False)
+    pa.res_mode, pa.res_relu, pa.sum_scale, pa.coeff, pa.scale_res = L.RES_ELTWISE, bool(res_relu), 1.0, (c, c), s_res
+    pa.res_stride, pa.res_hw = 2, (Hs, Ws)
+    ca = S.SaberConv2D(int8=True).init((N, Cc, Ho, Wo), pa, mdt, O.S8, s_in, s_mid)
+    y0, y1 = c0.new_output(), ca.new_output()
+    c0.dispatch(dev(x), y0)
+    ca.dispatch(y0, y1, dev(res_full))
+    assert np.array_equal(host(y0), t0) and np.array_equal(host(y1), want)        # the two launches
+    chain = S.SaberConvChain(ca, None, conv3x3=c0)
+    if tn is not None:
+        chain.set_tile(tn)
+    z1 = ca.new_output()
+    z1.fill_(77)
+    chain.dispatch(dev(x), dev(res_full), z1)
+    assert np.array_equal(host(z1), want), ("strided head", chain.tile())
+    # a stride-2 head in front of a chain WITH a second 1x1 conv, or without the sub-sampled shortcut, does not exist
+    pb = S.ConvParam(w1, b1, 1, (0, 0), (1, 1), (1, 1), False)
+    pb.res_mode, pb.res_relu, pb.sum_scale, pb.coeff, pb.scale_res = L.RES_ELTWISE, True, 1.0, (c, c), s_res
+    plain = S.SaberConv2D(int8=True).init((N, Cc, Ho, Wo), pb, mdt, O.S8, s_in, s_mid)
+    with pytest.raises(L.SaberHipError):
+        S.SaberConvChain(plain, None, conv3x3=c0)
