@@ -1,0 +1,130 @@
+// anakin_amd/csrc/api_autotune.hip - saber_hip_conv2d_autotune.
+#include "api_internal.h"
+
+namespace saber_api {
+thread_local ColdBench* g_cold = nullptr;
+thread_local std::vector<unsigned long long>* g_used_kernels = nullptr;
+}  // namespace saber_api
+
+// RUNTIME strategy (BaseFunc::pick_best_runtime, saber/funcs/base.h:194,205-247): time every kernel variant
+// (implicit-GEMM tiles x stage depths x stagings, stem, LDS-halo, small-image) on the real tensors and keep the
+// fastest. Leaves y with one clean output of the selected kernel - except for RES_SUM_INPLACE ops, whose timed
+// launches accumulate into y (the caller re-initialises it). On error the entry selection is restored.
+int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
+                                         saber_hip_stream_t stream, int iters) {
+    if (op->algo > ALGO_IGEMM_F32 || op->pool_fused) return SABER_HIP_OK;   // (one fused conv+pooling kernel)
+    if (op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "sibling pair: use saber_hip_conv2d_autotune_pair");
+    hipStream_t s = (hipStream_t)stream;
+    EventPair ev;
+    HIP_TRY(ev.init());
+    const ConvChoice entry = get_choice(op);
+    ConvChoice best_c = entry;
+    float best = 1e30f;
+    int err = SABER_HIP_OK;
+    // times the op's CURRENT selection; a variant that fails to launch is skipped (its error is kept only if nothing works)
+    ColdScope scope;
+    HIP_TRY(scope.enter(7));
+    std::vector<std::pair<float, ConvChoice>> cands;
+    auto time_current = [&]() {
+        if (g_cold) {   // operands cold in L2, as inside the op list
+            const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run(op, x, y, res, workspace, s); });
+            if (us < 0.f) { err = SABER_HIP_RUNTIME_ERROR; return; }
+            cands.emplace_back(us, get_choice(op));
+            if (us < best) {
+                best = us;
+                best_c = get_choice(op);
+            }
+            return;
+        }
+        int rc = saber_hip_conv2d_run(op, x, y, res, workspace, s);   // warm-up
+        if (rc) { err = rc; return; }
+        if (hipEventRecord(ev.e0, s) != hipSuccess) { err = SABER_HIP_RUNTIME_ERROR; return; }
+        for (int i = 0; i < iters; ++i) rc |= saber_hip_conv2d_run(op, x, y, res, workspace, s);
+        float ms = 0;
+        if (rc || hipEventRecord(ev.e1, s) != hipSuccess || hipEventSynchronize(ev.e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, ev.e0, ev.e1) != hipSuccess) {
+            err = rc ? rc : SABER_HIP_RUNTIME_ERROR;
+            return;
+        }
+        if (ms < best) {
+            best = ms;
+            best_c = get_choice(op);
+        }
+    };
+    ConvChoice c = {op->tile, op->ks, 0, 0, 0, 0, 0, 4, 0, 0};
+    if (op->fc_small && fc_small_ok(op)) return SABER_HIP_OK;   // small-batch fc: one launch at the latency floor, nothing to tune
+    const int ks_list[3] = {1, 2, 4};
+    const int dma_list[4] = {0, 1, 2, 4};
+    const int nvar = op->algo == ALGO_IGEMM_I8_C4 ? 1 : 4;
+    for (int vi = 0; vi < nvar; ++vi)
+        for (int t = 0; t < TILE_COUNT; ++t)
+            for (int ki = 0; ki < 3; ++ki) {
+                if (dma_list[vi] > 1 && (ks_list[ki] != 4 || t > TILE_64x64)) continue;
+                if (dma_list[vi] == 4 && t != TILE_32x32) continue;
+                c.tile = t; c.ks = ks_list[ki]; c.dma = dma_list[vi];
+                set_choice(op, c);
+                time_current();
+            }
+    if (b3_ok(op))      // FP32 on the bf16 matrix cores: every tile
+        for (int kd = 1; kd <= 2; ++kd)
+            for (int t = 0; t < TILE_COUNT; ++t) {
+                if (kd == 2 && t == TILE_128x128) continue;
+                ConvChoice cb = {t, kd, 0, 0, 0, 0, 0, 4, 0, 1};
+                set_choice(op, cb);
+                time_current();
+            }
+    c = best_c;
+    if (fc_small_ok(op)) {
+        ConvChoice cf = c;
+        cf.fc_small = 1;
+        set_choice(op, cf);
+        time_current();
+    }
+    if (stem_ok(op)) {
+        ConvChoice cs = c;
+        cs.stem = 1;
+        set_choice(op, cs);
+        time_current();
+    }
+    if (halo_ok(op)) {
+        for (int th = 4; th <= 8; th += 4) {
+            ConvChoice ch = c;
+            ch.halo = th;
+            set_choice(op, ch);
+            time_current();
+        }
+        // small-image kernel: every feasible (images, rows) slab
+        const int rbs[] = {1, 2, 3, 4, 7, 8, 14};
+        const int ibs[] = {1, 2, 4};
+        for (int nw = 4; nw <= 4; nw += 4)
+            for (int ib : ibs)
+                for (int rb : rbs) {
+                    if (!img_ok(op, nw, ib, rb)) continue;
+                    ConvChoice ci = c;
+                    ci.img_ib = ib; ci.img_rb = rb; ci.img_nw = nw;
+                    set_choice(op, ci);
+                    time_current();
+                }
+    }
+    if (best >= 1e30f) {   // nothing ran: restore the entry selection and report the last error
+        set_choice(op, entry);
+        name_algo(op);
+        return err ? err : fail(SABER_HIP_RUNTIME_ERROR, "autotune: no variant ran");
+    }
+    if (g_used_kernels) {   // prefer a kernel function the net already uses when it is within g_reuse_tol of the fastest
+        float reuse_best = best * (1.f + g_reuse_tol);
+        for (const auto& cd : cands) {
+            const unsigned long long key = kernel_key(op, cd.second);
+            if (cd.first <= reuse_best && std::find(g_used_kernels->begin(), g_used_kernels->end(), key) != g_used_kernels->end()) {
+                reuse_best = cd.first;
+                best_c = cd.second;
+            }
+        }
+        g_used_kernels->push_back(kernel_key(op, best_c));
+    }
+    set_choice(op, best_c);
+    name_algo(op);
+    // leave y holding one clean result of the selected kernel
+    return saber_hip_conv2d_run(op, x, y, res, workspace, s);
+}
+

@@ -1,0 +1,209 @@
+// anakin_amd/csrc/api_chain.hip - conv1x1 chains: two (or conv3x3 + two) INT8 convolutions in one launch (conv1x1_chain.hip).
+#include "api_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// conv1x1 chain: `a` (1x1, fused SaberEltwise epilogue, s8 out) feeding `b` (1x1, s8 / u8 out) in one launch
+// ------------------------------------------------------------------------------------------------
+static bool chain_1x1(const saber_hip_conv* o, bool sub_res_ok = false) {
+    const saber_hip_conv_desc& d = o->d;
+    return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.kh == 1 && d.kw == 1 &&
+           d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && d.group == 1 && !o->pair_k2 &&
+           !o->pool_fused && !o->pool2 && !o->pre_quant && !o->pre_pad && o->c_eff == d.c && d.act_negative_slope == 0.f &&
+           d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC && (d.res_stride <= 1 || sub_res_ok);
+}
+static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::vector<uint8_t>& out) {
+    const int K = o->d.k;
+    out.assign(chunks_pad * 16, 0);
+    for (int k4 = 0; k4 < K / 4; ++k4) {
+        float* f = (float*)(out.data() + (size_t)k4 * 48);
+        int* ip = (int*)(out.data() + (size_t)k4 * 48 + 32);
+        for (int r = 0; r < 4; ++r) {
+            const int k = k4 * 4 + r;
+            f[r] = o->scale_host.empty() ? 1.f : o->scale_host[k];
+            f[4 + r] = (o->has_bias && !o->bias_p_host.empty()) ? o->bias_p_host[k] : 0.f;
+            ip[r] = o->comp_host.empty() ? 0 : o->comp_host[k];
+        }
+    }
+}
+// one conv's weights [K][C] -> per wave, groups of 16*mfg channels, steps ordered [group][k-step][accumulator], each step
+// = 64 lanes x 16 bytes in MFMA A-operand order (row = lane & 15, k-group = lane >> 4); row rho of accumulator mf is
+// channel  base + (rho >> 2) * 4*mfg + mf*4 + (rho & 3)   (conv1x1_chain.hip)
+static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out, int kbase = 0,
+                               int nw = 4) {
+    // K: channels of this workgroup's share (rows kbase .. kbase + K - 1 of w), nw waves
+    const int kw = K / nw, groups = kw / (16 * mfg), ksn = C / 64;
+    for (int g = 0; g < groups; ++g)
+        for (int ks = 0; ks < ksn; ++ks)
+            for (int mf = 0; mf < mfg; ++mf)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, kq = lane >> 4;
+                    const int ch = kbase + wave * kw + g * 16 * mfg + (rho >> 2) * 4 * mfg + mf * 4 + (rho & 3);
+                    const int8_t* src = w + (size_t)ch * C + ks * 64 + kq * 16;
+                    out.insert(out.end(), (const uint8_t*)src, (const uint8_t*)src + 16);
+                }
+}
+// the 3x3 conv's weights [K][C][3][3] -> per wave, steps ordered [tap][k-step][accumulator] (conv1x1_chain.hip phase 0)
+static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out, int nw = 4) {
+    const int kw = C / nw, mf0 = kw / 16, ksn = C / 64;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ks = 0; ks < ksn; ++ks)
+            for (int mf = 0; mf < mf0; ++mf)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, kq = lane >> 4;
+                    const int ch = wave * kw + (rho >> 2) * 4 * mf0 + mf * 4 + (rho & 3);
+                    for (int t = 0; t < 16; ++t) {
+                        const int c = ks * 64 + kq * 16 + t;
+                        out.push_back((uint8_t)w[((size_t)ch * C + c) * 9 + tap]);
+                    }
+                }
+}
+static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out) {
+    // b == nullptr (with c3): conv3x3 + first 1x1 conv only
+    if (!a || !out || (!b && !c3)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    // a sub-sampled shortcut (saber_hip_conv_desc::res_stride) is read by the conv3x3 + conv1x1 form with a strided head only
+    const bool strided = c3 && !b && c3->d.stride_h == 2 && c3->d.stride_w == 2;
+    if (!chain_1x1(a, strided) || (b && !chain_1x1(b))) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
+    if (strided != (a->d.res_stride > 1) || (strided && a->d.res_stride != 2))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: a stride-2 head goes with a shortcut sub-sampled by 2 (and only with one)");
+    const saber_hip_conv_desc& da = a->d;
+    if (da.res_mode != SABER_HIP_RES_ELTWISE || da.out_dtype != SABER_HIP_S8 || (da.res_has_dtype && da.res_dtype != SABER_HIP_S8))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: the first conv must carry the fused eltwise epilogue with s8 residual and output");
+    if (b) {
+        const saber_hip_conv_desc& db = b->d;
+        if (db.res_mode != SABER_HIP_RES_NONE || b->x_dtype != DT_S8 || (db.out_dtype != SABER_HIP_S8 && db.out_dtype != SABER_HIP_U8))
+            return fail(SABER_HIP_INVALID_VALUE, "chain: the second conv must be a plain s8-input conv with an 8-bit output");
+        if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || db.k != da.c)
+            return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
+    }
+    if (!conv1x1_chain_ok(da.c, da.k, da.c))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
+    if (c3) {
+        const saber_hip_conv_desc& d3 = c3->d;
+        const bool ok = c3->is_i8 && c3->weights_set && c3->algo == ALGO_IGEMM_I8 && c3->epi == EPI_I8_CONV && d3.kh == 3 && d3.kw == 3 &&
+                        d3.stride_h == (strided ? 2 : 1) && d3.stride_w == d3.stride_h && d3.pad_h == 1 && d3.pad_w == 1 && d3.dil_h == 1 && d3.dil_w == 1 &&
+                        d3.group == 1 && !c3->pair_k2 && !c3->pool_fused && !c3->pool2 && !c3->pre_quant && !c3->pre_pad &&
+                        c3->c_eff == d3.c && d3.act_negative_slope == 0.f && d3.in_layout == SABER_HIP_NHWC &&
+                        d3.out_layout == SABER_HIP_NHWC && d3.res_mode == SABER_HIP_RES_NONE && d3.c == da.c && d3.k == da.c &&
+                        d3.n == da.n && c3->oh == da.h && c3->ow == da.w && da.c <= 256 &&
+                        (d3.out_dtype == SABER_HIP_S8 || d3.out_dtype == SABER_HIP_U8) &&
+                        (d3.out_dtype == SABER_HIP_U8) == (a->x_dtype == DT_U8);
+        if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: the head must be the 3x3 pad-1 INT8 conv (C -> C, C <= 256; stride 1, or 2 in front of a lone 1x1 conv) whose 8-bit output the first 1x1 conv reads");
+    }
+    saber_hip_chain* ch = new saber_hip_chain();
+    const int k2 = b ? b->d.k : 0, c2 = b ? b->d.c : 0;
+    ch->c3 = c3; ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = k2;
+    ch->tn = conv1x1_chain_tn(da.c, da.n * a->oh * a->ow);
+    const int mfg2 = (k2 / 4) / 16 >= 4 ? 4 : (k2 / 4) / 16;
+    std::vector<uint8_t> stream, p0, p1, p2;
+    stream.reserve((size_t)da.k * da.c + (size_t)k2 * c2 + (c3 ? (size_t)9 * da.c * da.c : 0));
+    for (int w = 0; w < 4; ++w) {
+        if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, stream);
+        pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, stream);
+        if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, mfg2, w, stream);
+    }
+    pack_chain_params(a, (size_t)da.k / 4 * 3, p1);
+    if (b) pack_chain_params(b, ((size_t)k2 / 4 * 3 + 63) / 64 * 64, p2);
+    hipError_t e = ch->d_stream.upload(stream);
+    if (e == hipSuccess && !c3 && da.c >= 256) {
+        std::vector<uint8_t> sp;
+        sp.reserve(2 * (size_t)da.k * da.c + (size_t)k2 * c2);
+        const int k2w = k2 / 2, mfgw = (k2w / 4) / 16 >= 4 ? 4 : (k2w / 4) / 16;
+        for (int half = 0; half < 2; ++half)
+            for (int w = 0; w < 4; ++w) {
+                pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, sp);
+                pack_chain_weights(b->wq_oihw.data(), k2w, c2, mfgw, w, sp, half * k2w);
+            }
+        e = ch->d_stream_split.upload(sp);
+        if (e == hipSuccess && da.c == 256) {   // 8 waves: 128 first-conv channels (2 groups) and 16 second-conv channels per wave
+            std::vector<uint8_t> s8;
+            s8.reserve(sp.size());
+            for (int half = 0; half < 2; ++half)
+                for (int w = 0; w < 8; ++w) {
+                    pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, s8, 0, 8);
+                    pack_chain_weights(b->wq_oihw.data(), k2w, c2, 1, w, s8, half * k2w, 8);
+                }
+            e = ch->d_stream_split8.upload(s8);
+        }
+    }
+    if (e == hipSuccess && da.c == 128) {   // 8 waves: 16 channels of the 3x3 / 64 of the first / 16 of the second 1x1 conv per wave
+        std::vector<uint8_t> s8;
+        s8.reserve(stream.size());
+        for (int w = 0; w < 8; ++w) {
+            if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, s8, 8);
+            pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, s8, 0, 8);
+            if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, 1, w, s8, 0, 8);
+        }
+        e = ch->d_stream_w8.upload(s8);
+    }
+    if (e == hipSuccess) e = ch->d_prm1.upload(p1);
+    if (e == hipSuccess && b) e = ch->d_prm2.upload(p2);
+    if (e == hipSuccess && c3) {
+        pack_chain_params(c3, ((size_t)da.c / 4 * 3 + 63) / 64 * 64, p0);
+        e = ch->d_prm0.upload(p0);
+    }
+    if (e != hipSuccess) {
+        delete ch;
+        return hip_fail(e, "chain: device copies");
+    }
+    *out = ch;
+    return SABER_HIP_OK;
+}
+int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+    if (!b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    return chain_build(nullptr, a, b, out);
+}
+int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out) {
+    if (!conv3x3) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    return chain_build(conv3x3, a, b, out);
+}
+void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
+int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
+    if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
+                    (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) ||
+                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b);
+    if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
+    ch->tn = tn;
+    return SABER_HIP_OK;
+}
+int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* ch) { return ch ? ch->tn : 0; }
+int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void* res, void* y_a, void* y_b,
+                               saber_hip_stream_t stream) {
+    if (!ch || !x || !res || !y_a || (ch->b && !y_b)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv* a = ch->a;
+    const saber_hip_conv* b = ch->b;
+    ChainKArgs k;
+    std::memset(&k, 0, sizeof k);
+    k.x = x; k.res = res;
+    k.wstream = ch->tn == 11 ? ch->d_stream_split8.p : ((ch->tn & 8) ? ch->d_stream_split.p : ch->d_stream.p);
+    if (ch->c1 == 128 && (ch->tn & 4)) k.wstream = ch->d_stream_w8.p; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
+    k.y1 = y_a; k.y2 = y_b;
+    k.M = a->d.n * a->oh * a->ow;
+    k.in_u8 = a->x_dtype == DT_U8;
+    k.relu1 = a->d.act == SABER_HIP_ACT_RELU;
+    k.res_relu = a->d.res_act == SABER_HIP_ACT_RELU;
+    k.coeff_conv = a->d.coeff_conv; k.scale_conv = a->out_scale; k.coeff_res = a->d.coeff_res; k.scale_res = a->d.scale_res;
+    if (b) {
+        k.relu2 = b->d.act == SABER_HIP_ACT_RELU;
+        k.out_u8_2 = b->d.out_dtype == SABER_HIP_U8;
+    }
+    if (ch->c3) {   // x is the 3x3 conv's input; tiles of tn rows x 16 columns
+        auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };
+        k.prm0 = ch->d_prm0.p;
+        k.zero = zero_page();
+        k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
+        k.tiles_x = (k.W + 15) / 16;
+        const int rows = ch->c1 == 128 ? ch->tn & 3 : ch->tn & 7;    // tile rows (C = 128: bit 2 of the code = 8 waves)
+        k.tiles_per_img = k.tiles_x * ((k.H + rows - 1) / rows);
+        k.mg_tiles_x = magic(k.tiles_x);
+        k.mg_tpi = magic(k.tiles_per_img);
+        k.in0_u8 = ch->c3->x_dtype == DT_U8;
+        k.relu0 = ch->c3->d.act == SABER_HIP_ACT_RELU;
+        k.s0 = ch->c3->d.stride_h;
+        k.H0 = ch->c3->d.h; k.W0 = ch->c3->d.w;
+        if (a->d.res_stride > 1) { k.res_sub = a->d.res_stride; k.res_H = a->d.res_h; k.res_W = a->d.res_w; }
+    }
+    HIP_TRY(launch_conv1x1_chain(k, ch->c1, ch->k1, ch->k2, ch->tn, ch->c3 ? 1 : 0, (hipStream_t)stream));
+    return SABER_HIP_OK;
+}
+

@@ -1,0 +1,324 @@
+// anakin_amd/csrc/api_internal.h - what the translation units behind include/saber_hip.h share: error reporting, device
+// buffers, the operator structs behind the opaque handles, the autotuner's kernel-selection record and timing loop, and the
+// op-list executor's structs. Nothing here is part of the ABI (the entry points get their C linkage from saber_hip.h).
+//   api_conv.hip          convolution: create / set_tile / set_weights (quantise + repack) / run, sibling pairs
+//   api_autotune.hip      per-op autotuner (cold-L2 timing loop, kernel-reuse preference)
+//   api_ops.hip           fc, INT8 / FP32 GEMM, the streaming operators' wrappers
+//   api_chain.hip         conv1x1 chains (two / three convs in one launch): stream repacking, create / run
+//   api_net.hip           op-list executor: arena, lanes, hipGraph capture / replay, in-pass timing
+//   api_net_optimize.hip  executor-level fusions (saber_hip_net_optimize)
+//   api_net_autotune.hip  whole-net autotuner, selection save / restore
+#pragma once
+#include "../../include/saber_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <type_traits>
+#include <vector>
+
+using namespace saber_mi355x;
+
+namespace saber_api {
+
+extern thread_local std::string g_err;      // defined in api_conv.hip; saber_hip_last_error reads it
+inline int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+inline int hip_fail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return SABER_HIP_RUNTIME_ERROR;
+}
+#define HIP_TRY(expr)                                    \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int conv_out(int in, int pad, int k, int dil, int stride) {
+    return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1;  // funcs_utils.h:29-53
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        release();
+        if (h.empty()) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, h.size() * sizeof(T));
+        if (e != hipSuccess) return e;
+        n = h.size();
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    hipError_t alloc_zero(size_t count) {
+        release();
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) return e;
+        n = count;
+        e = hipMemset(p, 0, count * sizeof(T));
+        return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+    }
+};
+
+// 256 zero bytes in device memory per device, shared by every op created on it (padded taps of the LDS-DMA kernels).
+// One page per device (an op on a second GPU must not DMA from the first one's memory), created under a lock, and
+// the memset is complete before any kernel on a non-blocking stream can read it.
+void* zero_page();      // api_conv.hip
+
+enum Algo { ALGO_IGEMM_I8 = 0, ALGO_IGEMM_I8_C4 = 1, ALGO_IGEMM_F32 = 2, ALGO_DIRECT_I8 = 3, ALGO_DIRECT_F32 = 4 };
+
+}  // namespace saber_api
+using namespace saber_api;
+
+struct saber_hip_conv {
+    saber_hip_conv_desc d;
+    int oh = 0, ow = 0;
+    int algo = ALGO_DIRECT_I8;
+    int tile = TILE_64x64;
+    int ks = 1;              // 64-byte k-steps per pipeline stage (1, 2, 4)
+    int dma = 0;             // 0: register-staged kernel; 1/2/4: LDS-DMA ring kernel with that many wave groups
+    int stem = 0;            // 1: LDS-patch stem kernel (conv_stem.h) instead of the NHWC4 implicit GEMM
+    int pool_fused = 0, pool_oh = 0, pool_ow = 0;   // SaberConv2DPooling: fused stem conv + 3x3/2 max pooling
+    int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
+    int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
+    int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
+    int b3 = 0;              // FP32: 1 = the implicit GEMM runs on the bf16 matrix cores (three bf16 operand planes, conv_igemm_impl.h
+                             // MODE 3): needs c_eff % 8 == 0 and the pre-split weight planes d_w3
+    int img_ib = 0, img_rb = 0, img_nw = 4;   // img_rb > 0: small-image 3x3 kernel (conv3x3_img.h): images / output rows
+                                              // per workgroup slab, waves per workgroup (4 or 8)
+    int epi = EPI_I8_CONV;
+    bool is_i8 = false;
+    int x_dtype = DT_S8;     // dtype of the tensor the conv kernel itself reads
+    int c_eff = 0;           // channel count the conv kernel sees (after padding)
+    bool pre_quant = false;  // f32 NCHW input quantised into the workspace first
+    bool pre_pad = false;    // 8-bit C<4 input padded to NHWC4 into the workspace
+    bool pre_transpose = false;  // f32 NCHW input transposed to NHWC(c_eff) into the workspace
+    size_t ws_bytes = 0;
+    int Kg = 0, Kg_pad = 0, kw_pad = 0;
+    float in_scale = 1.f, out_scale = 1.f;
+    bool weights_set = false;
+    std::vector<int8_t> wq_oihw;
+    std::vector<float> w_scale;
+    std::vector<float> bias_host;   // the op's f32 bias as handed to set_weights (saber_hip_net_optimize re-creates ops from it)
+    std::vector<float> bias_p_host, scale_host;   // INT8: the device-side bias' / scale / comp arrays (conv1x1 chain repacks them)
+    std::vector<int> comp_host;
+    DevBuf<uint8_t> d_w;
+    DevBuf<uint8_t> d_w3;    // FP32 convs: the repacked weights split into three bf16 planes [3][K_pad][Kg_pad] (b3 variant)
+    DevBuf<float> d_bias, d_scale;
+    DevBuf<int> d_comp;
+    bool has_bias = false, has_comp = false;
+    std::string algo_name;
+    // sibling pair (saber_hip_conv2d_create_pair): d.k = k1 + k2, rows >= k1 belong to the second conv
+    int pair_k1 = 0, pair_k2 = 0, pair_relu2 = 0, pair_dtype2 = 0;
+};
+
+// two 1x1 INT8 convs in one launch (conv1x1_chain.hip); refers to the two ops, owns the repacked stream
+struct saber_hip_chain {
+    saber_hip_conv* c3 = nullptr;   // the block's 3x3 conv in front of `a` (saber_hip_conv2d_chain_create3), or null
+    saber_hip_conv* a = nullptr;
+    saber_hip_conv* b = nullptr;
+    int c1 = 0, k1 = 0, k2 = 0, tn = 0;
+    DevBuf<uint8_t> d_stream, d_prm0, d_prm1, d_prm2;
+    DevBuf<uint8_t> d_stream_split;   // 1x1 chains with C >= 256: [half][wave] streams for the split second conv (tile | 8)
+    DevBuf<uint8_t> d_stream_split8;  // C == 256: the same for 8 waves per workgroup (tile 11)
+    DevBuf<uint8_t> d_stream_w8;      // C == 128: the whole stream for 8 waves per workgroup (tile | 4)
+};
+
+struct saber_hip_fc {
+    saber_hip_fc_desc d;
+    saber_hip_conv* conv = nullptr;
+    bool pre_quant = false;
+    float in_scale = 1.f;
+};
+
+namespace saber_api {
+// one selection of kernel variant for an op (what the autotuner saves / restores)
+struct ConvChoice {
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3;
+};
+inline ConvChoice get_choice(const saber_hip_conv* op) {
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3};
+}
+inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
+    op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3;
+}
+inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
+    return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr && !op->pair_k2;
+}
+inline bool fc_small_ok(const saber_hip_conv* op) {
+    if (op->algo == ALGO_IGEMM_F32)   // FP32 fc: a 1x1 "conv" on a [m, 1, 1, k] NHWC tensor, plain f32 epilogue, no residual
+        return op->epi == EPI_F32 && op->d.h == 1 && op->d.w == 1 && op->d.kh == 1 && op->d.kw == 1 && !op->pre_transpose &&
+               op->d.out_layout == SABER_HIP_NHWC && op->d.res_mode == SABER_HIP_RES_NONE && !op->pair_k2 && !op->pool2 &&
+               fc_f32_small_ok(op->d.n, op->c_eff, op->Kg_pad);
+    return op->algo == ALGO_IGEMM_I8 && (op->epi == EPI_I8_FC_S8 || op->epi == EPI_I8_FC_U8) && op->d.h == 1 && op->d.w == 1 &&
+           fc_i8_small_ok(op->d.n, op->c_eff, op->Kg_pad);
+}
+struct EventPair {   // RAII: destroyed on every exit path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t init() {
+        hipError_t e = hipEventCreate(&e0);
+        return e != hipSuccess ? e : hipEventCreate(&e1);
+    }
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+// Times launches the way they run inside an op list: between repetitions a 64 MB stream through every XCD pushes the
+// operands out of the L2s (the Infinity Cache keeps them), so a kernel that re-reads many weights per workgroup is not
+// flattered by finding them in L2 the way a back-to-back loop of the same launch does (measured: conv3x3 + chain at
+// C = 256 reads 12.9 us back to back, 16 us in the forward pass; the two launches it replaces 13.9 -> 15.3 us).
+struct ColdBench {
+    static constexpr size_t kBytes = (size_t)64 << 20;
+    void* buf = nullptr;
+    std::vector<hipEvent_t> ev;
+    int reps = 0;
+    hipError_t init(int r) {
+        reps = r < 3 ? 3 : (r > 32 ? 32 : r);
+        hipError_t e = hipMalloc(&buf, kBytes + 256);
+        if (e != hipSuccess) return e;
+        e = hipMemset(buf, 1, kBytes + 256);
+        if (e != hipSuccess) return e;
+        ev.assign(2 * (size_t)reps, nullptr);
+        for (hipEvent_t& x : ev)
+            if ((e = hipEventCreate(&x)) != hipSuccess) return e;
+        return hipStreamSynchronize(nullptr);
+    }
+    ~ColdBench() {
+        for (hipEvent_t x : ev)
+            if (x) (void)hipEventDestroy(x);
+        if (buf) (void)hipFree(buf);
+    }
+    // median microseconds of fn() (which enqueues on s and returns a status); < 0 on failure
+    float run(hipStream_t s, const std::function<int()>& fn) {
+        if (fn() != 0) return -1.f;                  // warm-up: code, kernel arguments
+        for (int r = 0; r < reps; ++r) {
+            if (launch_l2_flush(buf, kBytes, (unsigned*)((char*)buf + kBytes), s) != hipSuccess) return -1.f;
+            if (hipEventRecord(ev[2 * r], s) != hipSuccess) return -1.f;
+            if (fn() != 0) return -1.f;
+            if (hipEventRecord(ev[2 * r + 1], s) != hipSuccess) return -1.f;
+        }
+        if (hipEventSynchronize(ev[2 * reps - 1]) != hipSuccess) return -1.f;
+        std::vector<float> t(reps);
+        for (int r = 0; r < reps; ++r)
+            if (hipEventElapsedTime(&t[r], ev[2 * r], ev[2 * r + 1]) != hipSuccess) return -1.f;
+        std::sort(t.begin(), t.end());
+        return t[reps / 2] * 1000.f;
+    }
+};
+
+// One ColdBench per top-level autotune call: nested calls (saber_hip_net_autotune -> saber_hip_conv2d_autotune) share it.
+// SABER_HIP_AUTOTUNE_WARM=1 in the environment restores the back-to-back timing loop (kept for A/B measurements).
+extern thread_local ColdBench* g_cold;      // api_autotune.hip
+// Kernel reuse across the ops of one net: the FIRST launch of a given kernel function in a forward pass pays for its cold
+// code (0.3-0.6 us on most boxes of the pool, 3-9 us on some: profiles/r02/slow_box/ - repeats of the same function
+// later in the pass run at full speed), so among candidates within g_reuse_tol of the fastest the tuner prefers a
+// function another op of the net already uses. Set by saber_hip_net_autotune for the duration of its run.
+extern thread_local std::vector<unsigned long long>* g_used_kernels;      // api_autotune.hip
+constexpr float g_reuse_tol = 0.03f;
+inline unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice& c) {
+    const saber_hip_conv_desc& d = op->d;
+    int ek = 3;   // conv_igemm.hip: epilogue_kind
+    if (op->pair_k2) ek = 4;
+    else if (op->algo != ALGO_IGEMM_F32 && op->epi == EPI_I8_CONV && d.res_mode != SABER_HIP_RES_SUM_INPLACE && d.k % 16 == 0)
+        ek = d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : (d.out_dtype == SABER_HIP_U8 ? 1 : (d.out_dtype == SABER_HIP_S8 ? 0 : 3));
+    unsigned long long k = (unsigned long long)op->algo | ((unsigned long long)ek << 4);
+    if (c.fc_small) return k | (1ull << 8) | ((unsigned long long)((op->c_eff + 255) / 256) << 16);
+    if (c.stem) return k | (2ull << 8);
+    if (c.img_rb)   // <EK, NW, CW, NCH, GPW>: channel count and pixel groups per wave
+        return k | (3ull << 8) | ((unsigned long long)op->c_eff << 16) |
+               ((unsigned long long)((c.img_ib * c.img_rb * op->ow + 15) / 16) << 32);
+    if (c.halo) return k | (4ull << 8) | ((unsigned long long)c.halo << 16) | ((unsigned long long)(op->c_eff % 128 == 0) << 24);
+    return k | ((c.b3 ? 6ull : 5ull) << 8) | ((unsigned long long)c.tile << 16) | ((unsigned long long)c.ks << 24) | ((unsigned long long)c.dma << 32);
+}
+struct ColdScope {
+    ColdBench local;
+    bool owner = false;
+    hipError_t enter(int reps) {
+        const char* w = std::getenv("SABER_HIP_AUTOTUNE_WARM");
+        if (w && w[0] == '1') return hipSuccess;      // g_cold stays null: callers fall back to the warm loop
+        if (g_cold) return hipSuccess;
+        hipError_t e = local.init(reps);
+        if (e != hipSuccess) return e;
+        g_cold = &local;
+        owner = true;
+        return hipSuccess;
+    }
+    ~ColdScope() {
+        if (owner) g_cold = nullptr;
+    }
+};
+
+}  // namespace saber_api
+
+// op-list executor
+namespace saber_api {
+enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_FC_Q, OP_SOFTMAX };
+struct NetOp {
+    OpKind kind;
+    std::string name;
+    saber_hip_conv* conv = nullptr;
+    saber_hip_fc* fc = nullptr;
+    int in = -1, in2 = -1, out = -1, out2 = -1;
+    // conv1x1 chain (saber_hip_net_optimize flag 16): this conv and the NEXT op (a 1x1 conv reading its output) run as one
+    // launch while use_chain is set; the next op carries `skip` and launches nothing
+    saber_hip_chain* chain = nullptr;
+    int chain_out = -1;
+    bool use_chain = false, skip = false;
+    // ... with the block's 3x3 conv in front (flag 32): THIS op is that 3x3 conv, the next two are the chain; while use_chain3
+    // is set it launches all three (its own output edge is then not written) and both followers carry `skip`
+    saber_hip_chain* chain3 = nullptr;
+    int chain3_res = -1, chain3_y1 = -1, chain3_y2 = -1;
+    bool use_chain3 = false;
+    int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
+    bool record = false;     // an op on the other lane consumes this op's output: record an event after it
+    int p[16] = {0};
+    float f[6] = {0};
+    size_t count = 0;
+};
+}  // namespace saber_api
+
+struct saber_hip_net {
+    std::vector<size_t> tensor_bytes;
+    std::vector<size_t> tensor_off;
+    std::vector<NetOp> ops;
+    char* arena = nullptr;
+    size_t arena_bytes = 0, ws_off = 0, ws_bytes = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool finalized = false;
+    // two-lane execution: independent branches (ResNet branch1 vs branch2a/2b) run on a side stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_op;     // one per op that needs to publish its output to the other lane
+    std::vector<int> writer;           // tensor id -> index of the op that last wrote it (-1: external)
+    bool lanes_ready = false, has_side = false;
+    std::vector<saber_hip_conv*> owned;   // ops created by saber_hip_net_optimize (destroyed with the net)
+    std::vector<saber_hip_chain*> owned_chains;
+};
+
+// helpers one translation unit defines and another uses
+bool halo_ok(const saber_hip_conv* op);      // api_conv.hip
+bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb);      // api_conv.hip
+bool stem_ok(const saber_hip_conv* op);      // api_conv.hip
+void name_algo(saber_hip_conv* op);      // api_conv.hip
+int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s);      // api_net.hip
+void net_set_chain_mode(saber_hip_net* net, int ia, int mode);      // api_net_optimize.hip
+int net_chain_mode(const saber_hip_net* net, int ia);      // api_net_optimize.hip

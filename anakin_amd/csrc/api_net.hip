@@ -1,0 +1,448 @@
+// anakin_amd/csrc/api_net.hip - the op-list executor (saber_hip_net_*): arena, two lanes, hipGraph capture / replay, timing.
+#include "api_internal.h"
+
+int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
+    auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
+    void* ws = net->arena + net->ws_off;
+    switch (o.kind) {
+    case OP_CONV:
+        if (o.skip) return SABER_HIP_OK;      // written by the previous op's chain launch
+        if (o.chain3 && o.use_chain3)
+            return saber_hip_conv2d_chain_run(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), s);
+        if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
+        return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
+    case OP_CONV_PAIR: return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
+    case OP_FC: return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
+    case OP_QUANT:
+        return saber_hip_quantize_nchw_to_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.f[0],
+                                               (const float*)T(o.in), T(o.out), s);
+    case OP_DEQUANT:
+        return saber_hip_dequantize_nhwc_to_nchw(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.f[0], T(o.in),
+                                                 (float*)T(o.out), s);
+    case OP_TRANSPOSE_IN:
+        return saber_hip_transpose_nchw_to_nhwc_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], (const float*)T(o.in),
+                                                    (float*)T(o.out), s);
+    case OP_ELT_I8:
+        return saber_hip_eltwise_sum_i8(o.count, (const int8_t*)T(o.in), (const int8_t*)T(o.in2), o.f[0], o.f[1],
+                                        o.f[2], o.f[3], o.p[0], (int8_t*)T(o.out), s);
+    case OP_ELT_F32:
+        return saber_hip_eltwise_sum_f32(o.count, (const float*)T(o.in), (const float*)T(o.in2), o.f[0], o.f[1],
+                                         o.p[0], (float*)T(o.out), s);
+    case OP_POOL_I8:
+        return saber_hip_pool2d_i8_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
+                                        o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.p[14], T(o.in), T(o.out), s);
+    case OP_POOL_F32:
+        return saber_hip_pool2d_f32(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.p[9],
+                                    o.p[10], o.p[11], o.p[12], o.p[13], (const float*)T(o.in), (float*)T(o.out), s);
+    case OP_POOL_F32_I8:
+        return saber_hip_pool2d_f32_from_i8_q(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
+                                              o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.f[0], T(o.in),
+                                              (float*)T(o.out), o.f[1], (int8_t*)T(o.out2), s);
+    case OP_FC_Q: return saber_hip_fc_run_q(o.fc, (const int8_t*)T(o.in), (float*)T(o.out), s);
+    case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
+    }
+    return SABER_HIP_UNIMPL;
+}
+
+
+int saber_hip_net_create(saber_hip_net_t** out) {
+    *out = new saber_hip_net();
+    return SABER_HIP_OK;
+}
+int saber_hip_net_add_tensor(saber_hip_net_t* net, size_t bytes) {
+    net->tensor_bytes.push_back(bytes);
+    return (int)net->tensor_bytes.size() - 1;
+}
+static int push(saber_hip_net* net, NetOp&& o) {
+    const int nt = (int)net->tensor_bytes.size();
+    if (o.in >= nt || o.in2 >= nt || o.out >= nt || o.in < 0 || o.out < 0) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    net->ops.push_back(std::move(o));
+    return (int)net->ops.size() - 1;
+}
+int saber_hip_net_add_conv(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id, int out_id, int res_id) {
+    NetOp o;
+    o.kind = OP_CONV; o.conv = op; o.in = in_id; o.out = out_id; o.in2 = res_id;
+    o.name = std::string("conv:") + op->algo_name;
+    if (op->ws_bytes > net->ws_bytes) net->ws_bytes = op->ws_bytes;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_conv_pair(saber_hip_net_t* net, saber_hip_conv_t* op, int in_id, int out_a_id, int out_b_id) {
+    if (!op || !op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "not a sibling pair");
+    if (out_b_id < 0 || out_b_id >= (int)net->tensor_bytes.size()) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    NetOp o;
+    o.kind = OP_CONV_PAIR; o.conv = op; o.in = in_id; o.out = out_a_id; o.out2 = out_b_id;
+    o.name = std::string("conv:") + op->algo_name;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_fc(saber_hip_net_t* net, saber_hip_fc_t* op, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_FC; o.fc = op; o.in = in_id; o.out = out_id;
+    o.name = std::string("fc:") + op->conv->algo_name;
+    const size_t w = saber_hip_fc_workspace_bytes(op);
+    if (w > net->ws_bytes) net->ws_bytes = w;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_quantize(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                               int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_QUANT; o.in = in_id; o.out = out_id; o.name = "quantize_nchw_to_nhwc";
+    o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = c_pad; o.p[5] = out_dtype; o.f[0] = scale;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_dequantize(saber_hip_net_t* net, int n, int c, int h, int w, int in_dtype, float scale,
+                                 int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_DEQUANT; o.in = in_id; o.out = out_id; o.name = "dequantize_nhwc_to_nchw";
+    o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = in_dtype; o.f[0] = scale;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_transpose_in_f32(saber_hip_net_t* net, int n, int c, int h, int w, int c_pad, int in_id,
+                                       int out_id) {
+    NetOp o;
+    o.kind = OP_TRANSPOSE_IN; o.in = in_id; o.out = out_id; o.name = "transpose_nchw_to_nhwc_f32";
+    o.p[0] = n; o.p[1] = c; o.p[2] = h; o.p[3] = w; o.p[4] = c_pad;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_eltwise_i8(saber_hip_net_t* net, size_t count, float sa, float sb, float c0, float c1, int relu,
+                                 int a_id, int b_id, int out_id) {
+    NetOp o;
+    o.kind = OP_ELT_I8; o.in = a_id; o.in2 = b_id; o.out = out_id; o.count = count; o.name = "eltwise_sum_i8";
+    o.f[0] = sa; o.f[1] = sb; o.f[2] = c0; o.f[3] = c1; o.p[0] = relu;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_eltwise_f32(saber_hip_net_t* net, size_t count, float c0, float c1, int relu, int a_id, int b_id,
+                                  int out_id) {
+    NetOp o;
+    o.kind = OP_ELT_F32; o.in = a_id; o.in2 = b_id; o.out = out_id; o.count = count; o.name = "eltwise_sum_f32";
+    o.f[0] = c0; o.f[1] = c1; o.p[0] = relu;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh,
+                              int sw, int ph, int pw, int type, int in_dtype, int out_dtype, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_POOL_I8; o.in = in_id; o.out = out_id; o.name = "pool2d_i8_nhwc";
+    const int v[15] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, out_dtype};
+    std::memcpy(o.p, v, sizeof v);
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_f32(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh,
+                               int sw, int ph, int pw, int type, int layout, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_POOL_F32; o.in = in_id; o.out = out_id; o.name = "pool2d_f32";
+    const int v[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout};
+    std::memcpy(o.p, v, sizeof v);
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_f32_from_i8(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                                       int sh, int sw, int ph, int pw, int type, int in_dtype, float scale, int in_id,
+                                       int out_id) {
+    NetOp o;
+    o.kind = OP_POOL_F32_I8; o.in = in_id; o.out = out_id; o.name = "pool2d_f32_from_i8";
+    const int v[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype};
+    std::memcpy(o.p, v, sizeof v);
+    o.f[0] = scale;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_pool_f32_from_i8_q(saber_hip_net_t* net, int n, int h, int w, int c, int oh, int ow, int kh, int kw,
+                                         int sh, int sw, int ph, int pw, int type, int in_dtype, float scale, int in_id,
+                                         int out_id, float q_scale, int q_out_id) {
+    if (q_out_id < 0 || q_out_id >= (int)net->tensor_bytes.size()) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    int idx = saber_hip_net_add_pool_f32_from_i8(net, n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale,
+                                                 in_id, out_id);
+    if (idx < 0) return idx;
+    net->ops[idx].out2 = q_out_id;
+    net->ops[idx].f[1] = q_scale;
+    net->ops[idx].name = "pool2d_f32_from_i8+quantize";
+    return idx;
+}
+int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id, int out_id) {
+    NetOp o;
+    o.kind = OP_FC_Q; o.fc = op; o.in = in_q_id; o.out = out_id;
+    o.name = std::string("fc:") + op->conv->algo_name;
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_SOFTMAX; o.in = in_id; o.out = out_id; o.name = "softmax_f32";
+    o.p[0] = rows; o.p[1] = cols;
+    return push(net, std::move(o));
+}
+
+int saber_hip_net_finalize(saber_hip_net_t* net) {
+    if (net->finalized) return SABER_HIP_OK;
+    size_t off = 0;
+    net->tensor_off.resize(net->tensor_bytes.size());
+    for (size_t i = 0; i < net->tensor_bytes.size(); ++i) {
+        net->tensor_off[i] = off;
+        off += (net->tensor_bytes[i] + 255) / 256 * 256;
+    }
+    net->ws_off = off;
+    off += (net->ws_bytes + 255) / 256 * 256;
+    net->arena_bytes = off ? off : 256;
+    HIP_TRY(hipMalloc((void**)&net->arena, net->arena_bytes));
+    HIP_TRY(hipMemset(net->arena, 0, net->arena_bytes));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // the kernels run on non-blocking streams: not ordered after null-stream work
+    net->finalized = true;
+    return SABER_HIP_OK;
+}
+void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id) {
+    if (!net->finalized || id < 0 || id >= (int)net->tensor_off.size()) return nullptr;
+    return net->arena + net->tensor_off[id];
+}
+size_t saber_hip_net_arena_bytes(const saber_hip_net_t* net) { return net->arena_bytes; }
+int saber_hip_net_num_ops(const saber_hip_net_t* net) { return (int)net->ops.size(); }
+const char* saber_hip_net_op_name(const saber_hip_net_t* net, int i) {
+    return (i >= 0 && i < (int)net->ops.size()) ? net->ops[i].name.c_str() : "";
+}
+static int net_prepare_lanes(saber_hip_net* net) {
+    if (net->lanes_ready) return SABER_HIP_OK;
+    const int nops = (int)net->ops.size();
+    net->writer.assign(net->tensor_bytes.size(), -1);
+    net->ev_op.assign(nops, nullptr);
+    net->has_side = false;
+    std::vector<int> w(net->tensor_bytes.size(), -1);
+    std::vector<std::vector<int>> rd(net->tensor_bytes.size());   // ops that read a tensor since its last write
+    for (int i = 0; i < nops; ++i) {
+        NetOp& o = net->ops[i];
+        if (o.lane) net->has_side = true;
+        const int ins[3] = {o.in, o.in2, o.out};   // `out` counts as an input: in-place epilogues read it
+        for (int t : ins)
+            if (t >= 0 && w[t] >= 0 && net->ops[w[t]].lane != o.lane) net->ops[w[t]].record = true;   // RAW / WAW
+        const int outs[2] = {o.out, o.out2};
+        for (int t : outs) {
+            if (t < 0) continue;
+            for (int r : rd[t])
+                if (net->ops[r].lane != o.lane) net->ops[r].record = true;   // WAR: a reader on the other lane must finish first
+            rd[t].clear();
+            w[t] = i;
+        }
+        if (o.in >= 0) rd[o.in].push_back(i);
+        if (o.in2 >= 0) rd[o.in2].push_back(i);
+    }
+    if (net->has_side) {
+        HIP_TRY(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&net->ev_start, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+        for (int i = 0; i < nops; ++i)
+            if (net->ops[i].record) HIP_TRY(hipEventCreateWithFlags(&net->ev_op[i], hipEventDisableTiming));
+    }
+    net->lanes_ready = true;
+    return SABER_HIP_OK;
+}
+
+int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream) {
+    if (!net->finalized) return fail(SABER_HIP_INVALID_VALUE, "net not finalized");
+    int rc = net_prepare_lanes(net);
+    if (rc) return rc;
+    hipStream_t main_s = (hipStream_t)stream;
+    if (!net->has_side) {
+        for (const NetOp& o : net->ops) {
+            rc = net_launch(net, o, main_s);
+            if (rc) return rc;
+        }
+        return SABER_HIP_OK;
+    }
+    // fork: the side lane starts after everything already queued on the caller's stream
+    HIP_TRY(hipEventRecord(net->ev_start, main_s));
+    HIP_TRY(hipStreamWaitEvent(net->side, net->ev_start, 0));
+    std::fill(net->writer.begin(), net->writer.end(), -1);
+    std::vector<std::vector<int>> readers(net->tensor_bytes.size());
+    bool side_dirty = false;
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        const NetOp& o = net->ops[i];
+        hipStream_t s = o.lane ? net->side : main_s;
+        const int ins[3] = {o.in, o.in2, o.out};
+        for (int t : ins) {
+            if (t < 0) continue;
+            const int wi = net->writer[t];
+            if (wi >= 0 && net->ops[wi].lane != o.lane) HIP_TRY(hipStreamWaitEvent(s, net->ev_op[wi], 0));
+        }
+        const int outs[2] = {o.out, o.out2};
+        for (int t : outs) {   // write-after-read across lanes: every reader of the old contents has to be done
+            if (t < 0) continue;
+            for (int r : readers[t])
+                if (net->ops[r].lane != o.lane) HIP_TRY(hipStreamWaitEvent(s, net->ev_op[r], 0));
+            readers[t].clear();
+        }
+        rc = net_launch(net, o, s);
+        if (rc) return rc;
+        if (o.record) HIP_TRY(hipEventRecord(net->ev_op[i], s));
+        if (o.lane) side_dirty = true;
+        net->writer[o.out] = (int)i;
+        if (o.out2 >= 0) net->writer[o.out2] = (int)i;
+        if (o.in >= 0) readers[o.in].push_back((int)i);
+        if (o.in2 >= 0) readers[o.in2].push_back((int)i);
+    }
+    if (side_dirty) {   // join: required before a capture ends, and so that the caller sees one ordered stream
+        HIP_TRY(hipEventRecord(net->ev_join, net->side));
+        HIP_TRY(hipStreamWaitEvent(main_s, net->ev_join, 0));
+    }
+    return SABER_HIP_OK;
+}
+int saber_hip_net_set_lane(saber_hip_net_t* net, int index, int lane) {
+    if (index < 0 || index >= (int)net->ops.size() || lane < 0 || lane > 1) return fail(SABER_HIP_INVALID_VALUE, "bad op index / lane");
+    if (net->lanes_ready) return fail(SABER_HIP_INVALID_VALUE, "lanes are fixed after the first run");
+    for (const NetOp& o : net->ops)
+        if (lane && (o.chain || o.chain3))
+            return fail(SABER_HIP_INVALID_VALUE, "the net has conv1x1 chain launches: lanes must be assigned before saber_hip_net_optimize (a chain launch spans several ops' tensors)");
+    if (lane) {   // both lanes share the arena's single workspace: an op that uses it stays on the main lane
+        const NetOp& o = net->ops[index];
+        const size_t ws = o.kind == OP_CONV && o.conv ? o.conv->ws_bytes : (o.kind == OP_FC && o.fc ? saber_hip_fc_workspace_bytes(o.fc) : 0);
+        if (ws) return fail(SABER_HIP_INVALID_VALUE, "an op that needs the shared workspace cannot run on the side lane");
+    }
+    net->ops[index].lane = lane;
+    return SABER_HIP_OK;
+}
+int saber_hip_net_run_op(saber_hip_net_t* net, int index, saber_hip_stream_t stream) {
+    if (!net->finalized || index < 0 || index >= (int)net->ops.size()) return fail(SABER_HIP_INVALID_VALUE, "bad op index");
+    return net_launch(net, net->ops[index], (hipStream_t)stream);
+}
+int saber_hip_net_capture(saber_hip_net_t* net, saber_hip_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (net->exec) {
+        (void)hipGraphExecDestroy(net->exec);
+        (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = saber_hip_net_run(net, stream);
+    hipError_t e = hipStreamEndCapture(s, &net->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+    HIP_TRY(hipGraphInstantiate(&net->exec, net->graph, nullptr, nullptr, 0));
+    return SABER_HIP_OK;
+}
+int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream) {
+    if (!net->exec) return fail(SABER_HIP_INVALID_VALUE, "net not captured");
+    HIP_TRY(hipGraphLaunch(net->exec, (hipStream_t)stream));
+    return SABER_HIP_OK;
+}
+// Algorithmic work of ONE launch of op `index` (every tensor touched once — input, output, residual — plus the
+// weights once; MACs x 2), summed over the operators the launch covers (a chain head reports its followers' work too, the
+// followers report 0). Streaming ops: bytes only.
+static void conv_work(const saber_hip_conv* c, double& bytes, double& flops) {
+    const saber_hip_conv_desc& d = c->d;
+    const double esz_in = d.in_dtype == SABER_HIP_F32 ? 4 : 1, esz_out = d.out_dtype == SABER_HIP_F32 ? 4 : 1;
+    const double esz_w = c->is_i8 ? 1 : 4;
+    const double in_el = (double)d.n * d.h * d.w * d.c;
+    const int oh = c->oh, ow = c->ow;
+    // a sibling pair carries k = k1 + k2 output channels; a fused pooling writes the pooled tensor
+    const double out_el = (double)d.n * ((c->pool_fused || c->pool2) ? c->pool_oh * c->pool_ow : oh * ow) * d.k;
+    bytes += in_el * esz_in + out_el * esz_out + (double)d.k * (d.c / d.group) * d.kh * d.kw * esz_w;
+    if (d.res_mode != SABER_HIP_RES_NONE) bytes += (double)d.n * oh * ow * d.k * esz_out;
+    flops += 2.0 * d.n * oh * ow * (double)d.k * (d.c / d.group) * d.kh * d.kw;
+}
+int saber_hip_net_op_work(const saber_hip_net_t* net, int index, double* bytes, double* flops) {
+    if (!net || index < 0 || index >= (int)net->ops.size() || !bytes || !flops) return fail(SABER_HIP_INVALID_VALUE, "bad argument");
+    *bytes = 0; *flops = 0;
+    const NetOp& o = net->ops[index];
+    auto tb = [&](int t) { return t >= 0 ? (double)net->tensor_bytes[t] : 0.0; };
+    switch (o.kind) {
+    case OP_CONV:
+        if (o.skip) return SABER_HIP_OK;
+        conv_work(o.conv, *bytes, *flops);
+        if (o.chain3 && o.use_chain3) {
+            for (int j = index + 1; j < (int)net->ops.size() && net->ops[j].skip; ++j) conv_work(net->ops[j].conv, *bytes, *flops);
+        } else if (o.chain && o.use_chain) {
+            if (index + 1 < (int)net->ops.size() && net->ops[index + 1].skip) conv_work(net->ops[index + 1].conv, *bytes, *flops);
+        }
+        return SABER_HIP_OK;
+    case OP_CONV_PAIR: conv_work(o.conv, *bytes, *flops); return SABER_HIP_OK;
+    case OP_FC:
+    case OP_FC_Q: {
+        const saber_hip_fc_desc& d = o.fc->d;
+        const double esz = d.int8_weights ? 1 : 4;
+        *bytes = (double)d.m * d.k * (o.kind == OP_FC_Q || d.in_dtype != SABER_HIP_F32 ? 1 : 4) + (double)d.m * d.n * 4 + (double)d.n * d.k * esz;
+        *flops = 2.0 * d.m * d.n * d.k;
+        return SABER_HIP_OK;
+    }
+    default: *bytes = tb(o.in) + tb(o.in2) + tb(o.out) + tb(o.out2); return SABER_HIP_OK;
+    }
+}
+// Per-op time INSIDE a forward pass: one event after every launch of an eager pass, averaged over `iters` passes
+// (out_us[i] = event[i] - event[i-1]; skipped ops report 0). Unlike saber_hip_net_time_ops (each op repeated back to back,
+// operands warm) this is the op in its place in the pipeline, boundary included; the events themselves add to the pass, so
+// use the SHARES and scale them to the untimed step time.
+int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {
+    if (!net || !net->finalized || iters <= 0 || !out_us) return fail(SABER_HIP_INVALID_VALUE, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = net->ops.size();
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters + 1; ++it) {      // the first pass warms up and is dropped
+        HIP_TRY(hipEventRecord(ev[0], s));
+        size_t last = 0;                          // index (into ev) of the newest recorded event
+        std::vector<size_t> prev(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const NetOp& o = net->ops[i];
+            int rc = net_launch(net, o, s);
+            if (rc) return rc;
+            prev[i] = last;
+            if (o.kind == OP_CONV && o.skip) continue;     // launches nothing: no event (a marker packet costs ~2.5 us itself)
+            HIP_TRY(hipEventRecord(ev[i + 1], s));
+            last = i + 1;
+        }
+        HIP_TRY(hipEventSynchronize(ev[last]));
+        if (!it) continue;
+        for (size_t i = 0; i < n; ++i) {
+            const NetOp& o = net->ops[i];
+            if (o.kind == OP_CONV && o.skip) continue;
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[prev[i]], ev[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) out_us[i] = (float)(acc[i] * 1000.0 / iters);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return SABER_HIP_OK;
+}
+int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        int rc = net_launch(net, net->ops[i], s);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e0, s));
+        for (int it = 0; it < iters; ++it) net_launch(net, net->ops[i], s);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        out_us[i] = ms * 1000.f / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SABER_HIP_OK;
+}
+// 1 when tensor `id` is the output edge of a 3x3 conv that currently runs inside a conv3x3 + chain launch (not written)
+int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id) {
+    if (id < 0 || id >= (int)net->tensor_bytes.size()) return 0;
+    if (net->tensor_bytes[id] == 0) return 1;      // the edge was removed by saber_hip_net_optimize (it has no storage)
+    for (const NetOp& o : net->ops)
+        if (o.chain3 && o.use_chain3 && o.out == id) return 1;
+    return 0;
+}
+int saber_hip_net_num_launches(const saber_hip_net_t* net) {
+    int n = 0;
+    for (const NetOp& o : net->ops) n += o.skip ? 0 : 1;
+    return n;
+}
+void saber_hip_net_destroy(saber_hip_net_t* net) {
+    if (!net) return;
+    if (net->exec) (void)hipGraphExecDestroy(net->exec);
+    if (net->graph) (void)hipGraphDestroy(net->graph);
+    if (net->arena) (void)hipFree(net->arena);
+    for (saber_hip_chain* c : net->owned_chains) saber_hip_conv2d_chain_destroy(c);
+    for (saber_hip_conv* c : net->owned) saber_hip_conv2d_destroy(c);
+    for (hipEvent_t e : net->ev_op)
+        if (e) (void)hipEventDestroy(e);
+    if (net->ev_start) (void)hipEventDestroy(net->ev_start);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->side) (void)hipStreamDestroy(net->side);
+    delete net;
+}
+

@@ -1,0 +1,296 @@
+// anakin_amd/csrc/api_ops.hip - fully connected, INT8 / FP32 GEMM and the streaming operators of include/saber_hip.h.
+#include "api_internal.h"
+
+// ================================================================================================
+// fully connected: a 1x1 convolution over a [m,1,1,k] tensor with the FC epilogues
+// ================================================================================================
+int saber_hip_fc_create(const saber_hip_fc_desc* desc, saber_hip_fc_t** out) {
+    if (!desc || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    saber_hip_conv_desc c;
+    std::memset(&c, 0, sizeof c);
+    c.n = desc->m; c.h = 1; c.w = 1; c.c = desc->k; c.k = desc->n; c.kh = c.kw = 1;
+    c.stride_h = c.stride_w = c.dil_h = c.dil_w = c.group = 1;
+    c.in_layout = c.out_layout = SABER_HIP_NHWC;
+    c.out_dtype = SABER_HIP_F32;
+    c.int8_weights = desc->int8_weights;
+    auto* fc = new saber_hip_fc();
+    fc->d = *desc;
+    if (desc->int8_weights) {
+        if (desc->in_dtype == SABER_HIP_F32) {
+            fc->pre_quant = true;  // PackedMKLInt8Gemm::dispatch: scale_fp32_int8 (mkl_packed_int8_gemm.cpp:52-57)
+            c.in_dtype = SABER_HIP_S8;
+        } else {
+            c.in_dtype = desc->in_dtype;
+        }
+    } else {
+        c.in_dtype = SABER_HIP_F32;
+    }
+    int rc = saber_hip_conv2d_create(&c, &fc->conv);
+    if (rc) {
+        delete fc;
+        return rc;
+    }
+    if (desc->int8_weights) {
+        if (fc->conv->algo != ALGO_IGEMM_I8) {
+            saber_hip_conv2d_destroy(fc->conv);
+            delete fc;
+            return fail(SABER_HIP_UNIMPL, "INT8 fc needs k % 16 == 0");
+        }
+        fc->conv->epi = c.in_dtype == SABER_HIP_U8 ? EPI_I8_FC_U8 : EPI_I8_FC_S8;
+        if (fc_small_ok(fc->conv)) {   // STATIC choice for inference batches (<= 16 rows): the weight-streaming kernel
+            fc->conv->fc_small = 1;
+            name_algo(fc->conv);
+        }
+    } else if (fc_small_ok(fc->conv)) {   // FP32: likewise
+        fc->conv->fc_small = 1;
+        name_algo(fc->conv);
+    }
+    *out = fc;
+    return SABER_HIP_OK;
+}
+
+int saber_hip_fc_set_weights(saber_hip_fc_t* fc, const void* w, int w_dtype, const float* w_scale,
+                             const float* bias, float in_scale, float out_scale) {
+    const int N = fc->d.n, K = fc->d.k;
+    fc->in_scale = in_scale;
+    // bring the weights to [n,k]
+    std::vector<uint8_t> wt;
+    const void* wnk = w;
+    const size_t es = w_dtype == SABER_HIP_F32 ? 4 : 1;
+    if (fc->d.w_is_kn) {
+        wt.resize((size_t)N * K * es);
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k)
+                std::memcpy(&wt[((size_t)n * K + k) * es], (const uint8_t*)w + ((size_t)k * N + n) * es, es);
+        wnk = wt.data();
+    }
+    saber_hip_conv* op = fc->conv;
+    if (!fc->d.int8_weights) return saber_hip_conv2d_set_weights(op, wnk, w_dtype, w_scale, bias, 1.f, 1.f);
+    // INT8: the conv-style set_weights gives us quantised weights + comp; then override scale/bias
+    int rc = saber_hip_conv2d_set_weights(op, wnk, w_dtype, w_scale, nullptr, in_scale, out_scale);
+    if (rc) return rc;
+    const int K_pad = round_up(N, 128);
+    std::vector<float> scale(K_pad, 0.f), b(K_pad, 0.f);
+    if (op->epi == EPI_I8_FC_S8) {
+        // _scale[n] = w_scale[n] * scale_a; out = acc*scale + bias   (mkl_packed_int8_gemm.cpp:36-38,78-81)
+        for (int n = 0; n < N; ++n) {
+            scale[n] = op->w_scale[n] * in_scale;
+            if (bias) b[n] = bias[n];
+        }
+        op->has_bias = bias != nullptr;
+        HIP_TRY(op->d_bias.upload(b));
+        HIP_TRY(op->d_scale.upload(scale));
+    } else {
+        // u8 input (vender_fc.cpp:284-300): scale = (in_scale*w_scale)/out_scale; bias_i = (int)(bias/scale)
+        std::vector<int> comp(K_pad, 0);
+        const int8_t* q = op->wq_oihw.data();
+        for (int n = 0; n < N; ++n) {
+            scale[n] = (in_scale * op->w_scale[n]) / out_scale;
+            int s = 0;
+            for (int k = 0; k < K; ++k) s += (int)q[(size_t)n * K + k];
+            comp[n] = 128 * s + (bias ? (int)(bias[n] / scale[n]) : 0);
+        }
+        op->has_bias = false;
+        op->has_comp = true;
+        HIP_TRY(op->d_comp.upload(comp));
+        HIP_TRY(op->d_scale.upload(scale));
+    }
+    return SABER_HIP_OK;
+}
+
+size_t saber_hip_fc_workspace_bytes(const saber_hip_fc_t* fc) {
+    return fc->pre_quant ? (size_t)fc->d.m * fc->d.k : 0;
+}
+
+int saber_hip_fc_run(saber_hip_fc_t* fc, const void* x, float* y, void* workspace, saber_hip_stream_t stream) {
+    const void* xin = x;
+    if (fc->pre_quant) {
+        if (!workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
+        HIP_TRY(launch_quantize_flat_s8((size_t)fc->d.m * fc->d.k, fc->in_scale, (const float*)x, (int8_t*)workspace,
+                                        (hipStream_t)stream));
+        xin = workspace;
+    }
+    return saber_hip_conv2d_run(fc->conv, xin, y, nullptr, nullptr, stream);
+}
+
+int saber_hip_fc_run_q(saber_hip_fc_t* fc, const int8_t* xq, float* y, saber_hip_stream_t stream) {
+    if (!fc || !xq || !y) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!fc->d.int8_weights || fc->conv->x_dtype != DT_S8) return fail(SABER_HIP_INVALID_VALUE, "fc_run_q: INT8 fc with s8 operand only");
+    return saber_hip_conv2d_run(fc->conv, xq, y, nullptr, nullptr, stream);
+}
+
+const char* saber_hip_fc_algo(const saber_hip_fc_t* fc) { return fc ? fc->conv->algo_name.c_str() : ""; }
+int saber_hip_fc_set_tile(saber_hip_fc_t* fc, int tile) {
+    if (!fc) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    return saber_hip_conv2d_set_tile(fc->conv, tile);
+}
+void saber_hip_fc_destroy(saber_hip_fc_t* fc) {
+    if (fc) saber_hip_conv2d_destroy(fc->conv);
+    delete fc;
+}
+
+// ================================================================================================
+// INT8 GEMM: C[m,n] (int32) = op(A)[m,k] (s8|u8) x op(B)[k,n] (s8), exact; B packed at create time
+// (MklDnnGemm<int8_t|uint8_t, int8_t, int> in PACKED_MKLGEMM mode, saber/funcs/impl/x86/mkl_gemm.cpp:138-256).
+// Runs on the implicit-GEMM kernel as a 1x1 convolution over [m,1,1,k] with the raw-accumulator epilogue.
+// ================================================================================================
+struct saber_hip_gemm_i8 {
+    int trans_a = 0, m = 0, n = 0, k = 0, k_pad = 0;
+    saber_hip_conv* conv = nullptr;
+};
+
+int saber_hip_gemm_i8_create(int trans_a, int trans_b, int m, int n, int k, int a_dtype, const int8_t* b_host,
+                             saber_hip_gemm_i8_t** out) {
+    if (!out || !b_host) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
+    if (a_dtype != SABER_HIP_S8 && a_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "A must be s8 or u8");
+    auto* g = new saber_hip_gemm_i8();
+    g->trans_a = trans_a ? 1 : 0; g->m = m; g->n = n; g->k = k; g->k_pad = round_up(k, 16);
+    saber_hip_conv_desc c;
+    std::memset(&c, 0, sizeof c);
+    c.n = m; c.h = 1; c.w = 1; c.c = g->k_pad; c.k = n; c.kh = c.kw = 1;
+    c.stride_h = c.stride_w = c.dil_h = c.dil_w = c.group = 1;
+    c.in_layout = c.out_layout = SABER_HIP_NHWC;
+    c.in_dtype = a_dtype;
+    c.out_dtype = SABER_HIP_F32;       // 4-byte outputs: the raw epilogue stores int32 bit patterns
+    c.int8_weights = 1;
+    int rc = saber_hip_conv2d_create(&c, &g->conv);
+    if (rc) { delete g; return rc; }
+    // op(B)[k,n] -> weight rows [n][k_pad]
+    std::vector<int8_t> w((size_t)n * g->k_pad, 0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < k; ++i) w[(size_t)j * g->k_pad + i] = trans_b ? b_host[(size_t)j * k + i] : b_host[(size_t)i * n + j];
+    std::vector<float> ones(n, 1.f);
+    rc = saber_hip_conv2d_set_weights(g->conv, w.data(), SABER_HIP_S8, ones.data(), nullptr, 1.f, 1.f);
+    if (rc) { saber_hip_conv2d_destroy(g->conv); delete g; return rc; }
+    g->conv->epi = EPI_I8_RAW_S32;
+    *out = g;
+    return SABER_HIP_OK;
+}
+size_t saber_hip_gemm_i8_workspace_bytes(const saber_hip_gemm_i8_t* g) {
+    return (g->trans_a || g->k_pad != g->k) ? (size_t)g->m * g->k_pad : 0;
+}
+int saber_hip_gemm_i8_run(saber_hip_gemm_i8_t* g, const void* a, int32_t* c, void* workspace, saber_hip_stream_t stream) {
+    if (!g || !a || !c) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const void* ain = a;
+    if (saber_hip_gemm_i8_workspace_bytes(g)) {
+        if (!workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
+        if (g->trans_a) HIP_TRY(launch_transpose_bytes(g->k, g->m, g->k_pad, a, workspace, (hipStream_t)stream));   // A is [k][m]
+        else HIP_TRY(launch_pad_channels_i8((size_t)g->m, g->k, g->k_pad, a, workspace, (hipStream_t)stream));
+        ain = workspace;
+    }
+    return saber_hip_conv2d_run(g->conv, ain, c, nullptr, nullptr, stream);
+}
+void saber_hip_gemm_i8_destroy(saber_hip_gemm_i8_t* g) {
+    if (g) saber_hip_conv2d_destroy(g->conv);
+    delete g;
+}
+
+// ================================================================================================
+// thin wrappers
+// ================================================================================================
+int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b, float beta,
+                       float* c, saber_hip_stream_t s) {
+    if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
+    HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
+                                    const float* x, void* y, saber_hip_stream_t s) {
+    if (c_pad < c || (out_dtype != SABER_HIP_S8 && out_dtype != SABER_HIP_U8))
+        return fail(SABER_HIP_INVALID_VALUE, "bad quantize arguments");
+    if ((size_t)n * c * h * w == 0) return SABER_HIP_OK;
+    HIP_TRY(launch_quantize_nchw_to_nhwc(n, c, h, w, c_pad, out_dtype, scale, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_dequantize_nhwc_to_nchw(int n, int c, int h, int w, int in_dtype, float scale, const void* x,
+                                      float* y, saber_hip_stream_t s) {
+    if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
+    if ((size_t)n * c * h * w == 0) return SABER_HIP_OK;
+    HIP_TRY(launch_dequantize_nhwc_to_nchw(n, c, h, w, in_dtype, scale, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                         saber_hip_stream_t s) {
+    HIP_TRY(launch_transpose_nchw_to_nhwc_f32(n, c, h, w, c_pad, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
+                                         saber_hip_stream_t s) {
+    HIP_TRY(launch_transpose_nhwc_to_nchw_f32(n, c, h, w, c_pad, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_quantize_flat_s8(count, scale, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float sa, float sb, float c0, float c1,
+                             int relu, int8_t* y, saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_eltwise_sum_i8(count, a, b, sa, sb, c0, c1, relu, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, float c0, float c1, int relu, float* y,
+                              saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_eltwise_sum_f32(count, a, b, c0, c1, relu, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_relu_f32(size_t count, const float* x, float* y, saber_hip_stream_t s) {
+    if (!count) return SABER_HIP_OK;
+    HIP_TRY(launch_relu_f32(count, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_pool_out_dim2(int in, int pad, int window, int stride, int floor_mode, int any_pad) {
+    int o;  // Pooling<>::compute_output_shape, saber/funcs/pooling.h:92-121
+    if (floor_mode) {
+        o = (int)((float)(in + 2 * pad - window) / stride) + 1;
+        if (o <= 0) o = 1;
+    } else {
+        o = (int)ceilf((float)(in + 2 * pad - window) / stride) + 1;
+    }
+    // the reference applies the clip to BOTH dimensions whenever pooling_padded(), i.e. pad_h || pad_w
+    // (pooling.h:113-120, saber_funcs_param.h:2141), not per dimension
+    if (any_pad && (o - 1) * stride >= in + pad) --o;
+    return o;
+}
+int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode) {
+    return saber_hip_pool_out_dim2(in, pad, window, stride, floor_mode, pad > 0);
+}
+int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                             int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
+                             saber_hip_stream_t s) {
+    if (type == SABER_HIP_POOL_MAX && out_dtype == SABER_HIP_F32)
+        return fail(SABER_HIP_UNIMPL, "dst format (AK_FLOAT) and pooling type (Pooling_max): NOT supported");
+    HIP_TRY(launch_pool2d_i8_nhwc(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, out_dtype, x, y,
+                                  (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int type, int layout, const float* x, float* y, saber_hip_stream_t s) {
+    HIP_TRY(launch_pool2d_f32(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout == SABER_HIP_NCHW, x, y,
+                              (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_pool2d_f32_from_i8_q(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                                   int pw, int type, int in_dtype, float scale, const void* x, float* y, float q_scale,
+                                   int8_t* yq, saber_hip_stream_t s) {
+    if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
+    if (yq && !(q_scale > 0.f)) return fail(SABER_HIP_INVALID_VALUE, "bad quantisation scale");
+    HIP_TRY(launch_pool2d_f32_from_i8(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y, q_scale,
+                                      yq, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph,
+                                 int pw, int type, int in_dtype, float scale, const void* x, float* y,
+                                 saber_hip_stream_t s) {
+    return saber_hip_pool2d_f32_from_i8_q(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y, 1.f,
+                                          nullptr, s);
+}
+int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t s) {
+    if (rows <= 0 || cols <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad softmax shape");
+    HIP_TRY(launch_softmax_f32(rows, cols, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+
