@@ -101,6 +101,7 @@ static_assert(offsetof(ConvKArgs, y) == 128, "hot kernel arguments fill exactly 
 
 // conv1x1_chain_kernel (conv1x1_chain.hip): a 1x1 conv with the fused eltwise epilogue (ResNet branch2c + sum + relu)
 // followed by the next block's 1x1 branch2a conv on the same pixels, one launch.
+constexpr int STAGE_MAX_TENSORS = 24;
 struct ChainKArgs {
     const void* x;        // first conv's input [M][C1], s8 or u8
     const void* wstream;  // both convs' s8 weights in the order the four waves consume them (api.hip: pack_chain_stream)
@@ -128,6 +129,37 @@ bool conv1x1_chain_ok(int c1, int k1, int k2);
 int conv1x1_chain_tn(int c1, int m);
 // bytes of the packed weight stream / its per-wave step geometry
 hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, int with3x3, hipStream_t s);
+
+// stage_xcd_kernel (stage_xcd.hip): a run of INT8 convolutions over small images as ONE persistent launch, one image per XCD
+// at a time, the phases separated by an XCD-local barrier instead of a kernel boundary.
+struct StagePhase {              // in device memory, read with scalar loads
+    int type;                    // kernel variant: stage_xcd_type(tiles per CU, k-steps per wave, 3x3)
+    int cin, cout;
+    int in_t, out_t, res_t;      // tensor slots (StageKArgs::t)
+    int in_u8, relu, out_u8;     // input dtype, the conv's own relu, output dtype of the plain epilogue
+    int elt, res_relu;           // fused SaberEltwise epilogue (s8 residual, s8 output); relu after the sum
+    float coeff_conv, scale_conv, coeff_res, scale_res;
+    unsigned w_chunk, prm_chunk; // offsets in 16-byte chunks into StageKArgs::weights / prm
+    int barrier;                 // an earlier phase of this launch wrote this phase's input / residual: XCD barrier first
+    int reload;                  // bring the input image into LDS (0: the previous phase left it there)
+    unsigned pch, mg_pch;        // LDS pixel pitch in chunks (cin / 16 + 1) and ceil(2^32 / pch)
+    int red_chunk;               // LDS offset (chunks) of the cross-wave reduction buffer
+    int pad[2];
+};
+static_assert(sizeof(StagePhase) == 96, "StagePhase layout");
+struct StageKArgs {
+    const StagePhase* phases;
+    const void* weights;         // per phase [cu 32][wave 4][k-step][tile][lane 64][16 B]
+    const void* prm;             // per phase, per 4 channels {scale[4], bias'[4], comp[4]}
+    const void* zero;            // >= 16 zero bytes
+    unsigned long long* sync;    // [8] registration counters, [8] arrival counters (one 128-byte line each), [16*16] abort flag
+    int n_phases, n_barriers;
+    int n_img, H, W;             // H * W <= 64
+    unsigned long long* trace;   // diagnostics (saber_hip_stage_trace): [256 workgroups][n_phases][8] wall-clock stamps, or null
+    void* t[STAGE_MAX_TENSORS];
+};
+bool stage_xcd_type(int tiles_per_cu, int ksteps_per_wave, int is3x3, int* type);
+hipError_t launch_stage_xcd(const StageKArgs& a, size_t lds_bytes, hipStream_t s);
 
 // hipcc fetches kernel arguments lazily with scalar loads and places each load near its first use; every batch that is
 // issued after an `s_waitcnt lgkmcnt(0)` is one more DEPENDENT round trip (~0.2-0.25 us, measured) before the kernel's

@@ -28,6 +28,7 @@ SYMBOLS = [
     "saber_hip_net_add_conv_pair",
     "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_create3", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
     "saber_hip_conv2d_chain_set_tile", "saber_hip_conv2d_chain_get_tile",
+    "saber_hip_stage_create", "saber_hip_stage_num_tensors", "saber_hip_stage_run", "saber_hip_stage_status", "saber_hip_stage_trace", "saber_hip_stage_destroy",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
     "saber_hip_fc_destroy", "saber_hip_fc_algo", "saber_hip_fc_set_tile", "saber_hip_gemm_f32",
     "saber_hip_gemm_i8_create", "saber_hip_gemm_i8_workspace_bytes", "saber_hip_gemm_i8_run", "saber_hip_gemm_i8_destroy",
@@ -44,6 +45,10 @@ SYMBOLS = [
     "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_time_pass", "saber_hip_net_op_work", "saber_hip_net_op_name",
     "saber_hip_net_autotune", "saber_hip_net_destroy",
 ]
+
+
+class StagePhase(C.Structure):      # saber_hip_stage_phase
+    _fields_ = [("conv", C.c_void_p), ("in_", C.c_int), ("out", C.c_int), ("res", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -114,6 +119,13 @@ def load():
     lib.saber_hip_conv2d_chain_run.argtypes = [P, P, P, P, P, P]
     lib.saber_hip_conv2d_chain_set_tile.argtypes = [P, I]
     lib.saber_hip_conv2d_chain_get_tile.argtypes = [P]
+    lib.saber_hip_stage_create.argtypes = [C.POINTER(StagePhase), I, C.POINTER(P)]
+    lib.saber_hip_stage_num_tensors.argtypes = [P]
+    lib.saber_hip_stage_run.argtypes = [P, C.POINTER(P), I, P]
+    lib.saber_hip_stage_status.argtypes = [P]
+    lib.saber_hip_stage_trace.argtypes = [P, P, C.c_size_t]
+    lib.saber_hip_stage_destroy.argtypes = [P]
+    lib.saber_hip_stage_destroy.restype = None
     lib.saber_hip_fc_create.argtypes = [C.POINTER(FcDesc), C.POINTER(P)]
     lib.saber_hip_fc_set_weights.argtypes = [P, P, I, P, P, F, F]
     lib.saber_hip_fc_workspace_bytes.argtypes = [P]
@@ -195,6 +207,13 @@ def check(rc):
         e = SaberHipError("saber_hip status %d: %s" % (rc, load().saber_hip_last_error().decode()))
         e.status = rc
         raise e
+
+
+def check_count(rc):
+    """entry points that return a count (>= 0) or a negative status"""
+    if rc < 0:
+        check(rc)
+    return rc
 
 
 def source_sha():

@@ -276,6 +276,45 @@ class SaberConvChain:
             pass
 
 
+class SaberStage:
+    """XCD-resident stage (saber_hip_stage_create): `phases` = [(conv, in_slot, out_slot, res_slot | -1), ...] run as ONE
+    persistent launch, image i on XCD i % 8; dispatch(tensors) takes the device tensors by slot. Every output slot holds
+    the bits of dispatching the convs one after the other (the reference's op-by-op Net::prediction, net.cpp:417-509)."""
+
+    def __init__(self, phases):
+        self.convs = [p[0] for p in phases]          # keep the ops alive
+        arr = (L.StagePhase * len(phases))()
+        for i, (c, a, b, r) in enumerate(phases):
+            arr[i].conv, arr[i].in_, arr[i].out, arr[i].res = c.h, a, b, r
+        self.h = C.c_void_p()
+        L.check(L.load().saber_hip_stage_create(arr, len(phases), C.byref(self.h)))
+        self.n = L.load().saber_hip_stage_num_tensors(self.h)
+
+    def dispatch(self, tensors):
+        ptrs = (C.c_void_p * self.n)(*[None if t is None else t.data_ptr() for t in tensors[:self.n]])
+        L.check(L.load().saber_hip_stage_run(self.h, ptrs, self.n, _stream()))
+
+    def trace(self, arm=False):
+        """arm=True: start recording; otherwise the stamps of the last launch as [256, n_phases, 8] (100 MHz ticks)"""
+        if arm:
+            return L.check_count(L.load().saber_hip_stage_trace(self.h, None, 0))
+        n = 256 * len(self.convs) * 8
+        out = np.zeros(n, np.uint64)
+        L.check_count(L.load().saber_hip_stage_trace(self.h, _np_ptr(out), n))
+        return out.reshape(256, len(self.convs), 8)
+
+    def status(self):
+        """synchronises; raises if a launch since the last call gave up waiting for its XCD"""
+        L.check(L.load().saber_hip_stage_status(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_stage_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SaberFc:
     """Fc<MI355X, AK_FLOAT|AK_INT8> (saber/funcs/fc.h:48-127): out[m,n] = in[m,k] W[n,k]^T + bias."""
 

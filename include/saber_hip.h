@@ -184,6 +184,39 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* chain, const void* x, const vo
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* chain, int tn);
 int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* chain);
 
+/* XCD-resident stage: a run of INT8 convolutions over SMALL feature maps (h * w <= 64 pixels per image: ResNet's res5) as
+ * ONE persistent launch. Image i is computed entirely on XCD i % 8 (32 CUs, one workgroup each); the convolutions
+ * ("phases") follow each other inside the kernel, separated by an XCD-local barrier where one reads what an earlier one
+ * wrote - the edge tensors are handed over through that XCD's L2 instead of across a kernel boundary. Every edge is written
+ * to its tensor as usual and holds the bits of running the phases' ops one after the other with saber_hip_conv2d_run
+ * (reference: the same sequence of GemmX8S8S32XConv::dispatch / SaberEltwise calls, net.cpp:417-509).
+ * Phase i runs convs `conv` on tensor slot `in` -> slot `out` (+ slot `res` for an op with the fused eltwise epilogue, -1
+ * otherwise). The ops: 1x1 (pad 0) or 3x3 (pad 1) INT8 NHWC convs, stride 1, group 1, 8-bit in / out, weights set, all
+ * with the same n / h / w; channel shapes as in ResNet's res5 (1024 -> 2048, 1024 -> 512, 3x3 512 -> 512, 512 -> 2048,
+ * 2048 -> 512). The stage refers to the ops (they must outlive it) and owns the repacked weights.
+ * The launch needs all 256 CUs to itself for its duration (a second stream's kernels holding CUs delay it; two stages in
+ * flight on different streams can starve each other): a workgroup that waits ~20 ms gives up, the outputs are then
+ * garbage and saber_hip_stage_status (synchronises the device) returns SABER_HIP_RUNTIME_ERROR once and re-arms the stage.
+ * One stage object must not be in flight on two streams at once.
+ * MEASURED (profiles/r03/stage_trace.txt): correct, but at batch 8 / 16 slower than the separate launches (104 vs 73 us for
+ * res5): every XCD pulls the whole stage's weights (8 x 15 MB through the per-XCD fabric ports, ~2.7 us + 1.5 us / MB per
+ * phase) - saber_hip_net_optimize therefore does not form stages; the entry points stay for the measurement. */
+typedef struct saber_hip_stage saber_hip_stage_t;
+typedef struct {
+    saber_hip_conv_t* conv;
+    int in, out, res;
+} saber_hip_stage_phase;
+int saber_hip_stage_create(const saber_hip_stage_phase* phases, int n_phases, saber_hip_stage_t** out);
+int saber_hip_stage_num_tensors(const saber_hip_stage_t* stage);
+int saber_hip_stage_run(saber_hip_stage_t* stage, void* const* tensors, int n_tensors, saber_hip_stream_t stream);
+int saber_hip_stage_status(saber_hip_stage_t* stage);
+/* Diagnostics: out == NULL arms the trace (returns the number of 64-bit words a read needs); afterwards every launch
+ * records, per workgroup and phase, 8 stamps of the 100 MHz wall clock (phase start, arrived, weights issued, barrier
+ * passed, image DMA issued, image in LDS, matrix loop done, phase end); a call with a buffer synchronises and copies them
+ * out as [256][n_phases][8]. */
+int saber_hip_stage_trace(saber_hip_stage_t* stage, unsigned long long* out, size_t cap);
+void saber_hip_stage_destroy(saber_hip_stage_t* stage);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Fully connected (SaberFc / VenderFc), FP32 and INT8                                          */
 /* ------------------------------------------------------------------------------------------- */
