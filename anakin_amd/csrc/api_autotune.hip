@@ -25,9 +25,16 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     ColdScope scope;
     HIP_TRY(scope.enter(7));
     std::vector<std::pair<float, ConvChoice>> cands;
+    const char* log_env = std::getenv("SABER_HIP_AUTOTUNE_LOG");
+    const bool log_cands = log_env && log_env[0] == '1';
     auto time_current = [&]() {
         if (g_cold) {   // operands cold in L2, as inside the op list
             const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run(op, x, y, res, workspace, s); });
+            if (log_cands) {      // SABER_HIP_AUTOTUNE_LOG=1: every candidate and its cold-L2 median
+                name_algo(op);
+                std::fprintf(stderr, "autotune [%dx%dx%d c%d k%d %dx%d] %-40s %8.2f us\n", op->d.n, op->d.h, op->d.w, op->d.c, op->d.k, op->d.kh,
+                             op->d.kw, op->algo_name.c_str(), us);
+            }
             if (us < 0.f) { err = SABER_HIP_RUNTIME_ERROR; return; }
             cands.emplace_back(us, get_choice(op));
             if (us < best) {
@@ -69,9 +76,23 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         for (int kd = 1; kd <= 2; ++kd)
             for (int t = 0; t < TILE_COUNT; ++t) {
                 if (kd == 2 && t == TILE_128x128) continue;
-                ConvChoice cb = {t, kd, 0, 0, 0, 0, 0, 4, 0, 1};
+                ConvChoice cb = {t, kd, 0, 0, 0, 0, 0, 4, 0, 1, 0};
                 set_choice(op, cb);
                 time_current();
+                // deep reductions on few pixels: 2 / 4 / 8 workgroups per tile (split-K inside one XCD), tiles up to 128 x 64
+                for (int sh = 1; sh <= 3 && t <= TILE_128x64; ++sh) {
+                    if (!split_ok(op, t, kd, sh) || split_prepare(op) != SABER_HIP_OK) {
+                        if (log_cands && kd == 1 && t == TILE_64x64) std::fprintf(stderr, "autotune: split %d refused (%s)\n", 1 << sh, saber_hip_last_error());
+                        continue;
+                    }
+                    int bmk, bnp;
+                    tile_dims(t, &bmk, &bnp);
+                    const long tiles = (long)((op->d.n * op->oh * op->ow + bnp - 1) / bnp) * ((op->d.k + bmk - 1) / bmk);
+                    if ((tiles << sh) > 2048) continue;          // the unsplit grid already fills the CUs
+                    cb.ksplit = sh;
+                    set_choice(op, cb);
+                    time_current();
+                }
             }
     c = best_c;
     if (fc_small_ok(op)) {

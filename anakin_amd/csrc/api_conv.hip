@@ -86,6 +86,53 @@ bool stem_ok(const saber_hip_conv* op) {
 static bool f32_static_b3(const saber_hip_conv* op) {
     return op->d.kh * op->d.kw > 1 && op->c_eff >= 64 && (long)op->d.n * op->oh * op->ow >= 3136;
 }
+// 1 when workgroup b of a 1-D grid runs on XCD (b + const) % 8 on the current device - workgroups 8 apart share an XCD
+// (checked once per device with 2048-workgroup launches; 0 also on any failure): the split-K kernels hand partial sums over inside one XCD's L2 and are offered only then.
+static bool xcd_round_robin() {
+    static std::mutex mu;
+    static int state[64] = {0};          // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev]) return state[dev] == 1;
+    state[dev] = 2;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount != 256) {
+        if (std::getenv("SABER_HIP_AUTOTUNE_LOG")) std::fprintf(stderr, "xcd_round_robin: %d CUs\n", prop.multiProcessorCount);
+        return false;
+    }
+    const int n = 2048;
+    DevBuf<unsigned> d;
+    if (d.alloc_zero(n) != hipSuccess) return false;
+    std::vector<unsigned> h(n, 99u);
+    for (int rep = 0; rep < 2; ++rep) {
+        if (launch_xcd_map_probe(d.p, n, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return false;
+        if (hipMemcpy(h.data(), d.p, n * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        for (int b = 0; b < n; ++b)
+            if (h[b] != ((h[0] + (unsigned)b) & 7u)) {      // (the first workgroup's XCD depends on what the queue dispatched before)
+                if (std::getenv("SABER_HIP_AUTOTUNE_LOG")) std::fprintf(stderr, "xcd_round_robin: workgroup %d ran on XCD %u\n", b, h[b]);
+                return false;
+            }
+    }
+    state[dev] = 1;
+    return true;
+}
+bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh) {
+    if (sh == 0) return true;
+    if (sh < 0 || sh > 3 || !b3_ok(op) || tile < 0 || tile >= TILE_COUNT || (ks != 1 && ks != 2)) return false;
+    const int steps = (op->Kg + 32 * ks - 1) / (32 * ks);
+    if ((steps >> sh) < 2) return false;
+    const size_t m = (size_t)op->d.n * op->oh * op->ow;
+    if ((m + 127) * ((size_t)op->d.k + 127) * 4 * 8 > ((size_t)96 << 20)) return false;   // partial buffer: <= 96 MB
+    return xcd_round_robin();
+}
+int split_prepare(saber_hip_conv* op) {
+    if (op->d_part.p) return SABER_HIP_OK;
+    const size_t m = (size_t)op->d.n * op->oh * op->ow;
+    HIP_TRY(op->d_part.alloc_zero((m + 127) * ((size_t)op->d.k + 127) * 8));        // 8 splits of the padded f32 output
+    HIP_TRY(op->d_part_ctr.alloc_zero(((m + 31) / 32) * (((size_t)op->d.k + 31) / 32)));
+    return SABER_HIP_OK;
+}
 void name_algo(saber_hip_conv* op) {
     static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
     int bmk = 0, bnp = 0;
@@ -97,7 +144,8 @@ void name_algo(saber_hip_conv* op) {
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
-        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s", op->b3 ? "igemm_f32_bf16x3" : an[op->algo], bmk, bnp, op->ks,
+        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s%s", op->b3 ? "igemm_f32_bf16x3" : an[op->algo], bmk, bnp, op->ks,
+                 op->b3 && op->ksplit ? (op->ksplit == 1 ? "_split2" : (op->ksplit == 2 ? "_split4" : "_split8")) : "",
                  op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")),
                  op->pool2 ? "+maxpool2x2" : "");
     else snprintf(buf, sizeof buf, "%s", an[op->algo]);
@@ -281,8 +329,14 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     if (var == 11) {   // FP32 implicit GEMM on three bf16 planes (register-staged, one 32-deep slab per stage)
         if (!b3_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 variant: FP32 implicit-GEMM conv with C % 8 == 0 (not a sibling pair, not an fc)");
         if (tile < 0 || tile >= TILE_COUNT) return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
-        if (!(ks == 0 || ks == 1 || (ks == 2 && tile != TILE_128x128))) return fail(SABER_HIP_INVALID_VALUE, "bf16x3: stage depth 1, or 2 below 128x128");
-        op->b3 = 1; op->dma = 0; op->ks = ks ? ks : 1; op->tile = tile; op->fc_small = 0;
+        const int sh = ks >> 4, ksd = ks & 15;      // bits 12..15 of the code: log2 of the split-K factor
+        if (!(ksd == 0 || ksd == 1 || (ksd == 2 && tile != TILE_128x128))) return fail(SABER_HIP_INVALID_VALUE, "bf16x3: stage depth 1, or 2 below 128x128");
+        if (!split_ok(op, tile, ksd ? ksd : 1, sh)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 split-K: 2 / 4 / 8 splits with >= 2 stages each, bounded output, 8 x 32 CU device");
+        if (sh) {
+            const int rc = split_prepare(op);
+            if (rc) return rc;
+        }
+        op->b3 = 1; op->dma = 0; op->ks = ksd ? ksd : 1; op->tile = tile; op->fc_small = 0; op->ksplit = sh;
         name_algo(op);
         return SABER_HIP_OK;
     }
@@ -311,6 +365,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     }
     if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
         op->b3 = 0;
+        op->ksplit = 0;
         op->halo = 0;
         op->stem = 0;
         op->img_ib = op->img_rb = 0;
@@ -329,7 +384,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
     if (op->fc_small) return 10 << 16;
-    if (op->b3) return op->tile | (op->ks << 8) | (11 << 16);
+    if (op->b3) return op->tile | ((op->ks | (op->ksplit << 4)) << 8) | (11 << 16);
     if (op->stem) return 7 << 16;
     if (op->img_rb) return op->img_rb | ((op->img_ib | (op->img_nw == 8 ? 0x80 : 0)) << 8) | (9 << 16);
     if (op->halo) return op->tile | (op->ks << 8) | ((op->halo == 4 ? 5 : 6) << 16);
@@ -520,6 +575,9 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     if (op->b3) {
         a.w = op->d_w3.p;
         a.w_plane_chunks = (int)((size_t)round_up(d.k, 128) * op->Kg_pad / 8);
+        a.ksplit_sh = op->ksplit;
+        a.part = op->d_part.p;
+        a.part_ctr = op->d_part_ctr.p;
     }
     a.steps = (op->Kg + estage - 1) / estage;
     a.inv_ohw = 1.0f / (float)(op->oh * op->ow);
@@ -616,6 +674,7 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
             HIP_TRY(launch_fc_f32_small(a, s));
             break;
         }
+        if (op->b3 && op->ksplit && !op->d_part.p) return fail(SABER_HIP_INVALID_VALUE, "split-K selected without its buffers (saber_hip_conv2d_set_tile / autotune allocate them)");
         if (op->b3) HIP_TRY(launch_conv_igemm(3, op->tile, op->ks, a, s));
         else HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
         break;
@@ -676,6 +735,14 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
         return e;
     };
     hipError_t e = cat(op->d_w, a->d_w, b->d_w, (size_t)a->Kg_pad * (a->is_i8 ? 1 : sizeof(float)));
+    if (e == hipSuccess && !a->is_i8 && a->d_w3.p && b->d_w3.p) {   // bf16-plane variant: [3][rows][Kg_pad] from the ops' planes
+        const size_t row = (size_t)a->Kg_pad * 2, pa = (size_t)round_up(da.k, 128) * row, pb = k2_pad * row;
+        e = op->d_w3.alloc_zero(3 * rows * row);
+        for (int pl = 0; pl < 3 && e == hipSuccess; ++pl) {
+            e = hipMemcpy(op->d_w3.p + pl * rows * row, a->d_w3.p + pl * pa, (size_t)da.k * row, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(op->d_w3.p + pl * rows * row + (size_t)da.k * row, b->d_w3.p + pl * pb, pb, hipMemcpyDeviceToDevice);
+        }
+    }
     if (e == hipSuccess) e = cat(op->d_bias, a->d_bias, b->d_bias, 1);
     if (e == hipSuccess && a->is_i8) e = cat(op->d_scale, a->d_scale, b->d_scale, 1);
     op->has_bias = a->has_bias || b->has_bias;
@@ -702,8 +769,9 @@ int saber_hip_conv2d_run_pair(saber_hip_conv_t* op, const void* x, void* y_a, vo
     ConvKArgs a;
     fill_args(op, a, x, y_a, nullptr, y_b);
     hipStream_t s = (hipStream_t)stream;
-    const int mode = op->is_i8 ? 0 : 2;
-    HIP_TRY(op->dma ? launch_conv_igemm_dma(mode, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(mode, op->tile, op->ks, a, s));
+    const int mode = op->is_i8 ? 0 : (op->b3 ? 3 : 2);
+    if (op->b3 && op->ksplit && !op->d_part.p) return fail(SABER_HIP_INVALID_VALUE, "split-K selected without its buffers (autotune / set_tile allocate them)");
+    HIP_TRY(op->dma && !op->b3 ? launch_conv_igemm_dma(mode, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(mode, op->tile, op->ks, a, s));
     return SABER_HIP_OK;
 }
 
@@ -717,7 +785,24 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
     HIP_TRY(scope.enter(7));
     std::vector<std::pair<float, ConvChoice>> pcands;
     float best = 1e30f;
-    int best_tile = op->tile, best_ks = op->ks, best_dma = op->dma;   // the entry selection stays if nothing runs
+    ConvChoice best_c = get_choice(op);   // the entry selection stays if nothing runs
+    auto time_current = [&]() {
+        if (g_cold) {
+            const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s); });
+            if (us >= 0.f) pcands.emplace_back(us, get_choice(op));
+            if (us >= 0.f && us < best) { best = us; best_c = get_choice(op); }
+            return;
+        }
+        int rc = saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
+        if (rc) return;   // a variant that does not launch is skipped
+        float ms = 0;
+        if (hipEventRecord(ev.e0, s) != hipSuccess) return;
+        for (int i = 0; i < iters; ++i) rc |= saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
+        if (rc || hipEventRecord(ev.e1, s) != hipSuccess || hipEventSynchronize(ev.e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, ev.e0, ev.e1) != hipSuccess)
+            return;
+        if (ms < best) { best = ms; best_c = get_choice(op); }
+    };
     const int ks_list[3] = {1, 2, 4};
     const int dma_list[4] = {0, 1, 2, 4};
     for (int vi = 0; vi < 4; ++vi)
@@ -725,31 +810,33 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
             for (int ki = 0; ki < 3; ++ki) {
                 if (dma_list[vi] > 1 && (ks_list[ki] != 4 || t > TILE_64x64)) continue;
                 if (dma_list[vi] == 4 && t != TILE_32x32) continue;
-                op->tile = t; op->ks = ks_list[ki]; op->dma = dma_list[vi];
-                if (g_cold) {
-                    const float us = g_cold->run(s, [&] { return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s); });
-                    if (us >= 0.f) pcands.emplace_back(us, get_choice(op));
-                    if (us >= 0.f && us < best) { best = us; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
-                    continue;
-                }
-                int rc = saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
-                if (rc) continue;   // a variant that does not launch is skipped
-                float ms = 0;
-                if (hipEventRecord(ev.e0, s) != hipSuccess) continue;
-                for (int i = 0; i < iters; ++i) rc |= saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);
-                if (rc || hipEventRecord(ev.e1, s) != hipSuccess || hipEventSynchronize(ev.e1) != hipSuccess ||
-                    hipEventElapsedTime(&ms, ev.e0, ev.e1) != hipSuccess)
-                    continue;
-                if (ms < best) { best = ms; best_tile = t; best_ks = ks_list[ki]; best_dma = dma_list[vi]; }
+                ConvChoice c = {t, ks_list[ki], dma_list[vi], 0, 0, 0, 0, 4, 0, 0, 0};
+                set_choice(op, c);
+                time_current();
             }
-    op->tile = best_tile; op->ks = best_ks; op->dma = best_dma;
+    if (b3_ok(op))      // FP32 pair on the bf16 matrix cores, with split-K where the reduction is deep and the pixels few
+        for (int kd = 1; kd <= 2; ++kd)
+            for (int t = 0; t < TILE_COUNT; ++t) {
+                if (kd == 2 && t == TILE_128x128) continue;
+                for (int sh = 0; sh <= 3; ++sh) {
+                    if (sh && (t > TILE_128x64 || !split_ok(op, t, kd, sh) || split_prepare(op) != SABER_HIP_OK)) continue;
+                    int bmk, bnp;
+                    tile_dims(t, &bmk, &bnp);
+                    const long tiles = (long)((op->d.n * op->oh * op->ow + bnp - 1) / bnp) * ((op->d.k + bmk - 1) / bmk);
+                    if (sh && (tiles << sh) > 2048) continue;
+                    ConvChoice c = {t, kd, 0, 0, 0, 0, 0, 4, 0, 1, sh};
+                    set_choice(op, c);
+                    time_current();
+                }
+            }
+    set_choice(op, best_c);
     if (g_used_kernels && best < 1e30f) {   // kernel reuse across the net's sibling pairs (see kernel_key)
         float reuse_best = best * (1.f + g_reuse_tol);
         for (const auto& cd : pcands) {
             const unsigned long long key = kernel_key(op, cd.second);
             if (cd.first <= reuse_best && std::find(g_used_kernels->begin(), g_used_kernels->end(), key) != g_used_kernels->end()) {
                 reuse_best = cd.first;
-                op->tile = cd.second.tile; op->ks = cd.second.ks; op->dma = cd.second.dma;
+                set_choice(op, cd.second);
             }
         }
         g_used_kernels->push_back(kernel_key(op, get_choice(op)));

@@ -99,6 +99,7 @@ struct saber_hip_conv {
     int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
+    int ksplit = 0;          // b3 only: log2 of the split-K factor (conv_igemm_impl.h: splits of one tile share an XCD), 0: none
     int b3 = 0;              // FP32: 1 = the implicit GEMM runs on the bf16 matrix cores (three bf16 operand planes, conv_igemm_impl.h
                              // MODE 3): needs c_eff % 8 == 0 and the pre-split weight planes d_w3
     int img_ib = 0, img_rb = 0, img_nw = 4;   // img_rb > 0: small-image 3x3 kernel (conv3x3_img.h): images / output rows
@@ -120,6 +121,8 @@ struct saber_hip_conv {
     std::vector<float> bias_p_host, scale_host;   // INT8: the device-side bias' / scale / comp arrays (conv1x1 chain repacks them)
     std::vector<int> comp_host;
     DevBuf<uint8_t> d_w;
+    DevBuf<float> d_part;    // split-K: partial accumulators [tile][split] and the tiles' arrival counters (split_prepare)
+    DevBuf<unsigned> d_part_ctr;
     DevBuf<uint8_t> d_w3;    // FP32 convs: the repacked weights split into three bf16 planes [3][K_pad][Kg_pad] (b3 variant)
     DevBuf<float> d_bias, d_scale;
     DevBuf<int> d_comp;
@@ -151,17 +154,17 @@ struct saber_hip_fc {
 namespace saber_api {
 // one selection of kernel variant for an op (what the autotuner saves / restores)
 struct ConvChoice {
-    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3;
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit;
 };
 inline ConvChoice get_choice(const saber_hip_conv* op) {
-    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3};
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit};
 }
 inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
-    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit;
 }
 inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
-    return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr && !op->pair_k2;
+    return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr;
 }
 inline bool fc_small_ok(const saber_hip_conv* op) {
     if (op->algo == ALGO_IGEMM_F32)   // FP32 fc: a 1x1 "conv" on a [m, 1, 1, k] NHWC tensor, plain f32 epilogue, no residual
@@ -320,6 +323,10 @@ bool halo_ok(const saber_hip_conv* op);      // api_conv.hip
 bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb);      // api_conv.hip
 bool stem_ok(const saber_hip_conv* op);      // api_conv.hip
 void name_algo(saber_hip_conv* op);      // api_conv.hip
+// FP32 split-K (b3 kernels): 2^sh workgroups per tile; needs >= 2 stages per split, a bounded partial buffer, and the
+// workgroup -> XCD placement the hand-off relies on (checked once per device). split_prepare allocates the buffers.
+bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh);      // api_conv.hip
+int split_prepare(saber_hip_conv* op);      // api_conv.hip
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s);      // api_net.hip
 void net_set_chain_mode(saber_hip_net* net, int ia, int mode);      // api_net_optimize.hip
 int net_chain_mode(const saber_hip_net* net, int ia);      // api_net_optimize.hip

@@ -414,6 +414,22 @@ __device__ __forceinline__ void xcd_tile(const ConvKArgs& a, int& px, int& ky) {
     px = L - ky * a.npx;
 }
 
+// ... with 2^ksplit_sh workgroups per tile (FP32 split-K): consecutive workgroups of an XCD are the splits of one tile. The
+// grid is 8 * ceil(T / 8) * S; returns false for the surplus workgroups of the XCDs with one tile less.
+__device__ __forceinline__ bool xcd_tile_split(const ConvKArgs& a, int& px, int& ky, int& split, int& L) {
+    const int T = a.npx * a.nky;
+    const int b = blockIdx.x;
+    const int q = T >> 3, r = T & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int lt = idx >> a.ksplit_sh;
+    split = idx & ((1 << a.ksplit_sh) - 1);
+    if (lt >= q + (xcd < r ? 1 : 0)) return false;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lt;
+    ky = a.mg_npx ? (int)__umulhi((unsigned)L, a.mg_npx) : (a.npx == 1 ? L : L / a.npx);
+    px = L - ky * a.npx;
+    return true;
+}
+
 // ceil(2^32 / d) if __umulhi(n, .) == n / d for every 0 <= n < n_max, else 0 (host side)
 static inline unsigned magic_div(int d, long long n_max) {
     if (d < 2 || n_max * d >= 0x100000000ll) return 0u;
@@ -523,7 +539,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int tile_px, tile_ky;
-    xcd_tile(a, tile_px, tile_ky);
+    int split = 0, tile_L = 0;           // FP32 split-K: this workgroup's slice of the stages and its tile's list index
+    if constexpr (F32) {
+        if (a.ksplit_sh > 0) {
+            if (!xcd_tile_split(a, tile_px, tile_ky, split, tile_L)) return;
+        } else xcd_tile(a, tile_px, tile_ky);
+    } else xcd_tile(a, tile_px, tile_ky);
     const int pix_base = tile_px * BNP;
     const int k_base = tile_ky * BMK;
     const int lq = tid % CPR;            // this thread's chunk column within a stage
@@ -545,6 +566,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         x_ih0[it] = oh * a.stride_h - a.pad_h;
         x_iw0[it] = ow * a.stride_w - a.pad_w;
     }
+    int s_begin = 0, s_end = a.steps;    // split-K: stages [s_begin, s_end) of the reduction
+    if constexpr (F32) {
+        if (a.ksplit_sh > 0) {
+            const int spp = (a.steps + (1 << a.ksplit_sh) - 1) >> a.ksplit_sh;
+            s_begin = min(split * spp, a.steps);
+            s_end = min(s_begin + spp, a.steps);
+        }
+    }
     int cur_c, cur_i, cur_j;             // normal: channel offset, tap row, tap col; C4: -, tap row, chunk-in-row
     const int cpr4 = C4 ? (a.kw_pad >> 2) : 1;
     if (C4) {
@@ -552,25 +581,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         cur_j = lq - cur_i * cpr4;
         cur_c = 0;
     } else {
-        const int kk0 = lq * EC;
+        const int kk0 = s_begin * ESTAGE + lq * EC;
         const int tap = kk0 / a.C;
         cur_c = kk0 - tap * a.C;
         cur_i = tap / a.kw;
         cur_j = tap - cur_i * a.kw;
     }
 
-    v4i xv[XIT][B3 ? 2 : 1], wv[NP][WIT];     // B3: an activation chunk is 8 f32 = two 16-byte loads, split at store time
+    // PF register sets: stage t + PF is requested while stage t is multiplied, so PF - 1 stages of global-memory latency are
+    // in flight behind every one that is consumed. The INT8 / f32-MFMA kernels keep the original depth 1 (their deep-K
+    // variants are the LDS-DMA rings); the bf16-plane kernel stages through registers (the split needs them) and on the
+    // few-pixel layers one stage of latency per stage of work was ALL its time (1.1 us per 32-deep slab against 0.16 us of
+    // matrix work, scripts/probe/splitk_time.py before this).
+    constexpr int PF = B3 ? 4 : 1;
+    v4i xv[PF][XIT][B3 ? 2 : 1], wv[PF][NP][WIT];     // B3: an activation chunk is 8 f32 = two 16-byte loads, split at store time
     const v4i* w16 = (const v4i*)a.w;
     const int w_row_chunks = a.Kg_pad / EC;
 
-    auto load_stage = [&](int s) {
+    auto load_stage = [&](int s, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        const int sw = PF > 1 ? min(s, a.steps - 1) : s;      // the ring requests up to PF stages past the end (never consumed)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int it = 0; it < WIT; ++it) {
                 const int r = lr + it * RPP;
                 if (W_FULL || r < BMK)
-                    wv[pl][it] = w16[(size_t)pl * a.w_plane_chunks + (size_t)(k_base + r) * w_row_chunks + s * CPR + lq];
+                    wv[SET][pl][it] = w16[(size_t)pl * a.w_plane_chunks + (size_t)(k_base + r) * w_row_chunks + sw * CPR + lq];
             }
         const bool tap_ok = cur_i < a.kh;
 #pragma unroll
@@ -593,12 +630,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 const char* xp = (const char*)a.x + ((size_t)x_base[it] + (size_t)(ih * a.W + iw) * a.C + cur_c) * XS;
                 xp = ok ? xp : (const char*)a.zero;
                 v = *(const v4i*)xp;
-                if constexpr (B3) xv[it][1] = *(const v4i*)(xp + 16);
+                if constexpr (B3) xv[SET][it][1] = *(const v4i*)(xp + 16);
             }
             if (!F32 && a.in_u8) {
                 v.x ^= 0x80808080; v.y ^= 0x80808080; v.z ^= 0x80808080; v.w ^= 0x80808080;
             }
-            xv[it][0] = v;
+            xv[SET][it][0] = v;
         }
         // advance the cursor by one stage
         if (C4) {
@@ -614,7 +651,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             cur_i += a.adv_i + wrap_j;
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int r = lr + it * RPP;
@@ -623,7 +661,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 const int rr = r % (TM * 16), wmr = r / (TM * 16);
                 const int lrow = (wmr * TM + ((rr >> 2) % TM)) * 16 + (rr / (TM * 4)) * 4 + (rr & 3);
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) lds[buf][pl][lrow * CPR + phys_chunk<CPR>(lrow, lq)] = wv[pl][it];
+                for (int pl = 0; pl < NP; ++pl) lds[buf][pl][lrow * CPR + phys_chunk<CPR>(lrow, lq)] = wv[SET][pl][it];
             }
         }
 #pragma unroll
@@ -632,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             if (X_FULL || r < BNP) {
                 const int li = (BMK + r) * CPR + phys_chunk<CPR>(r, lq);
                 if constexpr (B3) {
-                    const v4f f0 = __builtin_bit_cast(v4f, xv[it][0]), f1 = __builtin_bit_cast(v4f, xv[it][1]);
+                    const v4f f0 = __builtin_bit_cast(v4f, xv[SET][it][0]), f1 = __builtin_bit_cast(v4f, xv[SET][it][1]);
                     unsigned h[4], m[4], l[4];
                     split3_pair(f0.x, f0.y, h[0], m[0], l[0]);
                     split3_pair(f0.z, f0.w, h[1], m[1], l[1]);
@@ -642,7 +680,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                     lds[buf][1][li] = v4i{(int)m[0], (int)m[1], (int)m[2], (int)m[3]};
                     lds[buf][2][li] = v4i{(int)l[0], (int)l[1], (int)l[2], (int)l[3]};
                 } else {
-                    lds[buf][0][li] = xv[it][0];
+                    lds[buf][0][li] = xv[SET][it][0];
                 }
             }
         }
@@ -658,13 +696,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     SABER_TL(1);
-    load_stage(0);
+    using std::integral_constant;
+    load_stage(s_begin, integral_constant<int, 0>{});      // (an empty slice loads one stage it does not use: in-bounds, harmless)
+    if constexpr (PF > 1) {
+        load_stage(s_begin + 1, integral_constant<int, 1 % PF>{});
+        load_stage(s_begin + 2, integral_constant<int, 2 % PF>{});
+        load_stage(s_begin + 3, integral_constant<int, 3 % PF>{});
+    }
     // per-channel epilogue constants: requested before the reduction loop so their latency hides behind it, but AFTER the
     // first operand loads - their pointers live in the cold part of the argument block, and waiting for that second
     // batch of scalar loads ahead of the first operand request costs every launch ~0.1 us
     ChanParams<NV> cp;
     load_chan_params<NV>(a, kb, cp);
-    store_stage(0);
+    store_stage(0, integral_constant<int, 0>{});
     __syncthreads();
     SABER_TL(2);
 
@@ -683,9 +727,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const int row = (wn * TN + j) * 16 + frow;
         b_idx[j] = (BMK + row) * CPR + phys_chunk<CPR>(row, fq);
     }
-    for (int s = 0; s < a.steps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < a.steps) load_stage(s + 1);
+    auto mma_stage = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             v4i af[TM][NP], bf[TN][NP];
@@ -698,16 +740,112 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) bf[j][pl] = lds[buf][pl][b_idx[j] ^ (ks << 2)];
+            if constexpr (B3) {
+                // the six plane products of every accumulator in mma_step3's order (small terms first), but term-major: two
+                // consecutive MFMAs never touch the same accumulator, so none waits out its predecessor's 8 passes (accumulator-
+                // major, 24 dependent instructions took 0.56 us per stage against 0.16 us of issue time)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[i][PA[t]]),
+                                                                                __builtin_bit_cast(v8bf, bf[j][PB[t]]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mma_step(af[i][0], bf[j][0], acc[i][j]);
+            }
+        }
+    };
+    if constexpr (PF == 1) {
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            if (s + 1 < s_end) load_stage(s + 1, integral_constant<int, 0>{});
+            mma_stage(buf);
+            if (s + 1 < s_end) store_stage(buf ^ 1, integral_constant<int, 0>{});
+            __syncthreads();
+        }
+    } else {
+        static_assert(PF == 1 || PF == 4, "the unrolled ring below is written for 4 register sets");
+        // stage t = s + u sits in LDS buffer u & 1; set u has just been stored, so it takes the request for stage t + PF;
+        // set (u + 1) % PF (requested PF - 1 stages ago) goes to the other LDS buffer after the multiply.
+        // Requests and stores are UNCONDITIONAL (stages past the end are fetched from clamped / zero addresses and never
+        // multiplied): with a condition around them the compiler's s_waitcnt insertion has to assume the younger requests
+        // may not exist and waits for everything - the ring then overlaps nothing.
+#define SABER_PF_STEP(u)                                                                       \
+        load_stage(s + u + PF, integral_constant<int, u>{});                                   \
+        mma_stage(u & 1);                                                                      \
+        store_stage((u + 1) & 1, integral_constant<int, (u + 1) % PF>{});                      \
+        __syncthreads();
+        int s = s_begin;
+        for (; s + PF <= s_end; s += PF) {
+            SABER_PF_STEP(0)
+            SABER_PF_STEP(1)
+            SABER_PF_STEP(2)
+            SABER_PF_STEP(3)
+        }
+        if (s < s_end) {
+            SABER_PF_STEP(0)
+            if (s + 1 < s_end) {
+                SABER_PF_STEP(1)
+                if (s + 2 < s_end) {
+                    SABER_PF_STEP(2)
+                }
+            }
+        }
+#undef SABER_PF_STEP
+    }
+
+    SABER_TL(5);
+    if constexpr (F32) {
+        if (a.ksplit_sh > 0) {
+            // ---- split-K: partial accumulators -> this XCD's L2; the last arrival sums them in split order ------------
+            const int S = 1 << a.ksplit_sh;
+            v4f* pw = (v4f*)a.part + ((size_t)(tile_L * S + split) * 4 + wave) * (TM * TN * 64) + lane;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (B3) acc[i][j] = mma_step3(af[i], bf[j], acc[i][j]);
-                    else acc[i][j] = mma_step(af[i][0], bf[j][0], acc[i][j]);
-                }
+                for (int j = 0; j < TN; ++j) pw[(i * TN + j) * 64] = acc[i][j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __shared__ unsigned s_old;
+            __syncthreads();
+            // an arrival adds 1 + (its XCD << 8): the last one can tell whether all S ran on its XCD (the placement this hand-off
+            // needs, checked at selection time by api_conv.hip:xcd_round_robin); if not, the result is poisoned, never silently stale
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            if (tid == 0) s_old = __hip_atomic_fetch_add(a.part_ctr + tile_L, 1u + (xcc << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if ((s_old & 0xffu) != (unsigned)(S - 1)) {
+                SABER_TL_FLUSH();
+                return;
+            }
+            if (tid == 0) a.part_ctr[tile_L] = 0u;           // re-armed for the next launch
+            asm volatile("buffer_inv sc1" ::: "memory");     // this CU's L1 may hold the partials of an earlier launch
+            const v4f* pr = (const v4f*)a.part + ((size_t)(tile_L * S) * 4 + wave) * (TM * TN * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = pr[(i * TN + j) * 64];
+            for (int s2 = 1; s2 < S; ++s2) {
+                pr += 4 * (TM * TN * 64);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] + pr[(i * TN + j) * 64];
+            }
+            if ((s_old >> 8) + xcc != (unsigned)S * xcc) {
+                const float nan = __builtin_nanf("");
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = v4f{nan, nan, nan, nan};
+            }
         }
-        if (s + 1 < a.steps) store_stage(buf ^ 1);
-        __syncthreads();
     }
 
     SABER_TL(3);
@@ -763,7 +901,7 @@ static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
         b.adv_i = taps / a.kw;
         b.adv_j = taps - b.adv_i * a.kw;
     }
-    dim3 grid(b.npx * b.nky);
+    dim3 grid(MODE >= 2 && a.ksplit_sh > 0 ? 8 * ((b.npx * b.nky + 7) / 8) << a.ksplit_sh : b.npx * b.nky);
     dim3 block(256);
     switch (tile) {
     case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, KS, EK>), grid, block, 0, s, b); break;
@@ -794,7 +932,7 @@ static hipError_t launch_igemm_inst(int tile, int ks, const ConvKArgs& a, hipStr
         b.adv_c = estage - taps * a.C;
         b.adv_i = taps / a.kw;
         b.adv_j = taps - b.adv_i * a.kw;
-        dim3 grid(b.npx * b.nky), block(256);
+        dim3 grid(a.ksplit_sh > 0 ? 8 * ((b.npx * b.nky + 7) / 8) << a.ksplit_sh : b.npx * b.nky), block(256);
         switch (tile) {
         case TILE_32x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1, 2, EK>), grid, block, 0, s, b); break;
         case TILE_64x32: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 1, 2, EK>), grid, block, 0, s, b); break;

@@ -849,4 +849,18 @@ hipError_t launch_l2_flush(const void* buf, size_t bytes, unsigned* sink, hipStr
     return hipGetLastError();
 }
 
+// Workgroup b of a 1-D grid runs on XCD b % 8: the placement the XCD-aware tile orders assume and the FP32 split-K hand-off
+// RELIES on (its partial sums meet in one XCD's L2). out[b] = HW_REG_XCC_ID of workgroup b.
+__global__ void xcd_map_probe_kernel(unsigned* out) {
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = v & 0xfu;
+    }
+}
+hipError_t launch_xcd_map_probe(unsigned* out, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(xcd_map_probe_kernel, dim3(blocks), dim3(64), 0, s, out);
+    return hipGetLastError();
+}
+
 }  // namespace saber_mi355x

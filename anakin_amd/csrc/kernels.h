@@ -87,6 +87,14 @@ struct ConvKArgs {
     // folded into the read. res_sub <= 1: res is [M][K].
     int res_sub, res_H, res_W;
     int w_plane_chunks;     // MODE 3 (FP32 on three bf16 planes): 16-byte chunks between the weight planes (K_pad * Kg_pad / 8)
+    // FP32 split-K (conv_igemm_impl.h): 2^ksplit_sh workgroups share one output tile, each reduces a slice of the stages; the
+    // partial accumulators meet in `part` ([tile][split][wave][fragment][lane] v4f) and the LAST one to arrive on the tile's
+    // counter sums them in split order (deterministic) and runs the epilogue. All splits of a tile run on ONE XCD (workgroups
+    // 8 apart share an XCD), so the hand-off needs no L2 write-back: plain stores, s_waitcnt vmcnt(0), the counter, an L1
+    // invalidate, plain loads - what profiles/r03/boundary_probe.txt measured.
+    int ksplit_sh;          // log2 of the split count (0: ordinary launch)
+    float* part;
+    unsigned* part_ctr;     // [tiles], zero between launches
 };
 
 // conv3x3_img_kernel takes the common block plus its slab geometry (kept out of ConvKArgs: every byte of kernel
@@ -232,6 +240,7 @@ hipError_t launch_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow,
                                      int pw, int type, int in_dtype, float scale, const void* x, float* y,
                                      float q_scale, int8_t* yq, hipStream_t s);   // yq: optional fused s8 quantisation
 hipError_t launch_softmax_f32(int rows, int cols, const float* x, float* y, hipStream_t s);
+hipError_t launch_xcd_map_probe(unsigned* out, int blocks, hipStream_t s);   // out[b] = XCD of workgroup b
 hipError_t launch_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b,
                            float beta, float* c, hipStream_t s);
 

@@ -1,0 +1,51 @@
+"""FP32 bf16x3 convolution: unsplit tiles vs split-K (2/4/8 workgroups per tile on one XCD) on ResNet50's deep-K, few-pixel
+layers at batch 8. Cold-L2 style timing is the autotuner's job; this prints the back-to-back event time per launch."""
+import sys
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from anakin_amd import lib as L, saber as S   # noqa: E402
+
+CASES = [("res3 2b", 8, 28, 28, 128, 128, 3), ("res4 2b", 8, 14, 14, 256, 256, 3), ("res5 2b", 8, 7, 7, 512, 512, 3),
+         ("res5 2a", 8, 7, 7, 2048, 512, 1), ("res4 2a", 8, 14, 14, 1024, 256, 1), ("res5 2c", 8, 7, 7, 512, 2048, 1)]
+
+
+def timed(fn, iters=200):
+    for _ in range(10):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / iters
+
+
+rng = np.random.default_rng(0)
+for name, N, H, W, C, K, k in CASES:
+    x = torch.from_numpy((rng.random((N, H, W, C)) * 3).astype(np.float32)).cuda()
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = np.zeros(K, np.float32)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), S.ConvParam(w, b, 1, (k // 2, k // 2), (1, 1), (1, 1), True), L.F32, L.F32,
+                                          in_layout=L.NHWC, out_layout=L.NHWC)
+    y = conv.new_output()
+    rows = []
+    for t in range(5):
+        for ks in (1, 2):
+            for sh in range(4):
+                try:
+                    conv.set_tile(t | ((ks | (sh << 4)) << 8) | (11 << 16))
+                except L.SaberHipError:
+                    continue
+                rows.append((timed(lambda: conv.dispatch(x, y)), conv.algo()))
+    rows.sort()
+    flops = 2.0 * N * H * W * C * K * k * k
+    base = min(r for r in rows if "split" not in r[1])
+    print("%s: best unsplit %.2f us (%s) | best %.2f us (%s) %.0f TFLOP/s" % (name, base[0], base[1], rows[0][0], rows[0][1], flops / rows[0][0] / 1e6))
+    print("    " + "  ".join("%s %.2f" % (a.replace("igemm_f32_bf16x3_", ""), t) for t, a in rows[:6]))
+    conv.set_tile(2 | (1 << 8) | (11 << 16))
+    conv.autotune(x, y)
+    print("    autotune (cold-L2 timing) picks %s: %.2f us back to back" % (conv.algo(), timed(lambda: conv.dispatch(x, y))))

@@ -20,6 +20,7 @@ __device__ unsigned long long* saber_tl_buf = nullptr;
 #include "../../anakin_amd/csrc/img_e1.hip"
 #include "../../anakin_amd/csrc/igemm_m0_e1.hip"
 #include "../../anakin_amd/csrc/igemm_m0_e2.hip"
+#include "../../anakin_amd/csrc/igemm_m3_e3.hip"
 #include "../../anakin_amd/csrc/igemm_dma_m0_e1.hip"
 #include "../../anakin_amd/csrc/halo_e1.hip"
 #include "../../anakin_amd/csrc/stem_pool.hip"
@@ -256,6 +257,39 @@ int main(int argc, char** argv) {
             else if (g.elt) run(P, g.name, blocks, 5, [&] { launch_igemm_m0_e2(g.tile, g.ks, a, P.st); });
             else run(P, g.name, blocks, 5, [&] { launch_igemm_m0_e1(g.tile, g.ks, a, P.st); });
         }
+    }
+    // ---- FP32 on three bf16 planes (MODE 3), ResNet50 deep-K layers at batch 8, unsplit and split-K ----------------------
+    // phases: 0 entry, 1 gather state set up, 2 first stage in LDS, 5 reduction loop done, 3 split-K hand-off done, 4 stored
+    struct L3 { const char* name; int N, HW, C, K, k, tile, ks, sh; };
+    const L3 l3[] = {
+        {"f32 bf16x3 res4 3x3 256->256 @14  64x64 k1", 8, 14, 256, 256, 3, TILE_64x64, 1, 0},
+        {"f32 bf16x3 res4 3x3 256->256 @14  64x64 k1 split4", 8, 14, 256, 256, 3, TILE_64x64, 1, 2},
+        {"f32 bf16x3 res4 3x3 256->256 @14  32x32 k2", 8, 14, 256, 256, 3, TILE_32x32, 2, 0},
+        {"f32 bf16x3 res5 3x3 512->512 @7   64x64 k1 split8", 8, 7, 512, 512, 3, TILE_64x64, 1, 3},
+        {"f32 bf16x3 res3 3x3 128->128 @28  64x64 k2", 8, 28, 128, 128, 3, TILE_64x64, 2, 0},
+    };
+    for (const L3& g : l3) {
+        ConvKArgs a;
+        memset(&a, 0, sizeof a);
+        const int pad = g.k / 2, OHW = g.HW;
+        const int kg = g.k * g.k * g.C, kgp = (kg + 63) / 64 * 64, kpad = (g.K + 127) / 128 * 128;
+        a.N = g.N; a.H = a.W = g.HW; a.OH = a.OW = OHW; a.C = g.C; a.K = g.K; a.kh = a.kw = g.k; a.pad_h = a.pad_w = pad;
+        a.stride_h = a.stride_w = 1; a.dil_h = a.dil_w = 1;
+        a.M = g.N * OHW * OHW; a.Kg = kg; a.Kg_pad = kgp; a.epi = EPI_F32; a.out_dtype = DT_F32; a.relu = 1;
+        a.inv_ohw = 1.f / (OHW * OHW); a.inv_ow = 1.f / OHW;
+        a.x = dalloc((size_t)g.N * g.HW * g.HW * g.C * 4, 0); a.w = dalloc((size_t)3 * kpad * kgp * 2 + 65536, 0); a.zero = zero;
+        a.w_plane_chunks = (int)((size_t)kpad * kgp / 8);
+        a.y = dalloc((size_t)a.M * g.K * 4, 0);
+        a.bias = (const float*)dalloc(2048 * 4, 0);
+        a.ksplit_sh = g.sh;
+        a.part = (float*)dalloc(((size_t)a.M + 127) * (g.K + 127) * 4 * 8, 0);
+        a.part_ctr = (unsigned*)dalloc(65536, 0);
+        int bmk, bnp;
+        tile_dims(g.tile, &bmk, &bnp);
+        const int tiles = ((a.M + bnp - 1) / bnp) * ((g.K + bmk - 1) / bmk);
+        const int blocks = g.sh ? (8 * ((tiles + 7) / 8)) << g.sh : tiles;
+        a.steps = (kg + 32 * g.ks - 1) / (32 * g.ks);
+        run(P, g.name, blocks, 6, [&] { launch_igemm_m3_e3(g.tile, g.ks, a, P.st); });
     }
     return 0;
 }

@@ -1260,6 +1260,65 @@ def test_conv_f32_bf16x3_sweep_vs_oracle(case):
     assert np.abs(outs["f32"] - outs["bf16x3"]).max() <= 2e-5 * np.abs(want).max()
 
 
+F32_SPLITK_CASES = [
+    # N, H, W, C, K, k, pad, eltwise residual, tile ids, splits (log2)
+    (8, 14, 14, 256, 256, 3, 1, False, (0, 1, 2, 3), (1, 2, 3)),     # ResNet res4 branch2b at batch 8
+    (8, 7, 7, 512, 512, 3, 1, False, (2,), (1, 2, 3)),               # res5 branch2b
+    (3, 7, 9, 2048, 512, 1, 0, False, (1, 2), (2, 3)),               # res5 branch2a, ragged pixels (tiles % 8 != 0)
+    (2, 5, 5, 96, 40, 3, 1, False, (0, 2), (1, 2)),                  # ragged K / C, slabs straddle taps
+    (4, 14, 14, 256, 1024, 1, 0, True, (2,), (1,)),                  # ConvEltwise epilogue (in-place residual sum) after the sum
+]
+
+
+@pytest.mark.parametrize("case", F32_SPLITK_CASES)
+def test_conv_f32_bf16x3_split_k_vs_oracle_and_deterministic(case):
+    """FP32 split-K (2 / 4 / 8 workgroups per output tile on ONE XCD, partial sums handed over through that XCD's L2, summed
+    in split order by the last arrival): the oracle's convolution within 1e-4 (both criteria of the network tests), the same
+    bits on every launch (the order of the sum is fixed, not the order of arrival), the unsplit kernel within rounding."""
+    N, H, W, C, K, k, pad, elt, tiles, splits = case
+    rng = np.random.default_rng(N * 1000 + C + K)
+    x = (rng.random((N, C, H, W)) * 3.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    res = (rng.random((N, K, H, W)) * 2.0).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, not elt, (pad, pad), (1, 1), (1, 1))
+    if elt:
+        want = np.maximum(want + res, 0.0)
+    p = S.ConvParam(w, b, 1, (pad, pad), (1, 1), (1, 1), not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, True, 1.0
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rin = np.ascontiguousarray(res.transpose(0, 2, 3, 1))
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+
+    def run():
+        y = conv.new_output()
+        if elt:
+            y.copy_(dev(rin))
+        conv.dispatch(xin, y)
+        return host(y).transpose(0, 3, 1, 2)
+    conv.set_tile(conv.tile_id() | (1 << 8) | (11 << 16))
+    base = run()
+    for t in tiles:
+        for sh in splits:
+            code = t | ((1 | (sh << 4)) << 8) | (11 << 16)
+            try:
+                conv.set_tile(code)
+            except L.SaberHipError:
+                assert (C * k * k + 31) // 32 >> sh < 2, (case, t, sh)      # refused only for < 2 stages per split
+                continue
+            assert "split%d" % (1 << sh) in conv.algo(), conv.algo()
+            assert L.load().saber_hip_conv2d_get_tile(conv.h) == code
+            got = run()
+            d = np.abs(got - want)
+            e_max = float(d.max() / np.abs(want).max())
+            e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+            assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (conv.algo(), e_max, e_el)
+            assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
+            for _ in range(3):
+                assert np.array_equal(run(), got), ("not deterministic", conv.algo())
+
+
 STRIDED_HEAD_CASES = [
     # C, N, Hin, Win, 3x3 input dtype, mid dtype, eltwise relu, tile code (None: default)
     (64, 2, 56, 56, O.U8, O.U8, 1, None),        # res2c after the reference's stride-up: 56 -> 28
