@@ -64,7 +64,7 @@ def build_cpp_tests(verbose=False):
     outs = []
     for src in sorted(glob.glob(os.path.join(root, "tests", "cpp", "*.cpp"))):
         out = src[:-4] + ".bin"
-        deps = [src, os.path.join(root, "include", "saber_mi355x.hpp"), os.path.join(root, "include", "saber_hip.h"), LIB]
+        deps = [src, os.path.join(root, "include", "saber_mi355x.hpp"), os.path.join(root, "include", "saber_mi355x_impl.h"), os.path.join(root, "include", "saber_hip.h"), LIB]
         if _stale(out, deps):
             cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-o", out,
                    "-L" + HERE, "-lsaber_mi355x", "-L" + os.path.join(root, "oracle"), "-lsaber_oracle",
