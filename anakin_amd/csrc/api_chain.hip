@@ -176,7 +176,9 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     std::memset(&k, 0, sizeof k);
     k.x = x; k.res = res;
     k.wstream = ch->tn == 11 ? ch->d_stream_split8.p : ((ch->tn & 8) ? ch->d_stream_split.p : ch->d_stream.p);
-    if (ch->c1 == 128 && (ch->tn & 4)) k.wstream = ch->d_stream_w8.p; k.prm1 = ch->d_prm1.p; k.prm2 = ch->d_prm2.p;
+    if (ch->c1 == 128 && (ch->tn & 4)) k.wstream = ch->d_stream_w8.p;
+    k.prm1 = ch->d_prm1.p;
+    k.prm2 = ch->d_prm2.p;
     k.y1 = y_a; k.y2 = y_b;
     k.M = a->d.n * a->oh * a->ow;
     k.in_u8 = a->x_dtype == DT_U8;
@@ -191,6 +193,7 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };
         k.prm0 = ch->d_prm0.p;
         k.zero = zero_page();
+        if (!k.zero) return fail(SABER_HIP_RUNTIME_ERROR, "chain: zero page");
         k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
         k.tiles_x = (k.W + 15) / 16;
         const int rows = ch->c1 == 128 ? ch->tn & 3 : ch->tn & 7;    // tile rows (C = 128: bit 2 of the code = 8 waves)

@@ -154,6 +154,7 @@ def load():
     lib.saber_hip_eltwise_sum_i8.argtypes = [Z, P, P, F, F, F, F, I, P, P]
     lib.saber_hip_eltwise_sum_f32.argtypes = [Z, P, P, F, F, I, P, P]
     lib.saber_hip_pool_out_dim.argtypes = [I, I, I, I, I]
+    lib.saber_hip_pool_out_dim2.argtypes = [I, I, I, I, I, I]
     lib.saber_hip_pool2d_i8_nhwc.argtypes = [I] * 15 + [P, P, P]
     lib.saber_hip_pool2d_f32.argtypes = [I] * 14 + [P, P, P]
     lib.saber_hip_pool2d_f32_from_i8.argtypes = [I] * 14 + [F, P, P, P]

@@ -181,8 +181,7 @@ class SaberConv2DPooling:
             self.out_hw = (oh.value, ow.value)
         elif rc == L.UNIMPL:
             self.inner = torch.empty((n, ch, cw, self.conv.desc.k), dtype=_TORCH_DT[out_dtype], device="cuda")
-            self.out_hw = (pool_out_dim(ch, pad[0], window[0], stride[0], floor_mode),
-                           pool_out_dim(cw, pad[1], window[1], stride[1], floor_mode))
+            self.out_hw = pool_out_hw(ch, cw, pad, window, stride, floor_mode)
         else:
             L.check(rc)
         self.h = self.conv.h
@@ -450,8 +449,16 @@ def eltwise_sum(a, b, coeff=(1.0, 1.0), relu=True, scale_a=1.0, scale_b=1.0):
     return y
 
 
-def pool_out_dim(inp, pad, win, stride, floor_mode=False):
-    return L.load().saber_hip_pool_out_dim(inp, pad, win, stride, int(floor_mode))
+def pool_out_dim(inp, pad, win, stride, floor_mode=False, any_pad=None):
+    """Pooling output size along one dimension. any_pad: pad_h > 0 or pad_w > 0 - the reference clips the last window of BOTH
+    dimensions back inside the input whenever EITHER pad is non-zero (saber/funcs/pooling.h:113-120); None = this pad only."""
+    ap = int(pad > 0) if any_pad is None else int(bool(any_pad))
+    return L.load().saber_hip_pool_out_dim2(inp, pad, win, stride, int(floor_mode), ap)
+
+
+def pool_out_hw(h, w, pad, window, stride, floor_mode=False):
+    ap = pad[0] > 0 or pad[1] > 0
+    return (pool_out_dim(h, pad[0], window[0], stride[0], floor_mode, ap), pool_out_dim(w, pad[1], window[1], stride[1], floor_mode, ap))
 
 
 def pooling_i8(x, window, stride, pad, pool_type, out_dtype=None, global_pooling=False, floor_mode=False):
@@ -460,8 +467,7 @@ def pooling_i8(x, window, stride, pad, pool_type, out_dtype=None, global_pooling
     if global_pooling:
         window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
     else:
-        oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
-        ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
+        oh, ow = pool_out_hw(h, w, pad, window, stride, floor_mode)
     od = dtype_code(x) if out_dtype is None else out_dtype
     y = torch.empty((n, oh, ow, c), dtype=_TORCH_DT[od], device="cuda")
     L.check(L.load().saber_hip_pool2d_i8_nhwc(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1],
@@ -477,8 +483,7 @@ def pooling_f32(x, window, stride, pad, pool_type, layout=L.NCHW, global_pooling
     if global_pooling:
         window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
     else:
-        oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
-        ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
+        oh, ow = pool_out_hw(h, w, pad, window, stride, floor_mode)
     shape = (n, c, oh, ow) if layout == L.NCHW else (n, oh, ow, c)
     y = torch.empty(shape, dtype=torch.float32, device="cuda")
     L.check(L.load().saber_hip_pool2d_f32(n, h, w, c, oh, ow, window[0], window[1], stride[0], stride[1], pad[0],
@@ -494,8 +499,7 @@ def pooling_f32_from_i8(x, scale, window, stride, pad, pool_type, global_pooling
     if global_pooling:
         window, stride, pad, oh, ow = (h, w), (h, w), (0, 0), 1, 1
     else:
-        oh = pool_out_dim(h, pad[0], window[0], stride[0], floor_mode)
-        ow = pool_out_dim(w, pad[1], window[1], stride[1], floor_mode)
+        oh, ow = pool_out_hw(h, w, pad, window, stride, floor_mode)
     y = torch.empty((n, c, oh, ow), dtype=torch.float32, device="cuda")
     if q_scale is not None:
         yq = torch.empty((n, c, oh, ow), dtype=torch.int8, device="cuda")
