@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0   # dense i8 = 2x bf16 dense (~2.5 PF), MI355X_MICROARCH.md MFMA table
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 (no sparsity)
+# FP32 convolutions on three bf16 planes per operand issue SIX bf16 products per f32 product: the MFMA roof of those kernels in
+# f32-equivalent FLOP/s is the dense bf16 peak / 6
+MFMA_BF16X3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 
 
 def parse():
@@ -269,10 +273,11 @@ def main():
         for k in kern.values():
             gbs = k["bytes"] / (k["us"] * 1e-6) / 1e9
             tops = k["flops"] / (k["us"] * 1e-6) / 1e12
+            pk = MFMA_BF16X3_PEAK_TFLOPS if "bf16x3" in k["kernel"] else peak_ops     # the matrix pipe this kernel runs on
             per_kernel.append(dict(kernel=k["kernel"], launches=k["launches"], avg_us=round(k["us"] / k["launches"], 3),
                                    total_us=round(k["us"], 2), bytes_per_launch=int(k["bytes"] / k["launches"]),
                                    gops_per_launch=round(k["flops"] / k["launches"] / 1e9, 4), gbs=round(gbs, 1),
-                                   hbm_frac=round(gbs / HBM_PEAK_GBS, 4), mfma_frac=round(tops / peak_ops, 4)))
+                                   hbm_frac=round(gbs / HBM_PEAK_GBS, 4), mfma_peak=round(pk, 1), mfma_frac=round(tops / pk, 4)))
         per_kernel.sort(key=lambda r: -r["total_us"])
         convs = [r for r in per_kernel if r["kernel"].startswith(("conv:", "fc:"))]
         dom = convs[0]                           # the kernel function with the largest share of the step
@@ -281,11 +286,11 @@ def main():
         alg_ops = sum(r["gops_per_launch"] * r["launches"] for r in convs) * 1e9
         n_conv = sum(r["launches"] for r in convs)
         t_hbm = dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
-        t_mfma = dom["gops_per_launch"] * 1e9 / (peak_ops * 1e12)
+        t_mfma = dom["gops_per_launch"] * 1e9 / (dom["mfma_peak"] * 1e12)
         if t_hbm >= t_mfma:
             roof = dict(bound="hbm", achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["hbm_frac"], traffic=None)
         else:
-            roof = dict(bound="mfma", achieved=round(dom["mfma_frac"] * peak_ops, 2), peak=peak_ops, unit="TFLOP/s",
+            roof = dict(bound="mfma", achieved=round(dom["mfma_frac"] * dom["mfma_peak"], 2), peak=dom["mfma_peak"], unit="TFLOP/s",
                         frac=dom["mfma_frac"], traffic=None)
         # HBM traffic of that kernel from the committed PMC passes (profiles/r03/traffic.json: per launch, FETCH_SIZE doubled per
         # the gfx950 correction) - only while the sources it was measured on are unchanged (src_sha): a stale counter is worse than none
@@ -304,7 +309,10 @@ def main():
                     how="dominant kernel function of the pass by total time; avg_launch_us = its share of an event-per-launch eager "
                         "pass (saber_hip_net_time_pass, hipEvents on the launch stream) scaled to ms_per_step of the timed region",
                     frac_all_conv=round(all_gbs / HBM_PEAK_GBS, 4), achieved_all_conv_gbs=round(all_gbs, 1),
-                    mfma_frac_all_conv=round(alg_ops / (conv_us_step * 1e-6) / 1e12 / peak_ops, 4),
+                    # every conv / fc launch at its own matrix pipe's peak, over the time they take in the step
+                    mfma_frac_all_conv=round(sum(r["gops_per_launch"] * r["launches"] * 1e9 / (r["mfma_peak"] * 1e12) for r in convs)
+                                             / (conv_us_step * 1e-6), 4),
+                    achieved_all_conv_tflops=round(alg_ops / (conv_us_step * 1e-6) / 1e12, 1),
                     conv_fc_launches=n_conv, conv_fc_us_of_step=round(conv_us_step, 1),
                     algorithmic_bytes_per_forward=int(alg_bytes), algorithmic_ops_per_forward=int(alg_ops),
                     back_to_back_op_sum_us=round(sum(op_us), 1), per_kernel=per_kernel)
@@ -521,7 +529,9 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "int8" if args.precision == "int8" else "f32",
             "dtype_detail": "s8/u8 x s8 -> s32 (MFMA i8), f32 requantisation epilogue" if args.precision == "int8"
-            else "f32 (v_mfma_f32_16x16x4_f32)",
+            else "f32 tensors and accumulation; products on v_mfma_f32_16x16x4_f32, or - kernels named bf16x3 - on v_mfma_f32_16x16x32_bf16 "
+                 "with each operand split exactly into three bf16 planes (six products per f32 product; error vs f64 below the f32 MFMA's, "
+                 "profiles/r03/bf16_split_probe.txt)",
             "data": "synthetic (seeded uniform images, He-init weights with folded BN, MAXABS scales)",
             "config": {"workload": "%s %s, batch %d per GPU, 224x224: %s" %
                                    (args.model, args.precision, B,

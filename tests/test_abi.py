@@ -27,6 +27,19 @@ def test_header_symbols_are_exported(built):
         assert hasattr(built, name), name
 
 
+def test_nothing_else_is_exported_with_c_linkage(built):
+    """The ABI's translation units (api_*.hip) take their C linkage from the header: an entry point defined without a
+    declaration there would silently become a mangled C++ symbol (and a helper declared in an extern "C" block an
+    accidental export). The unmangled dynamic symbols of the library are exactly the header's."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+    plain = {n for n in exported if not n.startswith(("_Z", "__", "_init", "_fini", "_edata", "_end", "_bss"))}
+    assert plain == set(L.SYMBOLS), (plain ^ set(L.SYMBOLS))
+
+
 def test_create_validates_without_gpu(built):
     import ctypes as C
     d = L.ConvDesc()
