@@ -12,7 +12,7 @@ thread_local std::vector<unsigned long long>* g_used_kernels = nullptr;
 // launches accumulate into y (the caller re-initialises it). On error the entry selection is restored.
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                                          saber_hip_stream_t stream, int iters) {
-    if (op->algo > ALGO_IGEMM_F32 || op->pool_fused) return SABER_HIP_OK;   // (one fused conv+pooling kernel)
+    if (op->algo > ALGO_IGEMM_F32 || op->pool_fused || op->gpool) return SABER_HIP_OK;   // (one fused conv+pooling kernel)
     if (op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "sibling pair: use saber_hip_conv2d_autotune_pair");
     hipStream_t s = (hipStream_t)stream;
     EventPair ev;
@@ -105,6 +105,12 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         ConvChoice cs = c;
         cs.stem = 1;
         set_choice(op, cs);
+        time_current();
+    }
+    if (img_conv_ok(op) && img_conv_prepare(op) == SABER_HIP_OK) {   // <= 64 pixels per image: image-resident kernel
+        ConvChoice ci = c;
+        ci.img1 = 1;
+        set_choice(op, ci);
         time_current();
     }
     if (halo_ok(op)) {

@@ -6,7 +6,7 @@
 // ------------------------------------------------------------------------------------------------
 static bool chain_1x1(const saber_hip_conv* o, bool sub_res_ok = false) {
     const saber_hip_conv_desc& d = o->d;
-    return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.kh == 1 && d.kw == 1 &&
+    return o->is_i8 && o->weights_set && !o->gpool && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.kh == 1 && d.kw == 1 &&
            d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && d.group == 1 && !o->pair_k2 &&
            !o->pool_fused && !o->pool2 && !o->pre_quant && !o->pre_pad && o->c_eff == d.c && d.act_negative_slope == 0.f &&
            d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC && (d.res_stride <= 1 || sub_res_ok);

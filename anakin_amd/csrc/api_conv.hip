@@ -141,6 +141,7 @@ void name_algo(saber_hip_conv* op) {
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
+    else if (op->img1) snprintf(buf, sizeof buf, "imgres%dx%d_i8_%dch%s", op->d.kh, op->d.kw, 16 * ((op->d.k / 16 + 31) / 32), op->gpool ? "+gpool" : "");
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
@@ -340,6 +341,14 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         name_algo(op);
         return SABER_HIP_OK;
     }
+    if (var == 12) {   // image-resident kernel (<= 64 pixels per image: one workgroup = one image x a channel group)
+        const int rc = img_conv_prepare(op);
+        if (rc) return rc;
+        op->img1 = 1; op->halo = 0; op->img_ib = op->img_rb = 0; op->stem = 0; op->fc_small = 0;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
+    if (op->gpool) return fail(SABER_HIP_INVALID_VALUE, "conv + fused global pooling has a single kernel");
     if (var == 10) {   // small-batch fc kernel
         if (!fc_small_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "small-batch fc kernel: INT8 fc with <= 16 rows and k <= 4096");
         op->fc_small = 1;
@@ -364,6 +373,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         return SABER_HIP_OK;
     }
     if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
+        op->img1 = 0;
         op->b3 = 0;
         op->ksplit = 0;
         op->halo = 0;
@@ -383,6 +393,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
+    if (op->img1) return 12 << 16;
     if (op->fc_small) return 10 << 16;
     if (op->b3) return op->tile | ((op->ks | (op->ksplit << 4)) << 8) | (11 << 16);
     if (op->stem) return 7 << 16;
@@ -614,6 +625,8 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     hipStream_t s = (hipStream_t)stream;
     const saber_hip_conv_desc& d = op->d;
     const void* xin = x;
+    if (op->gpool) return fail(SABER_HIP_INVALID_VALUE, "conv + fused global pooling: use saber_hip_conv2d_run_gpool");
+    if (op->img1) return img_conv_run(op, x, y, res, nullptr, s);
     if (op->pool_fused) {
         ConvKArgs a;
         if (op->pre_pad) {
@@ -845,5 +858,26 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
     return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);   // both outputs hold the selected kernel's result
 }
 
-void saber_hip_conv2d_destroy(saber_hip_conv_t* op) { delete op; }
+int saber_hip_conv2d_set_global_pooling(saber_hip_conv_t* op) {
+    if (!op || !op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "set_weights first");
+    if (op->img_stage) img_conv_release(op);
+    op->gpool = 1;
+    const int rc = img_conv_prepare(op);
+    if (rc) {
+        op->gpool = 0;
+        return fail(SABER_HIP_UNIMPL, "conv + global average pooling: no fused kernel for this op (run the two ops)");
+    }
+    op->img1 = 1; op->halo = 0; op->img_ib = op->img_rb = 0; op->stem = 0; op->fc_small = 0;
+    name_algo(op);
+    return SABER_HIP_OK;
+}
+int saber_hip_conv2d_run_gpool(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* y_pool, saber_hip_stream_t stream) {
+    if (!op || !op->gpool) return fail(SABER_HIP_INVALID_VALUE, "not a conv with fused global pooling");
+    return img_conv_run(op, x, y, res, y_pool, (hipStream_t)stream);
+}
+
+void saber_hip_conv2d_destroy(saber_hip_conv_t* op) {
+    if (op) img_conv_release(op);
+    delete op;
+}
 

@@ -99,6 +99,9 @@ struct saber_hip_conv {
     int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
+    int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels
+    int gpool = 0;           // ... with the global average pooling of its output fused (saber_hip_net_optimize flag 128): img1 only
+    struct saber_hip_stage* img_stage = nullptr;   // the single-phase descriptor + repacked weights of that kernel (img_conv_prepare)
     int ksplit = 0;          // b3 only: log2 of the split-K factor (conv_igemm_impl.h: splits of one tile share an XCD), 0: none
     int b3 = 0;              // FP32: 1 = the implicit GEMM runs on the bf16 matrix cores (three bf16 operand planes, conv_igemm_impl.h
                              // MODE 3): needs c_eff % 8 == 0 and the pre-split weight planes d_w3
@@ -154,14 +157,14 @@ struct saber_hip_fc {
 namespace saber_api {
 // one selection of kernel variant for an op (what the autotuner saves / restores)
 struct ConvChoice {
-    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit;
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit, img1;
 };
 inline ConvChoice get_choice(const saber_hip_conv* op) {
-    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit};
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit, op->img1};
 }
 inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
-    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool;
 }
 inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
     return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr;
@@ -244,6 +247,7 @@ inline unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice&
     else if (op->algo != ALGO_IGEMM_F32 && op->epi == EPI_I8_CONV && d.res_mode != SABER_HIP_RES_SUM_INPLACE && d.k % 16 == 0)
         ek = d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : (d.out_dtype == SABER_HIP_U8 ? 1 : (d.out_dtype == SABER_HIP_S8 ? 0 : 3));
     unsigned long long k = (unsigned long long)op->algo | ((unsigned long long)ek << 4);
+    if (c.img1) return k | (7ull << 8) | ((unsigned long long)(op->d.kh == 3) << 16);      // one function for all image-resident shapes
     if (c.fc_small) return k | (1ull << 8) | ((unsigned long long)((op->c_eff + 255) / 256) << 16);
     if (c.stem) return k | (2ull << 8);
     if (c.img_rb)   // <EK, NW, CW, NCH, GPW>: channel count and pixel groups per wave
@@ -327,6 +331,11 @@ void name_algo(saber_hip_conv* op);      // api_conv.hip
 // workgroup -> XCD placement the hand-off relies on (checked once per device). split_prepare allocates the buffers.
 bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh);      // api_conv.hip
 int split_prepare(saber_hip_conv* op);      // api_conv.hip
+// image-resident kernel variant of an INT8 conv on <= 64-pixel images (api_stage.hip)
+bool img_conv_ok(const saber_hip_conv* op);
+int img_conv_prepare(saber_hip_conv* op);
+int img_conv_run(saber_hip_conv* op, const void* x, void* y, const void* res, void* y_pool, hipStream_t stream);
+void img_conv_release(saber_hip_conv* op);
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s);      // api_net.hip
 void net_set_chain_mode(saber_hip_net* net, int ia, int mode);      // api_net_optimize.hip
 int net_chain_mode(const saber_hip_net* net, int ia);      // api_net_optimize.hip

@@ -248,6 +248,34 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             ++removed;   // the fc's quantise-on-entry kernel
         }
     }
+    // ---- 128: conv + global average pooling (INT8): the pooling's launch disappears, both tensors are written -------
+    if (flags & 128) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (dead[i] || ops[i].kind != OP_POOL_I8) continue;
+            NetOp& q = ops[i];   // p[] = n,h,w,c,oh,ow,kh,kw,sh,sw,ph,pw,type,in_dtype,out_dtype
+            if (q.p[4] != 1 || q.p[5] != 1 || q.p[6] != q.p[1] || q.p[7] != q.p[2] || q.p[10] || q.p[11] ||
+                q.p[12] == SABER_HIP_POOL_MAX || q.p[13] != q.p[14])
+                continue;
+            const int p = producer(q.in, (int)i);
+            if (p < 0 || ops[p].kind != OP_CONV || !ops[p].conv || ops[p].lane != q.lane || ops[p].out2 >= 0) continue;
+            const saber_hip_conv* src = ops[p].conv;
+            if (!src->is_i8 || src->pair_k2 || src->pool_fused || src->gpool || !img_conv_ok(src) || src->d.n != q.p[0] ||
+                src->d.k != q.p[3] || src->oh != q.p[1] || src->ow != q.p[2] || src->d.out_dtype != q.p[13])
+                continue;
+            saber_hip_conv* fused = nullptr;
+            if (clone_conv_i8(src, src->d, &fused) != SABER_HIP_OK) continue;
+            if (saber_hip_conv2d_set_global_pooling(fused) != SABER_HIP_OK) {
+                saber_hip_conv2d_destroy(fused);
+                continue;
+            }
+            net->owned.push_back(fused);
+            ops[p].conv = fused;
+            ops[p].out2 = q.out;
+            ops[p].name = std::string("conv:") + fused->algo_name;
+            dead[i] = 1;
+            ++removed;
+        }
+    }
     (void)nt;
     std::vector<NetOp> live;
     for (size_t i = 0; i < ops.size(); ++i)

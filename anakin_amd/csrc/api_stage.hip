@@ -46,6 +46,15 @@ void pack_stage_weights(const saber_hip_conv* o, int nt, int kq, std::vector<uin
 }
 }  // namespace
 
+namespace {
+struct StageSpec {
+    saber_hip_conv* conv;
+    int in, out, res;
+    int pool;              // >= 0: slot of the fused global average pooling's output
+};
+int stage_build(const StageSpec* ph, int n, bool xcd_resident, saber_hip_stage_t** out);
+}  // namespace
+
 int saber_hip_stage_create(const saber_hip_stage_phase* ph, int n, saber_hip_stage_t** out) {
     if (!ph || !out || n <= 0 || n > 64) return fail(SABER_HIP_INVALID_VALUE, "stage: bad argument");
     int dev = 0;
@@ -53,6 +62,13 @@ int saber_hip_stage_create(const saber_hip_stage_phase* ph, int n, saber_hip_sta
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     if (prop.multiProcessorCount != 256) return fail(SABER_HIP_UNIMPL, "stage: needs the 8 x 32 CU partition");
+    std::vector<StageSpec> sp(n);
+    for (int i = 0; i < n; ++i) sp[i] = {ph[i].conv, ph[i].in, ph[i].out, ph[i].res, -1};
+    return stage_build(sp.data(), n, true, out);
+}
+
+namespace {
+int stage_build(const StageSpec* ph, int n, bool xcd_resident, saber_hip_stage_t** out) {
     std::unique_ptr<saber_hip_stage> st(new saber_hip_stage());
     std::vector<uint8_t> wbytes, pbytes;
     std::vector<char> dirty(STAGE_MAX_TENSORS, 0), written(STAGE_MAX_TENSORS, 0);
@@ -65,7 +81,7 @@ int saber_hip_stage_create(const saber_hip_stage_phase* ph, int n, saber_hip_sta
         const bool elt = d.res_mode == SABER_HIP_RES_ELTWISE;
         if (i == 0) { st->n_img = d.n; st->h = d.h; st->w = d.w; }
         if (d.n != st->n_img || d.h != st->h || d.w != st->w || d.h * d.w > 64) return fail(SABER_HIP_INVALID_VALUE, "stage: all phases run on the same n x h x w, h * w <= 64");
-        const int slots[3] = {ph[i].in, ph[i].out, elt ? ph[i].res : 0};
+        const int slots[4] = {ph[i].in, ph[i].out, elt ? ph[i].res : 0, ph[i].pool >= 0 ? ph[i].pool : 0};
         for (int s : slots)
             if (s < 0 || s >= STAGE_MAX_TENSORS) return fail(SABER_HIP_INVALID_VALUE, "stage: tensor slot out of range");
         if (ph[i].out == ph[i].in || (elt && ph[i].out == ph[i].res) || written[ph[i].out])
@@ -96,7 +112,9 @@ int saber_hip_stage_create(const saber_hip_stage_phase* ph, int n, saber_hip_sta
         p.mg_pch = (unsigned)((0x100000000ull + p.pch - 1) / p.pch);
         const size_t a64 = ((size_t)(d.h * d.w + 1) * p.pch + 63) / 64 * 64;
         p.red_chunk = (int)a64;
-        lds_chunks = std::max(lds_chunks, a64 + (size_t)4 * nt * 4 * 64);
+        lds_chunks = std::max(lds_chunks, a64 + (size_t)4 * nt * 4 * 64 + (size_t)4 * nt * 4);   // image, partial accumulators, pooling partials
+        p.pool_t = ph[i].pool;
+        p.pool_idiv = 1.0f / (float)(d.h * d.w);
         p.w_chunk = (unsigned)(wbytes.size() / 16);
         pack_stage_weights(o, nt, ksteps / 4, wbytes);
         // per 4 channels {scale[4], bias'[4], comp[4]}, padded to the 32 CUs' tiles
@@ -110,21 +128,55 @@ int saber_hip_stage_create(const saber_hip_stage_phase* ph, int n, saber_hip_sta
             ((float*)q)[4 + k % 4] = (o->has_bias && !o->bias_p_host.empty()) ? o->bias_p_host[k] : 0.f;
             ((int*)q)[8 + k % 4] = o->comp_host.empty() ? 0 : o->comp_host[k];
         }
-        st->n_tensors = std::max(st->n_tensors, std::max(p.in_t, std::max(p.out_t, p.res_t)) + 1);
+        st->n_tensors = std::max(st->n_tensors, std::max(std::max(p.in_t, p.pool_t), std::max(p.out_t, p.res_t)) + 1);
         st->phases.push_back(p);
         st->convs.push_back(o);
     }
-    st->lds_bytes = std::max<size_t>(lds_chunks * 16, 81 * 1024);     // > 80 KB: one workgroup per CU
+    st->lds_bytes = xcd_resident ? std::max<size_t>(lds_chunks * 16, 81 * 1024) : lds_chunks * 16;     // stage: > 80 KB = one workgroup per CU
     if (st->lds_bytes > 160 * 1024 - 64) return fail(SABER_HIP_UNIMPL, "stage: the image does not fit in LDS");
     std::vector<uint8_t> pt((const uint8_t*)st->phases.data(), (const uint8_t*)st->phases.data() + st->phases.size() * sizeof(StagePhase));
     hipError_t e = st->d_phases.upload(pt);
     if (e == hipSuccess) e = st->d_w.upload(wbytes);
     if (e == hipSuccess) e = st->d_prm.upload(pbytes);
-    if (e == hipSuccess) e = st->d_sync.alloc_zero(kSyncWords);
+    if (e == hipSuccess && xcd_resident) e = st->d_sync.alloc_zero(kSyncWords);
     if (e != hipSuccess) return hip_fail(e, "stage: device copies");
     if (!zero_page()) return fail(SABER_HIP_RUNTIME_ERROR, "stage: zero page");
     *out = st.release();
     return SABER_HIP_OK;
+}
+}  // namespace
+
+// ---- the same phase code as an ordinary kernel for ONE conv (a kernel variant of saber_hip_conv2d_run: image-resident) ----------
+bool img_conv_ok(const saber_hip_conv* op) {
+    if (!stage_conv_ok(op) || op->d.h * op->d.w > 64) return false;
+    const int taps = op->d.kh * op->d.kw, ksteps = op->d.c * taps / 64;
+    int type = 0;
+    return ksteps % 4 == 0 && stage_xcd_type((op->d.k / 16 + 31) / 32, ksteps / 4, taps == 9, &type);
+}
+int img_conv_prepare(saber_hip_conv* op) {
+    if (op->img_stage) return SABER_HIP_OK;
+    if (!img_conv_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "image-resident kernel: 1x1 / 3x3 stride-1 INT8 conv on <= 64 pixels per image with ResNet res5 channel shapes");
+    const StageSpec sp = {op, 0, 1, op->d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : -1, op->gpool ? 3 : -1};
+    return stage_build(&sp, 1, false, &op->img_stage);
+}
+int img_conv_run(saber_hip_conv* op, const void* x, void* y, const void* res, void* y_pool, hipStream_t stream) {
+    saber_hip_stage* st = op->img_stage;
+    if (!st) return fail(SABER_HIP_INVALID_VALUE, "image-resident kernel selected without its buffers (set_tile / autotune build them)");
+    const StagePhase& p = st->phases[0];
+    if (!x || !y || (p.elt && !res) || (p.pool_t >= 0 && !y_pool)) return fail(SABER_HIP_INVALID_VALUE, "null tensor");
+    StageKArgs k;
+    std::memset(&k, 0, sizeof k);
+    k.phases = (const StagePhase*)st->d_phases.p;
+    k.weights = st->d_w.p; k.prm = st->d_prm.p; k.zero = zero_page();
+    k.n_phases = 1;
+    k.n_img = st->n_img; k.H = st->h; k.W = st->w;
+    k.t[0] = const_cast<void*>(x); k.t[1] = y; k.t[2] = const_cast<void*>(res); k.t[3] = y_pool;
+    HIP_TRY(launch_img_conv(k, st->lds_bytes, stream));
+    return SABER_HIP_OK;
+}
+void img_conv_release(saber_hip_conv* op) {
+    delete op->img_stage;
+    op->img_stage = nullptr;
 }
 
 int saber_hip_stage_num_tensors(const saber_hip_stage_t* st) { return st ? st->n_tensors : 0; }

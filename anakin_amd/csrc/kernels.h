@@ -152,7 +152,8 @@ struct StagePhase {              // in device memory, read with scalar loads
     int reload;                  // bring the input image into LDS (0: the previous phase left it there)
     unsigned pch, mg_pch;        // LDS pixel pitch in chunks (cin / 16 + 1) and ceil(2^32 / pch)
     int red_chunk;               // LDS offset (chunks) of the cross-wave reduction buffer
-    int pad[2];
+    int pool_t;                  // >= 0: also write the global AVERAGE pooling of this phase's output, [n_img][cout] 8-bit of the output's
+    float pool_idiv;             // dtype, to that slot: (float)(int32 sum over the pixels) * pool_idiv, rne, saturate (the INT8 pooling op)
 };
 static_assert(sizeof(StagePhase) == 96, "StagePhase layout");
 struct StageKArgs {
@@ -168,6 +169,9 @@ struct StageKArgs {
 };
 bool stage_xcd_type(int tiles_per_cu, int ksteps_per_wave, int is3x3, int* type);
 hipError_t launch_stage_xcd(const StageKArgs& a, size_t lds_bytes, hipStream_t s);
+// the same phase code as an ordinary kernel: ONE conv (a.phases[0]), grid = n_img x 32 workgroups - workgroup (img, c) computes
+// output channels [c * 16 NT, (c + 1) * 16 NT) of image img with the whole image in LDS and its weight slice in registers
+hipError_t launch_img_conv(const StageKArgs& a, size_t lds_bytes, hipStream_t s);
 
 // hipcc fetches kernel arguments lazily with scalar loads and places each load near its first use; every batch that is
 // issued after an `s_waitcnt lgkmcnt(0)` is one more DEPENDENT round trip (~0.2-0.25 us, measured) before the kernel's

@@ -49,6 +49,7 @@ __device__ __forceinline__ void stage_dma16(const void* src, void* dst_wave_base
 
 struct StageCtx {
     int xcd, cu;                  // this workgroup's XCD and its number within it
+    int img0, img_step;           // images this workgroup computes: img0, img0 + img_step, ... (stage: its XCD's, step 8)
     unsigned long long gen;       // launch generation of the registration counter
     unsigned long long* ctr;      // this XCD's arrival counter
     unsigned long long* abort_w;
@@ -129,12 +130,14 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
     const float lo_s8 = php->relu ? 0.f : -128.f;
     const float res_lo = php->res_relu ? 0.f : -3.0e38f;
     struct { float coeff_conv, scale_conv, coeff_res, scale_res; } ec = {php->coeff_conv, php->scale_conv, php->coeff_res, php->scale_res};
+    const int pool_t = php->pool_t;
+    v4i* pool_part = red + 4 * NT * 4 * 64;             // [wave][tile][channel quad] int32 x 4, behind the partial accumulators
     const int kspt = chunks >> 2;                       // k-steps per tap
     const int my_p = wave * 16 + frow;                  // epilogue: this lane's pixel slot
     bool first = true;
-    for (int img = cx.xcd; img < a.n_img; img += 8) {
+    for (int img = cx.img0; img < a.n_img; img += cx.img_step) {
         // ---- the input image -> LDS ------------------------------------------------------------------------------------
-        if (php->reload || !first || cx.xcd + 8 < a.n_img) {       // (several images on this XCD: LDS holds the last one)
+        if (php->reload || !first || cx.img0 + cx.img_step < a.n_img) {       // (several images for this workgroup: LDS holds the last one)
             __syncthreads();                            // nobody still reads the previous image / partial sums
             const char* xg = xin + (size_t)img * HW * cin;
             for (int i = wave; i < nA; i += 4) {
@@ -156,7 +159,7 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (img == cx.xcd) STAGE_TR(5);
+        if (img == cx.img0) STAGE_TR(5);
         // ---- this wave's quarter of the reduction, all 4 pixel fragments ---------------------------------------------------
         v4i acc[NT][4];
 #pragma unroll
@@ -188,7 +191,7 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[j][m] = mma_step(wreg[i * NT + j], bf[m], acc[j][m]);
         }
-        if (img == cx.xcd) STAGE_TR(6);
+        if (img == cx.img0) STAGE_TR(6);
         // ---- the four partial sums meet in LDS; wave w finishes pixel fragment w ---------------------------------------------
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -208,6 +211,40 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
             if (rin) o = chain_elt_pack(s, prm[j][2], __builtin_bit_cast(v4f, prm[j][1]), __builtin_bit_cast(v4f, prm[j][0]), rs[j], lo_s8, res_lo, ec);
             else o = chain_out_pack(s, prm[j][2], __builtin_bit_cast(v4f, prm[j][1]), __builtin_bit_cast(v4f, prm[j][0]), lo, off, xo);
             if (my_p < HW && ch < cout) *(unsigned*)(yout + ((size_t)img * HW + my_p) * cout + ch) = o;
+            if (pool_t >= 0) {      // global average pooling of the 8-bit values just stored: exact int32 sums, this wave's 16 pixels first
+                int ps[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int b = (int)((o >> (8 * t)) & 0xffu);
+                    ps[t] = (php->out_u8 && !rin) ? b : (int)(int8_t)b;      // (the eltwise epilogue writes s8)
+                    if (my_p >= HW) ps[t] = 0;
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) ps[t] += __shfl_xor(ps[t], m, 64);
+                }
+                if (frow == 0) pool_part[(wave * NT + j) * 4 + fq] = v4i{ps[0], ps[1], ps[2], ps[3]};
+            }
+        }
+        if (pool_t >= 0) {
+            __syncthreads();
+            if (tid < NT * 4) {          // (tile j, channel quad fq): the four waves' partial sums, then the pooling op's arithmetic
+                const int j = tid >> 2, q4 = tid & 3;
+                const int ch = cx.cu * (16 * NT) + 16 * j + q4 * 4;
+                v4i tot = pool_part[(0 * NT + j) * 4 + q4];
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const v4i t2 = pool_part[(w2 * NT + j) * 4 + q4];
+                    tot.x += t2.x; tot.y += t2.y; tot.z += t2.z; tot.w += t2.w;
+                }
+                const bool u8o = php->out_u8 && !rin;
+                unsigned w = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float f = rintf(__fmul_rn((float)tot[t], php->pool_idiv));
+                    const int q = u8o ? (int)fminf(fmaxf(f, 0.f), 255.f) : (int)fminf(fmaxf(f, -128.f), 127.f);
+                    w |= (unsigned)(q & 0xff) << (8 * t);
+                }
+                if (ch < cout) *(unsigned*)((char*)a.t[pool_t] + (size_t)img * cout + ch) = w;
+            }
         }
     }
     STAGE_TR(7);
@@ -239,6 +276,8 @@ __global__ __launch_bounds__(256) void stage_xcd_kernel(const StageKArgs a) {
     cx.abort_w = a.sync + 16 * 16;
     cx.bar = 0;
     cx.hw = a.H * a.W;
+    cx.img0 = cx.xcd;
+    cx.img_step = 8;
     if (cx.xcd >= a.n_img) {      // no image for this XCD: keep its arrival counter in step with the generations and leave
         if (tid == 0 && a.n_barriers) __hip_atomic_fetch_add(cx.ctr, (unsigned long long)a.n_barriers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -267,6 +306,40 @@ __global__ __launch_bounds__(256) void stage_xcd_kernel(const StageKArgs a) {
     }
 }
 
+// One convolution, ordinary grid: workgroup b = (image b / 32, channel group b % 32). No registration, no barrier: the phase's
+// `barrier` is 0 and the counters are never touched.
+__global__ __launch_bounds__(256) void img_conv_kernel(const StageKArgs a) {
+    extern __shared__ v4i stage_lds[];
+    __shared__ unsigned s_abort;
+    StageCtx cx;
+    cx.xcd = 0;
+    cx.cu = (int)(blockIdx.x & 31u);
+    cx.gen = 0;
+    cx.ctr = nullptr;
+    cx.abort_w = nullptr;
+    cx.bar = 0;
+    cx.hw = a.H * a.W;
+    cx.img0 = (int)(blockIdx.x >> 5);
+    cx.img_step = 1 << 30;
+    cx.tr = nullptr;
+    const int frow = threadIdx.x & 15;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int p = m * 16 + frow;
+        cx.py[m] = p < cx.hw ? p / a.W : -1;
+        cx.px[m] = p < cx.hw ? p - (p / a.W) * a.W : 0;
+    }
+    PhasePtr php = (PhasePtr)a.phases;
+    switch (php->type) {
+    case 0: (void)stage_phase<4, 4, false>(a, php, cx, stage_lds, &s_abort); break;
+    case 1: (void)stage_phase<1, 4, false>(a, php, cx, stage_lds, &s_abort); break;
+    case 2: (void)stage_phase<1, 18, true>(a, php, cx, stage_lds, &s_abort); break;
+    case 3: (void)stage_phase<4, 2, false>(a, php, cx, stage_lds, &s_abort); break;
+    case 4: (void)stage_phase<1, 8, false>(a, php, cx, stage_lds, &s_abort); break;
+    default: break;
+    }
+}
+
 bool stage_xcd_type(int tiles_per_cu, int ksteps_per_wave, int is3x3, int* type) {
     static const int tab[5][3] = {{4, 4, 0}, {1, 4, 0}, {1, 18, 1}, {4, 2, 0}, {1, 8, 0}};
     for (int i = 0; i < 5; ++i)
@@ -289,6 +362,21 @@ hipError_t launch_stage_xcd(const StageKArgs& a, size_t lds_bytes, hipStream_t s
         done[dev] = true;
     }
     hipLaunchKernelGGL(stage_xcd_kernel, dim3(256), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_img_conv(const StageKArgs& a, size_t lds_bytes, hipStream_t s) {
+    if (lds_bytes > 160 * 1024 - 64 || a.n_img <= 0 || a.n_img > (1 << 20)) return hipErrorInvalidValue;
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) return e != hipSuccess ? e : hipErrorInvalidDevice;
+    if (!done[dev]) {
+        e = hipFuncSetAttribute((const void*)img_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(img_conv_kernel, dim3(a.n_img * 32), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 

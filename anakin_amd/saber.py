@@ -128,6 +128,16 @@ class SaberConv2D:
     def set_tile(self, tile):
         L.check(L.load().saber_hip_conv2d_set_tile(self.h, tile))
 
+    def set_global_pooling(self):
+        """fuse the global average Pooling<AK_INT8> of this conv's output (saber_hip_conv2d_set_global_pooling); dispatch_gpool then
+        writes both tensors"""
+        L.check(L.load().saber_hip_conv2d_set_global_pooling(self.h))
+        return self
+
+    def dispatch_gpool(self, x, y, y_pool, res=None):
+        L.check(L.load().saber_hip_conv2d_run_gpool(self.h, _p(x), _p(y), _p(res), _p(y_pool), _stream()))
+        return y, y_pool
+
     def tile_id(self):
         """The current block tile (low byte of saber_hip_conv2d_get_tile)."""
         return L.load().saber_hip_conv2d_get_tile(self.h) & 0xff

@@ -412,6 +412,8 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
         net.removed = net.optimize(15)
     # a stride-up shortcut pooling (framework_spec) read only by a fused eltwise epilogue is folded into that read
     net.absorbed = net.optimize(64) if (fuse_eltwise or cxx_optimize) and absorb_pool else 0
+    # the last block's conv (+ fused eltwise) also writes the global average pooling of its output (flag 128): pool5's launch goes
+    net.gpooled = net.optimize(128) if (fuse_eltwise or cxx_optimize) and absorb_pool else 0
     net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0)) if chain else 0
     net.finalize()
     return net

@@ -144,11 +144,23 @@ const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op);
  * set_tile argument: tile id in the low byte, stage depth (1/2/4) in bits 8..15, variant in bits 16..23:
  *   1 register-staged implicit GEMM, 2 LDS-DMA ring, 3 / 4 ring with 2 / 4 wave groups, 5 / 6 LDS-halo 3x3 (4 / 8 rows),
  *   7 / 8 stem kernel on / off, 9 small-image 3x3 (low byte = output rows per slab, bits 8..15 = images per slab),
- *   10 small-batch fc. */
+ *   10 small-batch fc;
+ *   12 image-resident kernel (INT8 1x1 / 3x3 stride-1 convs on <= 64 pixels per image: workgroup = one image x a channel group,
+ *      the image in LDS, the weight slice in registers). */
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile);
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op);
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                               saber_hip_stream_t stream, int iters);
+
+/* SaberConv2D + global average Pooling<AK_INT8> in one launch (the last residual block of a ResNet feeding pool5): for an
+ * INT8 NHWC conv on <= 64 pixels per image that has the image-resident kernel (1x1 / 3x3, stride 1, ResNet res5 channel
+ * shapes; plain or fused-eltwise epilogue). After set_weights; the op then has this one kernel. run_gpool writes the conv's
+ * output y as usual AND y_pool = [n][k] 8-bit of y's dtype: (float)(int32 sum over the h*w pixels of y) * (1 / (h*w)), round
+ * to nearest even, saturate - the bytes of saber_hip_pool2d_i8_nhwc on y (the reference's JIT average pooling,
+ * saber/funcs/impl/x86/kernel/jit_uni_pool_kernel: int32 accumulate, one multiply, cvt). SABER_HIP_UNIMPL where no such kernel exists. */
+int saber_hip_conv2d_set_global_pooling(saber_hip_conv_t* op);
+int saber_hip_conv2d_run_gpool(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* y_pool,
+                               saber_hip_stream_t stream);
 
 /* Sibling pair: two convolutions (both INT8, or both FP32 with NHWC tensors) that read the SAME input tensor with the same geometry (kernel,
  * pad, stride, dilation; e.g. ResNet's stage-entry `branch1` projection and `branch2a`) executed by ONE
@@ -357,8 +369,9 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * form is faster); 32 (with 16) the block's 3x3 conv leads that chain launch when the chain head is its only consumer
  * (its output edge is then not written: saber_hip_net_tensor_unwritten); 64 a 1x1 / stride-s max pooling (the shortcut
  * pooling the reference's stride-up pass inserts) whose only reader is a fused eltwise epilogue -> folded into that read
- * (saber_hip_conv_desc::res_stride; the pooled edge no longer exists); 127 = all. Bytes of every surviving edge are
- * unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
+ * (saber_hip_conv_desc::res_stride; the pooled edge no longer exists); 128 a conv on <= 64-pixel images followed by the global
+ * average Pooling<AK_INT8> of its output -> saber_hip_conv2d_set_global_pooling (both tensors still written, one launch);
+ * 255 = all. Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 /* kernel launches of one forward pass (ops minus the ones absorbed into a chain launch) */
 int saber_hip_net_num_launches(const saber_hip_net_t* net);

@@ -95,3 +95,44 @@ def test_stage_rejects_what_it_has_no_kernel_for():
     ok = conv(rng, 1, 7, 7, 1024, 512, 1, True, O.S8, O.U8, 0.03, 0.03)
     with pytest.raises(RuntimeError):
         S.SaberStage([(ok, 0, 0, -1)])                      # in place
+
+
+IMG_CASES = [
+    # cin, cout, k, relu, in dtype, out dtype, eltwise
+    (1024, 2048, 1, False, O.S8, O.S8, False),
+    (1024, 512, 1, True, O.S8, O.U8, False),
+    (512, 512, 3, True, O.U8, O.U8, False),
+    (512, 2048, 1, False, O.U8, O.S8, True),
+    (2048, 512, 1, True, O.S8, O.U8, False),
+]
+
+
+@pytest.mark.parametrize("case", IMG_CASES)
+@pytest.mark.parametrize("N,H,W", [(8, 7, 7), (3, 8, 8), (1, 5, 6)])
+def test_image_resident_conv_kernel_equals_oracle_and_default_kernel(case, N, H, W):
+    """Kernel variant 12 of saber_hip_conv2d_run (one workgroup = one image x a channel group, the phase code of the stage kernel
+    as an ordinary launch): the oracle's bytes and the default kernel's, every res5 shape, ragged images, fewer images than XCDs."""
+    cin, cout, k, relu, idt, odt, elt = case
+    rng = np.random.default_rng(cin + cout + N)
+    s_in, s_out, s_res = 0.03, 0.05, 0.04
+    c = conv(rng, N, H, W, cin, cout, k, relu, idt, odt, s_in, s_out, (s_res, s_out) if elt else None)
+    x = (rng.integers(0, 256, (N, H, W, cin)).astype(np.uint8) if idt == O.U8 else rng.integers(-128, 128, (N, H, W, cin)).astype(np.int8))
+    res = rng.integers(-128, 128, (N, H, W, cout)).astype(np.int8)
+    y0 = c.new_output()
+    c.dispatch(dev(x), y0, dev(res) if elt else None)
+    want = host(y0)
+    c.set_tile(12 << 16)
+    assert c.algo().startswith("imgres"), c.algo()
+    y1 = torch.full_like(y0, 77)
+    c.dispatch(dev(x), y1, dev(res) if elt else None)
+    assert np.array_equal(host(y1), want), c.algo()
+    # fused global average pooling == the INT8 pooling op on the conv's output
+    pool = S.pooling_i8(y0, (H, W), (1, 1), (0, 0), 1, global_pooling=True)
+    c.set_global_pooling()
+    assert c.algo().endswith("+gpool")
+    y2, yp = torch.full_like(y0, 55), torch.zeros((N, 1, 1, cout), dtype=y0.dtype, device="cuda")
+    c.dispatch_gpool(dev(x), y2, yp, dev(res) if elt else None)
+    assert np.array_equal(host(y2), want)
+    want_pool = O.pool_i8_nhwc(want, None, None, None, 1, out_dtype=None, global_pool=True)
+    assert np.array_equal(host(yp).reshape(want_pool.shape), want_pool), c.algo()
+    assert np.array_equal(host(pool).reshape(want_pool.shape), want_pool)
