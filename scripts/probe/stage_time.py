@@ -57,7 +57,7 @@ for _ in range(3):
     stage.dispatch(t)
 tr = stage.trace().astype(np.int64)
 names = ["start", "arrived", "w issued", "barrier", "dma issued", "in LDS", "mma done", "end"]
-t0 = tr[:, 0, 0].min()
+t0 = tr[:, 0, 0][tr[:, 0, 0] > 0].min()      # (workgroups of XCDs without an image leave no stamps)
 print("stage trace (us; median over the workgroups of the active XCDs), one row per phase: stamp - phase start | phase start - launch start")
 for p in range(tr.shape[1]):
     rows = tr[:, p, :]
