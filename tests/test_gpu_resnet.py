@@ -351,3 +351,32 @@ def test_resnet50_int8_framework_list_batch8_invariance(setup_fw):
         net1.tensor("data").copy_(torch.from_numpy(x8[i:i + 1]).cuda())
         net1.run()
         assert np.array_equal(_h(net1.tensor("fc1000"))[0], l8[i]), i
+
+
+def test_resnet101_int8_framework_list_every_edge_bit_exact():
+    """BASELINE.json config 4 on the list the reference's optimiser emits for ResNet101 (tests/test_net_oplist.py): 144 operators,
+    stride-up poolings, 8-bit tail; every edge the executor materialises == the oracle running the same list, batch 1 at 224x224;
+    the same logits after autotuning."""
+    model = W.framework_model(W.build_model("resnet101"), "int8")
+    x = W.make_input(1, hw=224)
+    scales = W.calibrate(model, x)
+    ref = NO.run_int8(model, dict(scales), x)
+    net = W.build_int8_net(model, dict(scales), 1)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    checked = 0
+    for name in net.tensors:
+        if net.unwritten(name):
+            checked += 1
+            continue
+        if name in ref and name not in ("data", "prob"):
+            got, want = _h(net.tensor(name)), ref[name]
+            assert got.dtype == want.dtype, (name, got.dtype, want.dtype)
+            assert np.array_equal(got, want.reshape(got.shape)), name
+            checked += 1
+    assert checked >= 70, checked
+    logits = _h(net.tensor("fc1000")).copy()
+    net.autotune(iters=2)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    assert np.array_equal(_h(net.tensor("fc1000")), logits)

@@ -133,3 +133,4 @@ def test_resnet50_fp32_and_vgg16_pass_the_reference_optimiser(tmp_path):
     kinds = [o["type"] for o in ops]
     assert kinds.count("ConvRelu") == 13 and kinds.count("Pooling") == 5 and kinds.count("Dense") == 3
     assert kinds.count("ReLU") == 2 and kinds.count("Softmax") == 1
+
