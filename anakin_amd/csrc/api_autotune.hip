@@ -74,13 +74,13 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
             }
     if (b3_ok(op))      // FP32 on the bf16 matrix cores: every tile
         for (int kd = 1; kd <= 2; ++kd)
-            for (int t = 0; t < TILE_COUNT; ++t) {
-                if (kd == 2 && t == TILE_128x128) continue;
+            for (int t = 0; t < TILE_COUNT_B3; ++t) {      // 6..9: the 8-wave forms of 64x64, 128x64, 128x128 and 256x128
+                if (!b3_tile_ok(op, t, kd)) continue;
                 ConvChoice cb = {t, kd, 0, 0, 0, 0, 0, 4, 0, 1, 0};
                 set_choice(op, cb);
                 time_current();
-                // deep reductions on few pixels: 2 / 4 / 8 workgroups per tile (split-K inside one XCD), tiles up to 128 x 64
-                for (int sh = 1; sh <= 3 && t <= TILE_128x64; ++sh) {
+                // deep reductions on few pixels: 2 / 4 / 8 workgroups per tile (split-K inside one XCD) while the grid stays <= 2048
+                for (int sh = 1; sh <= 3; ++sh) {
                     if (!split_ok(op, t, kd, sh) || split_prepare(op) != SABER_HIP_OK) {
                         if (log_cands && kd == 1 && t == TILE_64x64) std::fprintf(stderr, "autotune: split %d refused (%s)\n", 1 << sh, saber_hip_last_error());
                         continue;

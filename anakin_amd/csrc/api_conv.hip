@@ -119,7 +119,7 @@ static bool xcd_round_robin() {
 }
 bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh) {
     if (sh == 0) return true;
-    if (sh < 0 || sh > 3 || !b3_ok(op) || tile < 0 || tile >= TILE_COUNT || (ks != 1 && ks != 2)) return false;
+    if (sh < 0 || sh > 3 || !b3_tile_ok(op, tile, ks)) return false;
     const int steps = (op->Kg + 32 * ks - 1) / (32 * ks);
     if ((steps >> sh) < 2) return false;
     const size_t m = (size_t)op->d.n * op->oh * op->ow;
@@ -137,7 +137,7 @@ void name_algo(saber_hip_conv* op) {
     static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
-    char buf[64];
+    char buf[96];
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
@@ -145,7 +145,8 @@ void name_algo(saber_hip_conv* op) {
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
     else if (op->algo <= ALGO_IGEMM_F32)
-        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s%s", op->b3 ? "igemm_f32_bf16x3" : an[op->algo], bmk, bnp, op->ks,
+        snprintf(buf, sizeof buf, "%s_%dx%d_k%d%s%s%s%s", op->b3 ? "igemm_f32_bf16x3" : an[op->algo], bmk, bnp, op->ks,
+                 op->b3 && op->tile >= TILE_W8_64x64 ? "_w8" : "",
                  op->b3 && op->ksplit ? (op->ksplit == 1 ? "_split2" : (op->ksplit == 2 ? "_split4" : "_split8")) : "",
                  op->dma == 0 ? "" : (op->dma == 1 ? "_dma" : (op->dma == 2 ? "_dma_wg2" : "_dma_wg4")),
                  op->pool2 ? "+maxpool2x2" : "");
@@ -329,9 +330,9 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     }
     if (var == 11) {   // FP32 implicit GEMM on three bf16 planes (register-staged, one 32-deep slab per stage)
         if (!b3_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 variant: FP32 implicit-GEMM conv with C % 8 == 0 (not a sibling pair, not an fc)");
-        if (tile < 0 || tile >= TILE_COUNT) return fail(SABER_HIP_INVALID_VALUE, "bad tile id");
         const int sh = ks >> 4, ksd = ks & 15;      // bits 12..15 of the code: log2 of the split-K factor
-        if (!(ksd == 0 || ksd == 1 || (ksd == 2 && tile != TILE_128x128))) return fail(SABER_HIP_INVALID_VALUE, "bf16x3: stage depth 1, or 2 below 128x128");
+        if (!b3_tile_ok(op, tile, ksd ? ksd : 1))     // tiles 6..9: the 8-wave forms
+            return fail(SABER_HIP_INVALID_VALUE, "bf16x3: tile 0..9, stage depth 1 (or 2 below 128x128), 256x128 only for k padded to a multiple of 256");
         if (!split_ok(op, tile, ksd ? ksd : 1, sh)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 split-K: 2 / 4 / 8 splits with >= 2 stages each, bounded output, 8 x 32 CU device");
         if (sh) {
             const int rc = split_prepare(op);
@@ -829,10 +830,10 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
             }
     if (b3_ok(op))      // FP32 pair on the bf16 matrix cores, with split-K where the reduction is deep and the pixels few
         for (int kd = 1; kd <= 2; ++kd)
-            for (int t = 0; t < TILE_COUNT; ++t) {
-                if (kd == 2 && t == TILE_128x128) continue;
+            for (int t = 0; t < TILE_COUNT_B3; ++t) {
+                if (!b3_tile_ok(op, t, kd)) continue;
                 for (int sh = 0; sh <= 3; ++sh) {
-                    if (sh && (t > TILE_128x64 || !split_ok(op, t, kd, sh) || split_prepare(op) != SABER_HIP_OK)) continue;
+                    if (sh && (!split_ok(op, t, kd, sh) || split_prepare(op) != SABER_HIP_OK)) continue;
                     int bmk, bnp;
                     tile_dims(t, &bmk, &bnp);
                     const long tiles = (long)((op->d.n * op->oh * op->ow + bnp - 1) / bnp) * ((op->d.k + bmk - 1) / bmk);

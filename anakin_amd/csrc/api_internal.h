@@ -169,6 +169,14 @@ inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
 inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
     return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr;
 }
+// (tile, stage depth) combinations of the bf16-plane kernels: depth 2 below 128 x 128; the 256-row tile reads 256 weight rows per
+// workgroup without a row predicate, the planes are padded to multiples of 128 rows
+inline bool b3_tile_ok(const saber_hip_conv* op, int tile, int ks) {
+    if (!b3_ok(op) || tile < 0 || tile >= TILE_COUNT_B3 || (ks != 1 && ks != 2)) return false;
+    if (ks == 2 && (tile == TILE_128x128 || tile >= TILE_W8_128x128)) return false;
+    if (tile == TILE_W8_256x128 && ((op->d.k + 127) / 128) % 2 != 0) return false;
+    return true;
+}
 inline bool fc_small_ok(const saber_hip_conv* op) {
     if (op->algo == ALGO_IGEMM_F32)   // FP32 fc: a 1x1 "conv" on a [m, 1, 1, k] NHWC tensor, plain f32 epilogue, no residual
         return op->epi == EPI_F32 && op->d.h == 1 && op->d.w == 1 && op->d.kh == 1 && op->d.kw == 1 && !op->pre_transpose &&

@@ -18,7 +18,7 @@ __device__ __forceinline__ int sat_u8(float v) {
 }
 
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
-    static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
+    static const int d[TILE_COUNT_B3][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 128}, {256, 128}};
     *bm_k = d[tile][0];
     *bn_pix = d[tile][1];
 }

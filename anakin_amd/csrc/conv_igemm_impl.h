@@ -508,8 +508,13 @@ __device__ __forceinline__ int phys_chunk(int row, int c) {
 // One pipeline stage = KS MFMA k-steps = KS*64 bytes of the reduction per row, double-buffered in LDS
 // with the next stage's global loads in flight (registers) while the current one is consumed.
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int TM, int TN, int KS, int EK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
+// NWM: wave rows of the workgroup (2: the 2 x 2 = 4 waves above; 4: 4 x 2 = 8 waves = two per SIMD, block tile 4 TM x 2 TN
+// fragments - MODE 3 only: with one wave per SIMD the phases of a stage - fragment reads, MFMAs, the split + LDS stores of
+// the next stage - run one after the other; a second wave per SIMD lets one's matrix work cover the other's LDS / VALU work).
+template <int MODE, int TM, int TN, int KS, int EK, int NWM = 2>
+__global__ __launch_bounds__(NWM * 128) void conv_igemm_kernel(const ConvKArgs a) {
+    constexpr int NTHR = NWM * 128;      // threads per workgroup
+    constexpr int NWAVE = NWM * 2;
     constexpr bool B3 = (MODE == 3);     // f32 tensors, three bf16 operand planes (see mma_step3)
     constexpr bool F32 = (MODE == 2) || B3;
     constexpr bool C4 = (MODE == 1);
@@ -519,8 +524,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr int EC = 16 / ES;          // elements per 16-byte chunk
     constexpr int CPR = 4 * KS;          // chunks per row per stage
     constexpr int ESTAGE = CPR * EC;     // elements per stage
-    constexpr int RPP = 256 / CPR;       // rows staged per pass of the 256 threads
-    constexpr int BMK = 2 * TM * 16;     // out channels per block
+    constexpr int RPP = NTHR / CPR;      // rows staged per pass of the workgroup's threads
+    constexpr int BMK = NWM * TM * 16;   // out channels per block
     constexpr int BNP = 2 * TN * 16;     // pixels per block
     constexpr int WIT = (BMK + RPP - 1) / RPP;
     constexpr int XIT = (BNP + RPP - 1) / RPP;
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     // variants are the LDS-DMA rings); the bf16-plane kernel stages through registers (the split needs them) and on the
     // few-pixel layers one stage of latency per stage of work was ALL its time (1.1 us per 32-deep slab against 0.16 us of
     // matrix work, scripts/probe/splitk_time.py before this).
-    constexpr int PF = B3 ? 4 : 1;
+    constexpr int PF = B3 ? (NWM * TM * TN >= 64 ? 2 : 4) : 1;      // (the 256 x 128 tile's 16 accumulators + 24 fragment registers leave room for 2 sets)
     v4i xv[PF][XIT][B3 ? 2 : 1], wv[PF][NP][WIT];     // B3: an activation chunk is 8 f32 = two 16-byte loads, split at store time
     const v4i* w16 = (const v4i*)a.w;
     const int w_row_chunks = a.Kg_pad / EC;
@@ -700,8 +705,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     load_stage(s_begin, integral_constant<int, 0>{});      // (an empty slice loads one stage it does not use: in-bounds, harmless)
     if constexpr (PF > 1) {
         load_stage(s_begin + 1, integral_constant<int, 1 % PF>{});
-        load_stage(s_begin + 2, integral_constant<int, 2 % PF>{});
-        load_stage(s_begin + 3, integral_constant<int, 3 % PF>{});
+        if constexpr (PF == 4) {
+            load_stage(s_begin + 2, integral_constant<int, 2 % PF>{});
+            load_stage(s_begin + 3, integral_constant<int, 3 % PF>{});
+        }
     }
     // per-channel epilogue constants: requested before the reduction loop so their latency hides behind it, but AFTER the
     // first operand loads - their pointers live in the cold part of the argument block, and waiting for that second
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             __syncthreads();
         }
     } else {
-        static_assert(PF == 1 || PF == 4, "the unrolled ring below is written for 4 register sets");
+        static_assert(PF == 2 || PF == 4, "the unrolled ring below is written for 2 or 4 register sets");
         // stage t = s + u sits in LDS buffer u & 1; set u has just been stored, so it takes the request for stage t + PF;
         // set (u + 1) % PF (requested PF - 1 stages ago) goes to the other LDS buffer after the multiply.
         // Requests and stores are UNCONDITIONAL (stages past the end are fetched from clamped / zero addresses and never
@@ -785,15 +792,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         for (; s + PF <= s_end; s += PF) {
             SABER_PF_STEP(0)
             SABER_PF_STEP(1)
-            SABER_PF_STEP(2)
-            SABER_PF_STEP(3)
+            if constexpr (PF == 4) {
+                SABER_PF_STEP(2)
+                SABER_PF_STEP(3)
+            }
         }
         if (s < s_end) {
             SABER_PF_STEP(0)
-            if (s + 1 < s_end) {
-                SABER_PF_STEP(1)
-                if (s + 2 < s_end) {
-                    SABER_PF_STEP(2)
+            if constexpr (PF == 4) {
+                if (s + 1 < s_end) {
+                    SABER_PF_STEP(1)
+                    if (s + 2 < s_end) {
+                        SABER_PF_STEP(2)
+                    }
                 }
             }
         }
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         if (a.ksplit_sh > 0) {
             // ---- split-K: partial accumulators -> this XCD's L2; the last arrival sums them in split order ------------
             const int S = 1 << a.ksplit_sh;
-            v4f* pw = (v4f*)a.part + ((size_t)(tile_L * S + split) * 4 + wave) * (TM * TN * 64) + lane;
+            v4f* pw = (v4f*)a.part + ((size_t)(tile_L * S + split) * NWAVE + wave) * (TM * TN * 64) + lane;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -826,13 +837,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             }
             if (tid == 0) a.part_ctr[tile_L] = 0u;           // re-armed for the next launch
             asm volatile("buffer_inv sc1" ::: "memory");     // this CU's L1 may hold the partials of an earlier launch
-            const v4f* pr = (const v4f*)a.part + ((size_t)(tile_L * S) * 4 + wave) * (TM * TN * 64) + lane;
+            const v4f* pr = (const v4f*)a.part + ((size_t)(tile_L * S) * NWAVE + wave) * (TM * TN * 64) + lane;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = pr[(i * TN + j) * 64];
             for (int s2 = 1; s2 < S; ++s2) {
-                pr += 4 * (TM * TN * 64);
+                pr += NWAVE * (TM * TN * 64);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -919,6 +930,31 @@ static hipError_t launch_mode(int tile, const ConvKArgs& a, hipStream_t s) {
 template <int MODE, int EK>
 static hipError_t launch_igemm_inst(int tile, int ks, const ConvKArgs& a, hipStream_t s) {
     if constexpr (MODE == 3) {   // three operand planes: one 32-deep slab per stage is already 96 KB of LDS at 128 x 128
+        if (tile >= TILE_W8_64x64) {      // 8 waves per workgroup
+            if (tile >= TILE_COUNT_B3 || (ks != 1 && ks != 2) || (ks == 2 && tile >= TILE_W8_128x128)) return hipErrorInvalidValue;
+            int bmk, bnp;
+            tile_dims(tile, &bmk, &bnp);
+            ConvKArgs b = a;
+            b.npx = (a.M + bnp - 1) / bnp;
+            b.nky = (a.K + bmk - 1) / bmk;
+            b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
+            const int estage = 4 * ks * 8;
+            const int taps = estage / a.C;
+            b.adv_c = estage - taps * a.C;
+            b.adv_i = taps / a.kw;
+            b.adv_j = taps - b.adv_i * a.kw;
+            dim3 grid(a.ksplit_sh > 0 ? 8 * ((b.npx * b.nky + 7) / 8) << a.ksplit_sh : b.npx * b.nky), block(512);
+            switch (tile * 4 + ks) {
+            case TILE_W8_64x64 * 4 + 1: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 2, 1, EK, 4>), grid, block, 0, s, b); break;
+            case TILE_W8_64x64 * 4 + 2: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 2, 2, EK, 4>), grid, block, 0, s, b); break;
+            case TILE_W8_128x64 * 4 + 1: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, 1, EK, 4>), grid, block, 0, s, b); break;
+            case TILE_W8_128x64 * 4 + 2: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2, 2, EK, 4>), grid, block, 0, s, b); break;
+            case TILE_W8_128x128 * 4 + 1: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 4, 1, EK, 4>), grid, block, 0, s, b); break;
+            case TILE_W8_256x128 * 4 + 1: hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4, 4, 1, EK, 4>), grid, block, 0, s, b); break;   // 144 KB of LDS
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
         if (ks == 1) return launch_mode<MODE, 1, EK>(tile, a, s);
         if (ks != 2 || tile == TILE_128x128) return hipErrorInvalidValue;     // two slabs per stage: up to 144 KB (128 x 64)
         int bmk, bnp;

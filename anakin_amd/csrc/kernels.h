@@ -185,7 +185,9 @@ __device__ __forceinline__ void pin_hot_args(const ConvKArgs& a) {
 
 // tile ids for launch_conv_igemm
 enum { TILE_32x32 = 0, TILE_64x32 = 1, TILE_64x64 = 2, TILE_128x64 = 3, TILE_64x128 = 4, TILE_128x128 = 5,
-       TILE_COUNT = 6 };
+       TILE_COUNT = 6,
+       // FP32 bf16-plane kernels only (conv_igemm_impl.h NWM = 4): the same block tiles computed by 8 waves (two per SIMD)
+       TILE_W8_64x64 = 6, TILE_W8_128x64 = 7, TILE_W8_128x128 = 8, TILE_W8_256x128 = 9, TILE_COUNT_B3 = 10 };
 void tile_dims(int tile, int* bm_k, int* bn_pix);
 
 // mode: 0 = int8 (C % 16 == 0), 1 = int8 C4 (input NHWC4), 2 = f32 (C % 4 == 0)

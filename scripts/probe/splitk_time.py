@@ -49,3 +49,23 @@ for name, N, H, W, C, K, k in CASES:
     conv.set_tile(2 | (1 << 8) | (11 << 16))
     conv.autotune(x, y)
     print("    autotune (cold-L2 timing) picks %s: %.2f us back to back" % (conv.algo(), timed(lambda: conv.dispatch(x, y))))
+
+# large-pixel layers (VGG16 conv3_x / conv4_x, ResNet50 res2 3x3): 4-wave vs 8-wave tiles
+for name, N, H, W, C, K, k in [("vgg conv3 56x56 256->256", 8, 56, 56, 256, 256, 3), ("vgg conv4 28x28 512->512", 8, 28, 28, 512, 512, 3),
+                               ("vgg conv2 112x112 128->128", 8, 112, 112, 128, 128, 3), ("res2 3x3 56x56 64->64", 8, 56, 56, 64, 64, 3)]:
+    x = torch.from_numpy((rng.random((N, H, W, C)) * 3).astype(np.float32)).cuda()
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), S.ConvParam(w, np.zeros(K, np.float32), 1, (1, 1), (1, 1), (1, 1), True), L.F32, L.F32,
+                                          in_layout=L.NHWC, out_layout=L.NHWC)
+    y = conv.new_output()
+    rows = []
+    for t in range(10):
+        for ks in (1, 2):
+            try:
+                conv.set_tile(t | (ks << 8) | (11 << 16))
+            except L.SaberHipError:
+                continue
+            rows.append((timed(lambda: conv.dispatch(x, y), 50), conv.algo()))
+    rows.sort()
+    flops = 2.0 * N * H * W * C * K * k * k
+    print("%s: " % name + "  ".join("%s %.1f us (%.0f TF)" % (a.replace("igemm_f32_bf16x3_", ""), t, flops / t / 1e6) for t, a in rows[:5]))

@@ -1197,7 +1197,7 @@ def test_global_average_pooling_i8_kernel(shape, dt):
 
 
 # ---- FP32 convolution on the bf16 matrix cores: x = h + m + l (three bf16 planes), six products, f32 accumulate ---------
-@pytest.mark.parametrize("tile", range(len(L.TILES)))
+@pytest.mark.parametrize("tile", list(range(len(L.TILES))) + [6, 7, 8, 9])      # 6..9: the 8-wave forms of 64x64, 128x64, 128x128, 256x128
 def test_conv_f32_bf16x3_every_tile_golden(tile):
     """The reference-made golden FP32 3x3 convolution through the bf16-plane variant (set_tile variant 11), every tile:
     within the same 1e-4 as the f32-MFMA kernels (BASELINE.json: FP32 'within 1e-4 rel')."""
@@ -1207,6 +1207,10 @@ def test_conv_f32_bf16x3_every_tile_golden(tile):
         pytest.skip("bf16x3 needs C % 8 == 0")
     p = S.ConvParam(g["w"], g["bias"], 1, (pad, pad), (stride, stride), (1, 1), True)
     conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32)
+    if tile == 9 and ((K + 127) // 128) % 2:
+        with pytest.raises(L.SaberHipError):          # the 256-row tile reads 256 weight rows unpredicated: refused for this K
+            conv.set_tile(tile | (1 << 8) | (11 << 16))
+        return
     conv.set_tile(tile | (1 << 8) | (11 << 16))
     assert "bf16x3" in conv.algo()
     y = conv.new_output()
@@ -1226,6 +1230,33 @@ F32_B3_SWEEP = [
     (1, 5, 5, 64, 32, 5, 2, 1, 1, "nchw"),       # NCHW in / out (transposed into the workspace)
     (2, 56, 56, 64, 256, 1, 0, 1, 1, "nhwc"),    # ResNet 1x1
 ]
+
+
+@pytest.mark.parametrize("tile", [6, 7, 8, 9])
+def test_conv_f32_bf16x3_eight_wave_tiles_vs_oracle(tile):
+    """The 8-wave forms (two waves per SIMD: 64x64, 128x64, 128x128, 256x128 block tiles) on a VGG-like layer with ragged pixel
+    tiles: oracle within 1e-4 on both criteria, and the same bits as the 4-wave kernel of the same block tile where one exists
+    (the accumulation order per output is the same)."""
+    N, H, W, C, K = 3, 19, 23, 64, 256
+    rng = np.random.default_rng(70 + tile)
+    x = (rng.random((N, C, H, W)) * 3.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) * np.sqrt(2.0 / (C * 9))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, True, (1, 1), (1, 1), (1, 1))
+    p = S.ConvParam(w, b, 1, (1, 1), (1, 1), (1, 1), True)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    outs = {}
+    for t in (tile, {6: 2, 7: 3, 8: 5, 9: 5}[tile]):
+        conv.set_tile(t | (1 << 8) | (11 << 16))
+        y = conv.new_output()
+        conv.dispatch(xin, y)
+        outs[t] = host(y).transpose(0, 3, 1, 2)
+    got = outs[tile]
+    d = np.abs(got - want)
+    assert float(d.max() / np.abs(want).max()) <= FP32_RTOL and float((d / (np.abs(want) + np.abs(want).mean())).max()) <= FP32_RTOL, conv.algo()
+    assert np.array_equal(got, outs[{6: 2, 7: 3, 8: 5, 9: 5}[tile]]), "8-wave and 4-wave kernels sum in the same order"
+
 
 
 @pytest.mark.parametrize("case", F32_B3_SWEEP)
@@ -1262,7 +1293,7 @@ def test_conv_f32_bf16x3_sweep_vs_oracle(case):
 
 F32_SPLITK_CASES = [
     # N, H, W, C, K, k, pad, eltwise residual, tile ids, splits (log2)
-    (8, 14, 14, 256, 256, 3, 1, False, (0, 1, 2, 3), (1, 2, 3)),     # ResNet res4 branch2b at batch 8
+    (8, 14, 14, 256, 256, 3, 1, False, (0, 1, 2, 3, 6, 7), (1, 2, 3)),     # ResNet res4 branch2b at batch 8 (6, 7: 8-wave tiles)
     (8, 7, 7, 512, 512, 3, 1, False, (2,), (1, 2, 3)),               # res5 branch2b
     (3, 7, 9, 2048, 512, 1, 0, False, (1, 2), (2, 3)),               # res5 branch2a, ragged pixels (tiles % 8 != 0)
     (2, 5, 5, 96, 40, 3, 1, False, (0, 2), (1, 2)),                  # ragged K / C, slabs straddle taps
