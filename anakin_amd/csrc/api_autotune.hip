@@ -151,6 +151,10 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     }
     set_choice(op, best_c);
     name_algo(op);
+    if (!op->ksplit) {      // the split-K candidates' partial buffers (up to 96 MB) are only kept by an op that selected one
+        op->d_part.release();
+        op->d_part_ctr.release();
+    }
     // leave y holding one clean result of the selected kernel
     return saber_hip_conv2d_run(op, x, y, res, workspace, s);
 }

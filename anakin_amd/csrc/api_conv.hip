@@ -856,6 +856,10 @@ int saber_hip_conv2d_autotune_pair(saber_hip_conv_t* op, const void* x, void* y_
         g_used_kernels->push_back(kernel_key(op, get_choice(op)));
     }
     name_algo(op);
+    if (!op->ksplit) {
+        op->d_part.release();
+        op->d_part_ctr.release();
+    }
     return saber_hip_conv2d_run_pair(op, x, y_a, y_b, s);   // both outputs hold the selected kernel's result
 }
 
