@@ -94,6 +94,12 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
                     time_current();
                 }
             }
+    for (int hv = 1; hv <= 5; ++hv)      // FP32 3x3: the LDS-halo forms of the bf16-plane kernel
+        if (b3h_ok(op, hv)) {
+            ConvChoice chv = {op->tile, 1, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, hv};
+            set_choice(op, chv);
+            time_current();
+        }
     c = best_c;
     if (fc_small_ok(op)) {
         ConvChoice cf = c;

@@ -141,6 +141,11 @@ void name_algo(saber_hip_conv* op) {
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
+    else if (op->b3h) {
+        int hb, ht, htm, hthr;
+        (void)conv3x3_b3h_variant(op->b3h, &hb, &ht, &htm, &hthr);
+        snprintf(buf, sizeof buf, "halo3x3_f32_bf16x3_%dch_%dx16_w%d%s", hb, ht, hthr / 64, op->pool2 ? "+maxpool2x2" : "");
+    }
     else if (op->img1) snprintf(buf, sizeof buf, "imgres%dx%d_i8_%dch%s", op->d.kh, op->d.kw, 16 * ((op->d.k / 16 + 31) / 32), op->gpool ? "+gpool" : "");
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
     else if (op->halo) snprintf(buf, sizeof buf, "halo3x3_i8_%dx16", op->halo);
@@ -338,7 +343,13 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
             const int rc = split_prepare(op);
             if (rc) return rc;
         }
-        op->b3 = 1; op->dma = 0; op->ks = ksd ? ksd : 1; op->tile = tile; op->fc_small = 0; op->ksplit = sh;
+        op->b3 = 1; op->dma = 0; op->ks = ksd ? ksd : 1; op->tile = tile; op->fc_small = 0; op->ksplit = sh; op->b3h = 0;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
+    if (var == 13) {   // FP32 3x3 LDS-halo kernel on the bf16 planes, variant 1..5 in the low byte
+        if (!b3h_ok(op, tile)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 halo kernel: FP32 3x3 stride-1 pad-1 NHWC conv with C % 32 == 0, variant 1..5");
+        op->b3h = tile; op->b3 = 0; op->ksplit = 0; op->dma = 0; op->fc_small = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
@@ -375,6 +386,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     }
     if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
         op->img1 = 0;
+        op->b3h = 0;
         op->b3 = 0;
         op->ksplit = 0;
         op->halo = 0;
@@ -394,6 +406,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
+    if (op->b3h) return op->b3h | (13 << 16);
     if (op->img1) return 12 << 16;
     if (op->fc_small) return 10 << 16;
     if (op->b3) return op->tile | ((op->ks | (op->ksplit << 4)) << 8) | (11 << 16);
@@ -544,6 +557,30 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
                 pl[i] = h; pl[n + i] = m; pl[2 * n + i] = rne(r2);
             }
             HIP_TRY(op->d_w3.upload(planes));
+            // 3x3 / stride 1 / pad 1 on NHWC f32: the same planes once more in MFMA A-fragment order for the LDS-halo kernel
+            // (conv3x3_b3h.hip): [16-row tile][32-channel chunk][tap][plane][lane] x 8 bf16. Row rho of tile i of a wave's tm
+            // tiles is channel  base + (rho >> 2) * 4 tm + 4 i + (rho & 3)  (a lane then owns 4 tm consecutive channels).
+            if (kh == 3 && kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 && d.pad_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
+                d.group == 1 && op->c_eff % 32 == 0 && !op->pre_transpose && d.out_layout == SABER_HIP_NHWC) {
+                const int Ce = op->c_eff, nch = Ce / 32, ktiles = K_pad / 16;
+                for (int tm = 1; tm <= 2; ++tm) {
+                    std::vector<uint8_t> fr((size_t)ktiles * nch * 9 * 3 * 64 * 16, 0);
+                    uint16_t* fp = (uint16_t*)fr.data();
+                    for (int kt = 0; kt < ktiles; ++kt)
+                        for (int cc = 0; cc < nch; ++cc)
+                            for (int t = 0; t < 9; ++t)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int rho = lane & 15, fq = lane >> 4;
+                                    const int ch = (kt / tm) * tm * 16 + (rho >> 2) * 4 * tm + (kt % tm) * 4 + (rho & 3);
+                                    for (int e = 0; e < 8; ++e) {
+                                        const size_t src = (size_t)ch * op->Kg_pad + (size_t)t * Ce + cc * 32 + fq * 8 + e;
+                                        for (int pl3 = 0; pl3 < 3; ++pl3)
+                                            fp[((((size_t)(kt * nch + cc) * 9 + t) * 3 + pl3) * 64 + lane) * 8 + e] = pl[pl3 * n + src];
+                                    }
+                                }
+                    HIP_TRY((tm == 1 ? op->d_w3h1 : op->d_w3h2).upload(fr));
+                }
+            }
             // STATIC choice (BaseFunc STATIC strategy): SABER_HIP_F32_BF16X3=1 makes the bf16-plane kernel the default of every
             // eligible FP32 convolution (0 keeps the f32-MFMA kernels); unset: see f32_static_b3()
             const char* e = getenv("SABER_HIP_F32_BF16X3");
@@ -686,6 +723,13 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     case ALGO_IGEMM_F32:
         if (op->fc_small) {
             HIP_TRY(launch_fc_f32_small(a, s));
+            break;
+        }
+        if (op->b3h) {
+            int hb, ht, htm, hthr;
+            (void)conv3x3_b3h_variant(op->b3h, &hb, &ht, &htm, &hthr);
+            a.w = htm == 1 ? op->d_w3h1.p : op->d_w3h2.p;
+            HIP_TRY(launch_conv3x3_b3h(op->b3h, a, s));
             break;
         }
         if (op->b3 && op->ksplit && !op->d_part.p) return fail(SABER_HIP_INVALID_VALUE, "split-K selected without its buffers (saber_hip_conv2d_set_tile / autotune allocate them)");

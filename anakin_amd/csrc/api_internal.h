@@ -99,6 +99,8 @@ struct saber_hip_conv {
     int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
+    int b3h = 0;             // FP32 3x3: 1..5 = LDS-halo bf16-plane kernel variant (conv3x3_b3h.hip), 0: not used
+    DevBuf<uint8_t> d_w3h1, d_w3h2;   // its weight planes in MFMA fragment order for 1 / 2 row tiles per wave
     int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels
     int gpool = 0;           // ... with the global average pooling of its output fused (saber_hip_net_optimize flag 128): img1 only
     struct saber_hip_stage* img_stage = nullptr;   // the single-phase descriptor + repacked weights of that kernel (img_conv_prepare)
@@ -157,14 +159,14 @@ struct saber_hip_fc {
 namespace saber_api {
 // one selection of kernel variant for an op (what the autotuner saves / restores)
 struct ConvChoice {
-    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit, img1;
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit, img1, b3h;
 };
 inline ConvChoice get_choice(const saber_hip_conv* op) {
-    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit, op->img1};
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit, op->img1, op->b3h};
 }
 inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
-    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool; op->b3h = c.b3h;
 }
 inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
     return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr;
@@ -176,6 +178,11 @@ inline bool b3_tile_ok(const saber_hip_conv* op, int tile, int ks) {
     if (ks == 2 && (tile == TILE_128x128 || tile >= TILE_W8_128x128)) return false;
     if (tile == TILE_W8_256x128 && ((op->d.k + 127) / 128) % 2 != 0) return false;
     return true;
+}
+inline bool b3h_ok(const saber_hip_conv* op, int variant) {      // the halo variant exists for this op (planes packed by set_weights)
+    int bmk, th, tm, thr;
+    if (!conv3x3_b3h_variant(variant, &bmk, &th, &tm, &thr)) return false;
+    return op->algo == ALGO_IGEMM_F32 && (tm == 1 ? op->d_w3h1.p : op->d_w3h2.p) != nullptr && !op->pair_k2;
 }
 inline bool fc_small_ok(const saber_hip_conv* op) {
     if (op->algo == ALGO_IGEMM_F32)   // FP32 fc: a 1x1 "conv" on a [m, 1, 1, k] NHWC tensor, plain f32 epilogue, no residual
@@ -201,11 +208,17 @@ struct EventPair {   // RAII: destroyed on every exit path
 // flattered by finding them in L2 the way a back-to-back loop of the same launch does (measured: conv3x3 + chain at
 // C = 256 reads 12.9 us back to back, 16 us in the forward pass; the two launches it replaces 13.9 -> 15.3 us).
 struct ColdBench {
-    static constexpr size_t kBytes = (size_t)64 << 20;
+    // 64 MB pushes the operands out of the 8 x 4 MB of L2 (the 256 MB Infinity Cache keeps them: right for a net whose whole forward
+    // pass fits it, ResNet50 INT8 at batch 8 moves ~190 MB). A net whose pass moves more (VGG16 FP32 at batch 8: > 400 MB of
+    // activations) finds its weights in neither cache: saber_hip_net_autotune then asks for a flush of that size (up to 512 MB) -
+    // measured: with the 64 MB flush the tuner preferred the LDS-halo FP32 kernel for VGG16's 512-channel layers (90 / 169 us "cold")
+    // which then ran at 120 / 227 us in the pass, where every workgroup streams its 1.7 MB of weight planes from HBM.
+    size_t kBytes = (size_t)64 << 20;
     void* buf = nullptr;
     std::vector<hipEvent_t> ev;
     int reps = 0;
-    hipError_t init(int r) {
+    hipError_t init(int r, size_t bytes = 0) {
+        if (bytes) kBytes = std::min<size_t>(std::max<size_t>(bytes, (size_t)64 << 20), (size_t)512 << 20) & ~(size_t)0xfffff;
         reps = r < 3 ? 3 : (r > 32 ? 32 : r);
         hipError_t e = hipMalloc(&buf, kBytes + 256);
         if (e != hipSuccess) return e;
@@ -255,6 +268,7 @@ inline unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice&
     else if (op->algo != ALGO_IGEMM_F32 && op->epi == EPI_I8_CONV && d.res_mode != SABER_HIP_RES_SUM_INPLACE && d.k % 16 == 0)
         ek = d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : (d.out_dtype == SABER_HIP_U8 ? 1 : (d.out_dtype == SABER_HIP_S8 ? 0 : 3));
     unsigned long long k = (unsigned long long)op->algo | ((unsigned long long)ek << 4);
+    if (c.b3h) return k | (8ull << 8) | ((unsigned long long)c.b3h << 16);
     if (c.img1) return k | (7ull << 8) | ((unsigned long long)(op->d.kh == 3) << 16);      // one function for all image-resident shapes
     if (c.fc_small) return k | (1ull << 8) | ((unsigned long long)((op->c_eff + 255) / 256) << 16);
     if (c.stem) return k | (2ull << 8);
@@ -267,11 +281,11 @@ inline unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice&
 struct ColdScope {
     ColdBench local;
     bool owner = false;
-    hipError_t enter(int reps) {
+    hipError_t enter(int reps, size_t flush_bytes = 0) {
         const char* w = std::getenv("SABER_HIP_AUTOTUNE_WARM");
         if (w && w[0] == '1') return hipSuccess;      // g_cold stays null: callers fall back to the warm loop
         if (g_cold) return hipSuccess;
-        hipError_t e = local.init(reps);
+        hipError_t e = local.init(reps, flush_bytes);
         if (e != hipSuccess) return e;
         g_cold = &local;
         owner = true;

@@ -137,7 +137,9 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     }
     auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
     ColdScope scope;
-    HIP_TRY(scope.enter(iters < 7 ? 7 : (iters > 15 ? 15 : iters)));
+    // flush size between timed repetitions: a net whose tensor arena exceeds the 256 MB Infinity Cache finds its weights in no cache
+    // from one forward pass to the next - flush that much (up to 512 MB); smaller nets keep the 64 MB L2-only flush
+    HIP_TRY(scope.enter(iters < 7 ? 7 : (iters > 15 ? 15 : iters), net->arena_bytes > ((size_t)256 << 20) ? net->arena_bytes : 0));
     std::vector<unsigned long long> used_kernels;
     struct UsedScope {
         UsedScope(std::vector<unsigned long long>* v) { g_used_kernels = g_cold ? v : nullptr; }

@@ -201,6 +201,10 @@ hipError_t launch_conv3x3_halo(int th, const ConvKArgs& a, hipStream_t s);
 // LDS, 16 output channels per workgroup with the weights in registers (conv3x3_img.h)
 hipError_t launch_conv3x3_img(const ConvKArgs& a, int nw, int ib, int rb, hipStream_t s);
 bool conv3x3_img_feasible(int C, int OW, int OH, int N, int nw, int ib, int rb);
+// FP32 3x3 / stride 1 / pad 1 on the bf16 matrix cores with an LDS-resident input halo (conv3x3_b3h.hip); variant 1..5 = (output
+// channels per workgroup, tile rows, 16-channel tiles per wave, threads): a.w = the fragment-ordered weight planes for that tm
+bool conv3x3_b3h_variant(int variant, int* bmk, int* th, int* tm, int* threads);
+hipError_t launch_conv3x3_b3h(int variant, const ConvKArgs& a, hipStream_t s);
 // INT8 fc for <= 16 batch rows: 16 outputs per workgroup, reduction split over its 4 waves, operands loaded straight
 // into MFMA registers (fc_small.hip). a.M rows, a.C reduction, a.K outputs, FC epilogues only.
 hipError_t launch_fc_i8_small(const ConvKArgs& a, hipStream_t s);

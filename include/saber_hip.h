@@ -145,6 +145,10 @@ const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op);
  *   1 register-staged implicit GEMM, 2 LDS-DMA ring, 3 / 4 ring with 2 / 4 wave groups, 5 / 6 LDS-halo 3x3 (4 / 8 rows),
  *   7 / 8 stem kernel on / off, 9 small-image 3x3 (low byte = output rows per slab, bits 8..15 = images per slab),
  *   10 small-batch fc;
+ *   11 FP32 implicit GEMM on three bf16 operand planes: tile 0..5, or 6..9 = the 8-wave forms of 64x64 / 128x64 / 128x128 / 256x128;
+ *      bits 8..11 stage depth (1 | 2), bits 12..15 log2 of the split-K factor (2 / 4 / 8 workgroups per tile on one XCD);
+ *   13 FP32 3x3 stride-1 pad-1 LDS-halo kernel on the bf16 planes, variant 1..5 in the low byte (channels per workgroup x tile rows x
+ *      waves: 128x8x8, 64x8x4, 64x8x8, 64x4x4, 128x4x8); C % 32 == 0, NHWC;
  *   12 image-resident kernel (INT8 1x1 / 3x3 stride-1 convs on <= 64 pixels per image: workgroup = one image x a channel group,
  *      the image in LDS, the weight slice in registers). */
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile);

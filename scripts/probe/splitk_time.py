@@ -69,3 +69,23 @@ for name, N, H, W, C, K, k in [("vgg conv3 56x56 256->256", 8, 56, 56, 256, 256,
     rows.sort()
     flops = 2.0 * N * H * W * C * K * k * k
     print("%s: " % name + "  ".join("%s %.1f us (%.0f TF)" % (a.replace("igemm_f32_bf16x3_", ""), t, flops / t / 1e6) for t, a in rows[:5]))
+
+# the LDS-halo form (conv3x3_b3h.hip, variants 1..5) against the best implicit-GEMM bf16-plane kernel
+for name, N, H, W, C, K in [("vgg conv2 112x112 128->128", 8, 112, 112, 128, 128), ("vgg conv3 56x56 256->256", 8, 56, 56, 256, 256),
+                            ("vgg conv4 28x28 512->512", 8, 28, 28, 512, 512), ("vgg conv1_2 224x224 64->64", 8, 224, 224, 64, 64),
+                            ("res2 3x3 56x56 64->64", 8, 56, 56, 64, 64), ("res3 3x3 28x28 128->128", 8, 28, 28, 128, 128),
+                            ("res4 3x3 14x14 256->256", 8, 14, 14, 256, 256)]:
+    x = torch.from_numpy((rng.random((N, H, W, C)) * 3).astype(np.float32)).cuda()
+    w = (rng.standard_normal((K, C, 3, 3)) * np.sqrt(2.0 / (C * 9))).astype(np.float32)
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), S.ConvParam(w, np.zeros(K, np.float32), 1, (1, 1), (1, 1), (1, 1), True), L.F32, L.F32,
+                                          in_layout=L.NHWC, out_layout=L.NHWC)
+    y = conv.new_output()
+    conv.autotune(x, y)
+    t_auto, a_auto = timed(lambda: conv.dispatch(x, y), 50), conv.algo()
+    rows = []
+    for v in range(1, 6):
+        conv.set_tile(v | (13 << 16))
+        rows.append((timed(lambda: conv.dispatch(x, y), 50), conv.algo()))
+    flops = 2.0 * N * H * W * C * K * 9
+    print("%s: autotune %s %.1f us (%.0f TF) | halo: " % (name, a_auto.replace("igemm_f32_bf16x3_", ""), t_auto, flops / t_auto / 1e6) +
+          "  ".join("%s %.1f us (%.0f TF)" % (a.replace("halo3x3_f32_bf16x3_", ""), t, flops / t / 1e6) for t, a in rows))

@@ -1069,6 +1069,36 @@ def test_conv_f32_fused_relu_maxpool2x2(case):
     assert not S.SaberConv2DPooling(int8=False).init((N, C, H, W), p0, 0, (2, 2), (2, 2), (0, 0), L.F32, L.F32).fused
 
 
+@pytest.mark.parametrize("case", [(2, 32, 12, 20, 32), (1, 64, 28, 36, 48), (2, 96, 6, 10, 128)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+def test_conv_f32_halo_kernel_fused_relu_maxpool2x2(case, variant):
+    """SaberConv2DPooling FP32 on the LDS-halo bf16-plane kernel: a pooling window is two rows of one wave x a lane pair; the pooled
+    tensor is within 1e-4 of the oracle's conv -> pool and EQUAL to max-pooling this kernel's own unpooled output (a maximum has no
+    rounding)."""
+    N, C, H, W, K = case
+    rng = np.random.default_rng(N + C + H + K + variant)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) * np.sqrt(2.0 / (C * 9))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    p = S.ConvParam(w, b, 1, (1, 1), (1, 1), (1, 1), True)
+    want = O.pool_f32_nchw(O.conv_f32_nchw(x.transpose(0, 3, 1, 2), w, b, True, (1, 1)), (2, 2), (2, 2), (0, 0), 0)
+    two = S.SaberConv2D(False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    two.set_tile(variant | (13 << 16))
+    y2 = two.new_output()
+    two.dispatch(dev(x), y2)
+    unfused = host(S.pooling_f32(y2, (2, 2), (2, 2), (0, 0), 0, layout=L.NHWC))
+    cp = S.SaberConv2DPooling(int8=False).init((N, C, H, W), p, 0, (2, 2), (2, 2), (0, 0), L.F32, L.F32)
+    assert cp.fused
+    cp.conv.set_tile(variant | (13 << 16))
+    assert cp.algo().startswith("halo3x3_f32_bf16x3") and cp.algo().endswith("+maxpool2x2"), cp.algo()
+    y = cp.new_output()
+    y.fill_(-5.0)
+    cp.dispatch(dev(x), y)
+    got = host(y)
+    assert np.array_equal(got, unfused), cp.algo()
+    assert np.abs(got.transpose(0, 3, 1, 2) - want).max() <= FP32_RTOL * np.abs(want).max()
+
+
 def test_conv_f32_leaky_relu():
     """ActivationParam::negative_slope of an Active_relu on the FP32 conv: "if (t < 0) t *= slope" after the bias
     (saber_im2col_conv.cpp:153-207, saber_conv_1x1.cpp:61-64). INT8 convs reject it (the x86 INT8 conv clamps to 0)."""
@@ -1348,6 +1378,56 @@ def test_conv_f32_bf16x3_split_k_vs_oracle_and_deterministic(case):
             assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
             for _ in range(3):
                 assert np.array_equal(run(), got), ("not deterministic", conv.algo())
+
+
+F32_HALO_CASES = [
+    # N, H, W, C, K, eltwise residual
+    (2, 56, 56, 64, 64, False),       # ResNet res2 branch2b
+    (1, 28, 28, 128, 128, False),     # res3
+    (2, 19, 23, 32, 40, False),       # ragged tiles, K % 16 != 0
+    (1, 9, 40, 96, 200, True),        # in-place residual sum, three channel chunks
+    (3, 14, 14, 256, 256, False),     # res4: 14 of 16 columns used
+]
+
+
+@pytest.mark.parametrize("case", F32_HALO_CASES)
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+def test_conv_f32_bf16x3_halo_kernel_vs_oracle(case, variant):
+    """FP32 3x3 on the bf16 planes with the input halo resident in LDS (conv3x3_b3h.hip, set_tile variant 13): the oracle's naive
+    convolution within 1e-4 on both criteria, and within rounding of the implicit-GEMM bf16-plane kernel."""
+    N, H, W, C, K, elt = case
+    rng = np.random.default_rng(N * 100 + C + K + variant)
+    x = (rng.random((N, C, H, W)) * 3.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, 3, 3)) * np.sqrt(2.0 / (C * 9))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    res = (rng.random((N, K, H, W)) * 2.0).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, not elt, (1, 1), (1, 1), (1, 1))
+    if elt:
+        want = np.maximum(want + res, 0.0)
+    p = S.ConvParam(w, b, 1, (1, 1), (1, 1), (1, 1), not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, True, 1.0
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rin = np.ascontiguousarray(res.transpose(0, 2, 3, 1))
+
+    def run():
+        y = conv.new_output()
+        if elt:
+            y.copy_(dev(rin))
+        conv.dispatch(xin, y)
+        return host(y).transpose(0, 3, 1, 2)
+    conv.set_tile(conv.tile_id() | (1 << 8) | (11 << 16))
+    base = run()
+    conv.set_tile(variant | (13 << 16))
+    assert conv.algo().startswith("halo3x3_f32_bf16x3"), conv.algo()
+    assert L.load().saber_hip_conv2d_get_tile(conv.h) == variant | (13 << 16)
+    got = run()
+    d = np.abs(got - want)
+    e_max = float(d.max() / np.abs(want).max())
+    e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+    assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (conv.algo(), e_max, e_el)
+    assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
 
 
 STRIDED_HEAD_CASES = [
