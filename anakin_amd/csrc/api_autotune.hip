@@ -94,7 +94,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
                     time_current();
                 }
             }
-    for (int hv = 1; hv <= 5; ++hv)      // FP32 3x3: the LDS-halo forms of the bf16-plane kernel
+    for (int hv = 1; hv <= 8; ++hv)      // FP32 3x3: the LDS-halo forms of the bf16-plane kernel; 1x1: its pointwise forms (6..8)
         if (b3h_ok(op, hv)) {
             ConvChoice chv = {op->tile, 1, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, hv};
             set_choice(op, chv);

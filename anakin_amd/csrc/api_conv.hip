@@ -144,7 +144,8 @@ void name_algo(saber_hip_conv* op) {
     else if (op->b3h) {
         int hb, ht, htm, hthr;
         (void)conv3x3_b3h_variant(op->b3h, &hb, &ht, &htm, &hthr);
-        snprintf(buf, sizeof buf, "halo3x3_f32_bf16x3_%dch_%dx16_w%d%s", hb, ht, hthr / 64, op->pool2 ? "+maxpool2x2" : "");
+        if (op->b3h >= 6) snprintf(buf, sizeof buf, "pw1x1_f32_bf16x3_%dch_%dpx_w%d", hb, ht * 16, hthr / 64);
+        else snprintf(buf, sizeof buf, "halo3x3_f32_bf16x3_%dch_%dx16_w%d%s", hb, ht, hthr / 64, op->pool2 ? "+maxpool2x2" : "");
     }
     else if (op->img1) snprintf(buf, sizeof buf, "imgres%dx%d_i8_%dch%s", op->d.kh, op->d.kw, 16 * ((op->d.k / 16 + 31) / 32), op->gpool ? "+gpool" : "");
     else if (op->img_rb) snprintf(buf, sizeof buf, "img3x3_i8_%dimg_x_%drows_k16_w%d", op->img_ib, op->img_rb, op->img_nw);
@@ -348,7 +349,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         return SABER_HIP_OK;
     }
     if (var == 13) {   // FP32 3x3 LDS-halo kernel on the bf16 planes, variant 1..5 in the low byte
-        if (!b3h_ok(op, tile)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 halo kernel: FP32 3x3 stride-1 pad-1 NHWC conv with C % 32 == 0, variant 1..5");
+        if (!b3h_ok(op, tile)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 halo kernel: FP32 NHWC stride-1 conv, 3x3 pad 1 with C % 32 == 0 (variant 1..5) or 1x1 with C % 64 == 0 (6..8)");
         op->b3h = tile; op->b3 = 0; op->ksplit = 0; op->dma = 0; op->fc_small = 0;
         name_algo(op);
         return SABER_HIP_OK;
@@ -560,22 +561,24 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
             // 3x3 / stride 1 / pad 1 on NHWC f32: the same planes once more in MFMA A-fragment order for the LDS-halo kernel
             // (conv3x3_b3h.hip): [16-row tile][32-channel chunk][tap][plane][lane] x 8 bf16. Row rho of tile i of a wave's tm
             // tiles is channel  base + (rho >> 2) * 4 tm + 4 i + (rho & 3)  (a lane then owns 4 tm consecutive channels).
-            if (kh == 3 && kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 && d.pad_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
-                d.group == 1 && op->c_eff % 32 == 0 && !op->pre_transpose && d.out_layout == SABER_HIP_NHWC) {
-                const int Ce = op->c_eff, nch = Ce / 32, ktiles = K_pad / 16;
+            const bool h3 = kh == 3 && kw == 3 && d.pad_h == 1 && d.pad_w == 1 && op->c_eff % 32 == 0;
+            const bool h1 = kh == 1 && kw == 1 && d.pad_h == 0 && d.pad_w == 0 && op->c_eff % 64 == 0;      // the pointwise form of the same kernel
+            if ((h3 || h1) && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
+                d.group == 1 && !op->pre_transpose && d.out_layout == SABER_HIP_NHWC) {
+                const int Ce = op->c_eff, nch = Ce / 32, ktiles = K_pad / 16, taps = kh * kw;
                 for (int tm = 1; tm <= 2; ++tm) {
-                    std::vector<uint8_t> fr((size_t)ktiles * nch * 9 * 3 * 64 * 16, 0);
+                    std::vector<uint8_t> fr((size_t)ktiles * nch * taps * 3 * 64 * 16, 0);
                     uint16_t* fp = (uint16_t*)fr.data();
                     for (int kt = 0; kt < ktiles; ++kt)
                         for (int cc = 0; cc < nch; ++cc)
-                            for (int t = 0; t < 9; ++t)
+                            for (int t = 0; t < taps; ++t)
                                 for (int lane = 0; lane < 64; ++lane) {
                                     const int rho = lane & 15, fq = lane >> 4;
                                     const int ch = (kt / tm) * tm * 16 + (rho >> 2) * 4 * tm + (kt % tm) * 4 + (rho & 3);
                                     for (int e = 0; e < 8; ++e) {
                                         const size_t src = (size_t)ch * op->Kg_pad + (size_t)t * Ce + cc * 32 + fq * 8 + e;
                                         for (int pl3 = 0; pl3 < 3; ++pl3)
-                                            fp[((((size_t)(kt * nch + cc) * 9 + t) * 3 + pl3) * 64 + lane) * 8 + e] = pl[pl3 * n + src];
+                                            fp[((((size_t)(kt * nch + cc) * taps + t) * 3 + pl3) * 64 + lane) * 8 + e] = pl[pl3 * n + src];
                                     }
                                 }
                     HIP_TRY((tm == 1 ? op->d_w3h1 : op->d_w3h2).upload(fr));

@@ -182,6 +182,8 @@ inline bool b3_tile_ok(const saber_hip_conv* op, int tile, int ks) {
 inline bool b3h_ok(const saber_hip_conv* op, int variant) {      // the halo variant exists for this op (planes packed by set_weights)
     int bmk, th, tm, thr;
     if (!conv3x3_b3h_variant(variant, &bmk, &th, &tm, &thr)) return false;
+    if ((variant >= 6) != (op->d.kh == 1)) return false;       // 1..5: the 3x3 forms, 6..8: pointwise
+    if (variant >= 6 && op->pool2) return false;
     return op->algo == ALGO_IGEMM_F32 && (tm == 1 ? op->d_w3h1.p : op->d_w3h2.p) != nullptr && !op->pair_k2;
 }
 inline bool fc_small_ok(const saber_hip_conv* op) {

@@ -25,10 +25,13 @@ __device__ __forceinline__ int b3h_swz(int row, int q) { return ((0x9C >> (2 * q
 
 // NWM x NWN waves; TM: 16-channel tiles per wave; TH: tile rows (pixels = TH x 16); the NWN wave columns split the rows: wave
 // column wn owns rows [wn * TH / NWN, (wn + 1) * TH / NWN)
-template <int NWM, int TM, int TH, int NWN = 2>
+// KS = 1: the same structure for a 1x1 stride-1 convolution: the "tile" is a run of TH * 16 consecutive pixels of the [N*H*W] list
+// (no halo, one tap per chunk), C % 64 == 0.
+template <int NWM, int TM, int TH, int NWN = 2, int KS = 3>
 __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvKArgs a) {
     constexpr int NTHR = NWM * NWN * 64;
-    constexpr int TW = 16, HW_ = TW + 2, HP = (TH + 2) * HW_;
+    constexpr bool PW = KS == 1;                     // pointwise
+    constexpr int TW = 16, HW_ = PW ? TW : TW + 2, HP = PW ? TH * TW : (TH + 2) * HW_;
     constexpr int XCH = HP * 4;                      // 16-byte chunks of one plane of the halo (32 bf16 = 64 B per pixel)
     constexpr int XIT = (XCH + NTHR - 1) / NTHR;
     constexpr int TN = TH / NWN, NV = TM * 4;
@@ -40,13 +43,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
     const int frow = lane & 15, fq = lane >> 4;
 
     int ptile, tile_ky;
-    xcd_tile(a, ptile, tile_ky);                     // a.npx = N * tiles_y * tiles_x, a.nky = ceil(K / BMK)
-    const int tiles_x = (a.OW + TW - 1) / TW;
-    const int tiles_y = (a.OH + TH - 1) / TH;
+    xcd_tile(a, ptile, tile_ky);                     // a.npx = N * tiles_y * tiles_x (pointwise: ceil(M / HP)), a.nky = ceil(K / BMK)
+    const int tiles_x = PW ? 1 : (a.OW + TW - 1) / TW;
+    const int tiles_y = PW ? 1 : (a.OH + TH - 1) / TH;
     const int per_img = tiles_x * tiles_y;
-    const int n = ptile / per_img;
+    const int n = PW ? 0 : ptile / per_img;
     const int trem = ptile - n * per_img;
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+    const int p0 = ptile * HP;                       // pointwise: first pixel of the run
     const int k_base = tile_ky * BMK;
     const int kb = k_base + wm * (TM * 16) + fq * NV;
 
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
         const int hp = idx >> 2, q = idx & 3;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool ok = (idx < XCH) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        x_off[it] = ok ? ((n * a.H + iy) * a.W + ix) * a.C + q * 8 : -1;       // in f32 elements
+        const bool ok = PW ? (idx < XCH && p0 + hp < a.M) : ((idx < XCH) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+        x_off[it] = ok ? (PW ? (p0 + hp) : ((n * a.H + iy) * a.W + ix)) * a.C + q * 8 : -1;       // in f32 elements
         x_dst[it] = idx < XCH ? hp * 4 + b3h_swz(hp, q) : -1;
     }
     const float* xg = (const float*)a.x;
@@ -97,13 +101,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
     const v4i* wf = (const v4i*)a.w + lane;
     size_t w_tile[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) w_tile[i] = (size_t)(k_base / 16 + wm * TM + i) * nchunks * (9 * 3 * 64);
+    for (int i = 0; i < TM; ++i) w_tile[i] = (size_t)(k_base / 16 + wm * TM + i) * nchunks * (KS * KS * 3 * 64);
     v4i af[2][TM][3];
     auto load_w = [&](int cc, int t, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const v4i* p = wf + w_tile[i] + (size_t)(cc * 9 + t) * (3 * 64);
+            const v4i* p = wf + w_tile[i] + (size_t)(cc * (KS * KS) + t) * (3 * 64);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) af[SET][i][pl] = p[pl * 64];
         }
@@ -148,6 +152,27 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
                                                                         __builtin_bit_cast(v8bf, bf[j][PB[tt]]), acc[i][j], 0, 0, 0);
     };
 
+    if constexpr (PW) {
+        // one tap per chunk: chunks cc (set 0, buffer 0) and cc + 1 (set 1, buffer 1) per iteration (C % 64 == 0), the next chunk's
+        // pixels and weight fragments requested before the current one is multiplied
+        for (int cc = 0; cc < nchunks; cc += 2) {
+            load_chunk(cc + 1);
+            load_w(cc + 1, 0, integral_constant<int, 1>{});
+            mma_tap(lds[0], 0, integral_constant<int, 0>{});
+            store_chunk(1);
+            __syncthreads();
+            const bool more = cc + 2 < nchunks;
+            if (more) {
+                load_chunk(cc + 2);
+                load_w(cc + 2, 0, integral_constant<int, 0>{});
+            }
+            mma_tap(lds[1], 0, integral_constant<int, 1>{});
+            if (more) {
+                store_chunk(0);
+                __syncthreads();
+            }
+        }
+    } else
     for (int cc = 0; cc < nchunks; ++cc) {
         const int buf = cc & 1;
         const bool more = cc + 1 < nchunks;
@@ -182,7 +207,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------
-    if (a.pool_ow) {
+    if (!PW && a.pool_ow) {
         // SaberConv2DPooling<AK_FLOAT>: relu'd conv + 2x2 / stride-2 max pooling (OH, OW even). A window = rows j, j + 1 of this
         // wave (its TN rows start at an even row) x lanes frow, frow ^ 1: max in registers, then across the lane pair; the max of
         // the four relu(conv + bias) values, like epilogue_f32_pool2.
@@ -219,8 +244,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int oy = ty0 + wn * TN + j, ox = tx0 + frow;
-        if (oy >= a.OH || ox >= a.OW) continue;
-        const int p = (n * a.OH + oy) * a.OW + ox;
+        if (!PW && (oy >= a.OH || ox >= a.OW)) continue;
+        const int p = PW ? p0 + (wn * TN + j) * 16 + frow : (n * a.OH + oy) * a.OW + ox;
+        if (PW && p >= a.M) continue;
         float v[NV];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -235,8 +261,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_b3h_kernel(const ConvK
 bool conv3x3_b3h_variant(int variant, int* bmk, int* th, int* tm, int* threads) {
     // 1: 128 ch x 8 rows, 8 waves; 2: 64 ch x 8 rows, 4 waves; 3: 64 ch x 8 rows, 8 waves; 4: 64 ch x 4 rows, 4 waves; 5: 128 ch x 4 rows, 8 waves
     // (a 64 ch x 16 rows form with 2 x 4 waves was measured too: 156-165 TF on VGG16's layers against 172-206 for variant 2)
-    static const int tab[6][4] = {{0, 0, 0, 0}, {128, 8, 2, 512}, {64, 8, 2, 256}, {64, 8, 1, 512}, {64, 4, 2, 256}, {128, 4, 2, 512}};
-    if (variant < 1 || variant > 5) return false;
+    // 6..8: the pointwise (1x1) forms: 64 ch x 128 pixels 4 waves, 128 ch x 128 pixels 8 waves, 64 ch x 64 pixels 4 waves
+    static const int tab[9][4] = {{0, 0, 0, 0}, {128, 8, 2, 512}, {64, 8, 2, 256}, {64, 8, 1, 512}, {64, 4, 2, 256}, {128, 4, 2, 512},
+                                  {64, 8, 2, 256}, {128, 8, 2, 512}, {64, 4, 2, 256}};
+    if (variant < 1 || variant > 8) return false;
     *bmk = tab[variant][0]; *th = tab[variant][1]; *tm = tab[variant][2]; *threads = tab[variant][3];
     return true;
 }
@@ -246,11 +274,12 @@ bool conv3x3_b3h_variant(int variant, int* bmk, int* th, int* tm, int* threads) 
 hipError_t launch_conv3x3_b3h(int variant, const ConvKArgs& a, hipStream_t s) {
     int bmk, th, tm, thr;
     if (!conv3x3_b3h_variant(variant, &bmk, &th, &tm, &thr)) return hipErrorInvalidValue;
-    if (a.kh != 3 || a.kw != 3 || a.stride_h != 1 || a.stride_w != 1 || a.pad_h != 1 || a.pad_w != 1 || a.dil_h != 1 || a.dil_w != 1 ||
-        (a.C & 31) || a.out_nchw || a.K2 || (a.pool_ow && ((a.OH | a.OW) & 1)))
+    const bool pw = variant >= 6;
+    if (a.kh != (pw ? 1 : 3) || a.kw != a.kh || a.stride_h != 1 || a.stride_w != 1 || a.pad_h != (pw ? 0 : 1) || a.pad_w != a.pad_h || a.dil_h != 1 ||
+        a.dil_w != 1 || (a.C & (pw ? 63 : 31)) || a.out_nchw || a.K2 || (a.pool_ow && (pw || ((a.OH | a.OW) & 1))))
         return hipErrorInvalidValue;
     ConvKArgs b = a;
-    b.npx = a.N * ((a.OW + 15) / 16) * ((a.OH + th - 1) / th);
+    b.npx = pw ? (a.M + th * 16 - 1) / (th * 16) : a.N * ((a.OW + 15) / 16) * ((a.OH + th - 1) / th);
     b.nky = (a.K + bmk - 1) / bmk;
     b.mg_npx = magic_div(b.npx, (long long)b.npx * b.nky);
     dim3 grid(b.npx * b.nky), block(thr);
@@ -260,6 +289,9 @@ hipError_t launch_conv3x3_b3h(int variant, const ConvKArgs& a, hipStream_t s) {
     case 3: hipLaunchKernelGGL((conv3x3_b3h_kernel<4, 1, 8>), grid, block, 0, s, b); break;
     case 4: hipLaunchKernelGGL((conv3x3_b3h_kernel<2, 2, 4>), grid, block, 0, s, b); break;
     case 5: hipLaunchKernelGGL((conv3x3_b3h_kernel<4, 2, 4>), grid, block, 0, s, b); break;
+    case 6: hipLaunchKernelGGL((conv3x3_b3h_kernel<2, 2, 8, 2, 1>), grid, block, 0, s, b); break;
+    case 7: hipLaunchKernelGGL((conv3x3_b3h_kernel<4, 2, 8, 2, 1>), grid, block, 0, s, b); break;
+    case 8: hipLaunchKernelGGL((conv3x3_b3h_kernel<2, 2, 4, 2, 1>), grid, block, 0, s, b); break;
     }
     return hipGetLastError();
 }

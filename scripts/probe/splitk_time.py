@@ -89,3 +89,24 @@ for name, N, H, W, C, K in [("vgg conv2 112x112 128->128", 8, 112, 112, 128, 128
     flops = 2.0 * N * H * W * C * K * 9
     print("%s: autotune %s %.1f us (%.0f TF) | halo: " % (name, a_auto.replace("igemm_f32_bf16x3_", ""), t_auto, flops / t_auto / 1e6) +
           "  ".join("%s %.1f us (%.0f TF)" % (a.replace("halo3x3_f32_bf16x3_", ""), t, flops / t / 1e6) for t, a in rows))
+
+# the pointwise forms (variants 6..8) on ResNet50's 1x1 layers at batch 8, against what the autotuner picks among the others
+for name, N, HW, C, K, elt in [("res2 2c 64->256 +sum", 8, 56, 64, 256, True), ("res2 2a 256->64", 8, 56, 256, 64, False),
+                               ("res3 2c 128->512 +sum", 8, 28, 128, 512, True), ("res3 2a 512->128", 8, 28, 512, 128, False),
+                               ("res4 2c 256->1024 +sum", 8, 14, 256, 1024, True), ("res4 2a 1024->256", 8, 14, 1024, 256, False)]:
+    x = torch.from_numpy((rng.random((N, HW, HW, C)) * 3).astype(np.float32)).cuda()
+    w = (rng.standard_normal((K, C, 1, 1)) * np.sqrt(2.0 / C)).astype(np.float32)
+    p = S.ConvParam(w, np.zeros(K, np.float32), 1, (0, 0), (1, 1), (1, 1), not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, True, 1.0
+    conv = S.SaberConv2D(int8=False).init((N, C, HW, HW), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    y = conv.new_output()
+    rows = []
+    for v in (6, 7, 8):
+        conv.set_tile(v | (13 << 16))
+        rows.append((timed(lambda: conv.dispatch(x, y), 100), conv.algo()))
+    conv.autotune(x, y)
+    t_auto, a_auto = timed(lambda: conv.dispatch(x, y), 100), conv.algo()
+    byt = 4.0 * N * HW * HW * (C + K * (2 if elt else 1))
+    print("%s: autotune %s %.1f us (%.2f TB/s) | pw: " % (name, a_auto, t_auto, byt / t_auto / 1e6) +
+          "  ".join("%s %.1f us" % (a.replace("pw1x1_f32_bf16x3_", ""), t) for t, a in rows))

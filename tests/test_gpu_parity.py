@@ -1430,6 +1430,54 @@ def test_conv_f32_bf16x3_halo_kernel_vs_oracle(case, variant):
     assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
 
 
+F32_PW_CASES = [
+    # N, H, W, C, K, eltwise residual
+    (2, 56, 56, 64, 256, True),       # ResNet res2 branch2c + in-place residual sum
+    (1, 28, 28, 512, 128, False),     # res3 branch2a
+    (3, 7, 9, 128, 72, False),        # ragged pixels (189), K % 16 != 0
+    (1, 14, 14, 1024, 256, False),    # res4 branch2a: 32 channel chunks
+]
+
+
+@pytest.mark.parametrize("case", F32_PW_CASES)
+@pytest.mark.parametrize("variant", [6, 7, 8])
+def test_conv_f32_bf16x3_pointwise_kernel_vs_oracle(case, variant):
+    """The 1x1 forms of conv3x3_b3h.hip (variants 6..8: a run of 64 / 128 pixels x 64 / 128 channels per workgroup, weights straight
+    into MFMA registers, the pixel run split once per 32-channel chunk): oracle within 1e-4, implicit-GEMM bf16-plane kernel within rounding."""
+    N, H, W, C, K, elt = case
+    rng = np.random.default_rng(N * 10 + C + K + variant)
+    x = (rng.random((N, C, H, W)) * 3.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, 1, 1)) * np.sqrt(2.0 / C)).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    res = (rng.random((N, K, H, W)) * 2.0).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, not elt, (0, 0), (1, 1), (1, 1))
+    if elt:
+        want = np.maximum(want + res, 0.0)
+    p = S.ConvParam(w, b, 1, (0, 0), (1, 1), (1, 1), not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, True, 1.0
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rin = np.ascontiguousarray(res.transpose(0, 2, 3, 1))
+
+    def run():
+        y = conv.new_output()
+        if elt:
+            y.copy_(dev(rin))
+        conv.dispatch(xin, y)
+        return host(y).transpose(0, 3, 1, 2)
+    conv.set_tile(conv.tile_id() | (1 << 8) | (11 << 16))
+    base = run()
+    conv.set_tile(variant | (13 << 16))
+    assert conv.algo().startswith("pw1x1_f32_bf16x3"), conv.algo()
+    got = run()
+    d = np.abs(got - want)
+    assert float(d.max() / np.abs(want).max()) <= FP32_RTOL and float((d / (np.abs(want) + np.abs(want).mean())).max()) <= FP32_RTOL, conv.algo()
+    assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
+    with pytest.raises(L.SaberHipError):
+        conv.set_tile(2 | (13 << 16))          # a 3x3 variant on a 1x1 conv
+
+
 STRIDED_HEAD_CASES = [
     # C, N, Hin, Win, 3x3 input dtype, mid dtype, eltwise relu, tile code (None: default)
     (64, 2, 56, 56, O.U8, O.U8, 1, None),        # res2c after the reference's stride-up: 56 -> 28
