@@ -421,7 +421,7 @@ def main():
                         mt, wb = NM.write_model(base, dict(scales), B, td, "int8")
                         x.tofile(os.path.join(td, "input.bin"))
                         r = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, "200"], capture_output=True,
-                                           text=True, timeout=300)
+                                           text=True, timeout=300, cwd=td)      # (the reference's logger writes ./log/)
                         if r.returncode == 0:
                             tt = open(os.path.join(td, "timing.txt")).read().split()
                             ref_list["net_prediction"] = dict(

@@ -31,7 +31,7 @@ MI355X_BIN = os.path.join(ROOT, "integration", "_build", "test_saber_conv_mi355x
 
 
 @pytest.mark.gpu
-def test_mi355x_target_inside_the_reference_operator_stack():
+def test_mi355x_target_inside_the_reference_operator_stack(tmp_path):
     """The MI355X target executed by the reference's OWN Saber code (b, f-4 saber half):
     integration/test_saber_conv_mi355x.cpp is compiled against a patched copy of /root/reference/saber
     (integration/apply_mi355x_target.py: eMI355X, TargetWrapper<MI355X> on HIP, Device / Env / Context, SaberTimer,
@@ -39,7 +39,7 @@ def test_mi355x_target_inside_the_reference_operator_stack():
     re-create path, base.h:151-161) -> SaberConv2D<MI355X> -> integration/saber_mi355x_adaptor.h -> the C ABI;
     every output byte equals the oracle's."""
     assert os.path.exists(MI355X_BIN), "integration/_build/test_saber_conv_mi355x.bin is missing: run __graft_entry__.build()"
-    p = subprocess.run([MI355X_BIN], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([MI355X_BIN], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))   # (the reference's logger writes ./log/)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 failed" in p.stdout and "bit-exact" in p.stdout and "SaberTimer<MI355X>" in p.stdout
 

@@ -38,7 +38,7 @@ def run_net(tmp_path, name, precision, batch, iters=0):
     env = dict(os.environ)
     env.pop("LD_PRELOAD", None)
     cmd = [BIN, mt, wb, os.path.join(d, "input.bin"), d] + ([str(iters)] if iters else [])
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=d)   # (the reference's logger writes ./log/)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "net ok" in r.stdout
     return model, x, scales, NM.parse_oplist(os.path.join(d, "oplist.txt")), d

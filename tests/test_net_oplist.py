@@ -36,7 +36,8 @@ def dry_run(tmp_path, name, precision, batch=1):
     mt, wb = NM.write_model(model, scales, batch, d, precision)
     x.tofile(os.path.join(d, "input.bin"))
     env = dict(os.environ, LD_PRELOAD=MOCK)
-    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "dry"], env=env, capture_output=True, text=True)
+    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "dry"], env=env, capture_output=True, text=True,
+                       cwd=d)          # (the reference's logger writes ./log/ next to the working directory)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return model, scales, NM.parse_oplist(os.path.join(d, "oplist.txt"))
 
