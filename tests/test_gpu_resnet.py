@@ -380,3 +380,27 @@ def test_resnet101_int8_framework_list_every_edge_bit_exact():
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     assert np.array_equal(_h(net.tensor("fc1000")), logits)
+
+
+def test_resnet50_int8_framework_list_batch16_invariance(setup_fw):
+    """Batch 16 (two images per XCD-sized group for the image-resident last conv + pooling, M doubled everywhere else): image i of the
+    batch == the same image run alone, after autotuning, eager and as a hipGraph."""
+    model, x2, scales, ref = setup_fw
+    x16 = np.concatenate([x2, W.make_input(14, seed=123)], 0)
+    net = W.build_int8_net(model, dict(scales), 16)
+    net.tensor("data").copy_(torch.from_numpy(x16).cuda())
+    net.run()
+    net.autotune(iters=2)
+    net.tensor("data").copy_(torch.from_numpy(x16).cuda())
+    net.run()
+    l16 = _h(net.tensor("fc1000")).copy()
+    assert np.array_equal(l16[:2], ref["fc1000"].reshape(2, -1))
+    net.capture()
+    net.tensor("fc1000").zero_()
+    net.replay()
+    assert np.array_equal(_h(net.tensor("fc1000")), l16)
+    net1 = W.build_int8_net(model, dict(scales), 1)
+    for i in (3, 9, 15):
+        net1.tensor("data").copy_(torch.from_numpy(x16[i:i + 1]).cuda())
+        net1.run()
+        assert np.array_equal(_h(net1.tensor("fc1000"))[0], l16[i]), i
