@@ -161,6 +161,15 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         op->d_part.release();
         op->d_part_ctr.release();
     }
+    // ... and so are the weight repacks only ONE kernel family reads: the fragment-ordered bf16 planes of the FP32 halo /
+    // pointwise kernels (2 x 1.5 x the f32 weights: > 200 MB over VGG16) and the image-resident kernel's stage. (d_w and the
+    // bf16 planes d_w3 stay: the net-level consolidation pass still switches implicit-GEMM tiles. A later set_tile to a
+    // released family reports INVALID_VALUE; img_conv_prepare re-packs on demand.)
+    if (!op->b3h) {
+        op->d_w3h1.release();
+        op->d_w3h2.release();
+    }
+    if (!op->img1 && !op->gpool) img_conv_release(op);
     // leave y holding one clean result of the selected kernel
     return saber_hip_conv2d_run(op, x, y, res, workspace, s);
 }

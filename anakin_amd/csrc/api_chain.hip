@@ -169,6 +169,7 @@ int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
 int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* ch) { return ch ? ch->tn : 0; }
 int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void* res, void* y_a, void* y_b,
                                saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_conv2d_chain_run (saber_hip_net_optimize forms chains itself)");
     if (!ch || !x || !res || !y_a || (ch->b && !y_b)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const saber_hip_conv* a = ch->a;
     const saber_hip_conv* b = ch->b;

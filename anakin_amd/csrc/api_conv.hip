@@ -131,7 +131,21 @@ int split_prepare(saber_hip_conv* op) {
     const size_t m = (size_t)op->d.n * op->oh * op->ow;
     HIP_TRY(op->d_part.alloc_zero((m + 127) * ((size_t)op->d.k + 127) * 8));        // 8 splits of the padded f32 output
     HIP_TRY(op->d_part_ctr.alloc_zero(((m + 31) / 32) * (((size_t)op->d.k + 31) / 32)));
+    if (!op->h_part_err) {
+        HIP_TRY(hipHostMalloc((void**)&op->h_part_err, sizeof(unsigned), hipHostMallocMapped));
+        *op->h_part_err = 0u;
+    }
     return SABER_HIP_OK;
+}
+// A split-K launch of this operator found its splits on different XCDs (the kernel poisoned that output with NaN and counted
+// itself in the pinned word): report it as an error status NOW and run without split-K from here on.
+static int split_check(saber_hip_conv* op) {
+    if (!op->ksplit || !op->h_part_err || !*(volatile unsigned*)op->h_part_err) return SABER_HIP_OK;
+    *(volatile unsigned*)op->h_part_err = 0u;
+    op->ksplit = 0;
+    name_algo(op);
+    return fail(SABER_HIP_RUNTIME_ERROR, "FP32 split-K: in an earlier launch of this operator the splits of a tile ran on different XCDs "
+                "(that output was poisoned with NaN); split-K is now off for it");
 }
 void name_algo(saber_hip_conv* op) {
     static const char* an[] = {"igemm_i8", "igemm_i8_c4", "igemm_f32", "direct_i8", "direct_f32"};
@@ -316,6 +330,12 @@ size_t saber_hip_conv2d_workspace_bytes(const saber_hip_conv_t* op) { return op-
 const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op) { return op->algo_name.c_str(); }
 
 static inline bool tile_arg_ks(int ks) { return ks == 1 || ks == 2 || ks == 4; }
+// every specialised-kernel selector off (run / get_tile test img1 and b3h FIRST): a set_tile that selects one kernel family
+// starts from here, so a selection made by an earlier autotune / set_tile cannot keep running under the new one's name
+static void clear_selectors(saber_hip_conv* op) {
+    if (!op->gpool) op->img1 = 0;      // (conv + fused global pooling exists only as the image-resident kernel)
+    op->b3h = 0; op->b3 = 0; op->ksplit = 0; op->halo = 0; op->stem = 0; op->img_ib = op->img_rb = 0; op->fc_small = 0;
+}
 
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15,
@@ -344,26 +364,30 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
             const int rc = split_prepare(op);
             if (rc) return rc;
         }
-        op->b3 = 1; op->dma = 0; op->ks = ksd ? ksd : 1; op->tile = tile; op->fc_small = 0; op->ksplit = sh; op->b3h = 0;
+        clear_selectors(op);
+        op->b3 = 1; op->dma = 0; op->ks = ksd ? ksd : 1; op->tile = tile; op->ksplit = sh;
         name_algo(op);
         return SABER_HIP_OK;
     }
     if (var == 13) {   // FP32 3x3 LDS-halo kernel on the bf16 planes, variant 1..5 in the low byte
         if (!b3h_ok(op, tile)) return fail(SABER_HIP_INVALID_VALUE, "bf16x3 halo kernel: FP32 NHWC stride-1 conv, 3x3 pad 1 with C % 32 == 0 (variant 1..5) or 1x1 with C % 64 == 0 (6..8)");
-        op->b3h = tile; op->b3 = 0; op->ksplit = 0; op->dma = 0; op->fc_small = 0;
+        clear_selectors(op);
+        op->b3h = tile; op->dma = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
     if (var == 12) {   // image-resident kernel (<= 64 pixels per image: one workgroup = one image x a channel group)
         const int rc = img_conv_prepare(op);
         if (rc) return rc;
-        op->img1 = 1; op->halo = 0; op->img_ib = op->img_rb = 0; op->stem = 0; op->fc_small = 0;
+        clear_selectors(op);
+        op->img1 = 1;
         name_algo(op);
         return SABER_HIP_OK;
     }
     if (op->gpool) return fail(SABER_HIP_INVALID_VALUE, "conv + fused global pooling has a single kernel");
     if (var == 10) {   // small-batch fc kernel
         if (!fc_small_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "small-batch fc kernel: INT8 fc with <= 16 rows and k <= 4096");
+        clear_selectors(op);
         op->fc_small = 1;
         name_algo(op);
         return SABER_HIP_OK;
@@ -373,28 +397,19 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         if (!img_ok(op, nw, ib, rb))
             return fail(SABER_HIP_INVALID_VALUE, "small-image 3x3 kernel: needs an INT8 3x3 stride-1 conv with C in {64,128,256,512} "
                                                  "and a slab (images x rows) that fits its LDS / accumulator budget");
+        clear_selectors(op);
         op->img_ib = ib; op->img_rb = rb; op->img_nw = nw;
-        op->halo = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
     if (var == 5 || var == 6) {   // LDS-halo 3x3 kernel, 4 / 8 tile rows
         if (!halo_ok(op) || op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "halo kernel needs an INT8 3x3 stride-1 conv with C % 64 == 0");
+        clear_selectors(op);
         op->halo = var == 5 ? 4 : 8;
-        op->img_ib = op->img_rb = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
-    if (var) {   // an explicit implicit-GEMM variant switches the specialised kernels off
-        op->img1 = 0;
-        op->b3h = 0;
-        op->b3 = 0;
-        op->ksplit = 0;
-        op->halo = 0;
-        op->stem = 0;
-        op->img_ib = op->img_rb = 0;
-        op->fc_small = 0;
-    }
+    if (var) clear_selectors(op);   // an explicit implicit-GEMM variant switches the specialised kernels off
     if (var > 4 || (var >= 2 && op->algo == ALGO_IGEMM_I8_C4)) return fail(SABER_HIP_INVALID_VALUE, "bad staging variant");
     if ((var >= 3 && ((ks ? ks : op->ks) != 4 || tile > TILE_64x64)) || (var == 4 && tile != TILE_32x32))
         return fail(SABER_HIP_INVALID_VALUE, "wave groups need stage depth 4 and a tile <= 64x64 (32x32 for 4 groups)");
@@ -630,6 +645,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
         a.ksplit_sh = op->ksplit;
         a.part = op->d_part.p;
         a.part_ctr = op->d_part_ctr.p;
+        a.part_err = op->h_part_err;      // (unified addressing: the pinned word's host pointer is its device pointer)
     }
     a.steps = (op->Kg + estage - 1) / estage;
     a.inv_ohw = 1.0f / (float)(op->oh * op->ow);
@@ -658,6 +674,7 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
 
 int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                          saber_hip_stream_t stream) {
+    if (g_capture) return capture_conv(op, x, y, res);
     if (!op || !x || !y) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     if (!op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "set_weights not called");
     if (op->ws_bytes && !workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
@@ -736,6 +753,10 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
             break;
         }
         if (op->b3 && op->ksplit && !op->d_part.p) return fail(SABER_HIP_INVALID_VALUE, "split-K selected without its buffers (saber_hip_conv2d_set_tile / autotune allocate them)");
+        if (op->b3 && op->ksplit) {
+            const int rs = split_check(op);
+            if (rs) return rs;
+        }
         if (op->b3) HIP_TRY(launch_conv_igemm(3, op->tile, op->ks, a, s));
         else HIP_TRY(op->dma ? launch_conv_igemm_dma(2, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(2, op->tile, op->ks, a, s));
         break;
@@ -825,6 +846,7 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
 }
 
 int saber_hip_conv2d_run_pair(saber_hip_conv_t* op, const void* x, void* y_a, void* y_b, saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_conv2d_run_pair (an executor-level object: saber_hip_net_optimize forms pairs itself)");
     if (!op || !x || !y_a || !y_b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     if (!op->pair_k2) return fail(SABER_HIP_INVALID_VALUE, "not a sibling pair");
     ConvKArgs a;
@@ -832,6 +854,10 @@ int saber_hip_conv2d_run_pair(saber_hip_conv_t* op, const void* x, void* y_a, vo
     hipStream_t s = (hipStream_t)stream;
     const int mode = op->is_i8 ? 0 : (op->b3 ? 3 : 2);
     if (op->b3 && op->ksplit && !op->d_part.p) return fail(SABER_HIP_INVALID_VALUE, "split-K selected without its buffers (autotune / set_tile allocate them)");
+    if (op->b3 && op->ksplit) {
+        const int rs = split_check(op);
+        if (rs) return rs;
+    }
     HIP_TRY(op->dma && !op->b3 ? launch_conv_igemm_dma(mode, op->tile, op->ks, op->dma, a, s) : launch_conv_igemm(mode, op->tile, op->ks, a, s));
     return SABER_HIP_OK;
 }
@@ -924,12 +950,14 @@ int saber_hip_conv2d_set_global_pooling(saber_hip_conv_t* op) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_run_gpool(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* y_pool, saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_conv2d_run_gpool");
     if (!op || !op->gpool) return fail(SABER_HIP_INVALID_VALUE, "not a conv with fused global pooling");
     return img_conv_run(op, x, y, res, y_pool, (hipStream_t)stream);
 }
 
 void saber_hip_conv2d_destroy(saber_hip_conv_t* op) {
     if (op) img_conv_release(op);
+    if (op && op->h_part_err) (void)hipHostFree(op->h_part_err);
     delete op;
 }
 

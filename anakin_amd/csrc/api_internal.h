@@ -8,6 +8,7 @@
 //   api_net.hip           op-list executor: arena, lanes, hipGraph capture / replay, in-pass timing
 //   api_net_optimize.hip  executor-level fusions (saber_hip_net_optimize)
 //   api_net_autotune.hip  whole-net autotuner, selection save / restore
+//   api_capture.hip       op-list capture: the *_run calls of a caller's own op loop recorded into a saber_hip_net
 #pragma once
 #include "../../include/saber_hip.h"
 #include "kernels.h"
@@ -128,6 +129,7 @@ struct saber_hip_conv {
     DevBuf<uint8_t> d_w;
     DevBuf<float> d_part;    // split-K: partial accumulators [tile][split] and the tiles' arrival counters (split_prepare)
     DevBuf<unsigned> d_part_ctr;
+    unsigned* h_part_err = nullptr;   // pinned, device-mapped word the split-K kernels count placement violations in (split_prepare)
     DevBuf<uint8_t> d_w3;    // FP32 convs: the repacked weights split into three bf16 planes [3][K_pad][Kg_pad] (b3 variant)
     DevBuf<float> d_bias, d_scale;
     DevBuf<int> d_comp;
@@ -302,7 +304,7 @@ struct ColdScope {
 
 // op-list executor
 namespace saber_api {
-enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_FC_Q, OP_SOFTMAX };
+enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_FC_Q, OP_SOFTMAX, OP_RELU_F32 };
 struct NetOp {
     OpKind kind;
     std::string name;
@@ -330,6 +332,13 @@ struct NetOp {
 struct saber_hip_net {
     std::vector<size_t> tensor_bytes;
     std::vector<size_t> tensor_off;
+    std::vector<void*> tensor_ext;     // per tensor: caller-owned storage (saber_hip_net_bind_tensor) or null = a slot of the arena
+    std::vector<std::pair<const void*, int>> captured_ptr;   // captured nets: caller pointer -> id of the LAST tensor seen there
+    void* ptr(int id) const {
+        if (id < 0) return nullptr;
+        if ((size_t)id < tensor_ext.size() && tensor_ext[id]) return tensor_ext[id];
+        return (void*)(arena + tensor_off[id]);
+    }
     std::vector<NetOp> ops;
     char* arena = nullptr;
     size_t arena_bytes = 0, ws_off = 0, ws_bytes = 0;
@@ -345,6 +354,19 @@ struct saber_hip_net {
     std::vector<saber_hip_conv*> owned;   // ops created by saber_hip_net_optimize (destroyed with the net)
     std::vector<saber_hip_chain*> owned_chains;
 };
+
+// Op-list capture (api_capture.hip; saber_hip_capture_begin / _end): while g_capture is set on the calling thread every
+// capturable *_run entry point records itself into the capture's net instead of launching. Each recorder returns a status.
+namespace saber_api {
+struct Capture;
+extern thread_local Capture* g_capture;
+int capture_conv(saber_hip_conv* op, const void* x, void* y, const void* res);
+int capture_fc(saber_hip_fc* fc, const void* x, float* y, bool quantised_input);
+int capture_unsupported(const char* what);
+// streaming ops: kind + the argument block of the matching saber_hip_net_add_* call; in2 / out2 may be null
+int capture_stream_op(OpKind kind, const char* name, const int* p, int np, const float* f, int nf, size_t count, const void* in,
+                      size_t in_bytes, const void* in2, size_t in2_bytes, void* out, size_t out_bytes, void* out2, size_t out2_bytes);
+}  // namespace saber_api
 
 // helpers one translation unit defines and another uses
 bool halo_ok(const saber_hip_conv* op);      // api_conv.hip

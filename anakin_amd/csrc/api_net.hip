@@ -2,7 +2,7 @@
 #include "api_internal.h"
 
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
-    auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
+    auto T = [&](int id) -> void* { return net->ptr(id); };
     void* ws = net->arena + net->ws_off;
     switch (o.kind) {
     case OP_CONV:
@@ -41,6 +41,7 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
                                               (float*)T(o.out), o.f[1], (int8_t*)T(o.out2), s);
     case OP_FC_Q: return saber_hip_fc_run_q(o.fc, (const int8_t*)T(o.in), (float*)T(o.out), s);
     case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
+    case OP_RELU_F32: return saber_hip_relu_f32(o.count, (const float*)T(o.in), (float*)T(o.out), s);
     }
     return SABER_HIP_UNIMPL;
 }
@@ -52,7 +53,32 @@ int saber_hip_net_create(saber_hip_net_t** out) {
 }
 int saber_hip_net_add_tensor(saber_hip_net_t* net, size_t bytes) {
     net->tensor_bytes.push_back(bytes);
+    net->tensor_ext.push_back(nullptr);
     return (int)net->tensor_bytes.size() - 1;
+}
+int saber_hip_net_num_tensors(const saber_hip_net_t* net) { return net ? (int)net->tensor_bytes.size() : 0; }
+size_t saber_hip_net_tensor_bytes(const saber_hip_net_t* net, int id) {
+    return (net && id >= 0 && id < (int)net->tensor_bytes.size()) ? net->tensor_bytes[id] : 0;
+}
+int saber_hip_net_bind_tensor(saber_hip_net_t* net, int id, void* ptr) {
+    if (!net || id < 0 || id >= (int)net->tensor_bytes.size()) return fail(SABER_HIP_INVALID_VALUE, "bad tensor id");
+    if (net->finalized && !ptr && !net->tensor_ext[id]) return SABER_HIP_OK;
+    if (net->finalized && !net->tensor_ext[id]) return fail(SABER_HIP_INVALID_VALUE, "bind_tensor: an arena tensor cannot become external after finalize");
+    if (net->finalized && !ptr) return fail(SABER_HIP_INVALID_VALUE, "bind_tensor: an external tensor has no arena slot to fall back to after finalize");
+    net->tensor_ext[id] = ptr;
+    if (net->exec) {   // a captured hipGraph holds the old address
+        (void)hipGraphExecDestroy(net->exec);
+        (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
+    return SABER_HIP_OK;
+}
+int saber_hip_net_tensor_of_ptr(const saber_hip_net_t* net, const void* ptr) {
+    if (!net) return -1;
+    for (const auto& pr : net->captured_ptr)
+        if (pr.first == ptr) return pr.second;
+    return -1;
 }
 static int push(saber_hip_net* net, NetOp&& o) {
     const int nt = (int)net->tensor_bytes.size();
@@ -162,6 +188,11 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
     o.name = std::string("fc:") + op->conv->algo_name;
     return push(net, std::move(o));
 }
+int saber_hip_net_add_relu_f32(saber_hip_net_t* net, size_t count, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_RELU_F32; o.in = in_id; o.out = out_id; o.count = count; o.name = "relu_f32";
+    return push(net, std::move(o));
+}
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id) {
     NetOp o;
     o.kind = OP_SOFTMAX; o.in = in_id; o.out = out_id; o.name = "softmax_f32";
@@ -175,6 +206,7 @@ int saber_hip_net_finalize(saber_hip_net_t* net) {
     net->tensor_off.resize(net->tensor_bytes.size());
     for (size_t i = 0; i < net->tensor_bytes.size(); ++i) {
         net->tensor_off[i] = off;
+        if (net->tensor_ext[i]) continue;      // caller-owned storage: no arena slot
         off += (net->tensor_bytes[i] + 255) / 256 * 256;
     }
     net->ws_off = off;
@@ -188,7 +220,7 @@ int saber_hip_net_finalize(saber_hip_net_t* net) {
 }
 void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id) {
     if (!net->finalized || id < 0 || id >= (int)net->tensor_off.size()) return nullptr;
-    return net->arena + net->tensor_off[id];
+    return net->ptr(id);
 }
 size_t saber_hip_net_arena_bytes(const saber_hip_net_t* net) { return net->arena_bytes; }
 int saber_hip_net_num_ops(const saber_hip_net_t* net) { return (int)net->ops.size(); }
@@ -369,7 +401,15 @@ int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int
     if (!net || !net->finalized || iters <= 0 || !out_us) return fail(SABER_HIP_INVALID_VALUE, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = net->ops.size();
-    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    struct Events {      // destroyed on every exit path
+        std::vector<hipEvent_t> v;
+        ~Events() {
+            for (hipEvent_t e : v)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } evs;
+    evs.v.assign(n + 1, nullptr);
+    std::vector<hipEvent_t>& ev = evs.v;
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
     for (int it = 0; it < iters + 1; ++it) {      // the first pass warms up and is dropped
@@ -396,14 +436,13 @@ int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int
         }
     }
     for (size_t i = 0; i < n; ++i) out_us[i] = (float)(acc[i] * 1000.0 / iters);
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return SABER_HIP_OK;
 }
 int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    EventPair evp;
+    HIP_TRY(evp.init());
+    hipEvent_t e0 = evp.e0, e1 = evp.e1;
     for (size_t i = 0; i < net->ops.size(); ++i) {
         int rc = net_launch(net, net->ops[i], s);
         if (rc) return rc;
@@ -415,8 +454,6 @@ int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         out_us[i] = ms * 1000.f / iters;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return SABER_HIP_OK;
 }
 // 1 when tensor `id` is the output edge of a 3x3 conv that currently runs inside a conv3x3 + chain launch (not written)

@@ -135,7 +135,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         net->exec = nullptr;
         net->graph = nullptr;
     }
-    auto T = [&](int id) -> void* { return id < 0 ? nullptr : (void*)(net->arena + net->tensor_off[id]); };
+    auto T = [&](int id) -> void* { return net->ptr(id); };
     ColdScope scope;
     // flush size between timed repetitions: a net whose tensor arena exceeds the 256 MB Infinity Cache finds its weights in no cache
     // from one forward pass to the next - flush that much (up to 512 MB); smaller nets keep the 64 MB L2-only flush

@@ -262,6 +262,12 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             if (!src->is_i8 || src->pair_k2 || src->pool_fused || src->gpool || !img_conv_ok(src) || src->d.n != q.p[0] ||
                 src->d.k != q.p[3] || src->oh != q.p[1] || src->ow != q.p[2] || src->d.out_dtype != q.p[13])
                 continue;
+            {   // the pooled tensor is written at the CONV's position instead: nothing in (p, i) may read or write it
+                bool clash = false;
+                for (int j = p + 1; j < (int)i && !clash; ++j)
+                    if (!dead[j]) clash = ops[j].in == q.out || ops[j].in2 == q.out || ops[j].out == q.out || ops[j].out2 == q.out;
+                if (clash) continue;
+            }
             saber_hip_conv* fused = nullptr;
             if (clone_conv_i8(src, src->d, &fused) != SABER_HIP_OK) continue;
             if (saber_hip_conv2d_set_global_pooling(fused) != SABER_HIP_OK) {

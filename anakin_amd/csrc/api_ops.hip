@@ -103,6 +103,7 @@ size_t saber_hip_fc_workspace_bytes(const saber_hip_fc_t* fc) {
 }
 
 int saber_hip_fc_run(saber_hip_fc_t* fc, const void* x, float* y, void* workspace, saber_hip_stream_t stream) {
+    if (g_capture) return capture_fc(fc, x, y, false);
     const void* xin = x;
     if (fc->pre_quant) {
         if (!workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
@@ -116,6 +117,7 @@ int saber_hip_fc_run(saber_hip_fc_t* fc, const void* x, float* y, void* workspac
 int saber_hip_fc_run_q(saber_hip_fc_t* fc, const int8_t* xq, float* y, saber_hip_stream_t stream) {
     if (!fc || !xq || !y) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     if (!fc->d.int8_weights || fc->conv->x_dtype != DT_S8) return fail(SABER_HIP_INVALID_VALUE, "fc_run_q: INT8 fc with s8 operand only");
+    if (g_capture) return capture_fc(fc, xq, y, true);
     return saber_hip_conv2d_run(fc->conv, xq, y, nullptr, nullptr, stream);
 }
 
@@ -171,6 +173,7 @@ size_t saber_hip_gemm_i8_workspace_bytes(const saber_hip_gemm_i8_t* g) {
     return (g->trans_a || g->k_pad != g->k) ? (size_t)g->m * g->k_pad : 0;
 }
 int saber_hip_gemm_i8_run(saber_hip_gemm_i8_t* g, const void* a, int32_t* c, void* workspace, saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_gemm_i8_run");
     if (!g || !a || !c) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const void* ain = a;
     if (saber_hip_gemm_i8_workspace_bytes(g)) {
@@ -192,6 +195,7 @@ void saber_hip_gemm_i8_destroy(saber_hip_gemm_i8_t* g) {
 int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b, float beta,
                        float* c, saber_hip_stream_t s) {
     if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
+    if (g_capture) return capture_unsupported("saber_hip_gemm_f32");
     HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, (hipStream_t)s));
     return SABER_HIP_OK;
 }
@@ -200,6 +204,11 @@ int saber_hip_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int o
     if (c_pad < c || (out_dtype != SABER_HIP_S8 && out_dtype != SABER_HIP_U8))
         return fail(SABER_HIP_INVALID_VALUE, "bad quantize arguments");
     if ((size_t)n * c * h * w == 0) return SABER_HIP_OK;
+    if (g_capture) {
+        const int p[6] = {n, c, h, w, c_pad, out_dtype};
+        return capture_stream_op(OP_QUANT, "quantize_nchw_to_nhwc", p, 6, &scale, 1, 0, x, (size_t)n * c * h * w * 4, nullptr, 0, y,
+                                 (size_t)n * h * w * c_pad, nullptr, 0);
+    }
     HIP_TRY(launch_quantize_nchw_to_nhwc(n, c, h, w, c_pad, out_dtype, scale, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
@@ -207,38 +216,59 @@ int saber_hip_dequantize_nhwc_to_nchw(int n, int c, int h, int w, int in_dtype, 
                                       float* y, saber_hip_stream_t s) {
     if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
     if ((size_t)n * c * h * w == 0) return SABER_HIP_OK;
+    if (g_capture) {
+        const int p[5] = {n, c, h, w, in_dtype};
+        return capture_stream_op(OP_DEQUANT, "dequantize_nhwc_to_nchw", p, 5, &scale, 1, 0, x, (size_t)n * c * h * w, nullptr, 0, y,
+                                 (size_t)n * c * h * w * 4, nullptr, 0);
+    }
     HIP_TRY(launch_dequantize_nhwc_to_nchw(n, c, h, w, in_dtype, scale, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_transpose_nchw_to_nhwc_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
                                          saber_hip_stream_t s) {
+    if (g_capture) {
+        const int p[5] = {n, c, h, w, c_pad};
+        return capture_stream_op(OP_TRANSPOSE_IN, "transpose_nchw_to_nhwc_f32", p, 5, nullptr, 0, 0, x, (size_t)n * c * h * w * 4, nullptr, 0,
+                                 y, (size_t)n * h * w * c_pad * 4, nullptr, 0);
+    }
     HIP_TRY(launch_transpose_nchw_to_nhwc_f32(n, c, h, w, c_pad, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_transpose_nhwc_to_nchw_f32(int n, int c, int h, int w, int c_pad, const float* x, float* y,
                                          saber_hip_stream_t s) {
+    if (g_capture) return capture_unsupported("saber_hip_transpose_nhwc_to_nchw_f32");
     HIP_TRY(launch_transpose_nhwc_to_nchw_f32(n, c, h, w, c_pad, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_quantize_flat_s8(size_t count, float scale, const float* x, int8_t* y, saber_hip_stream_t s) {
     if (!count) return SABER_HIP_OK;
+    if (g_capture) return capture_unsupported("saber_hip_quantize_flat_s8");
     HIP_TRY(launch_quantize_flat_s8(count, scale, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b, float sa, float sb, float c0, float c1,
                              int relu, int8_t* y, saber_hip_stream_t s) {
     if (!count) return SABER_HIP_OK;
+    if (g_capture) {
+        const float f[4] = {sa, sb, c0, c1};
+        return capture_stream_op(OP_ELT_I8, "eltwise_sum_i8", &relu, 1, f, 4, count, a, count, b, count, y, count, nullptr, 0);
+    }
     HIP_TRY(launch_eltwise_sum_i8(count, a, b, sa, sb, c0, c1, relu, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, float c0, float c1, int relu, float* y,
                               saber_hip_stream_t s) {
     if (!count) return SABER_HIP_OK;
+    if (g_capture) {
+        const float f[2] = {c0, c1};
+        return capture_stream_op(OP_ELT_F32, "eltwise_sum_f32", &relu, 1, f, 2, count, a, count * 4, b, count * 4, y, count * 4, nullptr, 0);
+    }
     HIP_TRY(launch_eltwise_sum_f32(count, a, b, c0, c1, relu, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_relu_f32(size_t count, const float* x, float* y, saber_hip_stream_t s) {
     if (!count) return SABER_HIP_OK;
+    if (g_capture) return capture_stream_op(OP_RELU_F32, "relu_f32", nullptr, 0, nullptr, 0, count, x, count * 4, nullptr, 0, y, count * 4, nullptr, 0);
     HIP_TRY(launch_relu_f32(count, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
@@ -263,12 +293,22 @@ int saber_hip_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh,
                              saber_hip_stream_t s) {
     if (type == SABER_HIP_POOL_MAX && out_dtype == SABER_HIP_F32)
         return fail(SABER_HIP_UNIMPL, "dst format (AK_FLOAT) and pooling type (Pooling_max): NOT supported");
+    if (g_capture) {
+        const int p[15] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, out_dtype};
+        return capture_stream_op(OP_POOL_I8, "pool2d_i8_nhwc", p, 15, nullptr, 0, 0, x, (size_t)n * h * w * c, nullptr, 0, y,
+                                 (size_t)n * oh * ow * c * (out_dtype == SABER_HIP_F32 ? 4 : 1), nullptr, 0);
+    }
     HIP_TRY(launch_pool2d_i8_nhwc(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, out_dtype, x, y,
                                   (hipStream_t)s));
     return SABER_HIP_OK;
 }
 int saber_hip_pool2d_f32(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw, int ph, int pw,
                          int type, int layout, const float* x, float* y, saber_hip_stream_t s) {
+    if (g_capture) {
+        const int p[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout};
+        return capture_stream_op(OP_POOL_F32, "pool2d_f32", p, 14, nullptr, 0, 0, x, (size_t)n * h * w * c * 4, nullptr, 0, y,
+                                 (size_t)n * oh * ow * c * 4, nullptr, 0);
+    }
     HIP_TRY(launch_pool2d_f32(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, layout == SABER_HIP_NCHW, x, y,
                               (hipStream_t)s));
     return SABER_HIP_OK;
@@ -278,6 +318,12 @@ int saber_hip_pool2d_f32_from_i8_q(int n, int h, int w, int c, int oh, int ow, i
                                    int8_t* yq, saber_hip_stream_t s) {
     if (in_dtype != SABER_HIP_S8 && in_dtype != SABER_HIP_U8) return fail(SABER_HIP_INVALID_VALUE, "bad dtype");
     if (yq && !(q_scale > 0.f)) return fail(SABER_HIP_INVALID_VALUE, "bad quantisation scale");
+    if (g_capture) {
+        const int p[14] = {n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype};
+        const float f[2] = {scale, q_scale};
+        return capture_stream_op(OP_POOL_F32_I8, yq ? "pool2d_f32_from_i8+quantize" : "pool2d_f32_from_i8", p, 14, f, 2, 0, x,
+                                 (size_t)n * h * w * c, nullptr, 0, y, (size_t)n * oh * ow * c * 4, yq, (size_t)n * oh * ow * c);
+    }
     HIP_TRY(launch_pool2d_f32_from_i8(n, h, w, c, oh, ow, kh, kw, sh, sw, ph, pw, type, in_dtype, scale, x, y, q_scale,
                                       yq, (hipStream_t)s));
     return SABER_HIP_OK;
@@ -290,6 +336,11 @@ int saber_hip_pool2d_f32_from_i8(int n, int h, int w, int c, int oh, int ow, int
 }
 int saber_hip_softmax_f32(int rows, int cols, const float* x, float* y, saber_hip_stream_t s) {
     if (rows <= 0 || cols <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad softmax shape");
+    if (g_capture) {
+        const int p[2] = {rows, cols};
+        return capture_stream_op(OP_SOFTMAX, "softmax_f32", p, 2, nullptr, 0, 0, x, (size_t)rows * cols * 4, nullptr, 0, y, (size_t)rows * cols * 4,
+                                 nullptr, 0);
+    }
     HIP_TRY(launch_softmax_f32(rows, cols, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }

@@ -182,6 +182,7 @@ void img_conv_release(saber_hip_conv* op) {
 int saber_hip_stage_num_tensors(const saber_hip_stage_t* st) { return st ? st->n_tensors : 0; }
 
 int saber_hip_stage_run(saber_hip_stage_t* st, void* const* tensors, int n_tensors, saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_stage_run");
     if (!st || !tensors || n_tensors < st->n_tensors) return fail(SABER_HIP_INVALID_VALUE, "stage: tensor table too short");
     StageKArgs k;
     std::memset(&k, 0, sizeof k);

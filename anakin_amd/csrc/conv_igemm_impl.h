@@ -824,14 +824,18 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_kernel(const ConvKArgs a
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __shared__ unsigned s_old;
             __syncthreads();
-            // an arrival adds 1 + (its XCD << 8): the last one can tell whether all S ran on its XCD (the placement this hand-off
-            // needs, checked at selection time by api_conv.hip:xcd_round_robin); if not, the result is poisoned, never silently stale
+            // The tile's counter is eight 4-bit arrival counts, one per XCD: an arrival adds 1 << (4 * its XCD). The LAST arrival
+            // (S - 1 earlier ones in total, S <= 8) sees exactly who came before it: the hand-off is valid iff all of them are in
+            // its own XCD's field - the placement checked at selection time by api_conv.hip:xcd_round_robin. Anything else (an
+            // exact test: no combination of other XCDs can look like it) poisons the result with NaN AND counts the launch in the
+            // host-visible error word, which the operator's next run turns into an error status.
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 7u;
-            if (tid == 0) s_old = __hip_atomic_fetch_add(a.part_ctr + tile_L, 1u + (xcc << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) s_old = __hip_atomic_fetch_add(a.part_ctr + tile_L, 1u << (4u * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if ((s_old & 0xffu) != (unsigned)(S - 1)) {
+            const unsigned arrived = (((s_old & 0x0f0f0f0fu) + ((s_old >> 4) & 0x0f0f0f0fu)) * 0x01010101u) >> 24;
+            if (arrived != (unsigned)(S - 1)) {
                 SABER_TL_FLUSH();
                 return;
             }
@@ -849,7 +853,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_kernel(const ConvKArgs a
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] + pr[(i * TN + j) * 64];
             }
-            if ((s_old >> 8) + xcc != (unsigned)S * xcc) {
+            if (s_old != (unsigned)(S - 1) << (4u * xcc)) {
+                if (tid == 0 && a.part_err) __hip_atomic_fetch_add(a.part_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const float nan = __builtin_nanf("");
 #pragma unroll
                 for (int i = 0; i < TM; ++i)

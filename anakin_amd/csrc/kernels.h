@@ -95,6 +95,8 @@ struct ConvKArgs {
     int ksplit_sh;          // log2 of the split count (0: ordinary launch)
     float* part;
     unsigned* part_ctr;     // [tiles], zero between launches
+    unsigned* part_err;     // host-visible (pinned) word: a launch whose splits did NOT share an XCD counts itself here (the host
+                            // turns that into an error status on the operator's next run and switches its split-K off); may be null
 };
 
 // conv3x3_img_kernel takes the common block plus its slab geometry (kept out of ConvKArgs: every byte of kernel

@@ -45,6 +45,8 @@ SYMBOLS = [
     "saber_hip_net_arena_bytes", "saber_hip_net_num_ops", "saber_hip_net_run", "saber_hip_net_run_op",
     "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_time_pass", "saber_hip_net_op_work", "saber_hip_net_op_name",
     "saber_hip_net_autotune", "saber_hip_net_destroy",
+    "saber_hip_net_add_relu_f32", "saber_hip_net_bind_tensor", "saber_hip_net_num_tensors", "saber_hip_net_tensor_bytes",
+    "saber_hip_capture_begin", "saber_hip_capture_end", "saber_hip_capture_active", "saber_hip_net_tensor_of_ptr",
 ]
 
 
@@ -199,6 +201,15 @@ def load():
     lib.saber_hip_net_autotune.argtypes = [P, P, I]
     lib.saber_hip_net_destroy.argtypes = [P]
     lib.saber_hip_net_destroy.restype = None
+    lib.saber_hip_net_add_relu_f32.argtypes = [P, Z, I, I]
+    lib.saber_hip_net_bind_tensor.argtypes = [P, I, P]
+    lib.saber_hip_net_num_tensors.argtypes = [P]
+    lib.saber_hip_net_tensor_bytes.argtypes = [P, I]
+    lib.saber_hip_net_tensor_bytes.restype = Z
+    lib.saber_hip_capture_begin.argtypes = []
+    lib.saber_hip_capture_end.argtypes = [C.POINTER(P)]
+    lib.saber_hip_capture_active.argtypes = []
+    lib.saber_hip_net_tensor_of_ptr.argtypes = [P, P]
     _lib = lib
     return lib
 

@@ -717,6 +717,46 @@ class Net:
     def arena_bytes(self):
         return L.load().saber_hip_net_arena_bytes(self.h)
 
+    # ---- caller-owned tensors / captured lists (saber_hip_capture_begin / _end) ----
+    def tensor_of_ptr(self, t):
+        """captured lists: id of the newest tensor the pass saw at torch tensor `t`'s address (-1: none)"""
+        return int(L.load().saber_hip_net_tensor_of_ptr(self.h, t.data_ptr()))
+
+    def bind(self, tid, t):
+        """tensor `tid` lives in the caller's torch tensor `t` instead of the arena (the caller keeps `t` alive)"""
+        self.keep.append(t)
+        L.check(L.load().saber_hip_net_bind_tensor(self.h, int(tid), t.data_ptr()))
+
+    def num_tensors(self):
+        return int(L.load().saber_hip_net_num_tensors(self.h))
+
+
+class Capture:
+    """`with Capture() as cap:` every dispatch / streaming-op call of this thread is RECORDED instead of launched (the C-ABI
+    analogue of hipStreamBeginCapture; what the MI355X target does with the reference's Net::prediction loop,
+    integration/mi355x/framework/mi355x_net_plan.h). Afterwards `cap.net` is the op list as a Net (not finalized): tensors are
+    the call's device pointers renamed SSA-style, addresses read before written are bound to the caller's memory."""
+
+    def __init__(self, keep=()):
+        self.net = None
+        self._keep = list(keep)
+
+    def __enter__(self):
+        L.check(L.load().saber_hip_capture_begin())
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        rc = L.load().saber_hip_capture_end(C.byref(h))
+        if et is None:
+            L.check(rc)
+            net = Net.__new__(Net)
+            net.h, net.keep, net.tensors, net.finalized = h, list(self._keep), {}, False
+            self.net = net
+        elif h:
+            L.load().saber_hip_net_destroy(h)
+        return False
+
     def __del__(self):
         try:
             if self.h:

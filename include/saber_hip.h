@@ -417,6 +417,38 @@ int saber_hip_net_get_choice(saber_hip_net_t* net, int index);
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice);
 int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters);
 void saber_hip_net_destroy(saber_hip_net_t* net);
+/* standalone ReLU operator inside an op list (Activation<T,D>, Active_relu; VGG16's fc6 / fc7) */
+int saber_hip_net_add_relu_f32(saber_hip_net_t* net, size_t count, int in_id, int out_id);
+/* Caller-owned storage for tensor `id` instead of a slot of the net's arena (the net's inputs and outputs when the caller
+ * has buffers of its own: the reference's Net owns its edge tensors). Before finalize any tensor can be bound (ptr != NULL)
+ * or returned to the arena (NULL); after finalize only the address of an already external tensor can change. A captured
+ * hipGraph is dropped (capture again). */
+int saber_hip_net_bind_tensor(saber_hip_net_t* net, int id, void* ptr);
+int saber_hip_net_num_tensors(const saber_hip_net_t* net);
+size_t saber_hip_net_tensor_bytes(const saber_hip_net_t* net, int id);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Op-list capture: a caller's OWN op loop (Net<T,P,R>::prediction, net.cpp:417-509) -> saber_hip_net */
+/* ------------------------------------------------------------------------------------------- */
+/* The analogue of hipStreamBeginCapture one level up: between begin and end every saber_hip_conv2d_run / saber_hip_fc_run[_q] /
+ * quantize / dequantize / transpose_nchw_to_nhwc / eltwise / relu / pool2d / softmax call made BY THE CALLING THREAD is
+ * recorded into a new op list instead of being launched (stream arguments are ignored, workspaces come from the net's
+ * arena later). Tensors are identified by the device pointers of the calls, renamed SSA-style: a write to an address starts
+ * a new tensor of the list (the reference's memory planner aliases edges whose lifetimes do not overlap onto a few buffers:
+ * one pointer is many tensors over a pass), a read refers to the newest tensor written there; an address that is read before
+ * the pass wrote it is an INPUT of the pass and becomes a tensor bound to that address (saber_hip_net_bind_tensor); every
+ * other tensor gets its own slot of the arena at finalize. The conv + sum post-op (RES_SUM_INPLACE) reads and writes one
+ * tensor. The operator handles recorded are the caller's: they must outlive the net and keep their weights.
+ * capture_end returns the list (not finalized: bind the outputs the caller wants at its own addresses with
+ * saber_hip_net_tensor_of_ptr + saber_hip_net_bind_tensor, then saber_hip_net_optimize / finalize / autotune / capture as
+ * for a hand-built list) or SABER_HIP_UNIMPL when something in the loop cannot be expressed - an entry point without an
+ * op-list form (GEMM, pair / chain / stage launches), or an access overlapping a live tensor at a different base address -
+ * in which case the caller keeps running its own loop. */
+int saber_hip_capture_begin(void);
+int saber_hip_capture_end(saber_hip_net_t** out);
+int saber_hip_capture_active(void);
+/* captured lists: id of the NEWEST tensor the pass saw at `ptr` (for an output address: the tensor the last writer produced), -1: none */
+int saber_hip_net_tensor_of_ptr(const saber_hip_net_t* net, const void* ptr);
 
 #ifdef __cplusplus
 }

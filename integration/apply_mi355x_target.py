@@ -112,6 +112,26 @@ def patch_framework(ref, dst):
         "                                          _calibrator_parser.get_layout(edge_it->name()), \"mi355x\", bottom_op_name,\n"
         "                                          top_op_name, (*_graph_p)[edge_it->bottom()]));\n"
         "        } else if (std::is_same<X86, Ttype>::value) {\n            //set tensor layout\n")
+    # Net<MI355X>::prediction() as one executor call (mi355x_net_plan.h): the plan is a member of Net, built at the end of
+    # init() from the op loop run under saber_hip_capture_begin / _end, dropped when init() runs again
+    for n in ("mi355x_net_plan.h", "mi355x_net_planner.h"):
+        shutil.copy(os.path.join(HERE, "mi355x", "framework", n), net)
+    insert(os.path.join(net, "net.h"), "namespace anakin {", "#include \"framework/core/net/mi355x_net_plan.h\"\n\n", after=False)
+    sub(os.path.join(net, "net.h"), "    OperatorFunc<Ttype, Ptype>* _fusion{nullptr};\n};\n",
+        "    OperatorFunc<Ttype, Ptype>* _fusion{nullptr};\n\n"
+        "    template <typename T_, Precision P_, OpRunType R_> friend struct MI355XPlanner;\n"
+        "    MI355XNetPlan _mi355x_plan;\npublic:\n"
+        "    ///< the MI355X target's captured op list behind prediction() (inspection / switching it off: plan.enabled = false; plan.drop())\n"
+        "    MI355XNetPlan& mi355x_plan() { return _mi355x_plan; }\n};\n\n"
+        "}\n#include \"framework/core/net/mi355x_net_planner.h\"\nnamespace anakin {\n")
+    sub(os.path.join(net, "net.cpp"), "    init_env(graph);\n    // shallow copy\n",
+        "    _mi355x_plan.drop();\n    init_env(graph);\n    // shallow copy\n", count=0)
+    sub(os.path.join(net, "net.cpp"), "    init_memory();\n\n    graph.statistics = _graph_p->statistics; // copy statistic back\n",
+        "    init_memory();\n    MI355XPlanner<Ttype, Ptype, RunType>::prepare(*this);\n\n"
+        "    graph.statistics = _graph_p->statistics; // copy statistic back\n")
+    sub(os.path.join(net, "net.cpp"), "void Net<Ttype, Ptype, RunType>::prediction() {\n",
+        "void Net<Ttype, Ptype, RunType>::prediction() {\n"
+        "    if (MI355XPlanner<Ttype, Ptype, RunType>::run(*this)) {\n        return;\n    }\n")
     cp = os.path.join(net, "calibrator_parse.cpp")
     s = open(cp).read()
     # get_dtype: the "X86" block, once more for "MI355X" with PBlock<MI355X>

@@ -27,7 +27,8 @@
 //     prec   <node> int8|fp32          (after Freeze: Graph::SetOpPrec)
 //     precsplit <node> int8|fp32       (the Split node Graph::Freeze inserts behind <node>'s output when it has >1 readers)
 //     scale  <node> <float>            (Graph::SetVarScale on <node>'s output variable)
-// Outputs in <outdir>:  oplist.txt (the op list the reference's optimiser produced, with every edge's dtype / layout /
+// Outputs in <outdir>:  plan.txt (the captured plan behind prediction(): ops / launches / launch form), out_<o>_oploop.bin
+// (prediction() with the plan switched off), oplist.txt (the op list the reference's optimiser produced, with every edge's dtype / layout /
 // shape / scale / sharing), out_<graph output>.bin (after Net::prediction()), step_<i>_<j>.bin (output j of op i, dumped
 // right after that op ran in a second, op-by-op pass — the memory planner aliases edge buffers, so intermediate edges only
 // exist at that moment), timing.txt (Net::prediction() wall time per call, hipEvents through SaberTimer<MI355X>).
@@ -277,28 +278,55 @@ static int run(const std::vector<Record>& recs, const std::vector<float>& input,
         fclose(f);
     };
 
+    // ---- the plan behind prediction() (mi355x_net_plan.h): what the capture recorded and what the executor made of it --------
+    {
+        MI355XNetPlan& plan = net.mi355x_plan();
+        FILE* fp = fopen((outdir + "/plan.txt").c_str(), "w");
+        fprintf(fp, "plan %d captured_ops %d launches %d graph %d eager_ms %.6f graph_ms %.6f why %s\n", plan.net ? 1 : 0, plan.captured_ops,
+                plan.launches, plan.use_graph ? 1 : 0, plan.eager_ms, plan.graph_ms, plan.why.empty() ? "-" : plan.why.c_str());
+        if (plan.net) {
+            fprintf(fp, "tensors %d arena_bytes %zu\n", saber_hip_net_num_tensors(plan.net), saber_hip_net_arena_bytes(plan.net));
+            for (int i = 0; i < saber_hip_net_num_ops(plan.net); ++i) fprintf(fp, "op %d %s\n", i, saber_hip_net_op_name(plan.net, i));
+        }
+        fclose(fp);
+    }
+
     if (iters < 0) {      // "dry": graph + optimiser + Net::init only (runs on the mock HIP runtime without a GPU)
         printf("net dry run ok: %zu ops after Graph::Optimize + Net::init\n", net._exec_funcs.size());
         return 0;
     }
 
-    // ---- 1. the reference's executor, untouched ------------------------------------------------------------------
+    // ---- 1. Net::prediction(): through the captured plan (the default), then with the plan switched off = the reference's
+    //         operator loop untouched (all buffers aliased by its memory planner) ------------------------------------------
+    const bool planned = net.mi355x_plan().net != nullptr;
     feed();
     net.prediction();
     TargetWrapper<MI355X>::device_sync();
     for (auto& o : graph->get_outs()) dump(net.get_out(o), outdir + "/out_" + o + ".bin");
-
-    // ---- 2. timing of Net::prediction() ---------------------------------------------------------------------------
-    if (iters > 0) {
+    auto time_predictions = [&](int n) {
         Context<MI355X> ctx(0, 0, 0);
         for (int i = 0; i < 10; ++i) net.prediction();
         TargetWrapper<MI355X>::device_sync();
         SaberTimer<MI355X> timer;
         timer.start(ctx);
-        for (int i = 0; i < iters; ++i) net.prediction();
+        for (int i = 0; i < n; ++i) net.prediction();
         timer.end(ctx);
+        return timer.get_average_ms() / n;
+    };
+    const double ms_plan = (iters > 0 && planned) ? time_predictions(iters) : 0.0;
+    net.mi355x_plan().enabled = false;
+    net.mi355x_plan().drop();
+    feed();
+    net.prediction();
+    TargetWrapper<MI355X>::device_sync();
+    for (auto& o : graph->get_outs()) dump(net.get_out(o), outdir + "/out_" + o + "_oploop.bin");
+
+    // ---- 2. timing of Net::prediction() ---------------------------------------------------------------------------
+    if (iters > 0) {
+        const double ms_loop = time_predictions(iters);
         FILE* ft = fopen((outdir + "/timing.txt").c_str(), "w");
-        fprintf(ft, "ops %zu iters %d ms_per_prediction %.6f\n", net._exec_funcs.size(), iters, timer.get_average_ms() / iters);
+        fprintf(ft, "ops %zu iters %d ms_per_prediction %.6f ms_per_prediction_op_loop %.6f planned %d\n", net._exec_funcs.size(), iters,
+                planned ? ms_plan : ms_loop, ms_loop, planned ? 1 : 0);
         fclose(ft);
     }
 

@@ -35,10 +35,11 @@ def dry_run(tmp_path, name, precision, batch=1):
     d = str(tmp_path)
     mt, wb = NM.write_model(model, scales, batch, d, precision)
     x.tofile(os.path.join(d, "input.bin"))
-    env = dict(os.environ, LD_PRELOAD=MOCK)
+    env = dict(os.environ, LD_PRELOAD=MOCK, SABER_MI355X_NET_PLAN_TUNE="0")      # (no timing on the mock runtime)
     r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "dry"], env=env, capture_output=True, text=True,
                        cwd=d)          # (the reference's logger writes ./log/ next to the working directory)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    dry_run.plan = open(os.path.join(d, "plan.txt")).read().split("\n")
     return model, scales, NM.parse_oplist(os.path.join(d, "oplist.txt"))
 
 
@@ -120,6 +121,19 @@ def test_resnet50_int8_op_list_is_the_reference_optimisers(tmp_path):
     # the memory planner aliases edge buffers (MemoryScheduler): far fewer distinct buffers than edges
     ptrs = {e["ptr"] for o in compute for e in o["outs"]}
     assert len(ptrs) <= 8, len(ptrs)
+    # The plan behind Net<MI355X>::prediction() (integration/mi355x/framework/mi355x_net_plan.h): Net::init ran its operator
+    # loop once under saber_hip_capture_begin / _end - recording needs no device - and handed the list to saber_hip_net_optimize:
+    # 76 captured operators (the aliasing renamed away: one tensor per written edge + the input), fused to 51 ops with 16 eltwise
+    # epilogues, 4 sibling pairs, the stem + pooling, 3 absorbed stride-up poolings, pool5 inside the last conv; <= 36 launches
+    head = dry_run.plan[0].split()
+    val = lambda k: int(head[head.index(k) + 1])      # noqa: E731
+    assert val("plan") == 1 and val("captured_ops") == 76, dry_run.plan[0]
+    plan_ops = [ln.split(None, 2)[2] for ln in dry_run.plan[1:] if ln.startswith("op ")]
+    assert len(plan_ops) == 51 and val("launches") <= 36, (len(plan_ops), dry_run.plan[0])
+    assert sum(o.startswith("conv:pair_") for o in plan_ops) == 4
+    assert plan_ops[0].startswith("conv:stem7x7s2_maxpool3x3s2") and plan_ops[-1] == "softmax_f32" and "gpool" in plan_ops[-3]
+    assert not any(o.startswith(("eltwise", "pool2d")) for o in plan_ops)
+    assert int(dry_run.plan[1].split()[1]) == 77      # tensors: data + 76 written edges
 
 
 def test_resnet50_fp32_and_vgg16_pass_the_reference_optimiser(tmp_path):
@@ -130,8 +144,10 @@ def test_resnet50_fp32_and_vgg16_pass_the_reference_optimiser(tmp_path):
     assert kinds.count("ConvBatchnormScaleRelu") == 33 and kinds.count("ConvBatchnormScale") == 4
     assert kinds.count("Pooling") == 5 and kinds.count("Dense") == 1 and kinds.count("Softmax") == 1
     assert all(e["dtype"] == "f32" and e["layout"] == "nchw" for o in ops for e in o["outs"])
+    assert "plan 1 captured_ops 60 " in dry_run.plan[0], dry_run.plan[0]      # 53 conv + 5 pooling + fc + softmax behind prediction()
     _, _, ops = dry_run(tmp_path / "vgg", "vgg16", "fp32")
     kinds = [o["type"] for o in ops]
     assert kinds.count("ConvRelu") == 13 and kinds.count("Pooling") == 5 and kinds.count("Dense") == 3
     assert kinds.count("ReLU") == 2 and kinds.count("Softmax") == 1
+    assert "plan 1 captured_ops 24 " in dry_run.plan[0], dry_run.plan[0]
 
