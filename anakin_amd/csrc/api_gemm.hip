@@ -1,0 +1,202 @@
+// anakin_amd/csrc/api_gemm.hip - saber_hip_gemm_f32: Gemm<MI355X, SABER_IMPL, float, float>::dispatch
+// (saber/funcs/gemm.h:27-66; role of saber/funcs/impl/cuda/saber_gemm.cpp:6-29 -> the SASS sgemm, sass_funcs.h:632-697; numerics of
+// the x86 MKL cblas_sgemm path within 1e-4): row-major C[m,n] = alpha * op(A)[m,k] * op(B)[k,n] + beta * C on raw device pointers.
+//
+// Round 4: the GEMM runs on the bf16 matrix cores through the FP32 implicit-GEMM machinery of conv_igemm_impl.h MODE 3 (an f32 value
+// is exactly h + m + l with three bf16 terms; six products per f32 product accumulated in f32 reproduce it to ~2^-24) -
+// gfx950's f32 MFMA peaks at 157 TFLOP/s, its dense bf16 MFMA at 2.5 PFLOP/s; round 3's kernel (gemm_f32_kernel, elementwise.hip: one
+// 64 x 64 tile on v_mfma_f32_16x16x4_f32, 4-byte loads, two barriers per 16-deep step) reached 45 TFLOP/s = 28 % of the f32 peak and
+// stays as the path for shapes the plane kernels do not take (k % 8 != 0, tiny problems).
+//   C^T view: out-channels = n (MFMA rows), pixels = m (columns), reduction = k. The "convolution" is a 1 x 1 conv on an NHWC tensor
+//   [1, m, 1, k] -> [1, m, 1, n]: x = op(A) as it lies when A is [m, k] (trans_a: one transposing pre-pass into the plan's scratch),
+//   the weights W[n][k] = alpha * op(B)^T split on the DEVICE into the three bf16 planes the kernel streams (gemm_pack_planes_kernel: B is
+//   a raw device pointer whose contents may change from call to call, so the split is redone per call: 10 bytes moved per element of B
+//   against 2 m flops - 7 % of a 2048^3 GEMM, negligible for the tall problems of an fc);
+//   beta: 0 -> plain store, 1 -> the kernel's in-place sum epilogue (out = acc + C), otherwise C is scaled by beta first (exactly:
+//   beta/2 * C + beta/2 * C) and then summed in place.
+// The entry point is stateless, the device work is not: conv object (tile choice, zero bias), plane and transpose scratch live in a
+// small per-thread plan cache keyed by (device, stream, trans_a, trans_b, m, n, k, beta class) - the equivalent of Gemm<>::init's state
+// (gemm.h:30-33). Plans are built outside stream capture on first use.
+#include "api_internal.h"
+
+namespace saber_mi355x {
+
+// W[r][c] (r < n rows = out-channels, c < k) = alpha * (tb ? B[r * k + c] : B[c * n + r]) -> planes[p][r * kg_pad + c], p = 0..2
+// 64 x 64 tiles through LDS so that both the read (along B's contiguous dimension) and the write (along k) are coalesced.
+__global__ __launch_bounds__(256) void gemm_pack_planes_kernel(const float* __restrict__ B, int tb, int n, int k, float alpha,
+                                                               unsigned short* __restrict__ planes, int kg_pad, size_t plane_elems) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    if (tb) {
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + i, c = c0 + tx;
+            t[i][tx] = (r < n && c < k) ? B[(size_t)r * k + c] : 0.f;
+        }
+    } else {
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {                       // i: column offset (k), tx: row offset (n) - B's contiguous dim
+            const int c = c0 + i, r = r0 + tx;
+            t[tx][i] = (r < n && c < k) ? B[(size_t)c * n + r] : 0.f;
+        }
+    }
+    __syncthreads();
+    auto rne = [](float x) -> unsigned short {
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    };
+    auto bf = [](unsigned short h) -> float { return __uint_as_float((unsigned)h << 16); };
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < n && c < k) {
+            const float w = alpha * t[i][tx];
+            const unsigned short h = rne(w);
+            const float r1 = w - bf(h);
+            const unsigned short m = rne(r1);
+            const float r2 = r1 - bf(m);
+            const size_t o = (size_t)r * kg_pad + c;
+            planes[o] = h;
+            planes[plane_elems + o] = m;
+            planes[2 * plane_elems + o] = rne(r2);
+        }
+    }
+}
+
+}  // namespace saber_mi355x
+
+namespace {
+
+struct GemmPlan {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    int ta = 0, tb = 0, m = 0, n = 0, k = 0, sum = 0;
+    saber_hip_conv* op = nullptr;
+    DevBuf<float> a_t;           // trans_a: A transposed to [m][k]
+    unsigned long long stamp = 0;
+    ~GemmPlan() {
+        if (op) saber_hip_conv2d_destroy(op);
+    }
+};
+// leaked at thread exit on purpose: the HIP runtime may already be gone when thread_local destructors run
+thread_local std::vector<GemmPlan*>* g_plans = nullptr;
+thread_local unsigned long long g_stamp = 0;
+constexpr size_t kMaxPlans = 16;
+
+// the plane kernels need 8-element k granularity and pay off once the problem fills the chip
+bool plane_path(int m, int n, int k) {
+    if (const char* e = std::getenv("SABER_HIP_GEMM_F32_PLANES")) return e[0] == '1' && k % 8 == 0;
+    // (m < 32: a weight stream - the split would move 2.5 x B's bytes to save arithmetic that is not the bound)
+    return k % 8 == 0 && k >= 64 && m >= 32 && (double)m * n * k >= 64.0 * 64 * 64 * 64;
+}
+
+int pick_tile(const saber_hip_conv* op, int m, int n) {
+    // largest block tile (out-channels x pixels = n x m) that still gives every CU a workgroup; the 8-wave forms from 64 x 64 up
+    struct T { int id, bn, bm; } cand[] = {{TILE_W8_256x128, 256, 128}, {TILE_W8_128x128, 128, 128}, {TILE_W8_128x64, 128, 64},
+                                           {TILE_W8_64x64, 64, 64}, {TILE_64x32, 64, 32}, {TILE_32x32, 32, 32}};
+    for (const T& t : cand) {
+        if (!b3_tile_ok(op, t.id, 1)) continue;
+        const long tiles = (long)((n + t.bn - 1) / t.bn) * ((m + t.bm - 1) / t.bm);
+        if (tiles >= 256 || t.id == TILE_32x32) return t.id;
+    }
+    return TILE_32x32;
+}
+
+int build_plan(GemmPlan* p) {
+    saber_hip_conv_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n = 1; d.h = p->m; d.w = 1; d.c = p->k; d.k = p->n; d.kh = d.kw = 1;
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1;
+    d.group = 1;
+    d.in_dtype = d.out_dtype = SABER_HIP_F32;
+    d.in_layout = d.out_layout = SABER_HIP_NHWC;
+    d.act = SABER_HIP_ACT_NONE;
+    d.res_mode = p->sum ? SABER_HIP_RES_SUM_INPLACE : SABER_HIP_RES_NONE;
+    d.sum_scale = 1.f;
+    int rc = saber_hip_conv2d_create(&d, &p->op);
+    if (rc) return rc;
+    saber_hip_conv* op = p->op;
+    if (op->algo != ALGO_IGEMM_F32) return fail(SABER_HIP_UNIMPL, "gemm: shape not on the implicit-GEMM path");
+    // the device-side halves of set_weights for an FP32 op whose weights arrive as device planes: zero bias, zeroed (padded) planes
+    const int K_pad = round_up(p->n, 128);
+    HIP_TRY(op->d_w3.alloc_zero((size_t)3 * K_pad * op->Kg_pad * 2));
+    HIP_TRY(op->d_bias.alloc_zero(K_pad));
+    op->has_bias = false;
+    op->weights_set = true;
+    op->b3 = 1; op->ks = 1; op->dma = 0; op->ksplit = 0;
+    op->tile = pick_tile(op, p->m, p->n);
+    name_algo(op);
+    if (p->ta) HIP_TRY(p->a_t.alloc_zero((size_t)p->m * p->k));
+    return SABER_HIP_OK;
+}
+
+GemmPlan* find_plan(int dev, hipStream_t s, int ta, int tb, int m, int n, int k, int sum, int* rc) {
+    if (!g_plans) g_plans = new std::vector<GemmPlan*>();
+    for (GemmPlan* p : *g_plans)
+        if (p->dev == dev && p->stream == s && p->ta == ta && p->tb == tb && p->m == m && p->n == n && p->k == k && p->sum == sum) {
+            p->stamp = ++g_stamp;
+            return p;
+        }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        *rc = fail(SABER_HIP_INVALID_VALUE, "saber_hip_gemm_f32: the first call of a shape allocates its plan - run it once outside stream capture");
+        return nullptr;
+    }
+    if (g_plans->size() >= kMaxPlans) {      // evict the least recently used (its device buffers are idle: the stream is drained first)
+        size_t lru = 0;
+        for (size_t i = 1; i < g_plans->size(); ++i)
+            if ((*g_plans)[i]->stamp < (*g_plans)[lru]->stamp) lru = i;
+        (void)hipStreamSynchronize((*g_plans)[lru]->stream);
+        delete (*g_plans)[lru];
+        g_plans->erase(g_plans->begin() + lru);
+    }
+    GemmPlan* p = new GemmPlan();
+    p->dev = dev; p->stream = s; p->ta = ta; p->tb = tb; p->m = m; p->n = n; p->k = k; p->sum = sum;
+    p->stamp = ++g_stamp;
+    *rc = build_plan(p);
+    if (*rc) {
+        delete p;
+        return nullptr;
+    }
+    g_plans->push_back(p);
+    return p;
+}
+
+}  // namespace
+
+int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b, float beta,
+                       float* c, saber_hip_stream_t stream) {
+    if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
+    if (!a || !b || !c) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (g_capture) return capture_unsupported("saber_hip_gemm_f32");
+    hipStream_t s = (hipStream_t)stream;
+    ta = ta ? 1 : 0;
+    tb = tb ? 1 : 0;
+    if (!plane_path(m, n, k)) {
+        HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, s));
+        return SABER_HIP_OK;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int rc = SABER_HIP_OK;
+    GemmPlan* p = find_plan(dev, s, ta, tb, m, n, k, beta != 0.f ? 1 : 0, &rc);
+    if (!p) return rc;
+    saber_hip_conv* op = p->op;
+    // W = alpha * op(B)^T as three bf16 planes [3][K_pad][Kg_pad] (the padding stays zero from the plan's allocation)
+    {
+        const int K_pad = round_up(n, 128);
+        const dim3 grid((k + 63) / 64, (n + 63) / 64), block(256);
+        hipLaunchKernelGGL(gemm_pack_planes_kernel, grid, block, 0, s, b, tb, n, k, alpha, (unsigned short*)op->d_w3.p, op->Kg_pad,
+                           (size_t)K_pad * op->Kg_pad);
+        HIP_TRY(hipGetLastError());
+    }
+    const float* x = a;
+    if (ta) {      // A is stored [k][m]: NCHW [1, k, m, 1] -> NHWC [1, m, 1, k]
+        HIP_TRY(launch_transpose_nchw_to_nhwc_f32(1, k, m, 1, k, a, p->a_t.p, s));
+        x = p->a_t.p;
+    }
+    if (beta != 0.f && beta != 1.f) HIP_TRY(launch_eltwise_sum_f32((size_t)m * n, c, c, 0.5f * beta, 0.5f * beta, 0, c, s));
+    return saber_hip_conv2d_run(op, x, c, nullptr, nullptr, s);
+}

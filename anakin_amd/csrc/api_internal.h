@@ -8,6 +8,7 @@
 //   api_net.hip           op-list executor: arena, lanes, hipGraph capture / replay, in-pass timing
 //   api_net_optimize.hip  executor-level fusions (saber_hip_net_optimize)
 //   api_net_autotune.hip  whole-net autotuner, selection save / restore
+//   api_gemm.hip          FP32 GEMM on the bf16-plane kernels (device-side plane split, per-thread plan cache)
 //   api_capture.hip       op-list capture: the *_run calls of a caller's own op loop recorded into a saber_hip_net
 #pragma once
 #include "../../include/saber_hip.h"

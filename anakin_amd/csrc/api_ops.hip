@@ -192,13 +192,7 @@ void saber_hip_gemm_i8_destroy(saber_hip_gemm_i8_t* g) {
 // ================================================================================================
 // thin wrappers
 // ================================================================================================
-int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b, float beta,
-                       float* c, saber_hip_stream_t s) {
-    if (m <= 0 || n <= 0 || k <= 0) return fail(SABER_HIP_INVALID_VALUE, "bad gemm shape");
-    if (g_capture) return capture_unsupported("saber_hip_gemm_f32");
-    HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, (hipStream_t)s));
-    return SABER_HIP_OK;
-}
+// (saber_hip_gemm_f32: api_gemm.hip)
 int saber_hip_quantize_nchw_to_nhwc(int n, int c, int h, int w, int c_pad, int out_dtype, float scale,
                                     const float* x, void* y, saber_hip_stream_t s) {
     if (c_pad < c || (out_dtype != SABER_HIP_S8 && out_dtype != SABER_HIP_U8))

@@ -53,7 +53,9 @@ def test_bench_gpus_2_spawns_its_own_ranks_and_the_gather_is_cheap():
     share = dict(BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
     o2 = run(share, 2)
     o2n = run(dict(share, BENCH_NO_GATHER="1"), 2)
-    assert o2["n_gpus"] == 2 and o2["config"]["rccl_ranks"] == 2 and o2["config"]["global_batch"] == 16
+    assert o2["n_gpus"] == 2 and o2["config"]["global_batch"] == 16
+    # the dry run exchanges through gloo: no RCCL communicator exists, and the line must say so
+    assert o2["config"]["dist_backend"] == "gloo" and o2["config"]["rccl_ranks"] == 0
     assert o2["config"]["gather"]["every_steps"] == 16 and o2["config"]["gather"]["host_us_per_step"] > 0
     assert o2n["config"]["gather"] is None
     print("1 rank: %.4f ms/step; 2 ranks sharing the GPU: %.4f ms/step with the logits gather, %.4f without (x%.3f); "

@@ -1137,6 +1137,62 @@ def test_gemm_f32_vs_oracle(ta, tb):
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_plane_path_vs_oracle(ta, tb):
+    """Gemm<MI355X, float, float> on the bf16-plane kernels (api_gemm.hip: device-side split of alpha * op(B)^T into three bf16 planes,
+    the MODE 3 implicit-GEMM kernel, beta through the in-place sum epilogue): every transpose combination x ragged m / n (k % 8 == 0 is
+    the path's condition; other k take the f32-MFMA kernel, test above) x beta in {0, 1, general}, within 1e-4 of the oracle on the
+    max-norm AND element-wise with the mean magnitude as the floor; repeated calls (the plan cache) give the same bits."""
+    rng = np.random.default_rng(52 + ta * 2 + tb)
+    for (M, N, K), (alpha, beta) in (((333, 200, 264), (1.0, 0.0)), ((70, 1000, 2048), (0.7, 0.3)), ((512, 384, 512), (1.0, 1.0)),
+                                     ((8, 4096, 25088 // 8), (1.0, 0.0))):
+        A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+        B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+        C0 = rng.standard_normal((M, N)).astype(np.float32)
+        a64 = (A.T if ta else A).astype(np.float64)
+        b64 = (B.T if tb else B).astype(np.float64)
+        want = alpha * (a64 @ b64) + beta * C0
+        got = None
+        for rep in range(2):
+            c = dev(C0)
+            S.gemm(ta, tb, M, N, K, alpha, dev(A), dev(B), beta, c)
+            g = host(c)
+            assert got is None or np.array_equal(got, g)
+            got = g
+        d = np.abs(got - want)
+        e_max = float(d.max() / np.abs(want).max())
+        e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+        assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (M, N, K, e_max, e_el)
+        ref32 = O.gemm_f32(A, B, M, N, K, ta, tb, alpha, beta, C0) if M * N * K <= 70 * 1000 * 2048 else None
+        if ref32 is not None:
+            assert np.abs(got - ref32).max() <= FP32_RTOL * np.abs(ref32).max()
+
+
+def test_gemm_f32_b_changes_between_calls_and_streams_have_their_own_plans():
+    """B is a raw device pointer: its planes are re-split on every call (a weight that changed is picked up); two streams get
+    two plans (their scratch must not be shared)."""
+    rng = np.random.default_rng(58)
+    M = N = K = 256
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B1 = rng.standard_normal((K, N)).astype(np.float32)
+    B2 = rng.standard_normal((K, N)).astype(np.float32)
+    a, b, c = dev(A), dev(B1), dev(np.zeros((M, N), np.float32))
+    S.gemm(0, 0, M, N, K, 1.0, a, b, 0.0, c)
+    r1 = host(c)
+    b.copy_(dev(B2))
+    S.gemm(0, 0, M, N, K, 1.0, a, b, 0.0, c)
+    r2 = host(c)
+    assert np.abs(r1 - A @ B1).max() <= FP32_RTOL * np.abs(A @ B1).max()
+    assert np.abs(r2 - A @ B2).max() <= FP32_RTOL * np.abs(A @ B2).max()
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        c2 = torch.zeros_like(c)
+        S.gemm(0, 0, M, N, K, 1.0, a, b, 0.0, c2)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(c2), r2)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("adt", [O.S8, O.U8])
 def test_gemm_i8_exact(ta, tb, adt):
     """INT8 GEMM (MklDnnGemm<s8|u8, s8, int>): int32 results equal the integer matrix product exactly, for every
