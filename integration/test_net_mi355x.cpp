@@ -27,6 +27,8 @@
 //     prec   <node> int8|fp32          (after Freeze: Graph::SetOpPrec)
 //     precsplit <node> int8|fp32       (the Split node Graph::Freeze inserts behind <node>'s output when it has >1 readers)
 //     scale  <node> <float>            (Graph::SetVarScale on <node>'s output variable)
+//     calibrator <net_config.txt> <calibrator.txt>   (instead of prec / scale records: Graph::load_calibrator_config reads both
+//                                      text files - integration/net_model.py: calibrator_files writes them from the topology)
 // Outputs in <outdir>:  plan.txt (the captured plan behind prediction(): ops / launches / launch form), out_<o>_oploop.bin
 // (prediction() with the plan switched off), oplist.txt (the op list the reference's optimiser produced, with every edge's dtype / layout /
 // shape / scale / sharing), out_<graph output>.bin (after Net::prediction()), step_<i>_<j>.bin (output j of op i, dumped
@@ -103,6 +105,7 @@ static int run(const std::vector<Record>& recs, const std::vector<float>& input,
     std::vector<int> in_shape;
     std::vector<std::pair<std::string, std::string> > precs;
     std::vector<std::pair<std::string, float> > scales;
+    std::string cal_config, cal_table;      // `calibrator` record: Graph::load_calibrator_config instead of SetOpPrec / SetVarScale
     auto I = [](const std::string& s) { return atoi(s.c_str()); };
     // variable names live in their own namespace but Graph::Freeze names the Input / Output / Split nodes after them
     // (graph.cpp:237-296), so a layer's output variable must not be called like the layer's node
@@ -198,6 +201,9 @@ static int run(const std::vector<Record>& recs, const std::vector<float>& input,
             precs.push_back({V(f[1]) + "split", f[2]});
         } else if (kind == "scale") {
             scales.push_back({V(f[1]), (float)atof(f[2].c_str())});
+        } else if (kind == "calibrator") {
+            cal_config = f[1];
+            cal_table = f[2];
         } else if (kind != "precision") {
             fprintf(stderr, "unknown record %s\n", kind.c_str());
             return 2;
@@ -212,6 +218,9 @@ static int run(const std::vector<Record>& recs, const std::vector<float>& input,
             return 2;
         }
     for (auto& s : scales) graph->SetVarScale(s.first, s.second);
+    // the text-file route of a deployed model: node precisions from the net config, edge scales from the calibration table
+    // (Graph::load_calibrator_config, graph.cpp:555-571 -> CalibratorParser::parse_from_file, calibrator_parse.cpp:338-460)
+    if (!cal_config.empty()) graph->load_calibrator_config(cal_config, cal_table);
     graph->AddOpAttr(in_name, "input_shape", PTuple<int>(in_shape[0], in_shape[1], in_shape[2], in_shape[3]));
 
     graph->Optimize();      // the reference's fusion pass + stride-up + schedulers + memory planner

@@ -27,13 +27,13 @@ from oracle import net_oracle as NO            # noqa: E402
 NP = {"s8": np.int8, "u8": np.uint8, "f32": np.float32}
 
 
-def run_net(tmp_path, name, precision, batch, iters=0):
+def run_net(tmp_path, name, precision, batch, iters=0, calibrator_config=False, rename=None):
     assert os.path.exists(BIN), "integration/_build/test_net_mi355x.bin is missing: run __graft_entry__.build()"
     model = W.build_model(name)
     x = W.make_input(batch)
     scales = W.calibrate(model, x) if precision == "int8" else {}
     d = str(tmp_path)
-    mt, wb = NM.write_model(model, scales, batch, d, precision)
+    mt, wb = NM.write_model(model, scales, batch, d, precision, calibrator_config=calibrator_config, rename=rename)
     x.tofile(os.path.join(d, "input.bin"))
     env = dict(os.environ)
     env.pop("LD_PRELOAD", None)
@@ -61,7 +61,8 @@ def load(d, op, j, edge):
 
 def test_net_mi355x_resnet50_int8_every_edge_bit_exact(tmp_path):
     batch = 2
-    model, x, scales, ops, d = run_net(tmp_path, "resnet50", "int8", batch, iters=50)
+    # precisions and scales through the text files of a deployed model: Graph::load_calibrator_config (graph.cpp:555)
+    model, x, scales, ops, d = run_net(tmp_path, "resnet50", "int8", batch, iters=50, calibrator_config=True)
     fm = W.framework_model(model, "int8")
     ref = NO.run_int8(fm, dict(scales), x)
     checked = 0
@@ -90,6 +91,38 @@ def test_net_mi355x_resnet50_int8_every_edge_bit_exact(tmp_path):
     print("Net<MI355X,INT8>::prediction batch %d: %.4f ms through the plan (%d launches), %.4f ms through the operator loop (94 executors)"
           % (batch, ms, plan["launches"], ms_loop))
     assert 0 < ms < ms_loop < 50
+
+
+def test_net_mi355x_resnet101_int8_every_edge_bit_exact(tmp_path):
+    """BASELINE.json's deep-stack config through the reference's own Graph::Optimize -> Net<MI355X>::init -> prediction():
+    144 operators, every output edge bit-identical to the CPU oracle on workloads.framework_spec; the graph carries short node
+    names (net_model.short_names: the reference's remove_byio reads freed arcs, which names of >= 16 characters expose -
+    tests/test_net_oplist.py pins that diagnosis). prediction() through the captured plan == the operator loop == the oracle."""
+    batch = 2
+    model, x, scales, ops, d = run_net(tmp_path, "resnet101", "int8", batch, iters=50, calibrator_config=True, rename=NM.short_names)
+    fm = W.framework_model(model, "int8")
+    ref = {NM.short_names(k): v for k, v in NO.run_int8(fm, dict(scales), x).items()}
+    checked = 0
+    for o in ops:
+        if o["type"] in ("Input", "Output", "Split"):
+            continue
+        got, want = load(d, o, 0, o["outs"][0]), ref[o["name"]]
+        if o["type"] == "Softmax":
+            assert np.abs(got.reshape(batch, -1) - want.reshape(batch, -1)).max() <= 1e-4 * want.max()
+        else:
+            assert got.dtype == want.dtype, (o["name"], got.dtype, want.dtype)
+            assert np.array_equal(got.reshape(want.shape), want), o["name"]
+        checked += 1
+    assert checked == 144
+    last = [o for o in ops if o["type"] == "Softmax"][0]
+    want = load(d, last, 0, last["outs"][0]).ravel()
+    assert np.array_equal(np.fromfile(os.path.join(d, "out_prob_out.bin"), np.float32), want)
+    assert np.array_equal(np.fromfile(os.path.join(d, "out_prob_out_oploop.bin"), np.float32), want)
+    plan = read_plan(d)
+    assert plan["plan"] == 1 and plan["captured_ops"] == 144 and plan["launches"] <= 72, plan
+    t = open(os.path.join(d, "timing.txt")).read().split()
+    print("Net<MI355X,INT8>::prediction ResNet101 batch %d: %.4f ms through the plan (%d launches), %.4f ms through the operator loop"
+          % (batch, float(t[t.index("ms_per_prediction") + 1]), plan["launches"], float(t[t.index("ms_per_prediction_op_loop") + 1])))
 
 
 def _fp32_check(got, want, name):

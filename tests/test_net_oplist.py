@@ -28,16 +28,18 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(MOCK
 DT = {W.F32: "f32", W.S8: "s8", W.U8: "u8"}
 
 
-def dry_run(tmp_path, name, precision, batch=1):
+def dry_run(tmp_path, name, precision, batch=1, calibrator_config=False, rename=None, expect_fail=False):
     model = W.build_model(name)
     x = W.make_input(batch)
     scales = W.calibrate(model, x) if precision == "int8" else {}
     d = str(tmp_path)
-    mt, wb = NM.write_model(model, scales, batch, d, precision)
+    mt, wb = NM.write_model(model, scales, batch, d, precision, calibrator_config=calibrator_config, rename=rename)
     x.tofile(os.path.join(d, "input.bin"))
     env = dict(os.environ, LD_PRELOAD=MOCK, SABER_MI355X_NET_PLAN_TUNE="0")      # (no timing on the mock runtime)
-    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "dry"], env=env, capture_output=True, text=True,
+    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "dry"], env=env, capture_output=True, text=True, errors="replace",
                        cwd=d)          # (the reference's logger writes ./log/ next to the working directory)
+    if expect_fail:
+        return r
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     dry_run.plan = open(os.path.join(d, "plan.txt")).read().split("\n")
     return model, scales, NM.parse_oplist(os.path.join(d, "oplist.txt"))
@@ -67,23 +69,24 @@ def expected_type(l, raw):
     return {"pool": "Pooling", "gpool": "Pooling", "eltwise": "EltwiseRelu", "fc": "Dense", "softmax": "Softmax"}[l["kind"]]
 
 
-def test_resnet50_int8_op_list_is_the_reference_optimisers(tmp_path):
-    model, scales, ops = dry_run(tmp_path, "resnet50", "int8")
+def _check_int8_list(tmp_path, name, route="set_calls", rename=None):
+    model, scales, ops = dry_run(tmp_path, name, "int8", calibrator_config=route == "calibrator_files", rename=rename)
+    R = rename or (lambda n: n)
     prod = resolve_producers(ops)
     compute = [o for o in ops if o["type"] not in ("Input", "Output", "Split")]
     spec = W.framework_spec(model["spec"], "int8")
-    assert len(compute) == len(spec) == 76          # 53 conv + 16 eltwise + pool1 + 3 stride-up poolings + pool5 + fc + softmax
+    assert len(compute) == len(spec)
     by = {o["name"]: o for o in compute}
-    assert sorted(by) == sorted(l["name"] for l in spec)          # name for name
+    assert sorted(by) == sorted(R(l["name"]) for l in spec)          # name for name
     # both orders are schedules of the same DAG: every op of the reference's order runs after its producers
     pos = {o["name"]: i for i, o in enumerate(ops)}
     shape, dt, sc = {"data": (224, 3)}, {"data": W.F32}, dict(scales)
     for l in spec:
-        o = by[l["name"]]
+        o = by[R(l["name"])]
         assert o["type"] == expected_type(l, model["raw"]), l["name"]
         srcs = [l[k] for k in ("src", "a", "b") if k in l]
-        assert sorted(prod[o["name"]]) == sorted(srcs), (l["name"], prod[o["name"]], srcs)
-        assert all(pos[s] < pos[o["name"]] for s in srcs)
+        assert sorted(prod[o["name"]]) == sorted(R(s_) for s_ in srcs), (l["name"], prod[o["name"]], srcs)
+        assert all(pos[R(s_)] < pos[o["name"]] for s_ in srcs)
         out = o["outs"][0]
         if l["kind"] == "conv":
             hin, _ = shape[l["src"]]
@@ -111,9 +114,40 @@ def test_resnet50_int8_op_list_is_the_reference_optimisers(tmp_path):
             assert out["layout"] == "nhwc" and out["shape"] == [1, hw, hw, c], (l["name"], out)
             if l["kind"] not in ("pool", "gpool"):    # a pooling's output scale is overwritten at init (inherits its input's)
                 assert abs(out["scale"] - sc[l["name"]]) <= 1e-6 * sc[l["name"]], (l["name"], out["scale"], sc[l["name"]])
-        for e, s in zip(o["ins"], srcs if l["kind"] != "eltwise" else [l["a"], l["b"]]):
+        for e, s_ in zip(o["ins"], srcs if l["kind"] != "eltwise" else [l["a"], l["b"]]):
             if l["kind"] != "eltwise":
-                assert e["dtype"] == DT[dt[s]], (l["name"], e)
+                assert e["dtype"] == DT[dt[s_]], (l["name"], e)
+    return model, spec, compute
+
+
+def test_resnet101_int8_op_list_is_the_reference_optimisers(tmp_path):
+    """BASELINE.json's deep-stack config through the reference's OWN Graph::Optimize + Net<MI355X>::init: the 144-operator list
+    workloads.framework_spec predicts (rounds 2-3 could only extrapolate it: the reference aborted at graph_base.inl:99).
+    Root cause, found with AddressSanitizer (INTEGRATION.md): GraphBase::remove_byio (framework/graph/graph_base.inl:218-240),
+    called by graph_strategy::_stride_up_like_concat (optimize_strategy.h:236), erases the arc from the arc list and then
+    compares the ERASED node's names through the stale iterators of the per-vertex arc tables. Names of <= 15 characters sit in
+    the freed node's small-string buffer and still compare equal; ResNet101's `res4b10_branch2a` ... (16 characters: heap
+    storage) do not, wrong arcs survive, the fusion pass later trips over them. The graph is therefore built with short node
+    names (net_model.short_names: `r4b22_2c`) - and, to pin the diagnosis, ResNet50 with LONG names must fail the same way."""
+    model, spec, compute = _check_int8_list(tmp_path / "r101", "resnet101", rename=NM.short_names)
+    assert len(spec) == 144          # 104 conv + 33 eltwise + pool1 + 3 stride-up poolings + pool5 + fc + softmax
+    s2 = [l["name"] for l in spec if l["kind"] == "conv" and l["k"] == 3 and l["stride"] == 2]
+    assert s2 == ["res2c_branch2b", "res3d_branch2b", "res4b22_branch2b"], s2
+    head = dry_run.plan[0].split()
+    assert int(head[head.index("plan") + 1]) == 1 and int(head[head.index("captured_ops") + 1]) == 144, dry_run.plan[0]
+    assert int(head[head.index("launches") + 1]) <= 72
+    r = dry_run(tmp_path / "r101_long", "resnet101", "int8", expect_fail=True)                 # the model's own names: 16 characters
+    assert r.returncode != 0 and "graph_base.inl:99" in r.stderr, r.stderr[-800:]
+    r = dry_run(tmp_path / "r50_long", "resnet50", "int8", expect_fail=True, rename=lambda n: n if n == "data" else "a_rather_long_prefix_" + n)
+    assert r.returncode != 0, "ResNet50 with node names of > 15 characters was expected to trip over the same reference bug"
+
+
+@pytest.mark.parametrize("route", ["set_calls", "calibrator_files"])
+def test_resnet50_int8_op_list_is_the_reference_optimisers(tmp_path, route):
+    """route: how precisions and scales reach the graph - Graph::SetOpPrec / SetVarScale calls, or the two text files of a deployed
+    model through Graph::load_calibrator_config (framework/graph/graph.cpp:555, parser framework/core/net/calibrator_parse.cpp)"""
+    model, spec, compute = _check_int8_list(tmp_path, "resnet50", route)
+    assert len(spec) == 76          # 53 conv + 16 eltwise + pool1 + 3 stride-up poolings + pool5 + fc + softmax
     # the three stride-2 3x3 convolutions and their shortcut poolings (graph_strategy::apply_stride_up)
     s2 = [l["name"] for l in spec if l["kind"] == "conv" and l["k"] == 3 and l["stride"] == 2]
     assert s2 == ["res2c_branch2b", "res3d_branch2b", "res4f_branch2b"]
