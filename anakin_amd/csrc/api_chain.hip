@@ -125,13 +125,15 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
             e = ch->d_stream_split8.upload(s8);
         }
     }
-    if (e == hipSuccess && da.c == 128) {   // 8 waves: 16 channels of the 3x3 / 64 of the first / 16 of the second 1x1 conv per wave
+    if (e == hipSuccess && (da.c == 128 || (da.c == 256 && c3))) {
+        // 8 waves: C = 128: 16 channels of the 3x3 / 64 of the first / 16 of the second 1x1 conv per wave; C = 256 (3x3-led forms only):
+        // 32 / 128 / 32 (two accumulators per group of the second conv)
         std::vector<uint8_t> s8;
         s8.reserve(stream.size());
         for (int w = 0; w < 8; ++w) {
             if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, s8, 8);
             pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, s8, 0, 8);
-            if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, 1, w, s8, 0, 8);
+            if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, da.c == 128 ? 1 : 2, w, s8, 0, 8);
         }
         e = ch->d_stream_w8.upload(s8);
     }
@@ -160,7 +162,7 @@ void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
-                    (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) ||
+                    (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) || (ch->c1 == 256 && tn == 3 && ch->c3 && ch->d_stream_w8.p) ||
                     (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b);
     if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
     ch->tn = tn;
@@ -177,7 +179,7 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     std::memset(&k, 0, sizeof k);
     k.x = x; k.res = res;
     k.wstream = ch->tn == 11 ? ch->d_stream_split8.p : ((ch->tn & 8) ? ch->d_stream_split.p : ch->d_stream.p);
-    if (ch->c1 == 128 && (ch->tn & 4)) k.wstream = ch->d_stream_w8.p;
+    if ((ch->c1 == 128 && (ch->tn & 4)) || (ch->c1 == 256 && ch->tn == 3)) k.wstream = ch->d_stream_w8.p;
     k.prm1 = ch->d_prm1.p;
     k.prm2 = ch->d_prm2.p;
     k.y1 = y_a; k.y2 = y_b;
@@ -197,7 +199,7 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         if (!k.zero) return fail(SABER_HIP_RUNTIME_ERROR, "chain: zero page");
         k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
         k.tiles_x = (k.W + 15) / 16;
-        const int rows = ch->c1 == 128 ? ch->tn & 3 : ch->tn & 7;    // tile rows (C = 128: bit 2 of the code = 8 waves)
+        const int rows = ch->c1 == 128 ? ch->tn & 3 : (ch->c1 == 256 ? 1 : ch->tn & 7);    // tile rows (C = 128: bit 2 of the code = 8 waves; C = 256: one row, code 3 = 8 waves)
         k.tiles_per_img = k.tiles_x * ((k.H + rows - 1) / rows);
         k.mg_tiles_x = magic(k.tiles_x);
         k.mg_tpi = magic(k.tiles_per_img);

@@ -88,8 +88,9 @@ constexpr size_t kMaxPlans = 16;
 // the plane kernels need 8-element k granularity and pay off once the problem fills the chip
 bool plane_path(int m, int n, int k) {
     if (const char* e = std::getenv("SABER_HIP_GEMM_F32_PLANES")) return e[0] == '1' && k % 8 == 0;
-    // (m < 32: a weight stream - the split would move 2.5 x B's bytes to save arithmetic that is not the bound)
-    return k % 8 == 0 && k >= 64 && m >= 32 && (double)m * n * k >= 64.0 * 64 * 64 * 64;
+    // (also for a few rows: VGG16's fc6 as a GEMM, m = 8, is a 411 MB weight stream - 618 us on the planes, pack included, against
+    // 2 768 us on the 64 x 64 f32-MFMA tiles, whose 64 workgroups each walk 6 MB of B with 4-byte loads)
+    return k % 8 == 0 && k >= 64 && (double)m * n * k >= 64.0 * 64 * 64 * 64;
 }
 
 int pick_tile(const saber_hip_conv* op, int m, int n) {

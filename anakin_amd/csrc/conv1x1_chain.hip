@@ -392,6 +392,7 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
         case 128 * 32 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1, false, 4, 2); break;
         case 128 * 32 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1, false, 4, 2); break;
         case 256 * 32 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1, false, 4, 2); break;
+        case 256 * 32 + 3: SABER_CHAIN(4, 2, 2, 1, 1, 16, true, 1, false, 8, 2); break;     // 8 waves
         case 128 * 32 + 6: SABER_CHAIN(2, 1, 1, 1, 2, 8, true, 1, false, 8, 2); break;
         case 128 * 32 + 5: SABER_CHAIN(2, 1, 1, 1, 1, 8, true, 1, false, 8, 2); break;
         default: return hipErrorInvalidValue;
@@ -405,6 +406,7 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
         case 128 * 32 + 2: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1, false); break;
         case 128 * 32 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1, false); break;
         case 256 * 32 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1, false); break;
+        case 256 * 32 + 3: SABER_CHAIN(4, 2, 2, 1, 1, 16, true, 1, false, 8); break;        // 8 waves
         case 128 * 32 + 6: SABER_CHAIN(2, 1, 1, 1, 2, 8, true, 1, false, 8); break;
         case 128 * 32 + 5: SABER_CHAIN(2, 1, 1, 1, 1, 8, true, 1, false, 8); break;
         default: return hipErrorInvalidValue;
@@ -426,6 +428,7 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
     case 128 * 32 + 2 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 2, 8, true, 1); break;
     case 128 * 32 + 1 * 2 + 1: SABER_CHAIN(2, 2, 2, 1, 1, 8, true, 1); break;
     case 256 * 32 + 1 * 2 + 1: SABER_CHAIN(4, 4, 4, 1, 1, 16, true, 1); break;
+    case 256 * 32 + 3 * 2 + 1: SABER_CHAIN(4, 2, 2, 1, 1, 16, true, 1, true, 8); break;   // 3x3-led, 8 waves: 32 / 128 / 32 channels per wave
     case 128 * 32 + 6 * 2: SABER_CHAIN(2, 1, 1, 1, 2, 8, false, 1, true, 8); break;      // 8 waves
     case 128 * 32 + 5 * 2: SABER_CHAIN(2, 1, 1, 1, 1, 8, false, 1, true, 8); break;
     case 128 * 32 + 6 * 2 + 1: SABER_CHAIN(2, 1, 1, 1, 2, 8, true, 1, true, 8); break;

@@ -34,8 +34,9 @@ The framework half of the manual (:281-455) is applied to a copy of `framework/`
                                              In this scratch copy the twin REPLACES the X86 line (token substitution): the x86
                                              Saber implementations need xbyak / mkl-dnn, which this container does not have,
                                              so Operator<X86> cannot be linked here; X86 stays the HOST target only.
-    framework/model_parser/parser/parser.cpp replaced by integration/mi355x/framework/parser_stub.cpp (protobuf is absent; it
-                                             is the only protobuf consumer; graphs are built with Graph::AddOp / Freeze)
+    framework/model_parser/parser/parser.cpp replaced by integration/mi355x/framework/text_model_parser.cpp (protobuf is absent and this
+                                             is its only consumer): Graph::load(path) reads a TEXT model - the network as original
+                                             operators + raw weight blobs - and builds the graph with Graph::AddOp / AddOpAttr / Freeze
     + the facade ladders of saber/funcs/{pooling,eltwise,fc,softmax,activation,conv_pooling,gemm}.h"""
 import os
 import shutil
@@ -80,7 +81,7 @@ def patch_framework(ref, dst):
     shutil.copytree(os.path.join(ref, "framework"), F,
                     ignore=shutil.ignore_patterns("service", "c_api", "nanopb", "proto", "lite", "*.pb.*", "CMakeLists.txt"))
     shutil.copy(os.path.join(HERE, "mi355x", "framework", "mi355x_pblock.h"), os.path.join(F, "core"))
-    shutil.copy(os.path.join(HERE, "mi355x", "framework", "parser_stub.cpp"),
+    shutil.copy(os.path.join(HERE, "mi355x", "framework", "text_model_parser.cpp"),
                 os.path.join(F, "model_parser", "parser", "parser.cpp"))
     os.remove(os.path.join(F, "model_parser", "parser", "model_io.cpp"))
     insert(os.path.join(F, "core", "parameter.h"), "#endif",
@@ -96,6 +97,11 @@ def patch_framework(ref, dst):
     instantiate(os.path.join(net, "net.cpp"), r"template class Net<X86, [^;]*;")
     instantiate(os.path.join(net, "operator_func.cpp"), r"template class OperatorFunc<X86, [^;]*;")
     instantiate(os.path.join(net, "auto_layout_config.cpp"), r"template class AutoLayoutConfigHelper<X86, [^;]*;")
+    # Worker<MI355X, P, R> (the multi-instance serving shape: one Net per thread, framework/core/net/worker.h:38-60) and the
+    # calibration-table generator (EntropyCalibrator / BatchStream, framework/core/net/entropy_calibrator.cpp, calibrator.h)
+    instantiate(os.path.join(net, "worker.cpp"), r"template class Worker<X86, [^;]*;")
+    instantiate(os.path.join(net, "entropy_calibrator.cpp"), r"template class EntropyCalibrator<X86>;")
+    instantiate(os.path.join(net, "batch_stream.cpp"), r"template class BatchStream<X86>;")
     instantiate(os.path.join(F, "graph", "graph.cpp"), r"template class Graph<X86, [^;]*;")
     instantiate(os.path.join(F, "utils", "parameter_fusion.cpp"), r"template class WeightsFusion<[a-z]*, X86>;")
     # the x86 edge rule for MI355X: Net picks the branch by target type, CalibratorParser by name

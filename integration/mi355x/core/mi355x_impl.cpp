@@ -67,6 +67,11 @@ void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src
     mi355x_copy(dst, dst_offset, src, src_offset, count, hipMemcpyHostToDevice, stream, true);
 }
 void MI355X_API::sync_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count, __DtoH) {
+    // The target's compute streams are non-blocking (Device<MI355X>::create_stream): a null-stream hipMemcpy is not ordered after
+    // them. A SYNCHRONOUS device-to-host copy is the framework's "give me the tensor now" (Tensor::copy_from into a host tensor:
+    // Worker::sync_prediction, EntropyCalibrator::max_data / histgram, which on NV rely on the legacy default stream's implicit
+    // ordering): wait for the device first.
+    MI355X_CHECK(hipDeviceSynchronize());
     mi355x_copy(dst, dst_offset, src, src_offset, count, hipMemcpyDeviceToHost, nullptr, false);
 }
 void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count,

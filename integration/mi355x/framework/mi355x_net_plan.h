@@ -21,7 +21,9 @@
 // A shape or address change drops the plan; the next prediction() runs through the op loop under capture again (the impls
 // re-create themselves there, base.h:151-161) and builds a new one. Anything the capture cannot express (SABER_HIP_UNIMPL)
 // leaves the reference's loop in charge. SABER_MI355X_NET_PLAN=0 in the environment switches the plan off,
-// SABER_MI355X_NET_PLAN_TUNE=0 keeps the static kernel selection, SABER_MI355X_NET_PLAN_GRAPH=0|1 forces eager / hipGraph.
+// SABER_MI355X_NET_PLAN_TUNE=0 keeps the static kernel selection, SABER_MI355X_NET_PLAN_GRAPH=0|1 forces eager / hipGraph,
+// SABER_MI355X_NET_PLAN_STREAM=own gives every Net's plan a stream of its own (all Nets of a device otherwise share the
+// Context's compute stream `lane`, as on every target of the reference: Worker threads would serialise on the GPU).
 // New code of this repository (reference-side glue of the MI355X target).
 #ifndef ANAKIN_FRAMEWORK_CORE_NET_MI355X_NET_PLAN_H
 #define ANAKIN_FRAMEWORK_CORE_NET_MI355X_NET_PLAN_H
@@ -47,6 +49,9 @@ struct MI355XNetPlan {
     std::vector<const void*> in_ptr, out_ptr;
     std::vector<std::vector<int> > in_shape;
     void* stream = nullptr;
+    void* own_stream = nullptr;  // SABER_MI355X_NET_PLAN_STREAM=own: a stream of this plan's (serving: one Net per Worker thread, each
+    void* own_event = nullptr;   // pass then overlaps the others on the GPU); ordered after the context's compute stream by an event
+    void* ctx_stream = nullptr;
     MI355XNetPlan() {}
     MI355XNetPlan(const MI355XNetPlan&) {}                  // a plan belongs to ONE Net: a copy starts without one
     MI355XNetPlan& operator=(const MI355XNetPlan&) { drop(); return *this; }

@@ -65,6 +65,20 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
             plan.out_ptr.push_back(t->data());
         }
         plan.stream = (void*)net._exec_funcs[0].ctx_p->get_compute_stream();
+        {
+            const char* own = std::getenv("SABER_MI355X_NET_PLAN_STREAM");
+            if (own && std::string(own) == "own" && !plan.own_stream) {
+                API::stream_t s;
+                API::event_t e;
+                API::create_stream_with_flag(&s, 1);
+                API::create_event(&e, false);
+                plan.own_stream = (void*)s;
+                plan.own_event = (void*)e;
+            }
+        }
+        void* const ctx_stream = plan.stream;
+        if (plan.own_stream) plan.stream = plan.own_stream;
+        plan.ctx_stream = ctx_stream;
         if (ok) ok = saber_hip_net_optimize(n, 255) >= 0;
         if (ok) ok = saber_hip_net_finalize(n) == SABER_HIP_OK;
         if (ok && plan.builds == 0 && env_on("SABER_MI355X_NET_PLAN_TUNE", true))
@@ -134,6 +148,10 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
             if (plan.tried) return false;
             prepare(net);
             if (!plan.net) return false;
+        }
+        if (plan.own_stream) {      // after whatever the caller queued on the context's stream (asynchronous input copies)
+            API::record_event((API::event_t)plan.own_event, (API::stream_t)plan.ctx_stream);
+            API::sync_stream((API::event_t)plan.own_event, (API::stream_t)plan.own_stream);
         }
         const int rc = plan.use_graph ? saber_hip_net_replay(plan.net, plan.stream) : saber_hip_net_run(plan.net, plan.stream);
         CHECK_EQ(rc, (int)SABER_HIP_OK) << "MI355X net plan: " << saber_hip_last_error();

@@ -89,7 +89,7 @@ def write_model(model, scales, batch, outdir, precision="int8", hw=224, calibrat
         raw = {rename(k): v for k, v in raw.items()}
         scales = {rename(k): v for k, v in scales.items()}
         assert len(orig) == len(spec), "rename must be injective"
-    lines, blobs = ["precision " + precision, "input data %d 3 %d %d" % (batch, hw, hw)], []
+    lines, blobs = ["precision " + precision, "weights weights.bin", "input data %d 3 %d %d" % (batch, hw, hw)], []
     consumers = {}
     for l in spec:
         for key in ("src", "a", "b"):
@@ -121,7 +121,8 @@ def write_model(model, scales, batch, outdir, precision="int8", hw=224, calibrat
             lines.append("softmax %s %s" % (nm, l["src"]))
     if precision == "int8" and calibrator_config:
         cspec = [dict(l, _bn=l["name"] in raw) for l in spec]
-        lines.append("calibrator %s %s" % calibrator_files(cspec, scales, outdir))
+        cfg, cal = calibrator_files(cspec, scales, outdir)
+        lines.append("calibrator %s %s" % (os.path.basename(cfg), os.path.basename(cal)))      # relative to the model file
     elif precision == "int8":
         prec = int8_plan(spec)
         for l in spec:

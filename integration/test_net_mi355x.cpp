@@ -14,21 +14,12 @@
 //         -> Saber*<MI355X,...>::dispatch -> integration/saber_mi355x_adaptor.h -> include/saber_hip.h -> HIP kernels
 //
 // The program is a file-driven harness (the Python test writes the model and checks the dumps against the oracle):
-//     test_net_mi355x.bin <model.txt> <weights.bin> <input.bin> <outdir> [iters | dry]
-// model.txt (one record per line; the network BEFORE any fusion):
-//     precision int8|fp32
-//     input  <name> n c h w
-//     conv   <name> <src> cin cout k stride pad relu(0|1) bn(0|1)     weights.bin: w[cout,cin,k,k]; bn=0: bias[cout];
-//                                                                      bn=1: mean[cout] var[cout] gamma[cout] beta[cout]
-//     pool   <name> <src> MAX|AVG win stride pad global(0|1)
-//     eltwise <name> <a> <b> relu(0|1) coeff_a coeff_b
-//     fc     <name> <src> cin cout relu(0|1)                            weights.bin: w[cout,cin] bias[cout]
-//     softmax <name> <src>
-//     prec   <node> int8|fp32          (after Freeze: Graph::SetOpPrec)
-//     precsplit <node> int8|fp32       (the Split node Graph::Freeze inserts behind <node>'s output when it has >1 readers)
-//     scale  <node> <float>            (Graph::SetVarScale on <node>'s output variable)
-//     calibrator <net_config.txt> <calibrator.txt>   (instead of prec / scale records: Graph::load_calibrator_config reads both
-//                                      text files - integration/net_model.py: calibrator_files writes them from the topology)
+//     test_net_mi355x.bin <model.txt> <weights.bin (unused: named by the model)> <input.bin> <outdir> [iters | dry]
+//     ... <outdir> worker <threads> [requests]      Worker<MI355X, FP32>: one Net per pool thread (worker.txt, out_worker.bin)
+//     ... <outdir> calibrate <batches>              EntropyCalibrator<MI355X> over `batches` inputs (calibration_table.txt)
+// model.txt: the TEXT model format of integration/mi355x/framework/text_model_parser.cpp (this build's model parser: the network
+// BEFORE any fusion as original operators + raw weight blobs, per-node precisions and per-variable scales or the two calibrator
+// text files), loaded with Graph::load like an .anakin.bin.
 // Outputs in <outdir>:  plan.txt (the captured plan behind prediction(): ops / launches / launch form), out_<o>_oploop.bin
 // (prediction() with the plan switched off), oplist.txt (the op list the reference's optimiser produced, with every edge's dtype / layout /
 // shape / scale / sharing), out_<graph output>.bin (after Net::prediction()), step_<i>_<j>.bin (output j of op i, dumped
@@ -63,165 +54,30 @@
 #define private public
 #include "framework/core/net/net.h"
 #undef private
+#include "framework/core/net/worker.h"
+#include "framework/core/net/entropy_calibrator.h"
+#include <chrono>
+#include <future>
 
 using namespace anakin;
 using namespace anakin::saber;
 using anakin::graph::Graph;
-
-static std::vector<float> g_weights;
-static size_t g_wpos = 0;
-
-static const float* take(size_t n) {
-    if (g_wpos + n > g_weights.size()) { fprintf(stderr, "weights.bin too short\n"); exit(2); }
-    const float* p = g_weights.data() + g_wpos;
-    g_wpos += n;
-    return p;
-}
-
-// A weight block as the model parser creates it: host + device copy, registered with the graph's global weight guard
-// (Graph::RegistBlock, graph.h:108; GraphGlobalMem::apply — WeightsFusion::update_weights, trans_weights — looks it up).
-static PBlock<MI355X> block(const std::vector<int>& shape4, const float* src) {
-    Shape sh(shape4);
-    PBlock<MI355X> b(sh);
-    memcpy(b.h_tensor().mutable_data(), src, sizeof(float) * sh.count());
-    b.d_tensor().set_shape(sh);
-    b.d_tensor().copy_from(b.h_tensor());     // TargetWrapper<MI355X>::sync_memcpy(..., __HtoD)
-    graph::GraphGlobalMem<MI355X>::Global().register_block(&b);
-    return b;
-}
 
 static const char* dtype_name(DataType t) {
     return t == AK_FLOAT ? "f32" : (t == AK_INT8 ? "s8" : (t == AK_UINT8 ? "u8" : (t == AK_INT32 ? "s32" : "?")));
 }
 static const char* layout_name(LayoutType l) { return l == Layout_NHWC ? "nhwc" : (l == Layout_NCHW ? "nchw" : "other"); }
 
-struct Record { std::vector<std::string> f; };
-
 template <Precision P>
-static int run(const std::vector<Record>& recs, const std::vector<float>& input, const std::string& outdir, int iters) {
+static int run(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int iters) {
     typedef Graph<MI355X, P> graph_t;
     std::unique_ptr<graph_t> graph(new graph_t());
-    std::string in_name;
-    std::vector<int> in_shape;
-    std::vector<std::pair<std::string, std::string> > precs;
-    std::vector<std::pair<std::string, float> > scales;
-    std::string cal_config, cal_table;      // `calibrator` record: Graph::load_calibrator_config instead of SetOpPrec / SetVarScale
-    auto I = [](const std::string& s) { return atoi(s.c_str()); };
-    // variable names live in their own namespace but Graph::Freeze names the Input / Output / Split nodes after them
-    // (graph.cpp:237-296), so a layer's output variable must not be called like the layer's node
-    auto V = [&](const std::string& layer) { return layer == in_name ? layer : layer + "_out"; };
-
-    for (const Record& r : recs) {
-        const std::vector<std::string>& f = r.f;
-        const std::string& kind = f[0];
-        if (kind == "input") {
-            in_name = f[1];
-            in_shape = {I(f[2]), I(f[3]), I(f[4]), I(f[5])};
-        } else if (kind == "conv") {
-            const std::string name = f[1], src = V(f[2]);
-            const int cin = I(f[3]), cout = I(f[4]), k = I(f[5]), stride = I(f[6]), pad = I(f[7]);
-            const bool relu = I(f[8]) != 0, bn = I(f[9]) != 0;
-            std::string top = name;
-            graph->AddOp(name, "Convolution", {src}, {bn || relu ? name + "_conv" : V(name)});
-            graph->AddOpAttr(name, "group", 1);
-            graph->AddOpAttr(name, "bias_term", !bn);
-            graph->AddOpAttr(name, "padding", PTuple<int>(pad, pad));
-            graph->AddOpAttr(name, "strides", PTuple<int>(stride, stride));
-            graph->AddOpAttr(name, "dilation_rate", PTuple<int>(1, 1));
-            graph->AddOpAttr(name, "filter_num", cout);
-            graph->AddOpAttr(name, "kernel_size", PTuple<int>(k, k));
-            graph->AddOpAttr(name, "axis", 1);
-            graph->AddOpAttr(name, "weight_1", block({cout, cin, k, k}, take((size_t)cout * cin * k * k)));
-            std::string cur = name + "_conv";
-            if (!bn) {
-                graph->AddOpAttr(name, "weight_2", block({1, cout, 1, 1}, take(cout)));
-            } else {
-                // Caffe: BatchNorm (mean, variance, moving-average factor) then Scale (gamma, beta)
-                const std::string bnn = "bn_" + name, scn = "scale_" + name;
-                graph->AddOp(bnn, "BatchNorm", {cur}, {name + "_bn"});
-                graph->AddOpAttr(bnn, "epsilon", 1e-5f);
-                graph->AddOpAttr(bnn, "momentum", 0.999f);
-                graph->AddOpAttr(bnn, "weight_1", block({1, cout, 1, 1}, take(cout)));
-                graph->AddOpAttr(bnn, "weight_2", block({1, cout, 1, 1}, take(cout)));
-                const float one = 1.f;
-                graph->AddOpAttr(bnn, "weight_3", block({1, 1, 1, 1}, &one));
-                const std::string sc_out = relu ? name + "_scale" : V(name);
-                graph->AddOp(scn, "Scale", {name + "_bn"}, {sc_out});
-                graph->AddOpAttr(scn, "num_axes", 1);
-                graph->AddOpAttr(scn, "bias_term", true);
-                graph->AddOpAttr(scn, "axis", 1);
-                graph->AddOpAttr(scn, "weight_1", block({1, cout, 1, 1}, take(cout)));
-                graph->AddOpAttr(scn, "weight_2", block({1, cout, 1, 1}, take(cout)));
-                cur = sc_out;
-            }
-            if (relu) {
-                const std::string rn = name + "_relu";
-                graph->AddOp(rn, "ReLU", {cur}, {V(name)});
-                graph->AddOpAttr(rn, "alpha", 0.0f);
-            }
-        } else if (kind == "pool") {
-            const std::string name = f[1];
-            graph->AddOp(name, "Pooling", {V(f[2])}, {V(name)});
-            graph->AddOpAttr(name, "method", f[3]);
-            graph->AddOpAttr(name, "pool_size", PTuple<int>(I(f[4]), I(f[4])));
-            graph->AddOpAttr(name, "strides", PTuple<int>(I(f[5]), I(f[5])));
-            graph->AddOpAttr(name, "padding", PTuple<int>(I(f[6]), I(f[6])));
-            graph->AddOpAttr(name, "global_pooling", I(f[7]) != 0);
-            graph->AddOpAttr(name, "cmp_out_shape_floor_as_conv", false);     // Caffe: ceil mode
-        } else if (kind == "eltwise") {
-            const std::string name = f[1];
-            const bool relu = I(f[4]) != 0;
-            graph->AddOp(name, "Eltwise", {V(f[2]), V(f[3])}, {relu ? name + "_sum" : V(name)});
-            graph->AddOpAttr(name, "type", std::string("Add"));
-            graph->AddOpAttr(name, "coeff", PTuple<float>((float)atof(f[5].c_str()), (float)atof(f[6].c_str())));
-            if (relu) {
-                graph->AddOp(name + "_relu", "ReLU", {name + "_sum"}, {V(name)});
-                graph->AddOpAttr(name + "_relu", "alpha", 0.0f);
-            }
-        } else if (kind == "fc") {
-            const std::string name = f[1];
-            const int cin = I(f[3]), cout = I(f[4]);
-            const bool relu = I(f[5]) != 0;
-            graph->AddOp(name, "Dense", {V(f[2])}, {relu ? name + "_fc" : V(name)});
-            graph->AddOpAttr(name, "out_dim", cout);
-            graph->AddOpAttr(name, "bias_term", true);
-            graph->AddOpAttr(name, "axis", 1);
-            graph->AddOpAttr(name, "weight_1", block({1, 1, cout, cin}, take((size_t)cout * cin)));
-            graph->AddOpAttr(name, "weight_2", block({1, cout, 1, 1}, take(cout)));
-            if (relu) {
-                graph->AddOp(name + "_relu", "ReLU", {name + "_fc"}, {V(name)});
-                graph->AddOpAttr(name + "_relu", "alpha", 0.0f);
-            }
-        } else if (kind == "softmax") {
-            graph->AddOp(f[1], "Softmax", {V(f[2])}, {V(f[1])});
-            graph->AddOpAttr(f[1], "axis", 1);
-        } else if (kind == "prec") {
-            precs.push_back({f[1], f[2]});
-        } else if (kind == "precsplit") {       // the Split node Freeze inserts behind a variable with several readers
-            precs.push_back({V(f[1]) + "split", f[2]});
-        } else if (kind == "scale") {
-            scales.push_back({V(f[1]), (float)atof(f[2].c_str())});
-        } else if (kind == "calibrator") {
-            cal_config = f[1];
-            cal_table = f[2];
-        } else if (kind != "precision") {
-            fprintf(stderr, "unknown record %s\n", kind.c_str());
-            return 2;
-        }
-    }
-    if (g_wpos != g_weights.size()) { fprintf(stderr, "weights.bin: %zu floats left over\n", g_weights.size() - g_wpos); return 2; }
-
-    if (!graph->Freeze()) { fprintf(stderr, "Freeze failed\n"); return 2; }
-    for (auto& p : precs)
-        if (!graph->SetOpPrec(p.first, p.second == "int8" ? AK_INT8 : AK_FLOAT)) {
-            fprintf(stderr, "SetOpPrec: no node %s\n", p.first.c_str());
-            return 2;
-        }
-    for (auto& s : scales) graph->SetVarScale(s.first, s.second);
-    // the text-file route of a deployed model: node precisions from the net config, edge scales from the calibration table
-    // (Graph::load_calibrator_config, graph.cpp:555-571 -> CalibratorParser::parse_from_file, calibrator_parse.cpp:338-460)
-    if (!cal_config.empty()) graph->load_calibrator_config(cal_config, cal_table);
-    graph->AddOpAttr(in_name, "input_shape", PTuple<int>(in_shape[0], in_shape[1], in_shape[2], in_shape[3]));
+    // Graph::load -> parser::load (framework/graph/graph.cpp:16-26): on this build the text model parser
+    // (integration/mi355x/framework/text_model_parser.cpp): AddOp / AddOpAttr per original operator, weight blocks from
+    // GraphGlobalMem, Freeze, then SetOpPrec / SetVarScale or Graph::load_calibrator_config as the model says
+    Status st = graph->load(model_path);
+    if (!st) { fprintf(stderr, "Graph::load(%s) failed: %s\n", model_path.c_str(), st.info()); return 2; }
+    const std::string in_name = graph->get_ins()[0];
 
     graph->Optimize();      // the reference's fusion pass + stride-up + schedulers + memory planner
 
@@ -357,6 +213,85 @@ static int run(const std::vector<Record>& recs, const std::vector<float>& input,
     return 0;
 }
 
+// ---- `worker <threads> <requests>`: Worker<MI355X, FP32> (framework/core/net/worker.h:38-60) - the reference's multi-instance
+// serving shape: `threads` pool threads, each loads the model (Graph::load -> the text model parser), optimises it and owns a
+// Net; requests are host tensors, answers futures of host tensors. Every answer must equal the first; requests / s reported.
+static int run_worker(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int threads, int requests) {
+    typedef Worker<MI355X, Precision::FP32, OpRunType::ASYNC> worker_t;
+    std::string in_name, out_name;
+    std::vector<int> shape;
+    {
+        Graph<MI355X, Precision::FP32> g;
+        Status st = g.load(model_path);
+        if (!st) { fprintf(stderr, "Graph::load failed: %s\n", st.info()); return 2; }
+        in_name = g.get_ins()[0];
+        out_name = g.get_outs()[0];
+        auto sh = g[in_name]->template get_attr<PTuple<int> >("input_shape");
+        for (int i = 0; i < 4; ++i) shape.push_back(sh[i]);
+    }
+    worker_t worker(model_path, threads);
+    worker.register_inputs({in_name});
+    worker.register_outputs({out_name});
+    worker.Reshape(in_name, shape);
+    worker.launch();
+    Tensor4d<X86> host_in(Shape(shape), AK_FLOAT);
+    if ((size_t)host_in.valid_size() != input.size()) { fprintf(stderr, "input.bin does not match the model's input\n"); return 2; }
+    memcpy(host_in.mutable_data(), input.data(), input.size() * sizeof(float));
+    std::vector<Tensor4d<X86> > ins(1, host_in);
+    auto first = worker.sync_prediction(ins).get();      // also: every pool thread has finished its init by the time the queue drains
+    for (int w = 0; w < 2 * threads; ++w) worker.sync_prediction(ins).get();
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::future<std::vector<Tensor4d<X86> > > > fut;
+    for (int r = 0; r < requests; ++r) fut.push_back(worker.sync_prediction(ins));
+    int bad = 0;
+    for (auto& f : fut) {
+        auto out = f.get();
+        if (out.size() != 1 || out[0].valid_size() != first[0].valid_size() ||
+            memcmp(out[0].data(), first[0].data(), first[0].valid_size() * sizeof(float)) != 0) ++bad;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    FILE* f = fopen((outdir + "/out_worker.bin").c_str(), "wb");
+    fwrite(first[0].data(), sizeof(float), first[0].valid_size(), f);
+    fclose(f);
+    f = fopen((outdir + "/worker.txt").c_str(), "w");
+    fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f\n", threads, requests, bad, sec,
+            requests / sec, requests * (double)shape[0] / sec);
+    fclose(f);
+    printf("worker ok: %d threads, %d requests, %d mismatches, %.1f requests/s\n", threads, requests, bad, requests / sec);
+    return bad ? 3 : 0;
+}
+
+// ---- `calibrate <batches>`: the reference's calibration-table generator on this target (framework/core/net/entropy_calibrator.cpp,
+// calibrator.h, batch_stream.cpp): a Net<MI355X, FP32, SYNC> runs the calibration batches (input.bin = batches x the model's input),
+// EntropyCalibrator collects per-edge maxima and histograms through the FP32 operators of the MI355X target and writes
+// `<edge> <scale>` lines - the file Graph::load_calibrator_config reads back.
+static std::vector<Tensor<X86>*> g_cal_batches;
+static size_t g_cal_next = 0;
+static Tensor<X86>* next_calibration_batch() {
+    if (g_cal_next >= g_cal_batches.size()) { g_cal_next = 0; return nullptr; }     // end of a pass; the next pass starts over
+    return g_cal_batches[g_cal_next++];
+}
+static int run_calibrate(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int batches) {
+    Graph<MI355X, Precision::FP32> graph;
+    Status st = graph.load(model_path);
+    if (!st) { fprintf(stderr, "Graph::load failed: %s\n", st.info()); return 2; }
+    graph.Optimize();
+    Net<MI355X, Precision::FP32, OpRunType::SYNC> net(graph, true);
+    auto in = net.get_in(graph.get_ins()[0]);
+    const size_t per = (size_t)in->valid_size();
+    if (input.size() != per * (size_t)batches) { fprintf(stderr, "input.bin: %zu floats, expected %d batches of %zu\n", input.size(), batches, per); return 2; }
+    for (int b = 0; b < batches; ++b) {
+        Tensor<X86>* t = new Tensor<X86>(in->valid_shape(), AK_FLOAT);
+        memcpy(t->mutable_data(), input.data() + b * per, per * sizeof(float));
+        g_cal_batches.push_back(t);
+    }
+    BatchStream<MI355X> stream(next_calibration_batch);
+    EntropyCalibrator<MI355X> cal(&stream, in->num(), outdir + "/calibration_table.txt", &net, 2048);
+    cal.generate_calibrator_table();
+    printf("calibrate ok: %d batches through %zu executors\n", batches, net._exec_funcs.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) {
         fprintf(stderr, "usage: %s model.txt weights.bin input.bin outdir [timing iters]\n", argv[0]);
@@ -364,16 +299,11 @@ int main(int argc, char** argv) {
     }
     logger::init(argv[0]);
     std::ifstream fm(argv[1]);
-    std::vector<Record> recs;
     std::string line, precision = "int8";
     while (std::getline(fm, line)) {
         std::istringstream is(line);
-        Record r;
-        std::string tok;
-        while (is >> tok) r.f.push_back(tok);
-        if (r.f.empty() || r.f[0][0] == '#') continue;
-        if (r.f[0] == "precision") precision = r.f[1];
-        recs.push_back(r);
+        std::string k, v;
+        if ((is >> k >> v) && k == "precision") precision = v;
     }
     auto slurp = [](const char* path) {
         std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -383,10 +313,17 @@ int main(int argc, char** argv) {
         f.read((char*)v.data(), v.size() * sizeof(float));
         return v;
     };
-    g_weights = slurp(argv[2]);
     std::vector<float> input = slurp(argv[3]);
+    if (argc > 6 && std::string(argv[5]) == "worker") {
+        Env<MI355X>::env_init();
+        return run_worker(argv[1], input, argv[4], atoi(argv[6]), argc > 7 ? atoi(argv[7]) : 64);
+    }
+    if (argc > 6 && std::string(argv[5]) == "calibrate") {
+        Env<MI355X>::env_init();
+        return run_calibrate(argv[1], input, argv[4], atoi(argv[6]));
+    }
     const int iters = argc > 5 ? (std::string(argv[5]) == "dry" ? -1 : atoi(argv[5])) : 0;
     Env<MI355X>::env_init();
-    if (precision == "int8") return run<Precision::INT8>(recs, input, argv[4], iters);
-    return run<Precision::FP32>(recs, input, argv[4], iters);
+    if (precision == "int8") return run<Precision::INT8>(argv[1], input, argv[4], iters);
+    return run<Precision::FP32>(argv[1], input, argv[4], iters);
 }

@@ -521,6 +521,8 @@ CHAIN3_CASES = [
     (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, None),
     (128, 2, 28, 28, O.U8, O.U8, O.U8, 1, 1, 5),    # 8 waves per workgroup
     (128, 1, 5, 17, O.U8, O.S8, O.U8, 1, 1, 6),
+    (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, 3),    # C = 256, 8 waves per workgroup
+    (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, 3),
 ]
 
 
