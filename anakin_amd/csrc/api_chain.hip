@@ -43,14 +43,15 @@ static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave,
                 }
 }
 // the 3x3 conv's weights [K][C][3][3] -> per wave, steps ordered [tap][k-step][accumulator] (conv1x1_chain.hip phase 0)
-static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out, int nw = 4) {
-    const int kw = C / nw, mf0 = kw / 16, ksn = C / 64;
+static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out, int nw = 4, int kbase = 0, int kcount = 0) {
+    // kcount > 0: this workgroup's share of the output channels (rows kbase .. kbase + kcount - 1)
+    const int kw = (kcount ? kcount : C) / nw, mf0 = kw / 16, ksn = C / 64;
     for (int tap = 0; tap < 9; ++tap)
         for (int ks = 0; ks < ksn; ++ks)
             for (int mf = 0; mf < mf0; ++mf)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int rho = lane & 15, kq = lane >> 4;
-                    const int ch = wave * kw + (rho >> 2) * 4 * mf0 + mf * 4 + (rho & 3);
+                    const int ch = kbase + wave * kw + (rho >> 2) * 4 * mf0 + mf * 4 + (rho & 3);
                     for (int t = 0; t < 16; ++t) {
                         const int c = ks * 64 + kq * 16 + t;
                         out.push_back((uint8_t)w[((size_t)ch * C + c) * 9 + tap]);
@@ -102,7 +103,8 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, mfg2, w, stream);
     }
     pack_chain_params(a, (size_t)da.k / 4 * 3, p1);
-    if (b) pack_chain_params(b, ((size_t)k2 / 4 * 3 + 63) / 64 * 64, p2);
+    if (b) pack_chain_params(b, ((size_t)k2 / 4 * 3 + 63) / 64 * 64 + 64, p2);      // (+ 64 chunks of slack: the cooperative kernel
+                                                                                     // DMAs whole 64-chunk blocks from a half's offset)
     hipError_t e = ch->d_stream.upload(stream);
     if (e == hipSuccess && !c3 && da.c >= 256) {
         std::vector<uint8_t> sp;
@@ -137,10 +139,29 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         }
         e = ch->d_stream_w8.upload(s8);
     }
+    if (e == hipSuccess && da.c == 256 && c3 && b && c3->d.stride_h == 1 && xcd_round_robin()) {
+        // cooperative form (conv_chain_coop.hip): per (half, wave) [3x3: 16 channels][1x1: 64 channels][1x1: 16 channels]; tiles of one
+        // row x 16 columns; needs the workgroup -> XCD placement the hand-off relies on (probed once per device)
+        std::vector<uint8_t> sc;
+        sc.reserve(stream.size());
+        for (int half = 0; half < 2; ++half)
+            for (int w = 0; w < 8; ++w) {
+                pack_chain_weights3(c3->wq_oihw.data(), da.c, w, sc, 8, half * (da.c / 2), da.c / 2);
+                pack_chain_weights(a->wq_oihw.data(), da.k / 2, da.c, 4, w, sc, half * (da.k / 2), 8);
+                pack_chain_weights(b->wq_oihw.data(), k2 / 2, c2, 1, w, sc, half * (k2 / 2), 8);
+            }
+        ch->coop_tiles = da.n * da.h * ((da.w + 15) / 16);
+        e = ch->d_stream_coop.upload(sc);
+        if (e == hipSuccess) e = ch->d_coop_ctr.alloc_zero((size_t)ch->coop_tiles * 32);      // a 128-byte line per (tile, barrier)
+        if (e == hipSuccess) e = ch->d_coop_xcc.alloc_zero((size_t)ch->coop_tiles * 32);
+        if (e == hipSuccess) e = ch->d_coop_xch.alloc_zero((size_t)ch->coop_tiles * 16 * da.c);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&ch->h_coop_err, sizeof(unsigned), hipHostMallocMapped);
+        if (e == hipSuccess) *ch->h_coop_err = 0u;
+    }
     if (e == hipSuccess) e = ch->d_prm1.upload(p1);
     if (e == hipSuccess && b) e = ch->d_prm2.upload(p2);
     if (e == hipSuccess && c3) {
-        pack_chain_params(c3, ((size_t)da.c / 4 * 3 + 63) / 64 * 64, p0);
+        pack_chain_params(c3, ((size_t)da.c / 4 * 3 + 63) / 64 * 64 + 64, p0);
         e = ch->d_prm0.upload(p0);
     }
     if (e != hipSuccess) {
@@ -163,7 +184,8 @@ int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
                     (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) || (ch->c1 == 256 && tn == 3 && ch->c3 && ch->d_stream_w8.p) ||
-                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b);
+                    (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b) ||
+                    (ch->c1 == 256 && tn == 7 && ch->d_stream_coop.p);
     if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
     ch->tn = tn;
     return SABER_HIP_OK;
@@ -208,6 +230,24 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         k.s0 = ch->c3->d.stride_h;
         k.H0 = ch->c3->d.h; k.W0 = ch->c3->d.w;
         if (a->d.res_stride > 1) { k.res_sub = a->d.res_stride; k.res_H = a->d.res_h; k.res_W = a->d.res_w; }
+    }
+    if (ch->c1 == 256 && ch->tn == 7) {      // two cooperating workgroups per pixel tile
+        if (*(volatile unsigned*)ch->h_coop_err) {      // an earlier launch found its halves on different XCDs or timed out in a barrier
+            *(volatile unsigned*)ch->h_coop_err = 0u;
+            ch->tn = 3;
+            return fail(SABER_HIP_RUNTIME_ERROR, "cooperative chain: an earlier launch's workgroup pairs did not share an XCD or timed out at their "
+                        "barrier (its outputs are not valid); the chain now runs the single-workgroup form");
+        }
+        CoopKArgs ck;
+        ck.c = k;
+        ck.c.wstream = ch->d_stream_coop.p;
+        ck.coop_ctr = ch->d_coop_ctr.p;
+        ck.coop_xch = ch->d_coop_xch.p;
+        ck.coop_xcc = ch->d_coop_xcc.p;
+        ck.coop_err = ch->h_coop_err;
+        ck.n_tiles = ch->coop_tiles;
+        HIP_TRY(launch_conv_chain_coop(ck, (hipStream_t)stream));
+        return SABER_HIP_OK;
     }
     HIP_TRY(launch_conv1x1_chain(k, ch->c1, ch->k1, ch->k2, ch->tn, ch->c3 ? 1 : 0, (hipStream_t)stream));
     return SABER_HIP_OK;

@@ -88,7 +88,7 @@ static bool f32_static_b3(const saber_hip_conv* op) {
 }
 // 1 when workgroup b of a 1-D grid runs on XCD (b + const) % 8 on the current device - workgroups 8 apart share an XCD
 // (checked once per device with 2048-workgroup launches; 0 also on any failure): the split-K kernels hand partial sums over inside one XCD's L2 and are offered only then.
-static bool xcd_round_robin() {
+bool xcd_round_robin() {
     static std::mutex mu;
     static int state[64] = {0};          // 0 unknown, 1 yes, 2 no
     int dev = 0;

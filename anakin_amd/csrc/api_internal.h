@@ -150,6 +150,16 @@ struct saber_hip_chain {
     DevBuf<uint8_t> d_stream_split;   // 1x1 chains with C >= 256: [half][wave] streams for the split second conv (tile | 8)
     DevBuf<uint8_t> d_stream_split8;  // C == 256: the same for 8 waves per workgroup (tile 11)
     DevBuf<uint8_t> d_stream_w8;      // C == 128: the whole stream for 8 waves per workgroup (tile | 4)
+    // C == 256, 3x3-led, tile 7: two cooperating workgroups per pixel tile (conv_chain_coop.hip): [half][wave] streams, the pairs'
+    // arrival counters, the exchange buffer of the 3x3 conv's tile, the halves' XCC ids, and the pinned error word
+    DevBuf<uint8_t> d_stream_coop, d_coop_xch;
+    DevBuf<unsigned long long> d_coop_ctr;
+    DevBuf<unsigned> d_coop_xcc;
+    unsigned* h_coop_err = nullptr;
+    int coop_tiles = 0;
+    ~saber_hip_chain() {
+        if (h_coop_err) (void)hipHostFree(h_coop_err);
+    }
 };
 
 struct saber_hip_fc {
@@ -377,6 +387,7 @@ void name_algo(saber_hip_conv* op);      // api_conv.hip
 // FP32 split-K (b3 kernels): 2^sh workgroups per tile; needs >= 2 stages per split, a bounded partial buffer, and the
 // workgroup -> XCD placement the hand-off relies on (checked once per device). split_prepare allocates the buffers.
 bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh);      // api_conv.hip
+bool xcd_round_robin();      // api_conv.hip: workgroups 8 apart in a 1-D grid share an XCD on the current device (probed once)
 int split_prepare(saber_hip_conv* op);      // api_conv.hip
 // image-resident kernel variant of an INT8 conv on <= 64-pixel images (api_stage.hip)
 bool img_conv_ok(const saber_hip_conv* op);

@@ -201,8 +201,9 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         int rc = timed(&best);
         if (rc) return rc;
         const int c1 = A.chain ? A.chain->c1 : H->chain3->c1;
-        const int tns[4] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9), c1 == 256 ? 11 : (c1 == 128 ? 6 : 0),
-                            c1 == 128 ? 5 : (c1 == 256 ? 3 : 0)};      // (C = 256, code 3: the 3x3-led forms with 8 waves; refused elsewhere)
+        const int tns[5] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9), c1 == 256 ? 11 : (c1 == 128 ? 6 : 0),
+                            c1 == 128 ? 5 : (c1 == 256 ? 3 : 0),       // (C = 256, code 3: the 3x3-led forms with 8 waves; refused elsewhere)
+                            c1 == 256 ? 7 : 0};                        // (code 7: two cooperating workgroups per tile, 3x3-led with a second 1x1 conv)
         for (int mode = A.chain ? 1 : 2; mode <= (H ? 2 : 1); ++mode) {
             saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
             for (int tn : tns) {

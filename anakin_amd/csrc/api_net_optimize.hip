@@ -45,7 +45,8 @@ void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
         H->use_chain3 = mode == 2;
         H->name = mode == 2 ? std::string("conv:conv3x3+") + (H->chain3->b ? "chain1x1_c" : "conv1x1_c") + std::to_string(H->chain3->c1) +
                                   "_" + std::to_string(H->chain3->c1 == 128 ? H->chain3->tn & 3 : (H->chain3->c1 == 256 ? 1 : H->chain3->tn)) + "x16" +
-                                  ((H->chain3->c1 == 128 && (H->chain3->tn & 4)) || (H->chain3->c1 == 256 && H->chain3->tn == 3) ? "_w8" : "")
+                                  ((H->chain3->c1 == 128 && (H->chain3->tn & 4)) || (H->chain3->c1 == 256 && H->chain3->tn == 3) ? "_w8" : "") +
+                                  (H->chain3->c1 == 256 && H->chain3->tn == 7 ? "_coop2" : "")
                             : std::string("conv:") + H->conv->algo_name;
     }
     if (B) net_name_chain(A, *B);

@@ -53,6 +53,19 @@ __device__ __forceinline__ int sat_u8(float v) {
 }
 
 // One 16-row x 16-col x 64-byte MFMA step.
+// 16-byte loads that read the XCD's L2 as it is NOW (sc1: they do not hit in this CU's L1) - how one workgroup reads what another
+// workgroup OF THE SAME XCD has just stored (plain stores + s_waitcnt vmcnt(0) + a relaxed atomic flag), without the device-scope
+// `buffer_inv sc1`, which on this multi-XCD part also drops every non-coherent line of the XCD's L2. Buffer loads rather than
+// inline-asm global loads: the compiler tracks their s_waitcnt (an asm load's result may be copied before it has landed).
+// `base` must be wave-uniform; offsets are bytes, < 4 GB.
+struct L2Reader {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ explicit L2Reader(const void* base)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000)) {}
+    __device__ __forceinline__ v4i load16(unsigned byte_off) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16 /* sc1 */);
+    }
+};
 __device__ __forceinline__ v4i mma_step(v4i a, v4i b, v4i c) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
 }
@@ -840,18 +853,23 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_kernel(const ConvKArgs a
                 return;
             }
             if (tid == 0) a.part_ctr[tile_L] = 0u;           // re-armed for the next launch
-            asm volatile("buffer_inv sc1" ::: "memory");     // this CU's L1 may hold the partials of an earlier launch
-            const v4f* pr = (const v4f*)a.part + ((size_t)(tile_L * S) * NWAVE + wave) * (TM * TN * 64) + lane;
+            // The partials are read with sc1 buffer LOADS (L2Reader: they miss this CU's L1, which may hold an earlier launch's lines,
+            // and hit the XCD's L2). Round 3 used `buffer_inv sc1` + plain loads: a DEVICE-scope acquire, which on this multi-XCD part
+            // also drops the L2's non-coherent lines - every tile's last arrival wiped its XCD's cached weights and activations for all
+            // the workgroups sharing that L2 (found with the cooperative chain's in-kernel stamps, conv_chain_coop.hip; FP32 ResNet50
+            // batch 8: 7 723 -> 8 020 images/s from this line alone).
+            const L2Reader part_l2(a.part);
+            const unsigned pr0 = (unsigned)(((size_t)(tile_L * S) * NWAVE + wave) * (TM * TN * 64) + lane) * 16u;     // byte offset
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = pr[(i * TN + j) * 64];
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_bit_cast(v4f, part_l2.load16(pr0 + (i * TN + j) * 1024u));
             for (int s2 = 1; s2 < S; ++s2) {
-                pr += NWAVE * (TM * TN * 64);
+                const unsigned prs = pr0 + (unsigned)s2 * (NWAVE * (TM * TN * 64) * 16u);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] + pr[(i * TN + j) * 64];
+                    for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] + __builtin_bit_cast(v4f, part_l2.load16(prs + (i * TN + j) * 1024u));
             }
             if (s_old != (unsigned)(S - 1) << (4u * xcc)) {
                 if (tid == 0 && a.part_err) __hip_atomic_fetch_add(a.part_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -134,11 +134,24 @@ struct ChainKArgs {
     int s0, H0, W0;                    // stride of the leading 3x3 conv (1 | 2) and, for 2, its input dims (H, W are the output's)
     int res_sub, res_H, res_W;         // s0 == 2: the shortcut is [N][res_H][res_W][K1], read at (y * res_sub, x * res_sub)
 };
+// cooperative form (conv_chain_coop.hip): TWO workgroups of one XCD per pixel tile, each computing half of every conv's output
+// channels; the 3x3 conv's tile and the first 1x1 conv's tile are handed over through that XCD's L2. (Its own block: every byte of
+// kernel argument is copied per launch by the eager path - the ordinary chain launches do not pay for these fields.)
+struct CoopKArgs {
+    ChainKArgs c;
+    unsigned long long* coop_ctr;      // [tiles][2 barriers][16]: arrival counters, one per 128-byte line (parity protocol: never reset)
+    void* coop_xch;                    // [tiles][16 pixels][C1] the 3x3 conv's 8-bit output tile
+    unsigned* coop_xcc;                // [tiles][32]: words 0 / 1 = the XCD each half ran on (checked against each other); a line per tile
+    unsigned* coop_err;                // host-visible word: placement violations / barrier time-outs are counted here
+    int n_tiles;
+};
 bool conv1x1_chain_ok(int c1, int k1, int k2);
 // number of 16-pixel fragments per workgroup the launcher uses for (c1, m) / 0 if unsupported
 int conv1x1_chain_tn(int c1, int m);
 // bytes of the packed weight stream / its per-wave step geometry
 hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, int with3x3, hipStream_t s);
+// conv3x3 + conv1x1 (+ eltwise) + conv1x1 at C1 = 256 with the weight stream split over two cooperating workgroups per pixel tile
+hipError_t launch_conv_chain_coop(const CoopKArgs& a, hipStream_t s);
 
 // stage_xcd_kernel (stage_xcd.hip): a run of INT8 convolutions over small images as ONE persistent launch, one image per XCD
 // at a time, the phases separated by an XCD-local barrier instead of a kernel boundary.

@@ -46,6 +46,11 @@ __device__ __forceinline__ void stage_dma16(const void* src, void* dst_wave_base
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
 }
+// ... with sc1: the load misses this CU's L1 and reads the XCD's L2 - what another workgroup of the XCD stored in an earlier phase
+__device__ __forceinline__ void stage_dma16_l2(const void* src, void* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 16);
+}
 
 struct StageCtx {
     int xcd, cu;                  // this workgroup's XCD and its number within it
@@ -113,7 +118,11 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
         }
         __syncthreads();
         if (*s_abort) return false;
-        asm volatile("buffer_inv sc1" ::: "memory");     // drop this CU's L1 lines: what follows reads the L2
+        // (round 3 had `buffer_inv sc1` here - a DEVICE-scope acquire, which on this multi-XCD part also drops every non-coherent
+        // line of the XCD's L2: 32 workgroups x 10 phases wiped their XCD's cached weights and images continuously, which is
+        // most of what profiles/r03/stage_trace.txt blamed on the fabric ports. What other workgroups stored is read with sc1
+        // loads instead - stage_dma16_l2 for the image, an agent-scope atomic load for the residual - found with the cooperative
+        // chain's in-kernel stamps, conv_chain_coop.hip)
     }
     STAGE_TR(3);
     const unsigned pch = php->pch, mg = php->mg_pch;
@@ -144,7 +153,9 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
                 const unsigned L = (unsigned)(i * 64 + lane);
                 const unsigned hp = __umulhi(L, mg), cc = L - hp * pch;
                 const bool in = hp < (unsigned)HW && cc < (unsigned)chunks;
-                stage_dma16(in ? xg + (size_t)hp * cin + cc * 16 : (const char*)a.zero, lds + i * 64);
+                const char* src = in ? xg + (size_t)hp * cin + cc * 16 : (const char*)a.zero;
+                if (barrier) stage_dma16_l2(src, lds + i * 64);
+                else stage_dma16(src, lds + i * 64);
             }
         }
         if (first) STAGE_TR(4);
@@ -154,7 +165,8 @@ __device__ __forceinline__ bool stage_phase(const StageKArgs& a, PhasePtr php, S
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int ch = ch0 + 16 * j;
-                rs[j] = (my_p < HW && ch < cout) ? *(const unsigned*)(rin + ((size_t)img * HW + my_p) * cout + ch) : 0u;
+                // (sc1 load: the residual may be an earlier phase's output, stored by another workgroup of this XCD)
+                rs[j] = (my_p < HW && ch < cout) ? __hip_atomic_load((const unsigned*)(rin + ((size_t)img * HW + my_p) * cout + ch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

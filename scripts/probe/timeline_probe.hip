@@ -25,6 +25,7 @@ __device__ unsigned long long* saber_tl_buf = nullptr;
 #include "../../anakin_amd/csrc/halo_e1.hip"
 #include "../../anakin_amd/csrc/stem_pool.hip"
 #include "../../anakin_amd/csrc/conv1x1_chain.hip"
+#include "../../anakin_amd/csrc/conv_chain_coop.hip"
 namespace saber_mi355x {
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
     static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
@@ -126,6 +127,43 @@ int main(int argc, char** argv) {
     void* zero = dalloc(256, 0);
 
     run(P, "empty kernel (256 WGs)", 256, 1, [&] { hipLaunchKernelGGL(null_kernel, dim3(256), dim3(256), 0, P.st, P.out); });
+    if (argc > 1 && !strcmp(argv[1], "coop")) {
+        // 3x3-led chain at C = 256, 14 x 14: one workgroup per tile with 8 waves (tile code 3) against two cooperating workgroups
+        // (conv_chain_coop.hip). Coop phases: 0 entry, 1 DMA + ring landed, 2 3x3 done + tile stored, 3 past the first pair barrier,
+        // 4 first 1x1 done + y1 stored, 5 past the second barrier, 6 done
+        for (int n : {8, 1}) {
+            const int c = 256, hw = 14, K1 = 1024, M = n * hw * hw;
+            ChainKArgs a;
+            memset(&a, 0, sizeof a);
+            a.M = M; a.in_u8 = 1; a.relu1 = 0; a.res_relu = 1; a.coeff_conv = 16.f; a.scale_conv = 0.05f; a.coeff_res = 16.f;
+            a.scale_res = 0.04f; a.relu2 = 1; a.out_u8_2 = 1;
+            a.x = dalloc((size_t)M * c, -1); a.res = dalloc((size_t)M * K1, -1);
+            a.prm1 = dalloc((size_t)K1 * 12, 0); a.prm2 = dalloc((size_t)c * 12 + 2048, 0);
+            a.y1 = dalloc((size_t)M * K1, 0); a.y2 = dalloc((size_t)M * c, 0);
+            a.wstream = dalloc((size_t)2 * K1 * c + (size_t)9 * c * c + 65536, -1);
+            auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };
+            a.prm0 = dalloc((size_t)c * 12 + 2048, 0); a.zero = zero; a.N = n; a.H = a.W = hw;
+            a.tiles_x = 1; a.tiles_per_img = hw; a.mg_tiles_x = magic(1); a.mg_tpi = magic(hw); a.in0_u8 = 1; a.relu0 = 1;
+            a.s0 = 1;
+            const int tiles = n * hw;
+            char nm[96];
+            snprintf(nm, sizeof nm, "conv3x3+chain C=256 14x14 b%d 1x16 w8", n);
+            run(P, nm, tiles, 6, [&] { launch_conv1x1_chain(a, c, K1, c, 3, 1, P.st); });
+            CoopKArgs ck;
+            ck.c = a;
+            ck.coop_ctr = (unsigned long long*)dalloc((size_t)tiles * 32 * 8, 0);
+            ck.coop_xcc = (unsigned*)dalloc((size_t)tiles * 32 * 4, 0);
+            ck.coop_xch = dalloc((size_t)tiles * 16 * c, 0);
+            ck.coop_err = (unsigned*)dalloc(64, 0);
+            ck.n_tiles = tiles;
+            snprintf(nm, sizeof nm, "conv3x3+chain C=256 14x14 b%d coop2", n);
+            run(P, nm, (tiles + 7) / 8 * 16, 7, [&] { launch_conv_chain_coop(ck, P.st); });
+            unsigned errs = 0;
+            CK(hipMemcpy(&errs, ck.coop_err, 4, hipMemcpyDeviceToHost));
+            printf("    coop error word: %u\n", errs);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "chain")) {
         // conv1x1 chain: phases 0 entry, 1 loads / DMA issued, 2 first group's MFMAs done + DMA barrier, 3 first conv done,
         // 4 tile stored / second conv's operand in registers, 5 done

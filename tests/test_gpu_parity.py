@@ -523,6 +523,10 @@ CHAIN3_CASES = [
     (128, 1, 5, 17, O.U8, O.S8, O.U8, 1, 1, 6),
     (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, 3),    # C = 256, 8 waves per workgroup
     (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, 3),
+    (256, 8, 14, 14, O.U8, O.U8, O.U8, 1, 1, 7),    # C = 256, two cooperating workgroups per tile (conv_chain_coop.hip): res4 at batch 8
+    (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, 7),
+    (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, 7),      # ragged: 3 tiles of 5 columns
+    (256, 3, 5, 37, O.U8, O.S8, O.U8, 1, 0, 7),     # three column tiles per row, the last one ragged
 ]
 
 
@@ -574,12 +578,16 @@ def test_conv3x3_chain_equals_three_launches_and_oracle(case):
     z1, z2 = ca.new_output(), cb.new_output()
     z1.fill_(77)
     z2.fill_(77)
-    chain.dispatch(dev(x), dev(res), z1, z2)
-    assert np.array_equal(host(z1), want1), ("y1", chain.tile())
-    assert np.array_equal(host(z2), want2), ("y2", chain.tile())
+    for rep in range(3 if tn == 7 else 1):        # (the cooperative form's pair counters are never reset: launch after launch)
+        z1.fill_(77)
+        z2.fill_(77)
+        chain.dispatch(dev(x), dev(res), z1, z2)
+        assert chain.tile() == (tn if tn is not None else chain.tile())
+        assert np.array_equal(host(z1), want1), ("y1", chain.tile(), rep)
+        assert np.array_equal(host(z2), want2), ("y2", chain.tile(), rep)
     # conv3x3 + first 1x1 conv only (the last block of a stage: no 1x1 conv follows on the same pixels)
     double = S.SaberConvChain(ca, None, conv3x3=c0)
-    if tn is not None:
+    if tn is not None and tn != 7:
         double.set_tile(tn)
     z1.fill_(55)
     double.dispatch(dev(x), dev(res), z1)
