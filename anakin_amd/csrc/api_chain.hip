@@ -29,18 +29,21 @@ static void pack_chain_params(const saber_hip_conv* o, size_t chunks_pad, std::v
 // = 64 lanes x 16 bytes in MFMA A-operand order (row = lane & 15, k-group = lane >> 4); row rho of accumulator mf is
 // channel  base + (rho >> 2) * 4*mfg + mf*4 + (rho & 3)   (conv1x1_chain.hip)
 static void pack_chain_weights(const int8_t* w, int K, int C, int mfg, int wave, std::vector<uint8_t>& out, int kbase = 0,
-                               int nw = 4) {
-    // K: channels of this workgroup's share (rows kbase .. kbase + K - 1 of w), nw waves
+                               int nw = 4, int ks0 = 0) {
+    // K: channels of this workgroup's share (rows kbase .. kbase + K - 1 of w), nw waves; ks0: the k-step the stream starts with
+    // (cooperative form: the k-steps over this workgroup's OWN half of the input channels come first)
     const int kw = K / nw, groups = kw / (16 * mfg), ksn = C / 64;
     for (int g = 0; g < groups; ++g)
-        for (int ks = 0; ks < ksn; ++ks)
-            for (int mf = 0; mf < mfg; ++mf)
+        for (int ksi = 0; ksi < ksn; ++ksi)
+            for (int mf = 0; mf < mfg; ++mf) {
+                const int ks = (ks0 + ksi) % ksn;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int rho = lane & 15, kq = lane >> 4;
                     const int ch = kbase + wave * kw + g * 16 * mfg + (rho >> 2) * 4 * mfg + mf * 4 + (rho & 3);
                     const int8_t* src = w + (size_t)ch * C + ks * 64 + kq * 16;
                     out.insert(out.end(), (const uint8_t*)src, (const uint8_t*)src + 16);
                 }
+            }
 }
 // the 3x3 conv's weights [K][C][3][3] -> per wave, steps ordered [tap][k-step][accumulator] (conv1x1_chain.hip phase 0)
 static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<uint8_t>& out, int nw = 4, int kbase = 0, int kcount = 0) {
@@ -147,8 +150,8 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         for (int half = 0; half < 2; ++half)
             for (int w = 0; w < 8; ++w) {
                 pack_chain_weights3(c3->wq_oihw.data(), da.c, w, sc, 8, half * (da.c / 2), da.c / 2);
-                pack_chain_weights(a->wq_oihw.data(), da.k / 2, da.c, 4, w, sc, half * (da.k / 2), 8);
-                pack_chain_weights(b->wq_oihw.data(), k2 / 2, c2, 1, w, sc, half * (k2 / 2), 8);
+                pack_chain_weights(a->wq_oihw.data(), da.k / 2, da.c, 4, w, sc, half * (da.k / 2), 8, half * (da.c / 128));
+                pack_chain_weights(b->wq_oihw.data(), k2 / 2, c2, 1, w, sc, half * (k2 / 2), 8, half * (c2 / 128));
             }
         ch->coop_tiles = da.n * da.h * ((da.w + 15) / 16);
         e = ch->d_stream_coop.upload(sc);

@@ -6,11 +6,12 @@
 // 64 B/clk with eight waves, so the launch's 11.5 us IS its weight stream, while 112 of 256 CUs have a workgroup at all. The
 // only lever left is fewer weight bytes per CU: two workgroups share a tile, each computes HALF of every convolution's output
 // channels (integer sums: the bits cannot change), 557 KB per CU, 224 CUs busy.
-//   phase 0   3x3: mid channels [h * 128, + 128)                         -> xch[tile][pixel][256]   (global, through the L2)
-//   -- pair barrier --                                                      both read the whole 16 x 256 mid tile
-//   phase 1   1x1 + eltwise: channels [h * 512, + 512), residual half     -> y1 (the operator's own output tensor)
-//   -- pair barrier --                                                      both read the whole 16 x 1024 tile of y1
+//   phase 0   3x3: mid channels [h * 128, + 128)                         -> xch[tile][pixel][256] (global, through the L2) + LDS
+//   arrive 1 ... phase 1's k-steps over THIS half's mid channels (LDS) ... wait 1 ... the partner's half (sc1 loads from the L2)
+//   phase 1   1x1 + eltwise: channels [h * 512, + 512), residual half     -> y1 (the operator's own output tensor) + LDS
+//   arrive 2 ... phase 2's k-steps over this half's y1 channels (LDS) ... wait 2 ... the partner's half (sc1 loads)
 //   phase 2   1x1: channels [h * 128, + 128)                              -> y2
+// (each half's weight stream is packed with its own k-steps first; integer sums: the order cannot change a bit)
 // The two workgroups of a tile are 8 apart in the grid = the same XCD (the placement api_conv.hip: xcd_round_robin verifies once
 // per device; each half also publishes its XCC_ID and the pair compares them), so the hand-off needs no L2 write-back: plain
 // stores, s_waitcnt vmcnt(0), one relaxed agent-scope atomic on the pair's counter, a spin on SCALAR loads (they do not queue
@@ -35,30 +36,33 @@ __device__ __forceinline__ unsigned long long coop_sload(const unsigned long lon
     return v;
 }
 
-// both workgroups of the pair have made their stores visible in the XCD's L2 when this returns
-__device__ __forceinline__ void coop_pair_barrier(unsigned long long* ctr, unsigned* err) {
+// The pair's barrier, split in two so that the wait can sit behind work that does not need the partner: ARRIVE (per wave: its
+// stores are in the XCD's L2, then one arrival on the pair's counter) ... work on this workgroup's own half ... WAIT (per wave:
+// spin on scalar loads - they do not queue behind the wave's weight loads - until all 16 waves of the pair have arrived).
+// The counter is never reset: 16 arrivals per launch bring it back to a multiple of 16.
+// NO cache invalidate anywhere: `buffer_inv sc1` is a DEVICE-scope acquire, which on this multi-XCD part also drops the L2's
+// non-coherent lines - every workgroup passing a barrier wiped its XCD's copy of the weight stream for all 28 workgroups sharing that
+// L2 (measured with the in-kernel stamps: 13 us in the first barrier, 14 us for the 1 us third phase at batch 8). What the partner
+// wrote is read with sc1 LOADS instead (L2Reader, conv_igemm_impl.h): they miss the L1 and hit the L2.
+// The arrival is a WORKGROUP-scope atomic on purpose: it executes in this XCD's L2, which is all the pair needs (both halves run on
+// one XCD); an AGENT-scope atomic is performed beyond the L2 on this multi-XCD part and took 1.6 us per arrival (in-kernel stamps).
+// Its return value is consumed only in coop_wait, so the wave does not stall on it here.
+__device__ __forceinline__ unsigned long long coop_arrive(unsigned long long* ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old & 1ull) == 0ull) {                      // first of the pair: wait for the partner's arrival
-            int spins = 0;
-            while ((coop_sload(ctr) & 1ull) != 0ull) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > 200000) {                  // ~20 ms: give up loudly (see the file header)
-                    if (err) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    // leave the counter even for the next launch: the partner's arrival, when it comes, finds an odd... so add ours back
-                    __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+    unsigned long long old = 0;
+    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return old;
+}
+__device__ __forceinline__ void coop_wait(const unsigned long long* ctr, unsigned long long token, unsigned* err) {
+    asm volatile("" ::"v"(token));                       // this wave's own arrival has been PERFORMED before it looks at the counter
+    int spins = 0;
+    while ((coop_sload(ctr) & 15ull) != 0ull) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 200000) {                          // ~20 ms: give up loudly (see the file header)
+            if (err && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
         }
     }
-    __syncthreads();
-    // NO cache invalidate here: `buffer_inv sc1` is a DEVICE-scope acquire, which on this multi-XCD part also drops the L2's
-    // non-coherent lines - i.e. every workgroup passing a barrier wiped its XCD's copy of the weight stream for all 28 workgroups
-    // sharing that L2 (measured with the in-kernel stamps: 13 us in the first barrier and 14 us for the 1 us third phase at
-    // batch 8). What the partner wrote is read with sc1 LOADS instead (L2Reader, conv_igemm_impl.h): they miss the L1 and hit the L2.
 }
 
 }  // namespace
@@ -75,9 +79,12 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
     constexpr int CPRW = K1W / 16;                           // 16-byte chunks per row of the residual / output half tile: 32
     constexpr int P0C = (K0W / 4 * 3 + 63) / 64 * 64, P1C = K1W / 4 * 3, P2C = (K2W / 4 * 3 + 63) / 64 * 64;
     static_assert(P1C % 64 == 0 && (16 * CPRW) % 64 == 0, "DMA granularity");
+    static_assert(T2 == R, "the second 1x1 conv's steps are all in the ring when it starts");
 
+    constexpr int MPC = K0W / 16 + 1;                        // LDS pitch (chunks) of this half's 3x3 output tile: 8 + 1 padding
     __shared__ v4i halo[HCH];
     __shared__ v4i tile[16 * CPRW];
+    __shared__ v4i mid_own[16 * MPC];
     __shared__ v4i prm0[P0C];
     __shared__ v4i prm1[P1C];
     __shared__ v4i prm2[P2C];
@@ -165,37 +172,52 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
         const float off0 = a.in_u8 ? 0.f : 128.f;
         const unsigned xo0 = a.in_u8 ? 0u : 0x80808080u;
         const unsigned o = chain_out_pack(acc, v4i{0, 0, 0, 0}, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), lo0, off0, xo0);
-        *(unsigned*)((char*)ka.coop_xch + ((size_t)t * 16 + frow) * C1 + half * K0W + c0) = o;
+        *(unsigned*)((char*)ka.coop_xch + ((size_t)t * 16 + frow) * C1 + half * K0W + c0) = o;     // for the partner (through the L2)
+        *(unsigned*)((char*)mid_own + frow * (MPC * 16) + c0) = o;                                   // for this workgroup (LDS)
     }
+    const unsigned long long tok1 = coop_arrive(ka.coop_ctr + t * 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // mid_own is complete
     SABER_TL(2);
-    coop_pair_barrier(ka.coop_ctr + t * 32, ka.coop_err);
-    if (tid == 0 && ka.coop_err &&
-        __hip_atomic_load(ka.coop_xcc + t * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-            __hip_atomic_load(ka.coop_xcc + t * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        __hip_atomic_fetch_add(ka.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    SABER_TL(3);
 
-    // ================= phase 1: 1x1 conv + eltwise, 64 channels per wave =========================================================
+    // ================= phase 1: 1x1 conv + eltwise, 64 channels per wave; k-steps of this half's mid channels first ===============
     {
-        v4i bx[KS1];
         const int xmask = a.in_u8 ? (int)0x80808080u : 0;
-        const L2Reader xch_l2(ka.coop_xch);
-        const unsigned mo = (unsigned)(((size_t)t * 16 + frow) * C1 + fq * 16);
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) bx[ks] = xch_l2.load16(mo + ks * 64);
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-            bx[ks].x ^= xmask; bx[ks].y ^= xmask; bx[ks].z ^= xmask; bx[ks].w ^= xmask;
-        }
         const int cg = wave * 64 + fq * 16;                  // within this half: 16 consecutive channels of pixel frow
         const v4i* pp = prm1 + (cg / 4) * 3;
         v4i acc[4];
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) acc[mf] = pp[mf * 3 + 2];
+        v4i bo[KS1 / 2];
 #pragma unroll
-        for (int s = 0; s < T1; ++s) {
-            const int ri = (T0 + s) % R, ks = s / 4, mf = s % 4;
-            acc[mf] = mma_step(ring[ri], bx[ks], acc[mf]);
+        for (int k = 0; k < KS1 / 2; ++k) {
+            bo[k] = mid_own[frow * MPC + k * 4 + fq];
+            bo[k].x ^= xmask; bo[k].y ^= xmask; bo[k].z ^= xmask; bo[k].w ^= xmask;
+        }
+#pragma unroll
+        for (int s = 0; s < T1 / 2; ++s) {                   // the stream holds this half's k-steps first (api_chain.hip: ks0)
+            const int ri = (T0 + s) % R, k = s / 4, mf = s % 4;
+            acc[mf] = mma_step(ring[ri], bo[k], acc[mf]);
+            ring[ri] = wsb[s * 64 + lane];
+        }
+        coop_wait(ka.coop_ctr + t * 32, tok1, ka.coop_err);        // the partner's half of the 3x3 tile is in the L2
+        if (tid == 0 && ka.coop_err &&
+            __hip_atomic_load(ka.coop_xcc + t * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                __hip_atomic_load(ka.coop_xcc + t * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_add(ka.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        SABER_TL(3);
+        const L2Reader xch_l2(ka.coop_xch);
+        const unsigned mo = (unsigned)(((size_t)t * 16 + frow) * C1 + (1 - half) * K0W + fq * 16);
+        v4i bp[KS1 / 2];
+#pragma unroll
+        for (int k = 0; k < KS1 / 2; ++k) {
+            bp[k] = xch_l2.load16(mo + k * 64);
+            bp[k].x ^= xmask; bp[k].y ^= xmask; bp[k].z ^= xmask; bp[k].w ^= xmask;
+        }
+#pragma unroll
+        for (int s = T1 / 2; s < T1; ++s) {
+            const int ri = (T0 + s) % R, k = s / 4 - KS1 / 2, mf = s % 4;
+            acc[mf] = mma_step(ring[ri], bp[k], acc[mf]);
             ring[ri] = wsb[s * 64 + lane];
         }
         wsb += T1 * 64;
@@ -219,27 +241,35 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
         const int p = pix(px, ok);
         if (ok) *(v4i*)((char*)a.y1 + (size_t)p * K1 + half * K1W + c * 16) = tile[L];
     }
+    const unsigned long long tok2 = coop_arrive(ka.coop_ctr + t * 32 + 16);
     SABER_TL(4);
-    coop_pair_barrier(ka.coop_ctr + t * 32 + 16, ka.coop_err);
-    SABER_TL(5);
 
-    // ================= phase 2: second 1x1 conv, 16 channels per wave ===========================================================
+    // ================= phase 2: second 1x1 conv, 16 channels per wave; k-steps of this half's y1 channels (still in LDS) first =====
     {
         bool ok;
         const int p = pix(frow, ok);
-        v4i b2[KS2];
-        const L2Reader y1_l2(a.y1);
-        const unsigned yo = (unsigned)((size_t)p * K1 + fq * 16);
-#pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) b2[ks] = y1_l2.load16(yo + ks * 64);
         const int c2 = wave * 16 + fq * 4;                   // within this half
         const v4i* pp = prm2 + (c2 / 4) * 3;
         v4i acc = pp[2];
+        v4i bo[KS2 / 2];
 #pragma unroll
-        for (int s = 0; s < T2; ++s) {
+        for (int k = 0; k < KS2 / 2; ++k) bo[k] = tile[frow * CPRW + ((k * 4 + fq) ^ frow)];
+#pragma unroll
+        for (int s = 0; s < T2 / 2; ++s) {
             const int ri = (T0 + T1 + s) % R;
-            acc = mma_step(ring[ri], b2[s], acc);
-            if (s + R < T2) ring[ri] = wsb[s * 64 + lane];   // the stream ends here
+            acc = mma_step(ring[ri], bo[s], acc);            // (T2 == R: the ring already holds the whole phase, no refills)
+        }
+        coop_wait(ka.coop_ctr + t * 32 + 16, tok2, ka.coop_err);   // the partner's half of the y1 tile is in the L2
+        SABER_TL(5);
+        const L2Reader y1_l2(a.y1);
+        const unsigned yo = (unsigned)((size_t)p * K1 + (1 - half) * K1W + fq * 16);
+        v4i bp[KS2 / 2];
+#pragma unroll
+        for (int k = 0; k < KS2 / 2; ++k) bp[k] = y1_l2.load16(yo + k * 64);
+#pragma unroll
+        for (int s = T2 / 2; s < T2; ++s) {
+            const int ri = (T0 + T1 + s) % R;
+            acc = mma_step(ring[ri], bp[s - T2 / 2], acc);
         }
         const float lo2 = a.relu2 ? 0.f : -3.0e38f;
         const float off2 = a.out_u8_2 ? 0.f : 128.f;

@@ -319,10 +319,16 @@ def main():
         else:
             roof = dict(bound="mfma", achieved=round(dom["mfma_frac"] * dom["mfma_peak"], 2), peak=dom["mfma_peak"], unit="TFLOP/s",
                         frac=dom["mfma_frac"], traffic=None)
-        # HBM traffic of that kernel from the committed PMC passes (profiles/r03/traffic.json: per launch, FETCH_SIZE doubled per
+        # HBM traffic of that kernel from the committed PMC passes (profiles/r04/traffic.json: per launch, FETCH_SIZE doubled per
         # the gfx950 correction) - only while the sources it was measured on are unchanged (src_sha): a stale counter is worse than none
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic.json")))
+            tr = None
+            for rd in ("r04", "r03"):      # the newest profile round whose sources still match
+                tp = os.path.join(ROOT, "profiles", rd, "traffic.json")
+                if os.path.exists(tp):
+                    tr = json.load(open(tp))
+                    if tr.get("src_sha") == L.source_sha():
+                        break
             if tr.get("batch") == B and tr.get("graph") == args.graph and args.precision == "int8" and args.model == "resnet50" \
                     and tr.get("src_sha") == L.source_sha():
                 roof["traffic"] = tr.get("per_kernel", {}).get(dom["kernel"])
