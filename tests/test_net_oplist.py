@@ -137,7 +137,8 @@ def test_resnet101_int8_op_list_is_the_reference_optimisers(tmp_path):
     assert int(head[head.index("plan") + 1]) == 1 and int(head[head.index("captured_ops") + 1]) == 144, dry_run.plan[0]
     assert int(head[head.index("launches") + 1]) <= 72
     r = dry_run(tmp_path / "r101_long", "resnet101", "int8", expect_fail=True)                 # the model's own names: 16 characters
-    assert r.returncode != 0 and "graph_base.inl:99" in r.stderr, r.stderr[-800:]
+    # (undefined behaviour: depending on the heap layout of the build it ends in the CHECK at graph_base.inl:99 or in a SIGSEGV)
+    assert r.returncode != 0, "ResNet101 with its 16-character node names was expected to trip over the reference's remove_byio"
     r = dry_run(tmp_path / "r50_long", "resnet50", "int8", expect_fail=True, rename=lambda n: n if n == "data" else "a_rather_long_prefix_" + n)
     assert r.returncode != 0, "ResNet50 with node names of > 15 characters was expected to trip over the same reference bug"
 
