@@ -6,7 +6,8 @@
 // is exactly h + m + l with three bf16 terms; six products per f32 product accumulated in f32 reproduce it to ~2^-24) -
 // gfx950's f32 MFMA peaks at 157 TFLOP/s, its dense bf16 MFMA at 2.5 PFLOP/s; round 3's kernel (gemm_f32_kernel, elementwise.hip: one
 // 64 x 64 tile on v_mfma_f32_16x16x4_f32, 4-byte loads, two barriers per 16-deep step) reached 45 TFLOP/s = 28 % of the f32 peak and
-// stays as the path for shapes the plane kernels do not take (k % 8 != 0, tiny problems).
+// stays as the path for shapes the plane kernels do not take (k % 8 != 0, tiny problems). A few rows (m <= 16) against [n][k] weights - the
+// shape of an fc - take neither: gemm_f32_rows_kernel below streams B exactly once.
 //   C^T view: out-channels = n (MFMA rows), pixels = m (columns), reduction = k. The "convolution" is a 1 x 1 conv on an NHWC tensor
 //   [1, m, 1, k] -> [1, m, 1, n]: x = op(A) as it lies when A is [m, k] (trans_a: one transposing pre-pass into the plan's scratch),
 //   the weights W[n][k] = alpha * op(B)^T split on the DEVICE into the three bf16 planes the kernel streams (gemm_pack_planes_kernel: B is
@@ -61,6 +62,65 @@ __global__ __launch_bounds__(256) void gemm_pack_planes_kernel(const float* __re
             planes[o] = h;
             planes[plane_elems + o] = m;
             planes[2 * plane_elems + o] = rne(r2);
+        }
+    }
+}
+
+// Few rows (m <= 16) against weights stored [n][k] (trans_b, how an fc keeps them): the problem is ONE pass over B - VGG16's fc6 as a GEMM is
+// a 411 MB stream for 1.6 GFLOP. A workgroup owns RN = 8 rows of B; its four waves split k in 1 KB steps (64 lanes x 16 bytes: coalesced,
+// RN + MR 16-byte loads in flight per lane), every lane keeps RN x MR partial sums, which meet through DPP reductions and LDS. A ([m][k],
+// <= 1.6 MB) is re-read by every workgroup from the L2. Summation order: per lane over its k positions, then lanes, then waves - fixed,
+// so the result is deterministic; vs MKL's order inside the 1e-4 tolerance like every FP32 path.
+template <int MR>
+__global__ __launch_bounds__(256) void gemm_f32_rows_kernel(int m, int n, int k, float alpha, const float* __restrict__ A,
+                                                            const float* __restrict__ B, float beta, float* __restrict__ C) {
+    constexpr int RN = 8;
+    __shared__ float red[4][RN * MR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * RN;
+    float acc[RN][MR];
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[r][i] = 0.f;
+    const int k4 = k >> 2;                                   // k % 4 == 0 (checked by the caller)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int c = wave * 64 + lane; c < k4; c += 256) {
+        f4 bv[RN], av[MR];
+#pragma unroll
+        for (int r = 0; r < RN; ++r) {
+            const int row = n0 + r < n ? n0 + r : n - 1;     // (rows beyond n repeat the last one, never stored)
+            bv[r] = __builtin_nontemporal_load((const f4*)(B + (size_t)row * k) + c);      // streamed once: do not keep it in the caches
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) av[i] = *((const f4*)(A + (size_t)(i < m ? i : m - 1) * k) + c);
+#pragma unroll
+        for (int r = 0; r < RN; ++r)
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                acc[r][i] = __builtin_fmaf(bv[r].x, av[i].x, acc[r][i]);
+                acc[r][i] = __builtin_fmaf(bv[r].y, av[i].y, acc[r][i]);
+                acc[r][i] = __builtin_fmaf(bv[r].z, av[i].z, acc[r][i]);
+                acc[r][i] = __builtin_fmaf(bv[r].w, av[i].w, acc[r][i]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < RN; ++r)
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            float v = acc[r][i];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) red[wave][r * MR + i] = v;
+        }
+    __syncthreads();
+    if (tid < RN * MR) {
+        const int r = tid / MR, i = tid % MR;
+        const float v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        if (n0 + r < n && i < m) {
+            const size_t o = (size_t)i * n + n0 + r;
+            const float av = alpha * v;
+            C[o] = beta == 0.f ? av : av + beta * C[o];
         }
     }
 }
@@ -175,6 +235,15 @@ int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const f
     hipStream_t s = (hipStream_t)stream;
     ta = ta ? 1 : 0;
     tb = tb ? 1 : 0;
+    if (m <= 16 && tb && !ta && k % 4 == 0 && (size_t)n * k >= ((size_t)1 << 20) && !std::getenv("SABER_HIP_GEMM_F32_PLANES")) {
+        // a few rows against [n][k] weights: one pass over B (gemm_f32_rows_kernel)
+        const dim3 grid((n + 7) / 8), block(256);
+        if (m <= 4) hipLaunchKernelGGL(gemm_f32_rows_kernel<4>, grid, block, 0, s, m, n, k, alpha, a, b, beta, c);
+        else if (m <= 8) hipLaunchKernelGGL(gemm_f32_rows_kernel<8>, grid, block, 0, s, m, n, k, alpha, a, b, beta, c);
+        else hipLaunchKernelGGL(gemm_f32_rows_kernel<16>, grid, block, 0, s, m, n, k, alpha, a, b, beta, c);
+        HIP_TRY(hipGetLastError());
+        return SABER_HIP_OK;
+    }
     if (!plane_path(m, n, k)) {
         HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, s));
         return SABER_HIP_OK;

@@ -1154,7 +1154,7 @@ def test_gemm_f32_plane_path_vs_oracle(ta, tb):
     max-norm AND element-wise with the mean magnitude as the floor; repeated calls (the plan cache) give the same bits."""
     rng = np.random.default_rng(52 + ta * 2 + tb)
     for (M, N, K), (alpha, beta) in (((333, 200, 264), (1.0, 0.0)), ((70, 1000, 2048), (0.7, 0.3)), ((512, 384, 512), (1.0, 1.0)),
-                                     ((8, 4096, 25088 // 8), (1.0, 0.0))):
+                                     ((8, 4096, 25088 // 8), (1.0, 0.0)), ((3, 1000, 2048), (0.5, 0.25)), ((16, 515, 4100), (1.0, 1.0))):
         A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
         B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
         C0 = rng.standard_normal((M, N)).astype(np.float32)
