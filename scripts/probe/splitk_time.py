@@ -80,12 +80,12 @@ for name, N, H, W, C, K in [("vgg conv2 112x112 128->128", 8, 112, 112, 128, 128
     conv = S.SaberConv2D(int8=False).init((N, C, H, W), S.ConvParam(w, np.zeros(K, np.float32), 1, (1, 1), (1, 1), (1, 1), True), L.F32, L.F32,
                                           in_layout=L.NHWC, out_layout=L.NHWC)
     y = conv.new_output()
-    conv.autotune(x, y)
-    t_auto, a_auto = timed(lambda: conv.dispatch(x, y), 50), conv.algo()
     rows = []
-    for v in range(1, 6):
+    for v in range(1, 6):      # (before the autotune: it releases the fragment-ordered planes of a family it does not select)
         conv.set_tile(v | (13 << 16))
         rows.append((timed(lambda: conv.dispatch(x, y), 50), conv.algo()))
+    conv.autotune(x, y)
+    t_auto, a_auto = timed(lambda: conv.dispatch(x, y), 50), conv.algo()
     flops = 2.0 * N * H * W * C * K * 9
     print("%s: autotune %s %.1f us (%.0f TF) | halo: " % (name, a_auto.replace("igemm_f32_bf16x3_", ""), t_auto, flops / t_auto / 1e6) +
           "  ".join("%s %.1f us (%.0f TF)" % (a.replace("halo3x3_f32_bf16x3_", ""), t, flops / t / 1e6) for t, a in rows))
