@@ -6,7 +6,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -f $O/tune.json
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-b1 --per-op --tune-cache $O/tune.json "$@" > $O/bench.json 2> $O/per_op.txt
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-b1 --per-op --retune --write-tune-cache --tune-cache $O/tune.json "$@" > $O/bench.json 2> $O/per_op.txt
 ARGS="--steps 10 --warmup 3 --timed-only --tune-cache $O/tune.json $*"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py $ARGS > $O/bench_trace.log 2>&1
 grep -h '"value"' $O/bench_trace.log | head -1 > $O/bench_under_trace.json
