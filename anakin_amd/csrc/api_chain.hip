@@ -61,6 +61,133 @@ static void pack_chain_weights3(const int8_t* w, int C, int wave, std::vector<ui
                     }
                 }
 }
+// one 1 KB MFMA A-operand fragment (64 lanes x 16 bytes: row = lane & 15, k-group = lane >> 4) of a 1x1 conv's weights [K][C]: rows =
+// channels ch_base + (rho >> 2) * 4*mfg + mf*4 + (rho & 3), input channels ks*64 .. +63; and of a 3x3 conv's [K][C][3][3] at one tap
+static void pack_frag1(const int8_t* w, int C, int ch_base, int mfg, int mf, int ks, std::vector<uint8_t>& out) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int rho = lane & 15, kq = lane >> 4;
+        const int8_t* src = w + (size_t)(ch_base + (rho >> 2) * 4 * mfg + mf * 4 + (rho & 3)) * C + ks * 64 + kq * 16;
+        out.insert(out.end(), (const uint8_t*)src, (const uint8_t*)src + 16);
+    }
+}
+static void pack_frag3(const int8_t* w, int C, int ch_base, int tap, int ks, std::vector<uint8_t>& out) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int rho = lane & 15, kq = lane >> 4;
+        for (int t = 0; t < 16; ++t) out.push_back((uint8_t)w[((size_t)(ch_base + rho) * C + ks * 64 + kq * 16 + t) * 9 + tap]);
+    }
+}
+// the four-workgroup cooperative form's streams (conv_chain_coop.hip: conv_chain_coop4_c256_kernel), C = 256: per (quarter q, wave w =
+// K-half kh * 4 + n-tile nt), in consumption order:
+//   3x3, channels q*64 + nt*16 .. +15:        [tap][k-step kh*2 + {0, 1}]                                        18 fragments
+//   1x1 + eltwise, channels q*256 + w*32 ..:  [k-step (q + i) % 4, i = 0..3][accumulator 0, 1]                    8 (its own mid k-step first)
+//   1x1, channels q*64 + nt*16 .. +15:        k-steps (q*4 + j) % 16, j = kh*2 + {0, 1} then 4 + kh*6 + {0..5}    8 (its own y1 channels first)
+static void pack_coop4_stream(const saber_hip_conv* c3, const saber_hip_conv* a, const saber_hip_conv* b, std::vector<uint8_t>& out) {
+    const int C = 256, K1 = 1024;
+    for (int q = 0; q < 4; ++q)
+        for (int w = 0; w < 8; ++w) {
+            const int nt = w & 3, kh = w >> 2;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int kl = 0; kl < 2; ++kl) pack_frag3(c3->wq_oihw.data(), C, q * 64 + nt * 16, tap, kh * 2 + kl, out);
+            for (int i = 0; i < 4; ++i)
+                for (int mf = 0; mf < 2; ++mf) pack_frag1(a->wq_oihw.data(), C, q * 256 + w * 32, 2, mf, (q + i) & 3, out);
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = jj < 2 ? kh * 2 + jj : 4 + kh * 6 + (jj - 2);
+                pack_frag1(b->wq_oihw.data(), K1, q * 64 + nt * 16, 1, 0, (q * 4 + j) & 15, out);
+            }
+        }
+}
+saber_hip_chain::~saber_hip_chain() {
+    if (h_coop_err) (void)hipHostFree(h_coop_err);
+    delete stage1;
+}
+// ------------------------------------------------------------------------------------------------
+// stage: a run of 3x3-led C = 256 chains in ONE persistent launch (conv_stage_coop.hip)
+// ------------------------------------------------------------------------------------------------
+static unsigned stage_magic(int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; }
+static int stage_build(saber_hip_chain* const* chains, int n, bool per_image, saber_hip_chain_stage** out) {
+    if (!chains || n <= 0 || n > saber_mi355x::STAGE4_LONG || !out) return fail(SABER_HIP_INVALID_VALUE, "stage: 1..24 chains");
+    if (n > 1 && !per_image) return fail(SABER_HIP_INVALID_VALUE, "stage: several blocks need an image per XCD");
+    const saber_hip_chain* c0 = chains[0];
+    std::vector<saber_mi355x::StageBlk> blk;
+    for (int k = 0; k < n; ++k) {
+        const saber_hip_chain* ch = chains[k];
+        if (!ch || ch->c1 != 256 || !ch->c3 || !ch->b || !ch->d_stream_coop4.p || ch->c3->d.stride_h != 1)
+            return fail(SABER_HIP_INVALID_VALUE, "stage: every block must be a conv3x3 (stride 1) + conv1x1 + conv1x1 chain at C = 256");
+        const saber_hip_conv_desc& da = ch->a->d;
+        if (da.n != c0->a->d.n || da.h != c0->a->d.h || da.w != c0->a->d.w) return fail(SABER_HIP_INVALID_VALUE, "stage: blocks of one tensor shape");
+        if (k && ((ch->c3->x_dtype == DT_U8) != (chains[k - 1]->b->d.out_dtype == SABER_HIP_U8)))
+            return fail(SABER_HIP_INVALID_VALUE, "stage: a block's 3x3 conv reads what the previous block's last conv writes");
+        saber_mi355x::StageBlk B;
+        std::memset(&B, 0, sizeof B);
+        B.wstream = ch->d_stream_coop4.p; B.prm0 = ch->d_prm0.p; B.prm1 = ch->d_prm1.p; B.prm2 = ch->d_prm2.p;
+        B.coeff_conv = da.coeff_conv; B.scale_conv = ch->a->out_scale; B.coeff_res = da.coeff_res; B.scale_res = da.scale_res;
+        B.in0_u8 = ch->c3->x_dtype == DT_U8; B.relu0 = ch->c3->d.act == SABER_HIP_ACT_RELU;
+        B.in_u8 = ch->a->x_dtype == DT_U8; B.relu1 = da.act == SABER_HIP_ACT_RELU; B.res_relu = da.res_act == SABER_HIP_ACT_RELU;
+        B.relu2 = ch->b->d.act == SABER_HIP_ACT_RELU; B.out_u8_2 = ch->b->d.out_dtype == SABER_HIP_U8;
+        blk.push_back(B);
+    }
+    const saber_hip_conv_desc& d0 = c0->a->d;
+    saber_hip_chain_stage* st = new saber_hip_chain_stage();
+    st->chains.assign(chains, chains + n);
+    st->n = d0.n; st->h = d0.h; st->w = d0.w;
+    st->tiles_x = (d0.w + 15) / 16;
+    st->tiles_per_img = st->tiles_x * ((d0.h + 1) / 2);
+    st->per_image = per_image;
+    if (per_image && (d0.n > 8 || st->tiles_per_img * 4 > 32 || st->tiles_x != 1)) {      // every workgroup of an image must hold a CU of its XCD at once
+        delete st;
+        return fail(SABER_HIP_INVALID_VALUE, "stage: an image per XCD needs batch <= 8, width <= 16 and <= 8 tiles of 2 x 16 pixels per image");
+    }
+    const size_t tiles = (size_t)d0.n * st->tiles_per_img;
+    hipError_t e = st->d_blk.upload(blk);
+    if (e == hipSuccess) e = st->d_grp_ctr.alloc_zero(tiles * 32);
+    if (e == hipSuccess) e = st->d_img_ctr.alloc_zero((size_t)d0.n * (st->tiles_per_img + 1) * 16);
+    if (e == hipSuccess) e = st->d_xcc.alloc_zero(tiles * 32);
+    if (e == hipSuccess) e = st->d_xch.alloc_zero(tiles * 32 * 256);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_err, sizeof(unsigned), hipHostMallocMapped);
+    if (e != hipSuccess) {
+        delete st;
+        return hip_fail(e, "stage: device buffers");
+    }
+    *st->h_err = 0u;
+    *out = st;
+    return SABER_HIP_OK;
+}
+template <int MAXB>
+static int stage_launch(saber_hip_chain_stage* st, const void* x, const void* res, void* const* y1, void* const* y2, hipStream_t s) {
+    saber_mi355x::Stage4KArgs<MAXB> k;
+    std::memset(&k, 0, sizeof k);
+    k.x = x; k.res = res; k.zero = zero_page();
+    if (!k.zero) return fail(SABER_HIP_RUNTIME_ERROR, "stage: zero page");
+    k.blk = st->d_blk.p; k.grp_ctr = st->d_grp_ctr.p; k.img_ctr = st->d_img_ctr.p; k.xch = st->d_xch.p; k.xcc = st->d_xcc.p; k.err = st->h_err;
+    k.nblk = (int)st->chains.size(); k.N = st->n; k.H = st->h; k.W = st->w;
+    k.tiles_x = st->tiles_x; k.tiles_per_img = st->tiles_per_img;
+    k.mg_tiles_x = stage_magic(st->tiles_x); k.mg_tpi = stage_magic(st->tiles_per_img); k.mg_wpi = stage_magic(st->tiles_per_img * 4);
+    k.per_image = st->per_image;
+    for (int i = 0; i < k.nblk; ++i) { k.y1[i] = y1[i]; k.y2[i] = y2[i]; }
+    HIP_TRY(saber_mi355x::launch_conv_stage4(k, s));
+    return SABER_HIP_OK;
+}
+int stage_run(saber_hip_chain_stage* st, const void* x, const void* res, void* const* y1, void* const* y2, hipStream_t s) {
+    if (*(volatile unsigned*)st->h_err) {      // an earlier launch found cooperating workgroups on different XCDs or timed out in a barrier
+        *(volatile unsigned*)st->h_err = 0u;
+        return fail(SABER_HIP_RUNTIME_ERROR, "cooperative stage: an earlier launch's workgroups did not share an XCD or timed out at a barrier "
+                    "(its outputs are not valid)");
+    }
+    return (int)st->chains.size() <= saber_mi355x::STAGE4_SHORT ? stage_launch<saber_mi355x::STAGE4_SHORT>(st, x, res, y1, y2, s)
+                                                                : stage_launch<saber_mi355x::STAGE4_LONG>(st, x, res, y1, y2, s);
+}
+int saber_hip_conv2d_stage_create(saber_hip_chain_t* const* chains, int n, saber_hip_chain_stage_t** out) {
+    if (!xcd_round_robin()) return fail(SABER_HIP_UNIMPL, "stage: this device does not place workgroup b on XCD b % 8");
+    return stage_build(chains, n, true, out);
+}
+void saber_hip_conv2d_stage_destroy(saber_hip_chain_stage_t* st) { delete st; }
+int saber_hip_conv2d_stage_run(saber_hip_chain_stage_t* st, const void* x, const void* res, void* const* y1, void* const* y2, saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_conv2d_stage_run (saber_hip_net_optimize forms stages itself)");
+    if (!st || !x || !res || !y1 || !y2) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    for (size_t i = 0; i < st->chains.size(); ++i)
+        if (!y1[i] || !y2[i]) return fail(SABER_HIP_INVALID_VALUE, "stage: an output pointer per block");
+    return stage_run(st, x, res, y1, y2, (hipStream_t)stream);
+}
 static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out) {
     // b == nullptr (with c3): conv3x3 + first 1x1 conv only
     if (!a || !out || (!b && !c3)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
@@ -155,6 +282,12 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
             }
         ch->coop_tiles = da.n * da.h * ((da.w + 15) / 16);
         e = ch->d_stream_coop.upload(sc);
+        if (e == hipSuccess) {
+            std::vector<uint8_t> s4;
+            s4.reserve(stream.size());
+            pack_coop4_stream(c3, a, b, s4);
+            e = ch->d_stream_coop4.upload(s4);
+        }
         if (e == hipSuccess) e = ch->d_coop_ctr.alloc_zero((size_t)ch->coop_tiles * 32);      // a 128-byte line per (tile, barrier)
         if (e == hipSuccess) e = ch->d_coop_xcc.alloc_zero((size_t)ch->coop_tiles * 32);
         if (e == hipSuccess) e = ch->d_coop_xch.alloc_zero((size_t)ch->coop_tiles * 16 * da.c);
@@ -170,6 +303,14 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
     if (e != hipSuccess) {
         delete ch;
         return hip_fail(e, "chain: device copies");
+    }
+    if (ch->d_stream_coop4.p) {      // tile 15: the four-workgroup form = a one-block stage, tiles spread over all XCDs
+        saber_hip_chain* one[1] = {ch};
+        int rc = stage_build(one, 1, false, &ch->stage1);
+        if (rc != SABER_HIP_OK) {
+            delete ch;
+            return rc;
+        }
     }
     *out = ch;
     return SABER_HIP_OK;
@@ -188,7 +329,7 @@ int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
                     (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) || (ch->c1 == 256 && tn == 3 && ch->c3 && ch->d_stream_w8.p) ||
                     (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b) ||
-                    (ch->c1 == 256 && tn == 7 && ch->d_stream_coop.p);
+                    (ch->c1 == 256 && tn == 7 && ch->d_stream_coop.p) || (ch->c1 == 256 && tn == 15 && ch->stage1);
     if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: no kernel with that many pixel fragments");
     ch->tn = tn;
     return SABER_HIP_OK;
@@ -224,7 +365,8 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         if (!k.zero) return fail(SABER_HIP_RUNTIME_ERROR, "chain: zero page");
         k.N = a->d.n; k.H = a->d.h; k.W = a->d.w;
         k.tiles_x = (k.W + 15) / 16;
-        const int rows = ch->c1 == 128 ? ch->tn & 3 : (ch->c1 == 256 ? 1 : ch->tn & 7);    // tile rows (C = 128: bit 2 of the code = 8 waves; C = 256: one row, code 3 = 8 waves)
+        // tile rows (C = 128: bit 2 of the code = 8 waves; C = 256: one row, code 3 = 8 waves, 7 = two cooperating workgroups; 15 = four, two rows)
+        const int rows = ch->c1 == 128 ? ch->tn & 3 : (ch->c1 == 256 ? (ch->tn == 15 ? 2 : 1) : ch->tn & 7);
         k.tiles_per_img = k.tiles_x * ((k.H + rows - 1) / rows);
         k.mg_tiles_x = magic(k.tiles_x);
         k.mg_tpi = magic(k.tiles_per_img);
@@ -233,6 +375,13 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
         k.s0 = ch->c3->d.stride_h;
         k.H0 = ch->c3->d.h; k.W0 = ch->c3->d.w;
         if (a->d.res_stride > 1) { k.res_sub = a->d.res_stride; k.res_H = a->d.res_h; k.res_W = a->d.res_w; }
+    }
+    if (ch->c1 == 256 && ch->tn == 15) {      // four cooperating workgroups per tile of 2 x 16 pixels: a one-block stage
+        void* y1s[1] = {y_a};
+        void* y2s[1] = {y_b};
+        const int rc = stage_run(ch->stage1, x, res, y1s, y2s, (hipStream_t)stream);
+        if (rc != SABER_HIP_OK) ch->tn = 3;
+        return rc;
     }
     if (ch->c1 == 256 && ch->tn == 7) {      // two cooperating workgroups per pixel tile
         if (*(volatile unsigned*)ch->h_coop_err) {      // an earlier launch found its halves on different XCDs or timed out in a barrier

@@ -152,13 +152,30 @@ struct saber_hip_chain {
     DevBuf<uint8_t> d_stream_w8;      // C == 128: the whole stream for 8 waves per workgroup (tile | 4)
     // C == 256, 3x3-led, tile 7: two cooperating workgroups per pixel tile (conv_chain_coop.hip): [half][wave] streams, the pairs'
     // arrival counters, the exchange buffer of the 3x3 conv's tile, the halves' XCC ids, and the pinned error word
-    DevBuf<uint8_t> d_stream_coop, d_coop_xch;
+    // tile 15: FOUR cooperating workgroups per tile of 2 rows x 16 columns (conv_stage_coop.hip with one block): [quarter][wave]
+    // streams here, everything else in `stage1`
+    DevBuf<uint8_t> d_stream_coop, d_stream_coop4, d_coop_xch;
     DevBuf<unsigned long long> d_coop_ctr;
     DevBuf<unsigned> d_coop_xcc;
     unsigned* h_coop_err = nullptr;
     int coop_tiles = 0;
-    ~saber_hip_chain() {
-        if (h_coop_err) (void)hipHostFree(h_coop_err);
+    struct saber_hip_chain_stage* stage1 = nullptr;
+    ~saber_hip_chain();      // api_chain.hip
+};
+
+// A run of 3x3-led C = 256 chains as ONE persistent launch (conv_stage_coop.hip): the chains' own weight streams and constants, the
+// hand-off counters / exchange tiles / XCC words of the launch, a pinned error word. The chains are NOT owned.
+struct saber_hip_chain_stage {
+    std::vector<saber_hip_chain*> chains;
+    DevBuf<saber_mi355x::StageBlk> d_blk;
+    DevBuf<unsigned long long> d_grp_ctr, d_img_ctr;
+    DevBuf<uint8_t> d_xch;
+    DevBuf<unsigned> d_xcc;
+    unsigned* h_err = nullptr;
+    int n = 0, h = 0, w = 0, tiles_x = 0, tiles_per_img = 0;
+    bool per_image = false;
+    ~saber_hip_chain_stage() {
+        if (h_err) (void)hipHostFree(h_err);
     }
 };
 
@@ -332,6 +349,11 @@ struct NetOp {
     saber_hip_chain* chain3 = nullptr;
     int chain3_res = -1, chain3_y1 = -1, chain3_y2 = -1;
     bool use_chain3 = false;
+    // ... and a RUN of such 3x3-led C = 256 chains (flag 256): THIS op is the first block's 3x3 conv; while use_stage is set it launches
+    // all stage_n chains (3 * stage_n ops, the others carry `skip`) as one persistent launch (saber_hip_conv2d_stage_run)
+    saber_hip_chain_stage* stage = nullptr;
+    int stage_n = 0;
+    bool use_stage = false;
     int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
     bool record = false;     // an op on the other lane consumes this op's output: record an event after it
     int p[16] = {0};
@@ -364,6 +386,7 @@ struct saber_hip_net {
     bool lanes_ready = false, has_side = false;
     std::vector<saber_hip_conv*> owned;   // ops created by saber_hip_net_optimize (destroyed with the net)
     std::vector<saber_hip_chain*> owned_chains;
+    std::vector<saber_hip_chain_stage*> owned_stages;
 };
 
 // Op-list capture (api_capture.hip; saber_hip_capture_begin / _end): while g_capture is set on the calling thread every
@@ -397,3 +420,6 @@ void img_conv_release(saber_hip_conv* op);
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s);      // api_net.hip
 void net_set_chain_mode(saber_hip_net* net, int ia, int mode);      // api_net_optimize.hip
 int net_chain_mode(const saber_hip_net* net, int ia);      // api_net_optimize.hip
+// the stage headed by ops[i0] (NetOp::stage) on / off: on forces every block's 3x3-led chain form and makes ops[i0] launch them all
+void net_set_stage(saber_hip_net* net, int i0, bool on);   // api_net_optimize.hip
+int stage_run(saber_hip_chain_stage* st, const void* x, const void* res, void* const* y1, void* const* y2, hipStream_t s);   // api_chain.hip

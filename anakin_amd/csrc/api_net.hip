@@ -7,6 +7,26 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     switch (o.kind) {
     case OP_CONV:
         if (o.skip) return SABER_HIP_OK;      // written by the previous op's chain launch
+        if (o.stage && o.use_stage) {         // this op's and the next stage_n - 1 blocks' chains in one persistent launch
+            void* y1[saber_mi355x::STAGE4_LONG];
+            void* y2[saber_mi355x::STAGE4_LONG];
+            const NetOp* ops = &o;            // (the ops of a net are contiguous: block k's 3x3 conv is ops[3 * k])
+            for (int k = 0; k < o.stage_n; ++k) {
+                y1[k] = T(ops[3 * k].chain3_y1);
+                y2[k] = T(ops[3 * k].chain3_y2);
+            }
+            const int rc = stage_run(o.stage, T(o.in), T(o.chain3_res), y1, y2, s);
+            if (rc == SABER_HIP_RUNTIME_ERROR) {      // an earlier launch of it timed out (conv_stage_coop.hip): block by block from now on
+                net_set_stage(net, (int)(&o - net->ops.data()), false);
+                if (net->exec) {
+                    (void)hipGraphExecDestroy(net->exec);
+                    (void)hipGraphDestroy(net->graph);
+                    net->exec = nullptr;
+                    net->graph = nullptr;
+                }
+            }
+            return rc;
+        }
         if (o.chain3 && o.use_chain3)
             return saber_hip_conv2d_chain_run(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), s);
         if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
@@ -474,6 +494,7 @@ void saber_hip_net_destroy(saber_hip_net_t* net) {
     if (net->exec) (void)hipGraphExecDestroy(net->exec);
     if (net->graph) (void)hipGraphDestroy(net->graph);
     if (net->arena) (void)hipFree(net->arena);
+    for (saber_hip_chain_stage* st : net->owned_stages) saber_hip_conv2d_stage_destroy(st);
     for (saber_hip_chain* c : net->owned_chains) saber_hip_conv2d_chain_destroy(c);
     for (saber_hip_conv* c : net->owned) saber_hip_conv2d_destroy(c);
     for (hipEvent_t e : net->ev_op)

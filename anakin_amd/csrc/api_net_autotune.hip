@@ -18,12 +18,18 @@ int saber_hip_net_get_choice(saber_hip_net_t* net, int index) {
     int choice = (c && !c->pool_fused && c->algo <= ALGO_IGEMM_F32) ? saber_hip_conv2d_get_tile(c) : 0;
     if (c && net->ops[index].chain) choice |= (1 << 28) | ((net->ops[index].use_chain ? net->ops[index].chain->tn : 0) << 24);
     if (c && net->ops[index].chain3) choice |= (1 << 29) | ((net->ops[index].use_chain3 ? net->ops[index].chain3->tn : 0) << 24);
+    if (c && net->ops[index].stage && net->ops[index].use_stage) choice |= 1 << 30;      // this op launches its whole stage
     return choice;
+}
+int saber_hip_net_stage_blocks(const saber_hip_net_t* net, int index) {
+    if (!net || index < 0 || index >= (int)net->ops.size()) return 0;
+    return net->ops[index].stage ? net->ops[index].stage_n : 0;
 }
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     saber_hip_conv* c = net_op_conv(net, index);
     if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
-    const int chain_bits = choice >> 24;
+    const int chain_bits = (choice >> 24) & 63;
+    const bool stage_on = (choice >> 30) & 1;
     choice &= 0xffffff;
     int rc = choice ? saber_hip_conv2d_set_tile(c, choice) : SABER_HIP_OK;
     if (rc) return rc;
@@ -39,6 +45,7 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
         if (tn && (rc = saber_hip_conv2d_chain_set_tile(o.chain, tn)) != SABER_HIP_OK) return rc;
         net_set_chain_mode(net, index, net_chain_mode(net, index) == 2 ? 2 : (tn ? 1 : 0));   // (also restores the names)
     }
+    if (o.stage) net_set_stage(net, index, stage_on);      // (a stage head comes before its blocks: set_choices runs in op order)
     if (o.skip) o.name = "conv:(in the chain launch)";
     if (net->exec) {
         (void)hipGraphExecDestroy(net->exec);
@@ -60,7 +67,7 @@ static int net_consolidate_kernels(saber_hip_net* net, hipStream_t s) {
         if (e[0] == '1') return SABER_HIP_OK;
     struct Site { int op; unsigned long long key; ConvChoice choice; };
     auto conv_of = [&](const NetOp& o) -> saber_hip_conv* {
-        if (o.skip || (o.chain && o.use_chain) || (o.chain3 && o.use_chain3)) return nullptr;
+        if (o.skip || (o.chain && o.use_chain) || (o.chain3 && o.use_chain3) || (o.stage && o.use_stage)) return nullptr;
         if (o.kind != OP_CONV && o.kind != OP_CONV_PAIR) return nullptr;
         return (o.conv && !o.conv->pool_fused && o.conv->algo <= ALGO_IGEMM_F32) ? o.conv : nullptr;
     };
@@ -166,6 +173,8 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     }
     // conv1x1 chains: the tuned separate launches against the chain launch (every pixel-tile size) and, where the block's
     // 3x3 conv can lead the chain, against that single launch too - on the real tensors
+    for (size_t i = 0; i < net->ops.size(); ++i)
+        if (net->ops[i].stage) net_set_stage(net, (int)i, false);      // (block by block first; the stages after this loop)
     for (size_t i = 0; i < net->ops.size(); ++i) {
         NetOp& A = net->ops[i];
         const int ia = (int)i;
@@ -201,9 +210,10 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         int rc = timed(&best);
         if (rc) return rc;
         const int c1 = A.chain ? A.chain->c1 : H->chain3->c1;
-        const int tns[5] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9), c1 == 256 ? 11 : (c1 == 128 ? 6 : 0),
+        const int tns[6] = {c1 == 64 ? 4 : (c1 == 128 ? 2 : 1), c1 == 64 ? 2 : (c1 == 128 ? 1 : 9), c1 == 256 ? 11 : (c1 == 128 ? 6 : 0),
                             c1 == 128 ? 5 : (c1 == 256 ? 3 : 0),       // (C = 256, code 3: the 3x3-led forms with 8 waves; refused elsewhere)
-                            c1 == 256 ? 7 : 0};                        // (code 7: two cooperating workgroups per tile, 3x3-led with a second 1x1 conv)
+                            c1 == 256 ? 7 : 0,                         // (code 7: two cooperating workgroups per tile, 3x3-led with a second 1x1 conv)
+                            c1 == 256 ? 15 : 0};                       // (code 15: four per tile of two rows)
         for (int mode = A.chain ? 1 : 2; mode <= (H ? 2 : 1); ++mode) {
             saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
             for (int tn : tns) {
@@ -217,6 +227,54 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         }
         if (best_mode) (void)saber_hip_conv2d_chain_set_tile(best_mode == 2 ? H->chain3 : A.chain, best_tn);
         net_set_chain_mode(net, ia, best_mode);
+        rc = run_all();   // every written output holds the selected form's result
+        if (rc) return rc;
+    }
+    // stages: the blocks' tuned launches one after the other against the one persistent launch
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        NetOp& H0 = net->ops[i];
+        if (!H0.stage) continue;
+        const int first = (int)i, last = first + 3 * H0.stage_n - 1;
+        hipStream_t s = (hipStream_t)stream;
+        auto run_all = [&]() -> int {
+            int rc = 0;
+            for (int k = first; k <= last; ++k) rc |= net_launch(net, net->ops[k], s);
+            return rc;
+        };
+        auto timed = [&](float* us) -> int {
+            if (g_cold) {
+                *us = g_cold->run(s, run_all);
+                return *us < 0.f ? SABER_HIP_RUNTIME_ERROR : SABER_HIP_OK;
+            }
+            EventPair ev;
+            HIP_TRY(ev.init());
+            int rc = run_all();
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev.e0, s));
+            for (int it = 0; it < 20; ++it) rc |= run_all();
+            HIP_TRY(hipEventRecord(ev.e1, s));
+            HIP_TRY(hipEventSynchronize(ev.e1));
+            HIP_TRY(hipEventElapsedTime(us, ev.e0, ev.e1));
+            return rc;
+        };
+        std::vector<int> modes(H0.stage_n), tns(H0.stage_n);
+        for (int k = 0; k < H0.stage_n; ++k) {
+            modes[k] = net_chain_mode(net, first + 3 * k + 1);
+            tns[k] = net->ops[first + 3 * k].chain3->tn;
+        }
+        float sep = 0.f, one = 0.f;
+        int rc = timed(&sep);
+        if (rc) return rc;
+        net_set_stage(net, first, true);
+        const bool ok = timed(&one) == SABER_HIP_OK && hipStreamSynchronize(s) == hipSuccess && !*(volatile unsigned*)H0.stage->h_err;
+        if (!ok || one >= sep) {
+            *(volatile unsigned*)H0.stage->h_err = 0u;
+            net_set_stage(net, first, false);
+            for (int k = 0; k < H0.stage_n; ++k) {
+                (void)saber_hip_conv2d_chain_set_tile(net->ops[first + 3 * k].chain3, tns[k]);
+                net_set_chain_mode(net, first + 3 * k + 1, modes[k]);
+            }
+        }
         rc = run_all();   // every written output holds the selected form's result
         if (rc) return rc;
     }

@@ -44,13 +44,29 @@ void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     if (H) {
         H->use_chain3 = mode == 2;
         H->name = mode == 2 ? std::string("conv:conv3x3+") + (H->chain3->b ? "chain1x1_c" : "conv1x1_c") + std::to_string(H->chain3->c1) +
-                                  "_" + std::to_string(H->chain3->c1 == 128 ? H->chain3->tn & 3 : (H->chain3->c1 == 256 ? 1 : H->chain3->tn)) + "x16" +
+                                  "_" + std::to_string(H->chain3->c1 == 128 ? H->chain3->tn & 3 : (H->chain3->c1 == 256 ? (H->chain3->tn == 15 ? 2 : 1) : H->chain3->tn)) + "x16" +
                                   ((H->chain3->c1 == 128 && (H->chain3->tn & 4)) || (H->chain3->c1 == 256 && H->chain3->tn == 3) ? "_w8" : "") +
-                                  (H->chain3->c1 == 256 && H->chain3->tn == 7 ? "_coop2" : "")
+                                  (H->chain3->c1 == 256 && H->chain3->tn == 7 ? "_coop2" : "") + (H->chain3->c1 == 256 && H->chain3->tn == 15 ? "_coop4" : "")
                             : std::string("conv:") + H->conv->algo_name;
     }
     if (B) net_name_chain(A, *B);
     else A.name = A.skip ? "conv:(in the chain launch)" : std::string("conv:") + A.conv->algo_name;
+}
+// The stage headed by ops[i0] on / off. On: every block runs its 3x3-led chain form (mode 2), ops[i0] launches them all and the
+// other blocks' 3x3 convs carry `skip` too. Off: the blocks' chains launch one by one again (mode 2, their own tile codes).
+void net_set_stage(saber_hip_net* net, int i0, bool on) {
+    NetOp& H0 = net->ops[i0];
+    if (!H0.stage) return;
+    for (int k = 0; k < H0.stage_n; ++k) {
+        if (on || H0.use_stage) net_set_chain_mode(net, i0 + 3 * k + 1, 2);
+        NetOp& Hk = net->ops[i0 + 3 * k];
+        if (k) {
+            Hk.skip = on;
+            if (on) Hk.name = "conv:(in the stage launch)";
+        }
+    }
+    H0.use_stage = on;
+    if (on) H0.name = "conv:stage_c256_" + std::to_string(H0.stage_n) + "x[conv3x3+chain1x1]_2x16_coop4";
 }
 int net_chain_mode(const saber_hip_net* net, int ia) {
     const NetOp& A = net->ops[ia];
@@ -352,6 +368,38 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             Hd.chain3_res = A.in2; Hd.chain3_y1 = A.out; Hd.chain3_y2 = -1;
             net_set_chain_mode(net, (int)i + 1, ch->c1 <= 128 ? 2 : 0);
             if (Hd.use_chain3) ++removed;
+        }
+    }
+    // ---- 256: runs of 3x3-led C = 256 chains whose blocks feed each other (ResNet's res4 stage) -> one persistent launch -------------
+    // NOT part of 255: the launch needs every workgroup of an image resident on its XCD at once - fine for one net on the GPU
+    // (the latency path), not for several nets in flight on their own streams (two such launches can each hold half of the CUs
+    // and wait for the other half: they time out, report an error and fall back; conv_stage_coop.hip)
+    if ((flags & 256) && (flags & 32) && !two_lanes) {
+        for (size_t i = 0; i + 2 < ops.size();) {
+            auto block_ok = [&](size_t j) {
+                return j + 2 < ops.size() && ops[j].chain3 && ops[j].chain3->b && ops[j].chain3->c1 == 256 && ops[j].chain3->stage1 && !ops[j].stage &&
+                       ops[j].chain3_y2 >= 0;
+            };
+            if (!block_ok(i)) { ++i; continue; }
+            std::vector<saber_hip_chain*> run{ops[i].chain3};
+            while ((int)run.size() < saber_mi355x::STAGE4_LONG) {
+                const size_t p = i + 3 * (run.size() - 1), j = p + 3;
+                if (!block_ok(j) || ops[j].in != ops[p].chain3_y2 || ops[j].chain3_res != ops[p].chain3_y1) break;
+                run.push_back(ops[j].chain3);
+            }
+            if (run.size() >= 2) {
+                saber_hip_chain_stage* st = nullptr;
+                if (saber_hip_conv2d_stage_create(run.data(), (int)run.size(), &st) == SABER_HIP_OK) {
+                    net->owned_stages.push_back(st);
+                    ops[i].stage = st;
+                    ops[i].stage_n = (int)run.size();
+                    int before = 0;
+                    for (size_t k = 0; k < run.size(); ++k) before += 3 - (ops[i + 3 * k].skip + ops[i + 3 * k + 1].skip + ops[i + 3 * k + 2].skip);
+                    net_set_stage(net, (int)i, true);          // default until the autotuner has timed both forms
+                    removed += before - 1;
+                }
+            }
+            i += 3 * run.size();
         }
     }
     // the shared workspace only has to cover the surviving ops

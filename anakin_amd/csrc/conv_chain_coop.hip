@@ -24,48 +24,9 @@
 // the launch finish with garbage - the host turns that into an error status on the next run and stops selecting this form.
 // Everything else (weights straight into MFMA A registers from a per-wave stream in consumption order, LDS-DMA halo with a
 // padded pixel pitch, XOR-swizzled residual tile, the requantising epilogues of epilogue_pack.h) is conv1x1_chain.hip's.
-#include "epilogue_pack.h"
+#include "coop_sync.h"
 
 namespace saber_mi355x {
-
-namespace {
-
-__device__ __forceinline__ unsigned long long coop_sload(const unsigned long long* p) {
-    unsigned long long v;
-    asm volatile("s_dcache_inv\n\ts_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p) : "memory");
-    return v;
-}
-
-// The pair's barrier, split in two so that the wait can sit behind work that does not need the partner: ARRIVE (per wave: its
-// stores are in the XCD's L2, then one arrival on the pair's counter) ... work on this workgroup's own half ... WAIT (per wave:
-// spin on scalar loads - they do not queue behind the wave's weight loads - until all 16 waves of the pair have arrived).
-// The counter is never reset: 16 arrivals per launch bring it back to a multiple of 16.
-// NO cache invalidate anywhere: `buffer_inv sc1` is a DEVICE-scope acquire, which on this multi-XCD part also drops the L2's
-// non-coherent lines - every workgroup passing a barrier wiped its XCD's copy of the weight stream for all 28 workgroups sharing that
-// L2 (measured with the in-kernel stamps: 13 us in the first barrier, 14 us for the 1 us third phase at batch 8). What the partner
-// wrote is read with sc1 LOADS instead (L2Reader, conv_igemm_impl.h): they miss the L1 and hit the L2.
-// The arrival is a WORKGROUP-scope atomic on purpose: it executes in this XCD's L2, which is all the pair needs (both halves run on
-// one XCD); an AGENT-scope atomic is performed beyond the L2 on this multi-XCD part and took 1.6 us per arrival (in-kernel stamps).
-// Its return value is consumed only in coop_wait, so the wave does not stall on it here.
-__device__ __forceinline__ unsigned long long coop_arrive(unsigned long long* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long old = 0;
-    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return old;
-}
-__device__ __forceinline__ void coop_wait(const unsigned long long* ctr, unsigned long long token, unsigned* err) {
-    asm volatile("" ::"v"(token));                       // this wave's own arrival has been PERFORMED before it looks at the counter
-    int spins = 0;
-    while ((coop_sload(ctr) & 15ull) != 0ull) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > 200000) {                          // ~20 ms: give up loudly (see the file header)
-            if (err && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
-}
-
-}  // namespace
 
 // C1 = 256, K1 = 1024, K2 = 256, 16-pixel tiles (one row x 16 columns of one image), 8 waves, 2 workgroups per tile.
 __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKArgs ka) {
@@ -142,12 +103,7 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
 #pragma unroll
     for (int r = 0; r < R; ++r) ring[r] = wsb[r * 64 + lane];
     wsb += R * 64;
-    if (tid == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        ka.coop_xcc[t * 32 + half] = xcc & 7u;
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R) : "memory");     // everything older than the ring: this wave's DMA
+    wait_vm_older_than<R>();                                 // everything older than the ring: this wave's DMA
     __builtin_amdgcn_s_barrier();
     SABER_TL(1);
 
@@ -175,7 +131,12 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
         *(unsigned*)((char*)ka.coop_xch + ((size_t)t * 16 + frow) * C1 + half * K0W + c0) = o;     // for the partner (through the L2)
         *(unsigned*)((char*)mid_own + frow * (MPC * 16) + c0) = o;                                   // for this workgroup (LDS)
     }
-    const unsigned long long tok1 = coop_arrive(ka.coop_ctr + t * 32);
+    if (tid == 0) {      // (stored HERE, not at entry: a store pending beside the ring's loads makes the compiler wait for vmcnt(0))
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ka.coop_xcc[t * 32 + half] = xcc & 7u;
+    }
+    coop_arrive(ka.coop_ctr + t * 32);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // mid_own is complete
     SABER_TL(2);
@@ -200,18 +161,14 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
             acc[mf] = mma_step(ring[ri], bo[k], acc[mf]);
             ring[ri] = wsb[s * 64 + lane];
         }
-        coop_wait(ka.coop_ctr + t * 32, tok1, ka.coop_err);        // the partner's half of the 3x3 tile is in the L2
-        if (tid == 0 && ka.coop_err &&
-            __hip_atomic_load(ka.coop_xcc + t * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-                __hip_atomic_load(ka.coop_xcc + t * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_add(ka.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        coop_wait(ka.coop_ctr + t * 32, ka.coop_err);        // the partner's half of the 3x3 tile is in the L2
         SABER_TL(3);
         const L2Reader xch_l2(ka.coop_xch);
         const unsigned mo = (unsigned)(((size_t)t * 16 + frow) * C1 + (1 - half) * K0W + fq * 16);
         v4i bp[KS1 / 2];
 #pragma unroll
         for (int k = 0; k < KS1 / 2; ++k) {
-            bp[k] = xch_l2.load16(mo + k * 64);
+            bp[k] = xch_l2.load16<SABER_COOP_AUX>(mo + k * 64);
             bp[k].x ^= xmask; bp[k].y ^= xmask; bp[k].z ^= xmask; bp[k].w ^= xmask;
         }
 #pragma unroll
@@ -241,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
         const int p = pix(px, ok);
         if (ok) *(v4i*)((char*)a.y1 + (size_t)p * K1 + half * K1W + c * 16) = tile[L];
     }
-    const unsigned long long tok2 = coop_arrive(ka.coop_ctr + t * 32 + 16);
+    coop_arrive(ka.coop_ctr + t * 32 + 16);
     SABER_TL(4);
 
     // ================= phase 2: second 1x1 conv, 16 channels per wave; k-steps of this half's y1 channels (still in LDS) first =====
@@ -259,13 +216,13 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
             const int ri = (T0 + T1 + s) % R;
             acc = mma_step(ring[ri], bo[s], acc);            // (T2 == R: the ring already holds the whole phase, no refills)
         }
-        coop_wait(ka.coop_ctr + t * 32 + 16, tok2, ka.coop_err);   // the partner's half of the y1 tile is in the L2
+        coop_wait(ka.coop_ctr + t * 32 + 16, ka.coop_err);   // the partner's half of the y1 tile is in the L2
         SABER_TL(5);
         const L2Reader y1_l2(a.y1);
         const unsigned yo = (unsigned)((size_t)p * K1 + (1 - half) * K1W + fq * 16);
         v4i bp[KS2 / 2];
 #pragma unroll
-        for (int k = 0; k < KS2 / 2; ++k) bp[k] = y1_l2.load16(yo + k * 64);
+        for (int k = 0; k < KS2 / 2; ++k) bp[k] = y1_l2.load16<SABER_COOP_AUX>(yo + k * 64);
 #pragma unroll
         for (int s = T2 / 2; s < T2; ++s) {
             const int ri = (T0 + T1 + s) % R;
@@ -276,6 +233,10 @@ __global__ __launch_bounds__(512) void conv_chain_coop_c256_kernel(const CoopKAr
         const unsigned xm2 = a.out_u8_2 ? 0u : 0x80808080u;
         const unsigned o = chain_out_pack(acc, v4i{0, 0, 0, 0}, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), lo2, off2, xm2);
         if (ok) *(unsigned*)((char*)a.y2 + (size_t)p * K2 + half * K2W + c2) = o;
+    }
+    if (tid == 0 && ka.coop_err) {      // both halves ran on one XCD? (off every wave's critical path: after the last store)
+        const v4i xc = L2Reader(ka.coop_xcc).load16((unsigned)t * 128u);
+        if (xc.x != xc.y) __hip_atomic_fetch_add(ka.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     SABER_TL(6);
     SABER_TL_FLUSH();

@@ -62,8 +62,9 @@ struct L2Reader {
     __amdgpu_buffer_rsrc_t rsrc;
     __device__ __forceinline__ explicit L2Reader(const void* base)
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000)) {}
+    template <int AUX = 16 /* sc1 */>
     __device__ __forceinline__ v4i load16(unsigned byte_off) const {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16 /* sc1 */);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, AUX);
     }
 };
 __device__ __forceinline__ v4i mma_step(v4i a, v4i b, v4i c) {

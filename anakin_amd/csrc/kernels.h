@@ -8,13 +8,13 @@
 // 100 MHz wall clock of each phase boundary in registers and thread 0 of every workgroup writes them out at the end
 // (no memory traffic at the stamps themselves). Expands to nothing in the product build.
 #ifdef SABER_TIMELINE
-extern __device__ unsigned long long* saber_tl_buf;   // [blocks][8]
-#define SABER_TL_DECL unsigned long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+extern __device__ unsigned long long* saber_tl_buf;   // [blocks][16]
+#define SABER_TL_DECL unsigned long long tl_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define SABER_TL(i) tl_[i] = wall_clock64()
 #define SABER_TL_FLUSH()                                                                   \
     do {                                                                                   \
         if (threadIdx.x == 0 && saber_tl_buf)                                              \
-            for (int i_ = 0; i_ < 8; ++i_) saber_tl_buf[(size_t)blockIdx.x * 8 + i_] = tl_[i_]; \
+            for (int i_ = 0; i_ < 16; ++i_) saber_tl_buf[(size_t)blockIdx.x * 16 + i_] = tl_[i_]; \
     } while (0)
 #else
 #define SABER_TL_DECL do { } while (0)
@@ -152,6 +152,38 @@ int conv1x1_chain_tn(int c1, int m);
 hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tn, int with3x3, hipStream_t s);
 // conv3x3 + conv1x1 (+ eltwise) + conv1x1 at C1 = 256 with the weight stream split over two cooperating workgroups per pixel tile
 hipError_t launch_conv_chain_coop(const CoopKArgs& a, hipStream_t s);
+
+// conv_stage4_c256_kernel (conv_stage_coop.hip): a RUN of res4 blocks (each: conv 3x3 -> conv 1x1 + eltwise -> next block's conv 1x1,
+// C = 256) as one persistent launch, four cooperating workgroups per tile of 2 rows x 16 columns, all tiles of an image on one XCD
+struct StageBlk {                      // one block's constants; a table of these in device memory, read with scalar loads
+    const void* wstream;               // [quarter][wave] fragments (api_chain.hip: pack_coop4_stream)
+    const void* prm0;                  // {scale, bias', comp} per 4 channels of the 3x3 / first 1x1 / second 1x1 conv (padded: ChainKArgs)
+    const void* prm1;
+    const void* prm2;
+    float coeff_conv, scale_conv, coeff_res, scale_res;
+    int in0_u8, relu0, in_u8, relu1, res_relu, relu2, out_u8_2, pad_;
+};
+template <int MAXB>                    // blocks per launch this argument block has room for (8: 192 bytes of output pointers, 24: 448)
+struct Stage4KArgs {
+    const void* x;                     // the first block's 3x3 input [N][H][W][256]
+    const void* res;                   // the first block's shortcut [N][H][W][1024] s8
+    const void* zero;                  // >= 16 zero bytes
+    const StageBlk* blk;
+    unsigned long long* grp_ctr;       // [tiles][32]: a tile's two hand-off counters (words 0 and 16), a 256-byte pair of lines per tile
+    unsigned long long* img_ctr;       // [images][tiles per image + 1][16]: one counter (its own 128-byte line) per edge between two tile rows
+    void* xch;                         // [tiles][32 pixels][256]: the 3x3 conv's 8-bit output tile
+    unsigned* xcc;                     // [tiles][32]: words 0..3 = the XCD each quarter ran on
+    unsigned* err;                     // host-visible word: placement violations / barrier time-outs are counted here
+    int nblk, N, H, W;
+    int tiles_x, tiles_per_img;        // 16-column tiles per row pair, tiles per image
+    unsigned mg_tiles_x, mg_tpi, mg_wpi;   // ceil(2^32 / d) for tiles_x, tiles_per_img, 4 * tiles_per_img; 0 when d == 1
+    int per_image;                     // 1: workgroup b -> image (b / 8 / wpi) * 8 + b % 8 (required for nblk > 1); 0: tiles round-robin
+    void* y1[MAXB];                    // per block [M][1024] s8: the eltwise output (the operator's own output tensor)
+    void* y2[MAXB];                    // per block [M][256] s8 / u8: the second 1x1 conv's output = the next block's 3x3 input
+};
+constexpr int STAGE4_SHORT = 8, STAGE4_LONG = 24;
+hipError_t launch_conv_stage4(const Stage4KArgs<STAGE4_SHORT>& a, hipStream_t s);
+hipError_t launch_conv_stage4(const Stage4KArgs<STAGE4_LONG>& a, hipStream_t s);
 
 // stage_xcd_kernel (stage_xcd.hip): a run of INT8 convolutions over small images as ONE persistent launch, one image per XCD
 // at a time, the phases separated by an XCD-local barrier instead of a kernel boundary.

@@ -28,6 +28,7 @@ SYMBOLS = [
     "saber_hip_net_add_conv_pair",
     "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_create3", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
     "saber_hip_conv2d_chain_set_tile", "saber_hip_conv2d_chain_get_tile",
+    "saber_hip_conv2d_stage_create", "saber_hip_conv2d_stage_destroy", "saber_hip_conv2d_stage_run",
     "saber_hip_conv2d_set_global_pooling", "saber_hip_conv2d_run_gpool",
     "saber_hip_stage_create", "saber_hip_stage_num_tensors", "saber_hip_stage_run", "saber_hip_stage_status", "saber_hip_stage_trace", "saber_hip_stage_destroy",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
@@ -37,7 +38,7 @@ SYMBOLS = [
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32", "saber_hip_relu_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool_out_dim2", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
-    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice",
+    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice", "saber_hip_net_stage_blocks",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
@@ -122,6 +123,10 @@ def load():
     lib.saber_hip_conv2d_chain_run.argtypes = [P, P, P, P, P, P]
     lib.saber_hip_conv2d_chain_set_tile.argtypes = [P, I]
     lib.saber_hip_conv2d_chain_get_tile.argtypes = [P]
+    lib.saber_hip_conv2d_stage_create.argtypes = [C.POINTER(P), I, C.POINTER(P)]
+    lib.saber_hip_conv2d_stage_destroy.argtypes = [P]
+    lib.saber_hip_conv2d_stage_destroy.restype = None
+    lib.saber_hip_conv2d_stage_run.argtypes = [P, P, P, C.POINTER(P), C.POINTER(P), P]
     lib.saber_hip_conv2d_set_global_pooling.argtypes = [P]
     lib.saber_hip_conv2d_run_gpool.argtypes = [P, P, P, P, P, P]
     lib.saber_hip_stage_create.argtypes = [C.POINTER(StagePhase), I, C.POINTER(P)]
@@ -138,6 +143,7 @@ def load():
     lib.saber_hip_fc_run.argtypes = [P, P, P, P, P]
     lib.saber_hip_fc_destroy.argtypes = [P]
     lib.saber_hip_net_optimize.argtypes = [P, I]
+    lib.saber_hip_net_stage_blocks.argtypes = [P, I]
     lib.saber_hip_net_get_choice.argtypes = [P, I]
     lib.saber_hip_net_set_choice.argtypes = [P, I, I]
     lib.saber_hip_fc_algo.argtypes = [P]

@@ -285,6 +285,31 @@ class SaberConvChain:
             pass
 
 
+class SaberChainStage:
+    """A run of 3x3-led C = 256 chains (SaberConvChain with conv3x3 and b) as ONE persistent launch (saber_hip_conv2d_stage_create):
+    chain i + 1 reads chain i's two outputs. dispatch(x, res, y1s, y2s): chain 0's inputs, every chain's two output tensors. The
+    outputs hold the bits of dispatching the chains (= the operators, net.cpp:417-509) one after the other."""
+
+    def __init__(self, chains):
+        self.chains = list(chains)                   # keep them alive: the stage borrows their weights
+        arr = (C.c_void_p * len(chains))(*[c.h for c in chains])
+        self.h = C.c_void_p()
+        L.check(L.load().saber_hip_conv2d_stage_create(arr, len(chains), C.byref(self.h)))
+
+    def dispatch(self, x, res, y1s, y2s):
+        n = len(self.chains)
+        a = (C.c_void_p * n)(*[t.data_ptr() for t in y1s])
+        b = (C.c_void_p * n)(*[t.data_ptr() for t in y2s])
+        L.check(L.load().saber_hip_conv2d_stage_run(self.h, _p(x), _p(res), a, b, _stream()))
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_conv2d_stage_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SaberStage:
     """XCD-resident stage (saber_hip_stage_create): `phases` = [(conv, in_slot, out_slot, res_slot | -1), ...] run as ONE
     persistent launch, image i on XCD i % 8; dispatch(tensors) takes the device tensors by slot. Every output slot holds
@@ -696,6 +721,23 @@ class Net:
         assert len(choices) == self.num_ops()
         for i, c in enumerate(choices):
             L.check(lib.saber_hip_net_set_choice(self.h, i, int(c)))
+
+    def stages(self):
+        """[(op index, blocks, selected)] of the ops that head a stage (saber_hip_net_optimize flag 256)"""
+        lib = L.load()
+        out = []
+        for i in range(self.num_ops()):
+            n = int(lib.saber_hip_net_stage_blocks(self.h, i))
+            if n:
+                out.append((i, n, bool(int(lib.saber_hip_net_get_choice(self.h, i)) >> 30 & 1)))
+        return out
+
+    def select_stages(self, on):
+        """every stage of the net on / off (what saber_hip_net_autotune decides per stage by timing)"""
+        ch = self.choices()
+        for i, _, _ in self.stages():
+            ch[i] = (ch[i] | (1 << 30)) if on else (ch[i] & ~(1 << 30))
+        self.set_choices(ch)
 
     def time_ops(self, iters=20):
         out = (C.c_float * self.num_ops())()

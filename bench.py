@@ -73,23 +73,27 @@ def parse():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    ap.add_argument("--no-stage", action="store_true",
+                    help="INT8: do not let runs of res4 block chains run as one persistent stage launch (saber_hip_net_optimize flag 256)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling aid: only warm-up + timed region (no latency / per-op / cpu legs), so the last "
                          "dispatches of a rocprofv3 trace are exactly one forward pass")
     return ap.parse_args()
 
 
-def build_net(W, model, scales, batch, args):
+def build_net(W, model, scales, batch, args, stage=True):
     if args.precision == "int8":
         cxx = not (args.py_fuse or args.no_fuse or args.lanes)      # the C++ host side finds the fusions (the north star's "host side stays C++")
-        return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx)
+        return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx,
+                                stage=stage and not args.no_stage)
     return W.build_fp32_net(model, batch)
 
 
 def tune_key(args, batch, L):
     """a cached selection is only valid for the sources and executor options it was tuned on"""
-    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
-                                                          int(args.lanes), args.chain, int(args.py_fuse), L.source_sha())
+    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
+                                                                  int(args.lanes), args.chain, int(args.py_fuse), int(not args.no_stage),
+                                                                  L.source_sha())
 
 
 def tune(net, args, batch, L, rank, iters=20, refill=None):
@@ -288,7 +292,7 @@ def main():
         peak_ops = MFMA_I8_PEAK_TOPS if args.precision == "int8" else MFMA_F32_PEAK_TFLOPS
         kern = {}
         for i, (nm, t) in enumerate(zip(names, pass_us)):
-            if "(in the chain launch)" in nm:
+            if "(in the chain launch)" in nm or "(in the stage launch)" in nm:
                 continue
             by, fl = net.op_work(i)
             k = kern.setdefault(nm, dict(kernel=nm, launches=0, us=0.0, bytes=0.0, flops=0.0))
@@ -387,7 +391,9 @@ def main():
                 for i in range(2):
                     st = torch.cuda.Stream()
                     with torch.cuda.stream(st):
-                        ne = build_net(W, model, scales, B, args)
+                        # (stage=False: a persistent stage launch needs its image's workgroups resident together - one such
+                        # launch at a time; these nets run their res4 blocks as the chain launches)
+                        ne = build_net(W, model, scales, B, args, stage=False)
                         ne.set_choices(net.choices())
                         ne.tensor("data").copy_(torch.from_numpy(W.make_input(B, seed=11 + i)).cuda())
                         ne.run()
@@ -450,7 +456,7 @@ def main():
                     from integration import net_model as NM
                     with tempfile.TemporaryDirectory() as td:
                         base = W.build_model(args.model)
-                        mt, wb = NM.write_model(base, dict(scales), B, td, "int8")
+                        mt, wb = NM.write_model(base, dict(scales), B, td, "int8", calibrator_config=True)
                         x.tofile(os.path.join(td, "input.bin"))
                         r = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, "200"], capture_output=True,
                                            text=True, timeout=300, cwd=td)      # (the reference's logger writes ./log/)
@@ -468,6 +474,21 @@ def main():
                                      "once (saber_hip_capture_begin / _end), the executor fused + autotuned it, prediction() replays that "
                                      "plan and syncs the outputs (integration/mi355x/framework/mi355x_net_plan.h); op_loop_ms_per_step = "
                                      "the same Net with the plan switched off (94 executors, one launch per operator)")
+                            # the reference's serving shape on the same model file: Worker<MI355X, INT8> (framework/core/net/
+                            # worker.h:38-60), 3 pool threads = 3 Nets, each replaying its own plan on its own stream; requests
+                            # and answers are HOST tensors (4.8 MB of f32 image per batch-8 request over PCIe - an inclusive rate)
+                            rw = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, "worker", "3", "300"],
+                                                capture_output=True, text=True, errors="replace", timeout=300, cwd=td,
+                                                env=dict(os.environ, SABER_MI355X_NET_PLAN_STREAM="own"))
+                            if rw.returncode == 0:
+                                wt = open(os.path.join(td, "worker.txt")).read().split()
+                                ref_list["worker"] = dict(
+                                    threads=3, requests=int(wt[wt.index("requests") + 1]), mismatches=int(wt[wt.index("mismatches") + 1]),
+                                    images_per_s=round(float(wt[wt.index("images_per_s") + 1]), 1),
+                                    what="Worker<MI355X, INT8>::sync_prediction, batch-%d requests from host memory (PCIe-inclusive), "
+                                         "3 threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan)" % B)
+                            else:
+                                ref_list["worker"] = {"error": "rc %d" % rw.returncode}
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
                 ref_list = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -200,6 +200,18 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* chain, const void* x, const vo
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* chain, int tn);
 int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* chain);
 
+/* A RUN of such 3x3-led chains at C = 256 (the blocks of ResNet's res4 stage; chain i + 1 reads chain i's two outputs) as ONE
+ * persistent launch: four cooperating workgroups per tile of 2 x 16 pixels, all tiles of an image on one XCD, an XCD-local barrier
+ * between two blocks instead of a kernel boundary (anakin_amd/csrc/conv_stage_coop.hip). Like the chains an executor-level
+ * fusion with no counterpart in the reference (framework/core/net/net.cpp:417-509 dispatches one operator at a time); results
+ * bit-identical to the separate launches. Batch <= 8, <= 8 tiles per image (14 x 14). The chains are not owned and must outlive
+ * the stage. y1[i] / y2[i]: chain i's outputs (saber_hip_conv2d_chain_run's y_a / y_b); x / res: chain 0's inputs. */
+typedef struct saber_hip_chain_stage saber_hip_chain_stage_t;
+int saber_hip_conv2d_stage_create(saber_hip_chain_t* const* chains, int n, saber_hip_chain_stage_t** out);
+void saber_hip_conv2d_stage_destroy(saber_hip_chain_stage_t* stage);
+int saber_hip_conv2d_stage_run(saber_hip_chain_stage_t* stage, const void* x, const void* res, void* const* y1, void* const* y2,
+                               saber_hip_stream_t stream);
+
 /* XCD-resident stage: a run of INT8 convolutions over SMALL feature maps (h * w <= 64 pixels per image: ResNet's res5) as
  * ONE persistent launch. Image i is computed entirely on XCD i % 8 (32 CUs, one workgroup each); the convolutions
  * ("phases") follow each other inside the kernel, separated by an XCD-local barrier where one reads what an earlier one
@@ -375,8 +387,16 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * pooling the reference's stride-up pass inserts) whose only reader is a fused eltwise epilogue -> folded into that read
  * (saber_hip_conv_desc::res_stride; the pooled edge no longer exists); 128 a conv on <= 64-pixel images followed by the global
  * average Pooling<AK_INT8> of its output -> saber_hip_conv2d_set_global_pooling (both tensors still written, one launch);
- * 255 = all. Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
+ * 255 = all of these. 256 (with 16 | 32; NOT in 255): a run of 3x3-led C = 256 chains whose blocks feed each other (ResNet's res4
+ * stage) -> one persistent launch (saber_hip_conv2d_stage_create); every op stays in the list, saber_hip_net_autotune keeps the
+ * faster form. Only for a net that has the GPU to itself while it runs: the launch needs all workgroups of an image resident on
+ * one XCD together, and two such launches in flight on different streams can starve each other (they time out after ~20 ms,
+ * the next run returns SABER_HIP_RUNTIME_ERROR and the chains launch one by one from then on).
+ * Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
+/* > 0: op `index` heads a stage of that many blocks (flag 256); bit 30 of its saber_hip_net_get_choice / _set_choice value says
+ * whether the stage launch is selected */
+int saber_hip_net_stage_blocks(const saber_hip_net_t* net, int index);
 /* kernel launches of one forward pass (ops minus the ones absorbed into a chain launch) */
 int saber_hip_net_num_launches(const saber_hip_net_t* net);
 /* 1 when tensor `id` is never written: the output edge of a 3x3 conv currently running inside a conv3x3 + chain launch, or an

@@ -120,7 +120,7 @@ def patch_framework(ref, dst):
         "        } else if (std::is_same<X86, Ttype>::value) {\n            //set tensor layout\n")
     # Net<MI355X>::prediction() as one executor call (mi355x_net_plan.h): the plan is a member of Net, built at the end of
     # init() from the op loop run under saber_hip_capture_begin / _end, dropped when init() runs again
-    for n in ("mi355x_net_plan.h", "mi355x_net_planner.h"):
+    for n in ("mi355x_net_plan.h", "mi355x_net_planner.h", "mi355x_created_nodes.h"):
         shutil.copy(os.path.join(HERE, "mi355x", "framework", n), net)
     insert(os.path.join(net, "net.h"), "namespace anakin {", "#include \"framework/core/net/mi355x_net_plan.h\"\n\n", after=False)
     sub(os.path.join(net, "net.h"), "    OperatorFunc<Ttype, Ptype>* _fusion{nullptr};\n};\n",
@@ -131,7 +131,8 @@ def patch_framework(ref, dst):
         "    MI355XNetPlan& mi355x_plan() { return _mi355x_plan; }\n};\n\n"
         "}\n#include \"framework/core/net/mi355x_net_planner.h\"\nnamespace anakin {\n")
     sub(os.path.join(net, "net.cpp"), "    init_env(graph);\n    // shallow copy\n",
-        "    _mi355x_plan.drop();\n    init_env(graph);\n    // shallow copy\n", count=0)
+        "    _mi355x_plan.drop();\n    mi355x_created_nodes_inherit(graph);\n    init_env(graph);\n    // shallow copy\n", count=0)
+    insert(os.path.join(net, "net.cpp"), "namespace anakin {", "#include \"framework/core/net/mi355x_created_nodes.h\"\n\n", after=False)
     sub(os.path.join(net, "net.cpp"), "    init_memory();\n\n    graph.statistics = _graph_p->statistics; // copy statistic back\n",
         "    init_memory();\n    MI355XPlanner<Ttype, Ptype, RunType>::prepare(*this);\n\n"
         "    graph.statistics = _graph_p->statistics; // copy statistic back\n")

@@ -79,7 +79,11 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
         void* const ctx_stream = plan.stream;
         if (plan.own_stream) plan.stream = plan.own_stream;
         plan.ctx_stream = ctx_stream;
-        if (ok) ok = saber_hip_net_optimize(n, 255) >= 0;
+        // 256 (a run of res4 blocks as one persistent launch) only for a plan on the context's own compute stream, which every Net of
+        // the process shares: with a stream of its own per Net (Worker threads serving concurrently) two such launches could each
+        // hold half of the CUs and wait for the other half (saber_hip.h: saber_hip_conv2d_stage_create)
+        const bool stage = env_on("SABER_MI355X_NET_STAGE", plan.own_stream == nullptr);
+        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0)) >= 0;
         if (ok) ok = saber_hip_net_finalize(n) == SABER_HIP_OK;
         if (ok && plan.builds == 0 && env_on("SABER_MI355X_NET_PLAN_TUNE", true))
             ok = saber_hip_net_autotune(n, plan.stream, 9) == SABER_HIP_OK;

@@ -22,7 +22,8 @@ def calibrator_files(spec, scales, outdir):
     framework/core/net/calibrator_parse.cpp:338-460), authored from the topology alone - what a user's calibration run hands to
     the framework next to the model:
       net_config.txt    one line per node of the FROZEN graph, `<node>(<op type>)    <precision>    <target>` (the format
-                        CalibratorParser::auto_config writes, :278-306): every node of an 8-bit layer `int8`, the softmax `fp32`;
+                        CalibratorParser::auto_config writes, :278-306): every node of an 8-bit layer `int8` (`uint8` for a conv with a fused relu),
+                        the softmax `fp32`;
       calibrator.txt    one line per edge carrying a calibrated tensor, `<bottom>_<top> <scale>` (Arc::name(); edges without a
                         line get the parser's default 1.0).
     Node names are the ones integration/test_net_mi355x.cpp gives the original operators (conv `x` -> `x`, `bn_x`, `scale_x`,
@@ -33,6 +34,11 @@ def calibrator_files(spec, scales, outdir):
     for l in spec:
         kd, nm = l["kind"], l["name"]
         p = prec[nm]
+        if kd == "conv" and l["relu"] and p == "int8":
+            # what Net::init's auto-configuration (AutoLayoutConfigHelper::auto_config_node_dtype, auto_layout_config.cpp:108-133)
+            # makes of an INT8 conv with a fused relu; stated in the file so that a Net initialised WITHOUT it - Worker's
+            # init(graph), worker.cpp:28 - runs the same plan (calibrator_parse.cpp:73, calibrator_factory.h:35: an INT8 operator)
+            p = "uint8"
         if kd == "conv":
             bn = l.get("_bn", False)
             chain = [(nm, "Convolution")] + ([("bn_" + nm, "BatchNorm"), ("scale_" + nm, "Scale")] if bn else []) + \

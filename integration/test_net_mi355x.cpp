@@ -81,30 +81,8 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
 
     graph->Optimize();      // the reference's fusion pass + stride-up + schedulers + memory planner
 
-    // Nodes the optimiser CREATED (apply_stride_up inserts 1x1 / stride-s max poolings on a shortcut,
-    // optimize_strategy.h:213-248) carry no precision and their new edges no scale: give them their producer's, as a user
-    // would in the calibrator config of the optimised model.
-    if (P == Precision::INT8) {
-        auto fix = [&](graph::NodePtr& node_p) {
-            if (node_p->bit_type() != AK_INVALID) return;
-            auto& ins = graph->get_in_arc_its(node_p->name());
-            if (ins.empty()) return;
-            graph::NodePtr src = (*graph)[ins[0]->bottom()];
-            if (src->bit_type() != AK_INT8 && src->bit_type() != AK_UINT8) return;
-            node_p->set_bit_type(AK_INT8);
-            std::vector<float> sc;
-            for (auto& e : graph->get_in_arc_its(src->name())) if (e->scale().size()) sc = e->scale();
-            if (sc.empty()) return;
-            for (auto& e : graph->get_in_arc_its(node_p->name())) e->set_scale(sc);
-            for (auto& e : graph->get_out_arc_its(node_p->name())) e->set_scale(sc);
-            // the same Edge objects are reachable from the other end's arc list
-            for (auto& e : graph->get_out_arc_its(src->name())) if (e->top() == node_p->name()) e->set_scale(sc);
-            for (auto& e : graph->get_out_arc_its(node_p->name()))
-                for (auto& e2 : graph->get_in_arc_its(e->top())) if (e2->bottom() == node_p->name()) e2->set_scale(sc);
-        };
-        graph->Scanner->BFS(fix);
-    }
-
+    // (nodes the optimiser CREATED - the stride-up poolings - get their producer's precision and scale at the top of
+    // Net<MI355X>::init: integration/mi355x/framework/mi355x_created_nodes.h)
     Net<MI355X, P> net(true);
     net.init(*graph, /*auto_config_layout=*/P == Precision::INT8);
 
@@ -216,12 +194,13 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
 // ---- `worker <threads> <requests>`: Worker<MI355X, FP32> (framework/core/net/worker.h:38-60) - the reference's multi-instance
 // serving shape: `threads` pool threads, each loads the model (Graph::load -> the text model parser), optimises it and owns a
 // Net; requests are host tensors, answers futures of host tensors. Every answer must equal the first; requests / s reported.
+template <Precision P>
 static int run_worker(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int threads, int requests) {
-    typedef Worker<MI355X, Precision::FP32, OpRunType::ASYNC> worker_t;
+    typedef Worker<MI355X, P, OpRunType::ASYNC> worker_t;
     std::string in_name, out_name;
     std::vector<int> shape;
     {
-        Graph<MI355X, Precision::FP32> g;
+        Graph<MI355X, P> g;
         Status st = g.load(model_path);
         if (!st) { fprintf(stderr, "Graph::load failed: %s\n", st.info()); return 2; }
         in_name = g.get_ins()[0];
@@ -316,7 +295,9 @@ int main(int argc, char** argv) {
     std::vector<float> input = slurp(argv[3]);
     if (argc > 6 && std::string(argv[5]) == "worker") {
         Env<MI355X>::env_init();
-        return run_worker(argv[1], input, argv[4], atoi(argv[6]), argc > 7 ? atoi(argv[7]) : 64);
+        const int th = atoi(argv[6]), rq = argc > 7 ? atoi(argv[7]) : 64;
+        if (precision == "int8") return run_worker<Precision::INT8>(argv[1], input, argv[4], th, rq);
+        return run_worker<Precision::FP32>(argv[1], input, argv[4], th, rq);
     }
     if (argc > 6 && std::string(argv[5]) == "calibrate") {
         Env<MI355X>::env_init();

@@ -56,7 +56,7 @@ for batch in ([int(sys.argv[1])] if len(sys.argv) > 1 else [8, 1]):
     big_a = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     big_b = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     ref = None
-    for tn in (1, 3, 7):
+    for tn in (1, 3, 7, 15):
         chain.set_tile(tn)
         chain.dispatch(x, res, z1, z2)
         torch.cuda.synchronize()

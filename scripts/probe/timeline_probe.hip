@@ -26,6 +26,7 @@ __device__ unsigned long long* saber_tl_buf = nullptr;
 #include "../../anakin_amd/csrc/stem_pool.hip"
 #include "../../anakin_amd/csrc/conv1x1_chain.hip"
 #include "../../anakin_amd/csrc/conv_chain_coop.hip"
+#include "../../anakin_amd/csrc/conv_stage_coop.hip"
 namespace saber_mi355x {
 void tile_dims(int tile, int* bm_k, int* bn_pix) {
     static const int d[TILE_COUNT][2] = {{32, 32}, {64, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 128}};
@@ -69,14 +70,14 @@ struct Probe {
 
 template <typename F>
 static void run(Probe& P, const char* name, int blocks, int nph, F launch) {
-    std::vector<unsigned long long> h((size_t)blocks * 8);
+    std::vector<unsigned long long> h((size_t)blocks * 16);
     for (int cold = 1; cold >= 0; --cold) {
         std::vector<float> ev;
         std::vector<std::vector<double>> ph(nph);   // per phase: all (block, rep) samples, us since the launch's first stamp
         for (int rep = 0; rep < 12; ++rep) {
             if (cold) hipLaunchKernelGGL(flush_kernel, dim3(2048), dim3(256), 0, P.st, P.big, P.nbig, P.out);
             else launch();
-            CK(hipMemsetAsync(P.tl, 0, (size_t)blocks * 64, P.st));
+            CK(hipMemsetAsync(P.tl, 0, (size_t)blocks * 128, P.st));
             CK(hipEventRecord(P.e0, P.st));
             launch();
             CK(hipEventRecord(P.e1, P.st));
@@ -85,12 +86,12 @@ static void run(Probe& P, const char* name, int blocks, int nph, F launch) {
             CK(hipEventElapsedTime(&ms, P.e0, P.e1));
             if (rep < 2) continue;
             ev.push_back(ms * 1000.f);
-            CK(hipMemcpy(h.data(), P.tl, (size_t)blocks * 64, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h.data(), P.tl, (size_t)blocks * 128, hipMemcpyDeviceToHost));
             unsigned long long t0 = ~0ull;
-            for (int b = 0; b < blocks; ++b) if (h[(size_t)b * 8]) t0 = std::min(t0, h[(size_t)b * 8]);
+            for (int b = 0; b < blocks; ++b) if (h[(size_t)b * 16]) t0 = std::min(t0, h[(size_t)b * 16]);
             for (int b = 0; b < blocks; ++b)
                 for (int i = 0; i < nph; ++i)
-                    if (h[(size_t)b * 8 + i]) ph[i].push_back((double)(h[(size_t)b * 8 + i] - t0) * 0.01);
+                    if (h[(size_t)b * 16 + i]) ph[i].push_back((double)(h[(size_t)b * 16 + i] - t0) * 0.01);
         }
         std::sort(ev.begin(), ev.end());
         float chain = 0;
@@ -108,7 +109,7 @@ static void run(Probe& P, const char* name, int blocks, int nph, F launch) {
         for (int i = 0; i < nph; ++i) {
             if (ph[i].empty()) continue;
             std::sort(ph[i].begin(), ph[i].end());
-            printf("    phase %d: min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us   (%zu samples)\n", i, ph[i].front(),
+            printf("    phase %2d: min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us   (%zu samples)\n", i, ph[i].front(),
                    ph[i][ph[i].size() / 2], ph[i][ph[i].size() * 9 / 10], ph[i].back(), ph[i].size());
         }
     }
@@ -122,7 +123,7 @@ int main(int argc, char** argv) {
     P.nbig = (size_t)192 << 16;   // 192 MB of uint4
     P.big = (uint4*)dalloc(P.nbig * 16, 3);
     P.out = (unsigned*)dalloc(4096, 0);
-    CK(hipMalloc((void**)&P.tl, (size_t)P.maxblocks * 64));
+    CK(hipMalloc((void**)&P.tl, (size_t)P.maxblocks * 128));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(saber_tl_buf), &P.tl, sizeof(P.tl)));
     void* zero = dalloc(256, 0);
 
@@ -158,6 +159,45 @@ int main(int argc, char** argv) {
             ck.n_tiles = tiles;
             snprintf(nm, sizeof nm, "conv3x3+chain C=256 14x14 b%d coop2", n);
             run(P, nm, (tiles + 7) / 8 * 16, 7, [&] { launch_conv_chain_coop(ck, P.st); });
+            // conv_stage_coop.hip: four cooperating workgroups per tile of 2 rows x 16 columns; one block with the tiles spread over the
+            // XCDs (the chain's tile code 15), one block with an image per XCD, five blocks in one launch. Stamps (of the LAST block
+            // where a launch has several): 0 entry, 1 first halo + constants + 20 fragments landed, 2 3x3 done + arrival 1 + barrier,
+            // 3 past wait 1, 4 1x1 + eltwise done, y1 stored, arrival 2, 5 past wait 2, 6 y2 stored, 7 past the last image barrier +
+            // the next halo landed
+            const int tiles4 = n * ((hw + 1) / 2);
+            std::vector<StageBlk> hb(5);
+            for (auto& B : hb) {
+                memset(&B, 0, sizeof B);
+                B.wstream = a.wstream; B.prm0 = a.prm0; B.prm1 = a.prm1; B.prm2 = a.prm2;
+                B.coeff_conv = 16.f; B.scale_conv = 0.05f; B.coeff_res = 16.f; B.scale_res = 0.04f;
+                B.in0_u8 = 1; B.relu0 = 1; B.in_u8 = 1; B.relu1 = 0; B.res_relu = 1; B.relu2 = 1; B.out_u8_2 = 1;
+            }
+            StageBlk* dblk;
+            CK(hipMalloc((void**)&dblk, sizeof(StageBlk) * 5));
+            CK(hipMemcpy(dblk, hb.data(), sizeof(StageBlk) * 5, hipMemcpyHostToDevice));
+            Stage4KArgs<STAGE4_SHORT> sk;
+            memset(&sk, 0, sizeof sk);
+            sk.x = a.x; sk.res = a.res; sk.zero = zero; sk.blk = dblk;
+            sk.grp_ctr = (unsigned long long*)dalloc((size_t)tiles4 * 32 * 8, 0);
+            sk.img_ctr = (unsigned long long*)dalloc((size_t)n * ((hw + 1) / 2 + 1) * 16 * 8, 0);
+            sk.xch = dalloc((size_t)tiles4 * 32 * c, 0);
+            sk.xcc = (unsigned*)dalloc((size_t)tiles4 * 32 * 4, 0);
+            sk.err = ck.coop_err;
+            sk.N = n; sk.H = sk.W = hw; sk.tiles_x = 1; sk.tiles_per_img = (hw + 1) / 2;
+            sk.mg_tiles_x = magic(1); sk.mg_tpi = magic(sk.tiles_per_img); sk.mg_wpi = magic(sk.tiles_per_img * 4);
+            for (int i = 0; i < 5; ++i) {      // ping-pong outputs: block i + 1 reads block i's y2 (and keeps its y1 tile in LDS)
+                sk.y1[i] = i % 2 ? a.y1 : dalloc((size_t)M * K1, 0);
+                sk.y2[i] = i % 2 ? a.y2 : dalloc((size_t)M * c, 0);
+            }
+            sk.nblk = 1; sk.per_image = 0;
+            snprintf(nm, sizeof nm, "stage4 C=256 14x14 b%d 1 block, tiles over XCDs", n);
+            run(P, nm, (tiles4 + 7) / 8 * 32, 8, [&] { launch_conv_stage4(sk, P.st); });
+            sk.per_image = 1;
+            snprintf(nm, sizeof nm, "stage4 C=256 14x14 b%d 1 block, image per XCD", n);
+            run(P, nm, (n + 7) / 8 * sk.tiles_per_img * 32, 8, [&] { launch_conv_stage4(sk, P.st); });
+            sk.nblk = 5;
+            snprintf(nm, sizeof nm, "stage4 C=256 14x14 b%d 5 blocks, image per XCD", n);
+            run(P, nm, (n + 7) / 8 * sk.tiles_per_img * 32, 8, [&] { launch_conv_stage4(sk, P.st); });
             unsigned errs = 0;
             CK(hipMemcpy(&errs, ck.coop_err, 4, hipMemcpyDeviceToHost));
             printf("    coop error word: %u\n", errs);

@@ -64,6 +64,21 @@ def _int8_every_edge(name, batch, min_edges):
                 assert np.array_equal(got, want.reshape(got.shape)), (name, batch, form, nm, names)
             checked += 1
         assert checked >= min_edges, checked
+    # the res4 stage as ONE persistent launch (conv_stage_coop.hip) and block by block: whichever the tuner picked, both forms
+    stages = net.stages()
+    for on in ((True, False) if stages else ()):
+        net.select_stages(on)
+        assert all(s[2] == on for s in net.stages())
+        for nm in net.tensors:
+            if nm != "data" and not net.unwritten(nm):
+                net.tensor(nm).zero_()
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+        for nm in net.tensors:
+            if nm == "data" or nm not in ref or net.unwritten(nm) or nm == "prob":
+                continue
+            assert np.array_equal(_h(net.tensor(nm)), ref[nm].reshape(_h(net.tensor(nm)).shape)), (name, batch, "stage on" if on else "stage off", nm)
+    net.stage_count = len(stages)
     return net
 
 
@@ -71,11 +86,13 @@ def _int8_every_edge(name, batch, min_edges):
 def test_resnet50_int8_framework_list_autotuned_every_edge_every_image(batch):
     net = _int8_every_edge("resnet50", batch, 40)
     print("ResNet50 INT8 batch %d: %d ops in %d launches, bit-exact on every materialised edge" % (batch, net.num_ops(), net.num_launches()))
+    assert net.stage_count == 1      # res4: five 3x3-led chains feeding each other
 
 
 def test_resnet101_int8_batch8_autotuned_every_edge_every_image():
     net = _int8_every_edge("resnet101", 8, 70)
     print("ResNet101 INT8 batch 8: %d ops in %d launches" % (net.num_ops(), net.num_launches()))
+    assert net.stage_count == 1      # res4: 22 blocks in one launch
 
 
 def _fp32_every_edge_autotuned(name, batch, min_edges):

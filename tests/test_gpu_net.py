@@ -188,11 +188,11 @@ def test_net_mi355x_resnet50_int8_batch8_prediction_through_the_plan(tmp_path):
     assert ms * 2 < ms_loop
 
 
-def _run_mode(tmp_path, name, batch, x, mode_args, env_extra=None):
+def _run_mode(tmp_path, name, batch, x, mode_args, env_extra=None, precision="fp32", scales=None):
     assert os.path.exists(BIN), "integration/_build/test_net_mi355x.bin is missing: run __graft_entry__.build()"
     model = W.build_model(name)
     d = str(tmp_path)
-    mt, wb = NM.write_model(model, {}, batch, d, "fp32")
+    mt, wb = NM.write_model(model, scales or {}, batch, d, precision, calibrator_config=precision == "int8")
     x.tofile(os.path.join(d, "input.bin"))
     env = dict(os.environ, **(env_extra or {}))
     env.pop("LD_PRELOAD", None)
@@ -217,6 +217,28 @@ def test_worker_mi355x_fp32_serves_requests_from_a_thread_pool(tmp_path):
     ref = NO.run_fp32(W.framework_model(model, "fp32"), x)
     _fp32_check(prob, ref["prob"], "prob (Worker<MI355X>::sync_prediction)")
     print("Worker<MI355X, FP32>, ResNet50 batch 8, 3 threads: %.0f images/s" % float(t[t.index("images_per_s") + 1]))
+
+
+def test_worker_mi355x_int8_serves_the_headline_model(tmp_path):
+    """Worker<MI355X, INT8>: BASELINE.json's headline model in the reference's serving shape. Each pool thread loads the model file,
+    reads precisions and scales from the calibrator files (Graph::load_calibrator_config inside parser::load), optimises, and owns a
+    Net<MI355X, INT8> whose prediction() replays its own captured plan on its own stream. 64 requests of one batch-8 input from host
+    memory: every answer identical, and the probabilities of the CPU oracle's s8 logits."""
+    batch = 8
+    x = W.make_input(batch)
+    model = W.build_model("resnet50")
+    scales = W.calibrate(model, x)
+    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["worker", "3", "64"], {"SABER_MI355X_NET_PLAN_STREAM": "own"},
+                            precision="int8", scales=scales)
+    assert "worker ok" in r.stdout
+    t = open(os.path.join(d, "worker.txt")).read().split()
+    assert int(t[t.index("mismatches") + 1]) == 0 and int(t[t.index("requests") + 1]) == 64
+    prob = np.fromfile(os.path.join(d, "out_worker.bin"), np.float32)
+    fm = W.framework_model(model, "int8")
+    ref = NO.run_int8(fm, dict(scales), x)
+    want = ref["prob"].reshape(batch, -1)
+    assert np.abs(prob.reshape(batch, -1) - want).max() <= 1e-4 * want.max()
+    print("Worker<MI355X, INT8>, ResNet50 batch 8, 3 threads, host tensors in and out: %.0f images/s" % float(t[t.index("images_per_s") + 1]))
 
 
 def test_entropy_calibrator_mi355x_writes_the_calibration_table(tmp_path):

@@ -527,6 +527,11 @@ CHAIN3_CASES = [
     (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, 7),
     (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, 7),      # ragged: 3 tiles of 5 columns
     (256, 3, 5, 37, O.U8, O.S8, O.U8, 1, 0, 7),     # three column tiles per row, the last one ragged
+    (256, 8, 14, 14, O.U8, O.U8, O.U8, 1, 1, 15),   # C = 256, FOUR cooperating workgroups per tile of 2 rows x 16 columns: res4 at batch 8
+    (256, 2, 14, 14, O.U8, O.U8, O.U8, 1, 1, 15),
+    (256, 1, 3, 5, O.S8, O.U8, O.S8, 0, 1, 15),     # ragged: an odd row count (the last tile's second row is outside the image)
+    (256, 3, 5, 37, O.U8, O.S8, O.U8, 1, 0, 15),    # three column tiles per row pair, the last one ragged
+    (256, 16, 14, 14, O.U8, O.U8, O.U8, 1, 1, 15),  # 448 workgroups: more than one per CU
 ]
 
 
@@ -578,7 +583,7 @@ def test_conv3x3_chain_equals_three_launches_and_oracle(case):
     z1, z2 = ca.new_output(), cb.new_output()
     z1.fill_(77)
     z2.fill_(77)
-    for rep in range(3 if tn == 7 else 1):        # (the cooperative form's pair counters are never reset: launch after launch)
+    for rep in range(3 if tn in (7, 15) else 1):  # (the cooperative forms' arrival counters are never reset: launch after launch)
         z1.fill_(77)
         z2.fill_(77)
         chain.dispatch(dev(x), dev(res), z1, z2)
@@ -587,11 +592,85 @@ def test_conv3x3_chain_equals_three_launches_and_oracle(case):
         assert np.array_equal(host(z2), want2), ("y2", chain.tile(), rep)
     # conv3x3 + first 1x1 conv only (the last block of a stage: no 1x1 conv follows on the same pixels)
     double = S.SaberConvChain(ca, None, conv3x3=c0)
-    if tn is not None and tn != 7:
+    if tn is not None and tn not in (7, 15):
         double.set_tile(tn)
     z1.fill_(55)
     double.dispatch(dev(x), dev(res), z1)
     assert np.array_equal(host(z1), want1), ("double y1", double.tile())
+
+
+def _res4_blocks(rng, N, H, Wd, nblk, first_u8=True):
+    """nblk ResNet res4 block chains at C = 256: [3x3 -> 1x1 expand + eltwise(relu) -> next block's 1x1 reduce], chain i + 1
+    reading chain i's outputs; returns the device ops, the first inputs and the oracle's outputs per block."""
+    Cc, K1 = 256, 1024
+    x = rng.integers(0, 256, (N, H, Wd, Cc)).astype(np.uint8) if first_u8 else rng.integers(-128, 128, (N, H, Wd, Cc)).astype(np.int8)
+    res = rng.integers(-128, 128, (N, H, Wd, K1)).astype(np.int8)
+    ops, wants = [], []
+    cur_x, cur_res, idt = x, res, (O.U8 if first_u8 else O.S8)
+    for k in range(nblk):
+        w0 = (rng.standard_normal((Cc, Cc, 3, 3)) * np.sqrt(2.0 / (9 * Cc))).astype(np.float32)
+        b0 = (rng.standard_normal(Cc) * 0.5).astype(np.float32)
+        w1 = (rng.standard_normal((K1, Cc, 1, 1)) * np.sqrt(2.0 / Cc)).astype(np.float32)
+        b1 = (rng.standard_normal(K1) * 0.5).astype(np.float32)
+        w2 = (rng.standard_normal((Cc, K1, 1, 1)) * np.sqrt(2.0 / K1)).astype(np.float32)
+        b2 = (rng.standard_normal(Cc) * 0.5).astype(np.float32)
+        s_x, s_in, s_mid, s_res, s_sum, s_out = 0.023 + 0.001 * k, 0.02, 0.05, 0.043 + 0.002 * k, 0.06, 0.031
+        c = 1.0 / s_sum
+        odt2 = O.U8 if k % 2 == 0 else O.S8          # the next block's 3x3 input: both kinds
+        relu2 = 1 if odt2 == O.U8 else 0
+        ws0 = O.weight_scales(w0)
+        bp0, sc0 = O.conv_i8_prepare(ws0, b0, s_x, s_in, idt, O.U8)
+        t0 = O.conv_i8(cur_x, O.quant_weights(w0, ws0), bp0, sc0, O.U8, 1, (1, 1))
+        ws1 = O.weight_scales(w1)
+        bp1, sc1 = O.conv_i8_prepare(ws1, b1, s_in, s_mid, O.U8, O.S8)
+        t1 = O.conv_i8(t0, O.quant_weights(w1, ws1), bp1, sc1, O.S8, 0)
+        want1 = O.eltwise_i8(t1, cur_res, s_mid, s_res, c, c, True)
+        ws2 = O.weight_scales(w2)
+        bp2, sc2 = O.conv_i8_prepare(ws2, b2, s_sum, s_out, O.S8, odt2)
+        want2 = O.conv_i8(want1, O.quant_weights(w2, ws2), bp2, sc2, odt2, relu2)
+        c0 = S.SaberConv2D(int8=True).init((N, Cc, H, Wd), S.ConvParam(w0, b0, 1, (1, 1), (1, 1), (1, 1), True), idt, O.U8, s_x, s_in)
+        pa = S.ConvParam(w1, b1, 1, (0, 0), (1, 1), (1, 1), False)
+        pa.res_mode, pa.res_relu, pa.sum_scale, pa.coeff, pa.scale_res = L.RES_ELTWISE, True, 1.0, (c, c), s_res
+        ca = S.SaberConv2D(int8=True).init((N, Cc, H, Wd), pa, O.U8, O.S8, s_in, s_mid)
+        cb = S.SaberConv2D(int8=True).init((N, K1, H, Wd), S.ConvParam(w2, b2, 1, (0, 0), (1, 1), (1, 1), bool(relu2)), O.S8, odt2, s_sum, s_out)
+        ops.append((c0, ca, cb))
+        wants.append((want1, want2))
+        cur_x, cur_res, idt = want2, want1, odt2
+    return x, res, ops, wants
+
+
+@pytest.mark.parametrize("shape", [(8, 14, 14, 5), (3, 14, 14, 3), (2, 7, 9, 2), (8, 14, 14, 1)])
+def test_chain_stage_equals_the_chains_and_oracle(shape):
+    """saber_hip_conv2d_stage_create: a RUN of res4 block chains in one persistent launch (conv_stage_coop.hip; four cooperating
+    workgroups per tile, an image per XCD, an XCD-local barrier between blocks) - every block's two outputs bit for bit the
+    oracle's and the chain launches', launch after launch (the arrival counters are never reset)."""
+    N, H, Wd, nblk = shape
+    rng = np.random.default_rng(4100 + N + H + nblk)
+    x, res, ops, wants = _res4_blocks(rng, N, H, Wd, nblk)
+    chains = [S.SaberConvChain(ca, cb, conv3x3=c0) for c0, ca, cb in ops]
+    y1 = [ca.new_output() for _, ca, _ in ops]
+    y2 = [cb.new_output() for _, _, cb in ops]
+    cx, cr = dev(x), dev(res)
+    for k, ch in enumerate(chains):                  # the chains one by one (their default single-workgroup form)
+        ch.dispatch(cx, cr, y1[k], y2[k])
+        assert np.array_equal(host(y1[k]), wants[k][0]) and np.array_equal(host(y2[k]), wants[k][1]), ("chain", k)
+        cx, cr = y2[k], y1[k]
+    stage = S.SaberChainStage(chains)
+    for rep in range(3):
+        for t in y1 + y2:
+            t.fill_(77)
+        stage.dispatch(dev(x), dev(res), y1, y2)
+        for k in range(nblk):
+            assert np.array_equal(host(y1[k]), wants[k][0]), ("stage y1", k, rep)
+            assert np.array_equal(host(y2[k]), wants[k][1]), ("stage y2", k, rep)
+
+
+def test_chain_stage_rejects_what_it_cannot_run():
+    rng = np.random.default_rng(5)
+    x, res, ops, wants = _res4_blocks(rng, 9, 14, 14, 2)          # batch 9: an image per XCD needs <= 8
+    chains = [S.SaberConvChain(ca, cb, conv3x3=c0) for c0, ca, cb in ops]
+    with pytest.raises(RuntimeError):
+        S.SaberChainStage(chains)
 
 
 def test_conv1x1_chain_rejects_other_shapes():
