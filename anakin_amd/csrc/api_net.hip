@@ -458,6 +458,32 @@ int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int
     for (size_t i = 0; i < n; ++i) out_us[i] = (float)(acc[i] * 1000.0 / iters);
     return SABER_HIP_OK;
 }
+// ONE op's launch duration inside a forward pass, undisturbed: whole eager passes with just two events, one in front of the op's
+// launch and one behind it (both on the launch stream: the first is reached when the previous kernel has finished). The per-launch
+// events of saber_hip_net_time_pass stretch a pass (a marker per launch), so its shares - scaled back to the untimed step -
+// understate a long kernel among many short ones; this is the figure that agrees with a rocprofv3 kernel trace.
+int saber_hip_net_time_op_in_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int index, int iters, float* out_us) {
+    if (!net || !net->finalized || iters <= 0 || !out_us || index < 0 || index >= (int)net->ops.size())
+        return fail(SABER_HIP_INVALID_VALUE, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    EventPair evp;
+    HIP_TRY(evp.init());
+    double acc = 0.0;
+    for (int it = 0; it < iters + 1; ++it) {      // the first pass warms up and is dropped
+        for (size_t i = 0; i < net->ops.size(); ++i) {
+            if ((int)i == index) HIP_TRY(hipEventRecord(evp.e0, s));
+            int rc = net_launch(net, net->ops[i], s);
+            if (rc) return rc;
+            if ((int)i == index) HIP_TRY(hipEventRecord(evp.e1, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, evp.e0, evp.e1));
+        if (it) acc += ms;
+    }
+    *out_us = (float)(acc * 1000.0 / iters);
+    return SABER_HIP_OK;
+}
 int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us) {
     hipStream_t s = (hipStream_t)stream;
     EventPair evp;

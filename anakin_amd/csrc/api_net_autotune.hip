@@ -46,7 +46,7 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
         net_set_chain_mode(net, index, net_chain_mode(net, index) == 2 ? 2 : (tn ? 1 : 0));   // (also restores the names)
     }
     if (o.stage) net_set_stage(net, index, stage_on);      // (a stage head comes before its blocks: set_choices runs in op order)
-    if (o.skip) o.name = "conv:(in the chain launch)";
+    if (o.skip) o.name = (o.chain3 && o.use_chain3) ? "conv:(in the stage launch)" : "conv:(in the chain launch)";
     if (net->exec) {
         (void)hipGraphExecDestroy(net->exec);
         (void)hipGraphDestroy(net->graph);

@@ -32,6 +32,7 @@ static void net_name_chain(NetOp& A, NetOp& B) {
 }
 // mode of the ops around A = ops[ia] (a 1x1 conv with the fused eltwise): 0 separate launches, 1 A + B chained (A.chain),
 // 2 the 3x3 conv ops[ia - 1] leads the launch (its chain3; with or without B)
+static std::string stage_name(const NetOp& H0) { return "conv:stage_c256_" + std::to_string(H0.stage_n) + "x[conv3x3+chain1x1]_2x16_coop4"; }
 void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     NetOp& A = net->ops[ia];
     NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
@@ -51,6 +52,8 @@ void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     }
     if (B) net_name_chain(A, *B);
     else A.name = A.skip ? "conv:(in the chain launch)" : std::string("conv:") + A.conv->algo_name;
+    if (H && H->stage && H->use_stage) H->name = stage_name(*H);      // (an active stage keeps its names: set_choice comes through here)
+    else if (H && H->skip) H->name = "conv:(in the stage launch)";
 }
 // The stage headed by ops[i0] on / off. On: every block runs its 3x3-led chain form (mode 2), ops[i0] launches them all and the
 // other blocks' 3x3 convs carry `skip` too. Off: the blocks' chains launch one by one again (mode 2, their own tile codes).
@@ -66,7 +69,7 @@ void net_set_stage(saber_hip_net* net, int i0, bool on) {
         }
     }
     H0.use_stage = on;
-    if (on) H0.name = "conv:stage_c256_" + std::to_string(H0.stage_n) + "x[conv3x3+chain1x1]_2x16_coop4";
+    if (on) H0.name = stage_name(H0);
 }
 int net_chain_mode(const saber_hip_net* net, int ia) {
     const NetOp& A = net->ops[ia];
@@ -395,8 +398,10 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
                     ops[i].stage_n = (int)run.size();
                     int before = 0;
                     for (size_t k = 0; k < run.size(); ++k) before += 3 - (ops[i + 3 * k].skip + ops[i + 3 * k + 1].skip + ops[i + 3 * k + 2].skip);
-                    net_set_stage(net, (int)i, true);          // default until the autotuner has timed both forms
-                    removed += before - 1;
+                    // default until the autotuner has timed both forms: on from batch 4 (an image per XCD: fewer images leave XCDs idle)
+                    const bool on = run[0]->a->d.n >= 4;
+                    net_set_stage(net, (int)i, on);
+                    if (on) removed += before - 1;
                 }
             }
             i += 3 * run.size();

@@ -744,6 +744,12 @@ class Net:
         L.check(L.load().saber_hip_net_time_ops(self.h, _stream(), iters, out))
         return list(out)
 
+    def time_op_in_pass(self, index, iters=20):
+        """one op's launch duration inside an otherwise untimed eager pass (two events around that launch only)"""
+        out = C.c_float()
+        L.check(L.load().saber_hip_net_time_op_in_pass(self.h, _stream(), int(index), int(iters), C.byref(out)))
+        return float(out.value)
+
     def time_pass(self, iters=20):
         """Per-op microseconds INSIDE a forward pass (one event after every launch; saber_hip_net_time_pass)."""
         out = (C.c_float * self.num_ops())()

@@ -208,7 +208,9 @@ def main():
         model = W.framework_model(model, "int8")
     x = W.make_input(B, seed=1234 + rank)
     scales = W.calibrate(model, W.make_input(2)) if args.precision == "int8" else {}
-    net = build_net(W, model, scales, B, args)
+    # (ranks sharing one GPU - the 2-rank test of tests/test_gpu_dist.py - run concurrently on it: no persistent stage launches there,
+    # two of them in flight can starve each other of CUs; one rank per GPU: the stage has its GPU to itself)
+    net = build_net(W, model, scales, B, args, stage=os.environ.get("BENCH_SHARE_GPU") != "1")
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     torch.cuda.synchronize()
@@ -311,7 +313,17 @@ def main():
                                    hbm_frac=round(gbs / HBM_PEAK_GBS, 4), mfma_peak=round(pk, 1), mfma_frac=round(tops / pk, 4)))
         per_kernel.sort(key=lambda r: -r["total_us"])
         convs = [r for r in per_kernel if r["kernel"].startswith(("conv:", "fc:"))]
-        dom = convs[0]                           # the kernel function with the largest share of the step
+        dom = dict(convs[0])                     # the kernel function with the largest share of the step
+        # ... re-timed UNDISTURBED: whole eager passes with only two events, around each of its launches in turn (the per-launch markers
+        # above stretch a pass, so the scaled shares understate a long kernel among many short ones - 42.5 us for a launch the
+        # rocprofv3 trace of the same command has at 54.9; this figure agrees with the trace)
+        dom_ops = [i for i, nm in enumerate(names) if nm == dom["kernel"]]
+        dom_us = [net.time_op_in_pass(i, iters=30) for i in dom_ops]
+        dom["avg_us_pass_share"] = dom["avg_us"]
+        dom["avg_us"] = round(sum(dom_us) / len(dom_us), 3)
+        dom["gbs"] = round(dom["bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9, 1)
+        dom["hbm_frac"] = round(dom["gbs"] / HBM_PEAK_GBS, 4)
+        dom["mfma_frac"] = round(dom["gops_per_launch"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12 / dom["mfma_peak"], 4)
         conv_us_step = sum(r["total_us"] for r in convs)
         alg_bytes = sum(r["bytes_per_launch"] * r["launches"] for r in convs)
         alg_ops = sum(r["gops_per_launch"] * r["launches"] for r in convs) * 1e9
@@ -343,8 +355,12 @@ def main():
         all_gbs = alg_bytes / (conv_us_step * 1e-6) / 1e9
         roof.update(kernel=dom["kernel"], launches=dom["launches"], avg_launch_us=dom["avg_us"],
                     algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_gops_per_launch=dom["gops_per_launch"],
-                    how="dominant kernel function of the pass by total time; avg_launch_us = its share of an event-per-launch eager "
-                        "pass (saber_hip_net_time_pass, hipEvents on the launch stream) scaled to ms_per_step of the timed region",
+                    avg_launch_us_pass_share=dom["avg_us_pass_share"],
+                    how="dominant kernel function of the pass (largest share of an event-per-launch eager pass, saber_hip_net_time_pass); "
+                        "avg_launch_us = hipEvents on the launch stream around each of ITS launches only, inside otherwise untimed eager "
+                        "forward passes (saber_hip_net_time_op_in_pass, 30 passes per launch) - the figure the rocprofv3 kernel trace of "
+                        "the same command shows; avg_launch_us_pass_share = its share of the event-per-launch pass scaled to ms_per_step "
+                        "(what per_kernel lists for every function: the markers stretch the pass, long kernels read short)",
                     frac_all_conv=round(all_gbs / HBM_PEAK_GBS, 4), achieved_all_conv_gbs=round(all_gbs, 1),
                     # every conv / fc launch at its own matrix pipe's peak, over the time they take in the step
                     mfma_frac_all_conv=round(sum(r["gops_per_launch"] * r["launches"] * 1e9 / (r["mfma_peak"] * 1e12) for r in convs)

@@ -426,6 +426,10 @@ int saber_hip_net_time_ops(saber_hip_net_t* net, saber_hip_stream_t stream, int 
  * over `iters` passes (the op in its place in the pipeline, kernel boundary included; ops absorbed into a chain launch: 0).
  * The events lengthen the pass: use the shares, scaled to an untimed step. */
 int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int iters, float* out_us);
+/* ONE op's launch duration inside a forward pass, undisturbed: whole eager passes with only two events, in front of and behind
+ * that op's launch (the per-launch markers of saber_hip_net_time_pass stretch the pass; this figure is the one that agrees with
+ * a rocprofv3 kernel trace - bench.py uses it for the dominant kernel's roofline) */
+int saber_hip_net_time_op_in_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int index, int iters, float* out_us);
 /* Algorithmic work of one launch of op `index` (input + output + residual activations once, weights once;
  * 2 x MACs), summed over the operators the launch covers (chain / pair launches). */
 int saber_hip_net_op_work(const saber_hip_net_t* net, int index, double* bytes, double* flops);

@@ -7,7 +7,9 @@ import json
 import sqlite3
 import sys
 
-CONV = ("conv_igemm", "conv3x3_halo", "conv3x3_img", "conv_stem", "conv1x1_chain", "fc_i8_small")
+# conv / fc launches = everything that is not one of the streaming kernels (an inclusion list missed every kernel added after it
+# was written: the cooperative chains, the stage launch, the conv + global-pooling kernel - round-4 finding)
+STREAMING = ("softmax", "pool2d", "quantize", "transpose", "eltwise", "relu_f32", "gemm_pack", "null_kernel")
 path, counter, nlast = sys.argv[1], sys.argv[2], int(sys.argv[3])
 c = sqlite3.connect(path)
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -26,7 +28,7 @@ for i, (_, ev, name, dur, blocks) in enumerate(rows):
     print("%3d %9.2f %7d %12.1f %12.1f  %s" % (i, dur / 1e3, blocks, v, v * mult, short))
     tot_all += v
     per.append(v * mult * 1024)
-    if any(k in name for k in CONV):
+    if not any(k in name for k in STREAMING):
         tot_conv += v
         n_conv += 1
 print(json.dumps({"counter": counter, "dispatches": len(rows), "conv_dispatches": n_conv, "sum_all_KB": tot_all,

@@ -282,6 +282,33 @@ def test_autotuned_selection_round_trips_through_choices(setup):
     assert np.array_equal(_h(b.tensor("fc1000")), ref["fc1000"].reshape(2, -1))
 
 
+def test_measurement_entry_points_agree_with_each_other(setup):
+    """What bench.py's roofline rests on: saber_hip_net_time_pass (an event per launch: shares of a pass), _time_op_in_pass (two
+    events around ONE launch inside otherwise untimed passes - the figure a rocprofv3 trace shows) and _op_work (algorithmic bytes /
+    ops per launch): every launching op has a positive time and work, ops absorbed into a chain / stage launch report 0,
+    and the bracketed time of the longest launch is of the order of its share (the markers stretch a pass, so the two differ -
+    by tens of per cent, not by factors)."""
+    model, x, scales, ref = setup
+    net = W.build_int8_net(model, dict(scales), 2)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    shares = net.time_pass(iters=5)
+    names = [net.op_name(i) for i in range(net.num_ops())]
+    launching = [i for i, nm in enumerate(names) if "(in the " not in nm]
+    assert len(launching) == net.num_launches()
+    for i, nm in enumerate(names):
+        by, fl = net.op_work(i)
+        if i in launching:
+            assert shares[i] > 0 and by > 0, (i, nm)
+        else:
+            assert shares[i] == 0 and by == 0 and fl == 0, (i, nm)
+    top = max(launching, key=lambda i: shares[i])
+    t = net.time_op_in_pass(top, iters=5)
+    assert 0.5 * shares[top] < t < 2.0 * shares[top] + 5.0, (names[top], t, shares[top])
+    with pytest.raises(L.SaberHipError):
+        net.time_op_in_pass(net.num_ops(), iters=5)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The list the reference's OWN optimiser emits (workloads.framework_spec; tests/test_net_oplist.py proves the equality,
 # tests/test_gpu_net.py runs it through the reference's Net): stride-up (three stride-2 3x3 convs + 1x1/2 shortcut
