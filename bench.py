@@ -50,6 +50,7 @@ def parse():
                     help="INT8: 'framework' = the op list the reference's own optimiser + edge rules emit (workloads.framework_spec: "
                          "stride-up, conv1 -> s8, INT8 tail; what Net<MI355X> runs), 'caffe' = the round-1/2 list (plain Caffe topology)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--force-graph", action="store_true", help="hipGraph replay without timing it against eager launches (A/B aid)")
     ap.add_argument("--no-fuse", action="store_true", help="keep the 16 eltwise ops separate (reference op list)")
     ap.add_argument("--py-fuse", action="store_true",
                     help="INT8: let workloads.py (Python) apply the executor-level fusions while it builds the list; default: the list is "
@@ -239,7 +240,7 @@ def main():
         gather_flush()
         torch.cuda.synchronize()
 
-    if use_graph:
+    if use_graph and not args.force_graph:
         use_graph, launch_probe = pick_launch_mode(net, gather=gather, flush=gather_flush)
         if world > 1:   # every rank uses the same mode (the slowest rank sets the step time anyway)
             flag = torch.tensor([1 if use_graph else 0], device="cuda")

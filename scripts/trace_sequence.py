@@ -29,17 +29,24 @@ def main(path, nops, nfwd=1):
     rows = rows[-nops * nfwd:]
     dur = [0.0] * nops
     gap = [0.0] * nops
-    for f in range(nfwd):
+    gaps = [[] for _ in range(nops)]       # per dispatch: the gap in every forward (a mean hides WHERE it comes from: one host stall
+    for f in range(nfwd):                  # of 60 us in one of 20 forwards reads as "3 us in front of this kernel")
         seg = rows[f * nops:(f + 1) * nops]
         for i, r in enumerate(seg):
             dur[i] += (r[1] - r[0]) / 1e3 / nfwd
             if i:
                 gap[i] += (r[0] - seg[i - 1][1]) / 1e3 / nfwd
+                gaps[i].append((r[0] - seg[i - 1][1]) / 1e3)
     seg = rows[-nops:]
     span = (seg[-1][1] - seg[0][0]) / 1e3
     print("one forward: %d dispatches, span %.1f us, sum of kernel durations %.1f us, sum of gaps %.1f us (avg over %d)"
           % (nops, span, sum(dur), sum(gap), nfwd))
     print("%3s %8s %7s %7s %6s %5s %7s %6s %5s  %s" % ("#", "dur_us", "gap_us", "blocks", "wgsz", "vgpr", "lds", "wg/CU", "fill", "kernel"))
+    if nfwd > 1:
+        big = [(i, sorted(g)) for i, g in enumerate(gaps) if g and sum(g) / len(g) > 0.3]
+        for i, g in big:
+            print("    gap in front of #%d over %d forwards: median %.2f us, max %.2f us, forwards above 1 us: %d"
+                  % (i, len(g), g[len(g) // 2], g[-1], sum(1 for v in g if v > 1.0)))
     for i, r in enumerate(seg):
         name = r[2].replace("_ZN12saber_mi355x", "").replace("NS_9ConvKArgsE", "")[:70]
         kr = res.get(r[2].replace(".kd", ""), dict(vgpr=r[5], lds=r[6], wg=r[4]))
