@@ -96,6 +96,19 @@ static void pack_coop4_stream(const saber_hip_conv* c3, const saber_hip_conv* a,
             }
         }
 }
+// ... and the one-workgroup-per-tile stage kernel's (conv_stage1_c128_kernel), C = 128: per wave w, in consumption order:
+//   3x3, channels w*16 .. +15: [tap][k-step 0, 1] (18) | 1x1 + eltwise, channels w*64 .. +63: [k-step 0, 1][accumulator 0..3] (8) |
+//   1x1, channels w*16 .. +15: [k-step 0..7] (8)
+static void pack_stage1_c128_stream(const saber_hip_conv* c3, const saber_hip_conv* a, const saber_hip_conv* b, std::vector<uint8_t>& out) {
+    const int C = 128, K1 = 512;
+    for (int w = 0; w < 8; ++w) {
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ks = 0; ks < 2; ++ks) pack_frag3(c3->wq_oihw.data(), C, w * 16, tap, ks, out);
+        for (int ks = 0; ks < 2; ++ks)
+            for (int mf = 0; mf < 4; ++mf) pack_frag1(a->wq_oihw.data(), C, w * 64, 4, mf, ks, out);
+        for (int ks = 0; ks < 8; ++ks) pack_frag1(b->wq_oihw.data(), K1, w * 16, 1, 0, ks, out);
+    }
+}
 saber_hip_chain::~saber_hip_chain() {
     if (h_coop_err) (void)hipHostFree(h_coop_err);
     delete stage1;
@@ -107,19 +120,21 @@ static unsigned stage_magic(int d) { return d >= 2 ? (unsigned)((0x100000000ull 
 static int stage_build(saber_hip_chain* const* chains, int n, bool per_image, saber_hip_chain_stage** out) {
     if (!chains || n <= 0 || n > saber_mi355x::STAGE4_LONG || !out) return fail(SABER_HIP_INVALID_VALUE, "stage: 1..24 chains");
     if (n > 1 && !per_image) return fail(SABER_HIP_INVALID_VALUE, "stage: several blocks need an image per XCD");
+    if (n < 2 && chains[0] && chains[0]->c1 == 128) return fail(SABER_HIP_INVALID_VALUE, "stage: at C = 128 a stage is at least two blocks");
     const saber_hip_chain* c0 = chains[0];
     std::vector<saber_mi355x::StageBlk> blk;
     for (int k = 0; k < n; ++k) {
         const saber_hip_chain* ch = chains[k];
-        if (!ch || ch->c1 != 256 || !ch->c3 || !ch->b || !ch->d_stream_coop4.p || ch->c3->d.stride_h != 1)
-            return fail(SABER_HIP_INVALID_VALUE, "stage: every block must be a conv3x3 (stride 1) + conv1x1 + conv1x1 chain at C = 256");
+        const uint8_t* stream = !ch ? nullptr : (ch->c1 == 256 ? ch->d_stream_coop4.p : (ch->c1 == 128 ? ch->d_stream_stage1.p : nullptr));
+        if (!ch || ch->c1 != c0->c1 || !ch->c3 || !ch->b || !stream || ch->c3->d.stride_h != 1)
+            return fail(SABER_HIP_INVALID_VALUE, "stage: every block must be a conv3x3 (stride 1) + conv1x1 + conv1x1 chain at C = 256 (or all at C = 128)");
         const saber_hip_conv_desc& da = ch->a->d;
         if (da.n != c0->a->d.n || da.h != c0->a->d.h || da.w != c0->a->d.w) return fail(SABER_HIP_INVALID_VALUE, "stage: blocks of one tensor shape");
         if (k && ((ch->c3->x_dtype == DT_U8) != (chains[k - 1]->b->d.out_dtype == SABER_HIP_U8)))
             return fail(SABER_HIP_INVALID_VALUE, "stage: a block's 3x3 conv reads what the previous block's last conv writes");
         saber_mi355x::StageBlk B;
         std::memset(&B, 0, sizeof B);
-        B.wstream = ch->d_stream_coop4.p; B.prm0 = ch->d_prm0.p; B.prm1 = ch->d_prm1.p; B.prm2 = ch->d_prm2.p;
+        B.wstream = stream; B.prm0 = ch->d_prm0.p; B.prm1 = ch->d_prm1.p; B.prm2 = ch->d_prm2.p;
         B.coeff_conv = da.coeff_conv; B.scale_conv = ch->a->out_scale; B.coeff_res = da.coeff_res; B.scale_res = da.scale_res;
         B.in0_u8 = ch->c3->x_dtype == DT_U8; B.relu0 = ch->c3->d.act == SABER_HIP_ACT_RELU;
         B.in_u8 = ch->a->x_dtype == DT_U8; B.relu1 = da.act == SABER_HIP_ACT_RELU; B.res_relu = da.res_act == SABER_HIP_ACT_RELU;
@@ -129,20 +144,27 @@ static int stage_build(saber_hip_chain* const* chains, int n, bool per_image, sa
     const saber_hip_conv_desc& d0 = c0->a->d;
     saber_hip_chain_stage* st = new saber_hip_chain_stage();
     st->chains.assign(chains, chains + n);
+    st->c1 = c0->c1;
     st->n = d0.n; st->h = d0.h; st->w = d0.w;
     st->tiles_x = (d0.w + 15) / 16;
     st->tiles_per_img = st->tiles_x * ((d0.h + 1) / 2);
     st->per_image = per_image;
-    if (per_image && (d0.n > 8 || st->tiles_per_img * 4 > 32 || st->tiles_x != 1)) {      // every workgroup of an image must hold a CU of its XCD at once
+    // every workgroup of an image must hold a CU of its XCD at once (one workgroup per CU: 235 - 250 VGPRs); C = 256: four workgroups per
+    // tile, edge counters for one column tile; C = 128: one per tile, 1 / 2 / 4 column tiles (arrivals per edge: a power of two)
+    const int wg_per_tile = st->c1 == 256 ? 4 : 1;
+    const bool fits = d0.n <= 8 && st->tiles_per_img * wg_per_tile <= 32 &&
+                      (st->c1 == 256 ? st->tiles_x == 1 : (st->tiles_x == 1 || st->tiles_x == 2 || st->tiles_x == 4));
+    if ((per_image && !fits) || (st->c1 == 128 && !per_image)) {
         delete st;
-        return fail(SABER_HIP_INVALID_VALUE, "stage: an image per XCD needs batch <= 8, width <= 16 and <= 8 tiles of 2 x 16 pixels per image");
+        return fail(SABER_HIP_INVALID_VALUE, "stage: an image per XCD needs batch <= 8 and <= 32 workgroups per image (C = 256: width <= 16, <= 8 tiles "
+                    "of 2 x 16 pixels; C = 128: width <= 64, <= 32 tiles)");
     }
     const size_t tiles = (size_t)d0.n * st->tiles_per_img;
     hipError_t e = st->d_blk.upload(blk);
-    if (e == hipSuccess) e = st->d_grp_ctr.alloc_zero(tiles * 32);
+    if (e == hipSuccess && st->c1 == 256) e = st->d_grp_ctr.alloc_zero(tiles * 32);
     if (e == hipSuccess) e = st->d_img_ctr.alloc_zero((size_t)d0.n * (st->tiles_per_img + 1) * 16);
     if (e == hipSuccess) e = st->d_xcc.alloc_zero(tiles * 32);
-    if (e == hipSuccess) e = st->d_xch.alloc_zero(tiles * 32 * 256);
+    if (e == hipSuccess && st->c1 == 256) e = st->d_xch.alloc_zero(tiles * 32 * 256);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_err, sizeof(unsigned), hipHostMallocMapped);
     if (e != hipSuccess) {
         delete st;
@@ -164,7 +186,7 @@ static int stage_launch(saber_hip_chain_stage* st, const void* x, const void* re
     k.mg_tiles_x = stage_magic(st->tiles_x); k.mg_tpi = stage_magic(st->tiles_per_img); k.mg_wpi = stage_magic(st->tiles_per_img * 4);
     k.per_image = st->per_image;
     for (int i = 0; i < k.nblk; ++i) { k.y1[i] = y1[i]; k.y2[i] = y2[i]; }
-    HIP_TRY(saber_mi355x::launch_conv_stage4(k, s));
+    HIP_TRY(st->c1 == 256 ? saber_mi355x::launch_conv_stage4(k, s) : saber_mi355x::launch_conv_stage1_c128(k, s));
     return SABER_HIP_OK;
 }
 int stage_run(saber_hip_chain_stage* st, const void* x, const void* res, void* const* y1, void* const* y2, hipStream_t s) {
@@ -293,6 +315,12 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         if (e == hipSuccess) e = ch->d_coop_xch.alloc_zero((size_t)ch->coop_tiles * 16 * da.c);
         if (e == hipSuccess) e = hipHostMalloc((void**)&ch->h_coop_err, sizeof(unsigned), hipHostMallocMapped);
         if (e == hipSuccess) *ch->h_coop_err = 0u;
+    }
+    if (e == hipSuccess && da.c == 128 && c3 && b && c3->d.stride_h == 1 && xcd_round_robin()) {
+        std::vector<uint8_t> s1;
+        s1.reserve(stream.size());
+        pack_stage1_c128_stream(c3, a, b, s1);
+        e = ch->d_stream_stage1.upload(s1);
     }
     if (e == hipSuccess) e = ch->d_prm1.upload(p1);
     if (e == hipSuccess && b) e = ch->d_prm2.upload(p2);

@@ -155,6 +155,7 @@ struct saber_hip_chain {
     // tile 15: FOUR cooperating workgroups per tile of 2 rows x 16 columns (conv_stage_coop.hip with one block): [quarter][wave]
     // streams here, everything else in `stage1`
     DevBuf<uint8_t> d_stream_coop, d_stream_coop4, d_coop_xch;
+    DevBuf<uint8_t> d_stream_stage1;  // C == 128, 3x3-led with a second 1x1 conv: per-wave streams of the one-workgroup-per-tile stage kernel
     DevBuf<unsigned long long> d_coop_ctr;
     DevBuf<unsigned> d_coop_xcc;
     unsigned* h_coop_err = nullptr;
@@ -172,7 +173,7 @@ struct saber_hip_chain_stage {
     DevBuf<uint8_t> d_xch;
     DevBuf<unsigned> d_xcc;
     unsigned* h_err = nullptr;
-    int n = 0, h = 0, w = 0, tiles_x = 0, tiles_per_img = 0;
+    int c1 = 0, n = 0, h = 0, w = 0, tiles_x = 0, tiles_per_img = 0;
     bool per_image = false;
     ~saber_hip_chain_stage() {
         if (h_err) (void)hipHostFree(h_err);

@@ -32,7 +32,9 @@ static void net_name_chain(NetOp& A, NetOp& B) {
 }
 // mode of the ops around A = ops[ia] (a 1x1 conv with the fused eltwise): 0 separate launches, 1 A + B chained (A.chain),
 // 2 the 3x3 conv ops[ia - 1] leads the launch (its chain3; with or without B)
-static std::string stage_name(const NetOp& H0) { return "conv:stage_c256_" + std::to_string(H0.stage_n) + "x[conv3x3+chain1x1]_2x16_coop4"; }
+static std::string stage_name(const NetOp& H0) {
+    return "conv:stage_c" + std::to_string(H0.stage->c1) + "_" + std::to_string(H0.stage_n) + "x[conv3x3+chain1x1]_2x16" + (H0.stage->c1 == 256 ? "_coop4" : "");
+}
 void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     NetOp& A = net->ops[ia];
     NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
@@ -373,21 +375,21 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             if (Hd.use_chain3) ++removed;
         }
     }
-    // ---- 256: runs of 3x3-led C = 256 chains whose blocks feed each other (ResNet's res4 stage) -> one persistent launch -------------
+    // ---- 256: runs of 3x3-led C = 256 (or C = 128) chains whose blocks feed each other (ResNet's res4 / res3 stage) -> one persistent launch
     // NOT part of 255: the launch needs every workgroup of an image resident on its XCD at once - fine for one net on the GPU
     // (the latency path), not for several nets in flight on their own streams (two such launches can each hold half of the CUs
     // and wait for the other half: they time out, report an error and fall back; conv_stage_coop.hip)
     if ((flags & 256) && (flags & 32) && !two_lanes) {
         for (size_t i = 0; i + 2 < ops.size();) {
             auto block_ok = [&](size_t j) {
-                return j + 2 < ops.size() && ops[j].chain3 && ops[j].chain3->b && ops[j].chain3->c1 == 256 && ops[j].chain3->stage1 && !ops[j].stage &&
-                       ops[j].chain3_y2 >= 0;
+                return j + 2 < ops.size() && ops[j].chain3 && ops[j].chain3->b && !ops[j].stage && ops[j].chain3_y2 >= 0 &&
+                       ((ops[j].chain3->c1 == 256 && ops[j].chain3->stage1) || (ops[j].chain3->c1 == 128 && ops[j].chain3->d_stream_stage1.p));
             };
             if (!block_ok(i)) { ++i; continue; }
             std::vector<saber_hip_chain*> run{ops[i].chain3};
             while ((int)run.size() < saber_mi355x::STAGE4_LONG) {
                 const size_t p = i + 3 * (run.size() - 1), j = p + 3;
-                if (!block_ok(j) || ops[j].in != ops[p].chain3_y2 || ops[j].chain3_res != ops[p].chain3_y1) break;
+                if (!block_ok(j) || ops[j].chain3->c1 != run[0]->c1 || ops[j].in != ops[p].chain3_y2 || ops[j].chain3_res != ops[p].chain3_y1) break;
                 run.push_back(ops[j].chain3);
             }
             if (run.size() >= 2) {

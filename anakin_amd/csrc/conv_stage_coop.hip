@@ -180,6 +180,7 @@ __global__ __launch_bounds__(512) void conv_stage4_c256_kernel(const Stage4KArgs
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             ka.xcc[t * 32 + q] = xcc & 7u;
+            if (rem == 0 && q == 0) ka.xcc[t * 32 + 4] = (xcc & 7u) + 1u;      // the image's first workgroup publishes its XCD (+ 1: 0 = not yet)
         }
         coop_arrive(ctr);
         // the rest of this block's stream, requested under the wait for the partners: 6 fragments of the first 1x1 conv, 8 of the second
@@ -344,12 +345,274 @@ __global__ __launch_bounds__(512) void conv_stage4_c256_kernel(const Stage4KArgs
         const L2Reader xr(ka.xcc);
         const v4i xc = xr.load16((unsigned)t * 128u);
         bool same = xc.x == xc.y && xc.x == xc.z && xc.x == xc.w;
-        if (ka.per_image && ka.nblk > 1) same = same && xr.load16((unsigned)(n * ka.tiles_per_img) * 128u).x == xc.x;
+        if (ka.per_image && ka.nblk > 1) {      // (0: the image's first workgroup has not published yet - nothing to compare)
+            const unsigned first = (unsigned)xr.load16((unsigned)(n * ka.tiles_per_img) * 128u + 16u).x;
+            same = same && (!first || first == (unsigned)xc.x + 1u);
+        }
         if (!same) __hip_atomic_fetch_add(ka.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     SABER_TL_FLUSH();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same persistent launch for the res3 stage (C = 128, 28 x 28): ONE workgroup per tile of 2 rows x 16 columns. At C = 128 a block's
+// weights are 277 KB - what a QUARTER of a C = 256 block is - so a workgroup computes all channels of its tile itself and the fragment
+// counts per wave are the same 18 + 8 + 8: no channel split, no hand-off inside a block (the 3x3 conv's tile and the y1 tile stay in
+// LDS), only the edge barrier between two blocks. Waves: 3x3 = n-tile w (both tile rows per fragment), 1x1 + eltwise = 64 channels
+// per wave (4 accumulators x 2 tile rows), last 1x1 = n-tile w. 28 tiles per image (14 tile rows x 2 column tiles) = 28 of an XCD's
+// 32 CUs; an edge between two tile rows has 4 arriving workgroups (2 at the image's top and bottom).
+template <int MAXB>
+__global__ __launch_bounds__(512) void conv_stage1_c128_kernel(const Stage4KArgs<MAXB> ka) {
+    constexpr int C1 = 128, K1 = 512, K2 = 128, NW = 8;
+    constexpr int F0 = 18, F1 = 8, F2 = 8;                   // 1 KB weight fragments per wave and phase
+    constexpr int CH1 = C1 / 16, PCH = CH1 + 1, HW = 18, HP = 4 * HW;
+    constexpr int HCH = (HP * PCH + 63) / 64 * 64;
+    constexpr int CPRW = K1 / 16;                            // 16-byte chunks per row of the shortcut / output tile: 32
+    constexpr int P0C = (C1 / 4 * 3 + 63) / 64 * 64, P1C = K1 / 4 * 3, P2C = (K2 / 4 * 3 + 63) / 64 * 64;
+    constexpr int MPC = C1 / 16 + 1;                         // LDS pitch (chunks) of the 3x3 output tile: 8 + 1 padding
+    static_assert(P1C % 64 == 0 && (32 * CPRW) % (64 * NW) == 0, "DMA granularity");
+    __shared__ v4i halo[HCH];
+    __shared__ v4i tile[32 * CPRW];
+    __shared__ v4i mid[32 * MPC];
+    __shared__ v4i prm0[P0C];
+    __shared__ v4i prm1[P1C];
+    __shared__ v4i prm2[P2C];
+    SABER_TL_DECL;
+    SABER_TL(0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x;
+    const int slot = b >> 3;                                 // all workgroups of an image on one XCD: image (slot / tiles) * 8 + b % 8
+    const int il = ka.mg_tpi ? (int)__umulhi((unsigned)slot, ka.mg_tpi) : slot;
+    const int rem = slot - il * ka.tiles_per_img;
+    const int n = il * 8 + (b & 7);
+    if (n >= ka.N) return;
+    const int t = n * ka.tiles_per_img + rem;
+    const int ty = ka.mg_tiles_x ? (int)__umulhi((unsigned)rem, ka.mg_tiles_x) : rem;
+    const int x0 = (rem - ty * ka.tiles_x) * 16, y0 = ty * 2;
+    const int tile_rows = ka.tiles_per_img / ka.tiles_x;
+    const int H = ka.H, W = ka.W;
+    auto pix = [&](int m, bool& ok) -> int {                  // m = tile row * 16 + column
+        int x = x0 + (m & 15), y = y0 + (m >> 4);
+        ok = x < W && y < H;
+        x = x < W ? x : W - 1;
+        y = y < H ? y : H - 1;
+        return (n * H + y) * W + x;
+    };
+    unsigned long long* const e_up = ka.img_ctr + ((size_t)n * (ka.tiles_per_img + 1) + ty) * 16;   // the edge above this tile row; + 16: below
+    bool ok0, ok1;
+    const int p0 = pix(frow, ok0), p1 = pix(16 + frow, ok1);
+
+    auto dma_halo = [&](const void* x, bool l2) {            // 4 rows x 18 columns x 128 channels, zero page for the padding
+        const char* xg = (const char*)x;
+        for (int i = wave; i < HCH / 64; i += NW) {
+            const int L = i * 64 + lane;
+            const int hp = L / PCH, cc = L - hp * PCH;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool in = hp < HP && cc < CH1 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const char* src = in ? xg + ((size_t)((n * H + gy) * W + gx) * C1 + cc * 16) : (const char*)ka.zero;
+            if (l2 && in) lds_dma16_l2(src, halo + i * 64);
+            else lds_dma16(src, halo + i * 64);
+        }
+    };
+    auto dma_prm = [&](const StageBlk& B) {
+        for (int i = wave; i < P0C / 64; i += NW) lds_dma16((const v4i*)B.prm0 + i * 64 + lane, prm0 + i * 64);
+        for (int i = wave; i < P1C / 64; i += NW) lds_dma16((const v4i*)B.prm1 + i * 64 + lane, prm1 + i * 64);
+        for (int i = wave; i < P2C / 64; i += NW) lds_dma16((const v4i*)B.prm2 + i * 64 + lane, prm2 + i * 64);
+    };
+    auto stream_of = [&](const StageBlk& B) -> const v4i* {   // this wave's fragments of block B, lane's 16 bytes
+        return (const v4i*)B.wstream + (size_t)wave * ((F0 + F1 + F2) * 64) + lane;
+    };
+
+    // ---- entry: the first block's halo, shortcut tile and constants by DMA; its first 20 weight fragments ------------------------
+    dma_halo(ka.x, false);
+    for (int i = wave; i < 32 * CPRW / 64; i += NW) {
+        const int L = i * 64 + lane;
+        const int px = L / CPRW, c = (L % CPRW) ^ (px & 15);
+        bool okp;
+        const int pp_ = pix(px, okp);
+        lds_dma16((const char*)ka.res + (size_t)pp_ * K1 + c * 16, tile + i * 64);
+    }
+    dma_prm(ka.blk[0]);
+    asm volatile("" ::: "memory");
+    v4i fr[F0 + 2];
+    {
+        const v4i* wsb = stream_of(ka.blk[0]);
+#pragma unroll
+        for (int r = 0; r < F0 + 2; ++r) {
+            fr[r] = wsb[r * 64];
+            asm volatile("" ::: "memory");                   // issue order = consumption order
+        }
+    }
+    wait_vm_older_than<F0 + 2>();                             // everything older than the fragments: this wave's DMA
+    __builtin_amdgcn_s_barrier();
+    SABER_TL(1);
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc = (my_xcc & 7u) + 1u;
+    if (rem == 0 && tid == 0) ka.xcc[(size_t)t * 32 + 4] = my_xcc;      // the image's first tile publishes its XCD (+ 1: 0 = not yet)
+
+    StageBlk B = ka.blk[0];
+    for (int k = 0; k < ka.nblk; ++k) {
+        const v4i z = {0, 0, 0, 0};
+        v4i fs[F1 - 2 + F2];                                 // the rest of this block's stream: lands under the 3x3 conv
+        {
+            const v4i* wsb = stream_of(B);
+#pragma unroll
+            for (int r = 0; r < F1 - 2 + F2; ++r) {
+                fs[r] = wsb[(F0 + 2 + r) * 64];
+                asm volatile("" ::: "memory");
+            }
+        }
+        // ================= phase 0: 3x3 conv, 16 mid channels per wave, both tile rows per fragment ==================================
+        {
+            const int xm0 = B.in0_u8 ? (int)0x80808080u : 0;
+            const int c0 = wave * 16 + fq * 4;
+            const v4i* pp = prm0 + (c0 / 4) * 3;
+            v4i acc0 = pp[2], acc1 = acc0;                   // starts at the compensation (exact integer sum)
+            const v4i* hb = halo + frow * PCH + fq;
+#pragma unroll
+            for (int s = 0; s < F0; ++s) {
+                const int kl = s % 2, tap = s / 2;
+                const int dy = tap / 3, dx = tap % 3;
+                v4i b0 = hb[(dy * HW + dx) * PCH + kl * 4];
+                v4i b1 = hb[((dy + 1) * HW + dx) * PCH + kl * 4];
+                b0.x ^= xm0; b0.y ^= xm0; b0.z ^= xm0; b0.w ^= xm0;
+                b1.x ^= xm0; b1.y ^= xm0; b1.z ^= xm0; b1.w ^= xm0;
+                acc0 = mma_step(fr[s], b0, acc0);
+                acc1 = mma_step(fr[s], b1, acc1);
+            }
+            const float lo0 = B.relu0 ? 0.f : -3.0e38f;
+            const float off0 = B.in_u8 ? 0.f : 128.f;
+            const unsigned xo0 = B.in_u8 ? 0u : 0x80808080u;
+            const unsigned o0 = chain_out_pack(acc0, z, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), lo0, off0, xo0);
+            const unsigned o1 = chain_out_pack(acc1, z, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), lo0, off0, xo0);
+            *(unsigned*)((char*)mid + frow * (MPC * 16) + c0) = o0;
+            *(unsigned*)((char*)mid + (16 + frow) * (MPC * 16) + c0) = o1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // the 3x3 conv's tile is complete
+        SABER_TL(2);
+
+        // ================= phase 1: 1x1 conv + eltwise, 64 channels per wave ==========================================================
+        {
+            const int xmask = B.in_u8 ? (int)0x80808080u : 0;
+            const int cg = wave * 64 + fq * 16;              // 16 consecutive channels of pixel (row, frow)
+            const v4i* pp = prm1 + (cg / 4) * 3;
+            v4i acc[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) acc[m][mf] = pp[mf * 3 + 2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    v4i bo = mid[(m * 16 + frow) * MPC + ks * 4 + fq];
+                    bo.x ^= xmask; bo.y ^= xmask; bo.z ^= xmask; bo.w ^= xmask;
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf) {
+                        const int f = ks * 4 + mf;           // fragments 0, 1 came with the previous block's prefetch
+                        acc[m][mf] = mma_step(f < 2 ? fr[F0 + f] : fs[f - 2], bo, acc[m][mf]);
+                    }
+                }
+            const float lo_s8 = B.relu1 ? 0.f : -128.f;
+            const float res_lo = B.res_relu ? 0.f : -3.0e38f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                v4i* tp = tile + (m * 16 + frow) * CPRW + ((cg / 16) ^ frow);
+                const v4i rs = *tp;
+                v4i o;
+                o.x = (int)chain_elt_pack(acc[m][0], z, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), (unsigned)rs.x, lo_s8, res_lo, B);
+                o.y = (int)chain_elt_pack(acc[m][1], z, __builtin_bit_cast(v4f, pp[4]), __builtin_bit_cast(v4f, pp[3]), (unsigned)rs.y, lo_s8, res_lo, B);
+                o.z = (int)chain_elt_pack(acc[m][2], z, __builtin_bit_cast(v4f, pp[7]), __builtin_bit_cast(v4f, pp[6]), (unsigned)rs.z, lo_s8, res_lo, B);
+                o.w = (int)chain_elt_pack(acc[m][3], z, __builtin_bit_cast(v4f, pp[10]), __builtin_bit_cast(v4f, pp[9]), (unsigned)rs.w, lo_s8, res_lo, B);
+                *tp = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 32 * CPRW / 512; ++j) {          // the 32 x 512 tile -> y1, coalesced
+            const int L = tid + j * 512;
+            const int px = L / CPRW, c = (L % CPRW) ^ (px & 15);
+            bool okp;
+            const int pp_ = pix(px, okp);
+            if (okp) *(v4i*)((char*)ka.y1[k] + (size_t)pp_ * K1 + c * 16) = tile[L];
+        }
+        SABER_TL(4);
+        const StageBlk Bn = ka.blk[k + 1 < ka.nblk ? k + 1 : k];      // the next block's constants, one phase ahead of their use
+        if (k + 1 < ka.nblk) {         // the next block's first 20 fragments: one block ahead
+            const v4i* wsb = stream_of(Bn);
+#pragma unroll
+            for (int r = 0; r < F0 + 2; ++r) {
+                fr[r] = wsb[r * 64];
+                asm volatile("" ::: "memory");
+            }
+        }
+
+        // ================= phase 2: second 1x1 conv, 16 channels per wave, its operand is the y1 tile in LDS ===========================
+        {
+            const int c2 = wave * 16 + fq * 4;
+            const v4i* pp = prm2 + (c2 / 4) * 3;
+            v4i acc0 = pp[2], acc1 = acc0;
+#pragma unroll
+            for (int ks = 0; ks < F2; ++ks) {
+                const int ch = (ks * 4 + fq) ^ frow;
+                acc0 = mma_step(fs[F1 - 2 + ks], tile[frow * CPRW + ch], acc0);
+                acc1 = mma_step(fs[F1 - 2 + ks], tile[(16 + frow) * CPRW + ch], acc1);
+            }
+            const float lo2 = B.relu2 ? 0.f : -3.0e38f;
+            const float off2 = B.out_u8_2 ? 0.f : 128.f;
+            const unsigned xm2 = B.out_u8_2 ? 0u : 0x80808080u;
+            const unsigned o0 = chain_out_pack(acc0, z, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), lo2, off2, xm2);
+            const unsigned o1 = chain_out_pack(acc1, z, __builtin_bit_cast(v4f, pp[1]), __builtin_bit_cast(v4f, pp[0]), lo2, off2, xm2);
+            if (ok0) *(unsigned*)((char*)ka.y2[k] + (size_t)p0 * K2 + c2) = o0;
+            if (ok1) *(unsigned*)((char*)ka.y2[k] + (size_t)p1 * K2 + c2) = o1;
+        }
+        SABER_TL(6);
+        if (k + 1 < ka.nblk) {
+            // ============= between two blocks: the edge barriers of conv_stage4_c256_kernel, tiles_x workgroups per tile row ================
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // (every wave is also done with this block's constants)
+            if (wave == 0 && lane == 0) {
+                (void)__hip_atomic_fetch_add(e_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(e_up + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            dma_prm(Bn);
+            if (wave == 0) {
+                const unsigned long long one = (unsigned long long)ka.tiles_x;     // arrivals at an edge: tiles_x per tile row
+                coop_wait_mask(e_up, (ty > 0 ? 2 * one : one) - 1, ka.err);
+                coop_wait_mask(e_up + 16, (ty + 1 < tile_rows ? 2 * one : one) - 1, ka.err);
+            }
+            __builtin_amdgcn_s_barrier();
+            dma_halo(ka.y2[k], true);
+            wait_vm_older_than<0>();
+            __builtin_amdgcn_s_barrier();
+            B = Bn;
+            SABER_TL(7);
+        }
+    }
+    if (tid == 0 && ka.err) {      // this tile ran on its image's XCD? (0: the first tile has not published yet - nothing to compare)
+        const unsigned first = (unsigned)L2Reader(ka.xcc).load16((unsigned)(n * ka.tiles_per_img) * 128u + 16u).x;
+        if (first && first != my_xcc) __hip_atomic_fetch_add(ka.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    SABER_TL_FLUSH();
+}
+
+template <int MAXB>
+static hipError_t launch_stage1(const Stage4KArgs<MAXB>& ka, hipStream_t s) {
+    if (ka.nblk <= 1 || ka.nblk > MAXB || ka.N <= 0 || !ka.blk || !ka.xcc || !ka.per_image || !ka.img_ctr ||
+        (ka.tiles_x != 1 && ka.tiles_x != 2 && ka.tiles_x != 4))
+        return hipErrorInvalidValue;
+    const dim3 grid((ka.N + 7) / 8 * ka.tiles_per_img * 8), block(512);
+    hipLaunchKernelGGL(conv_stage1_c128_kernel<MAXB>, grid, block, 0, s, ka);
+    return hipGetLastError();
+}
+hipError_t launch_conv_stage1_c128(const Stage4KArgs<STAGE4_SHORT>& a, hipStream_t s) { return launch_stage1(a, s); }
+hipError_t launch_conv_stage1_c128(const Stage4KArgs<STAGE4_LONG>& a, hipStream_t s) { return launch_stage1(a, s); }
 template <int MAXB>
 static hipError_t launch_stage4(const Stage4KArgs<MAXB>& ka, hipStream_t s) {
     if (ka.nblk <= 0 || ka.nblk > MAXB || ka.N <= 0 || !ka.blk || !ka.grp_ctr || !ka.xch || !ka.xcc ||

@@ -184,6 +184,9 @@ struct Stage4KArgs {
 constexpr int STAGE4_SHORT = 8, STAGE4_LONG = 24;
 hipError_t launch_conv_stage4(const Stage4KArgs<STAGE4_SHORT>& a, hipStream_t s);
 hipError_t launch_conv_stage4(const Stage4KArgs<STAGE4_LONG>& a, hipStream_t s);
+// the res3 stage (C = 128): one workgroup per tile, an image per XCD, nblk >= 2; grp_ctr / xch unused; tiles_x in {1, 2, 4}
+hipError_t launch_conv_stage1_c128(const Stage4KArgs<STAGE4_SHORT>& a, hipStream_t s);
+hipError_t launch_conv_stage1_c128(const Stage4KArgs<STAGE4_LONG>& a, hipStream_t s);
 
 // stage_xcd_kernel (stage_xcd.hip): a run of INT8 convolutions over small images as ONE persistent launch, one image per XCD
 // at a time, the phases separated by an XCD-local barrier instead of a kernel boundary.

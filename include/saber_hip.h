@@ -204,7 +204,9 @@ int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* chain);
  * persistent launch: four cooperating workgroups per tile of 2 x 16 pixels, all tiles of an image on one XCD, an XCD-local barrier
  * between two blocks instead of a kernel boundary (anakin_amd/csrc/conv_stage_coop.hip). Like the chains an executor-level
  * fusion with no counterpart in the reference (framework/core/net/net.cpp:417-509 dispatches one operator at a time); results
- * bit-identical to the separate launches. Batch <= 8, <= 8 tiles per image (14 x 14). The chains are not owned and must outlive
+ * bit-identical to the separate launches. Batch <= 8, <= 8 tiles per image (14 x 14). Also for runs of >= 2 chains at C = 128
+ * (res3: one workgroup per tile, width <= 64, <= 32 tiles per image; measured slower than its chain launches on MI355X - an
+ * autotune candidate). The chains are not owned and must outlive
  * the stage. y1[i] / y2[i]: chain i's outputs (saber_hip_conv2d_chain_run's y_a / y_b); x / res: chain 0's inputs. */
 typedef struct saber_hip_chain_stage saber_hip_chain_stage_t;
 int saber_hip_conv2d_stage_create(saber_hip_chain_t* const* chains, int n, saber_hip_chain_stage_t** out);

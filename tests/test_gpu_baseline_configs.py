@@ -86,13 +86,13 @@ def _int8_every_edge(name, batch, min_edges):
 def test_resnet50_int8_framework_list_autotuned_every_edge_every_image(batch):
     net = _int8_every_edge("resnet50", batch, 40)
     print("ResNet50 INT8 batch %d: %d ops in %d launches, bit-exact on every materialised edge" % (batch, net.num_ops(), net.num_launches()))
-    assert net.stage_count == 1      # res4: five 3x3-led chains feeding each other
+    assert net.stage_count == 2      # res3: three 3x3-led chains feeding each other (C = 128), res4: five (C = 256)
 
 
 def test_resnet101_int8_batch8_autotuned_every_edge_every_image():
     net = _int8_every_edge("resnet101", 8, 70)
     print("ResNet101 INT8 batch 8: %d ops in %d launches" % (net.num_ops(), net.num_launches()))
-    assert net.stage_count == 1      # res4: 22 blocks in one launch
+    assert net.stage_count == 2      # res3: 3 blocks, res4: 22 blocks in one launch
 
 
 def _fp32_every_edge_autotuned(name, batch, min_edges):

@@ -599,10 +599,10 @@ def test_conv3x3_chain_equals_three_launches_and_oracle(case):
     assert np.array_equal(host(z1), want1), ("double y1", double.tile())
 
 
-def _res4_blocks(rng, N, H, Wd, nblk, first_u8=True):
-    """nblk ResNet res4 block chains at C = 256: [3x3 -> 1x1 expand + eltwise(relu) -> next block's 1x1 reduce], chain i + 1
-    reading chain i's outputs; returns the device ops, the first inputs and the oracle's outputs per block."""
-    Cc, K1 = 256, 1024
+def _res4_blocks(rng, N, H, Wd, nblk, first_u8=True, Cc=256):
+    """nblk ResNet res4 (C = 256) / res3 (C = 128) block chains: [3x3 -> 1x1 expand + eltwise(relu) -> next block's 1x1 reduce],
+    chain i + 1 reading chain i's outputs; returns the device ops, the first inputs and the oracle's outputs per block."""
+    K1 = 4 * Cc
     x = rng.integers(0, 256, (N, H, Wd, Cc)).astype(np.uint8) if first_u8 else rng.integers(-128, 128, (N, H, Wd, Cc)).astype(np.int8)
     res = rng.integers(-128, 128, (N, H, Wd, K1)).astype(np.int8)
     ops, wants = [], []
@@ -639,14 +639,16 @@ def _res4_blocks(rng, N, H, Wd, nblk, first_u8=True):
     return x, res, ops, wants
 
 
-@pytest.mark.parametrize("shape", [(8, 14, 14, 5), (3, 14, 14, 3), (2, 7, 9, 2), (8, 14, 14, 1)])
+@pytest.mark.parametrize("shape", [(256, 8, 14, 14, 5), (256, 3, 14, 14, 3), (256, 2, 7, 9, 2), (256, 8, 14, 14, 1),
+                                   (128, 8, 28, 28, 3), (128, 2, 9, 21, 2), (128, 1, 5, 13, 4), (128, 3, 7, 50, 2)])
 def test_chain_stage_equals_the_chains_and_oracle(shape):
-    """saber_hip_conv2d_stage_create: a RUN of res4 block chains in one persistent launch (conv_stage_coop.hip; four cooperating
-    workgroups per tile, an image per XCD, an XCD-local barrier between blocks) - every block's two outputs bit for bit the
-    oracle's and the chain launches', launch after launch (the arrival counters are never reset)."""
-    N, H, Wd, nblk = shape
-    rng = np.random.default_rng(4100 + N + H + nblk)
-    x, res, ops, wants = _res4_blocks(rng, N, H, Wd, nblk)
+    """saber_hip_conv2d_stage_create: a RUN of res4 (C = 256: four cooperating workgroups per tile) or res3 (C = 128: one workgroup
+    per tile, 1 / 2 / 4 column tiles) block chains in one persistent launch (conv_stage_coop.hip; an image per XCD, XCD-local edge
+    barriers between blocks) - every block's two outputs bit for bit the oracle's and the chain launches', launch after launch (the
+    arrival counters are never reset)."""
+    Cc, N, H, Wd, nblk = shape
+    rng = np.random.default_rng(4100 + N + H + nblk + Cc)
+    x, res, ops, wants = _res4_blocks(rng, N, H, Wd, nblk, Cc=Cc)
     chains = [S.SaberConvChain(ca, cb, conv3x3=c0) for c0, ca, cb in ops]
     y1 = [ca.new_output() for _, ca, _ in ops]
     y2 = [cb.new_output() for _, _, cb in ops]
@@ -668,6 +670,14 @@ def test_chain_stage_equals_the_chains_and_oracle(shape):
 def test_chain_stage_rejects_what_it_cannot_run():
     rng = np.random.default_rng(5)
     x, res, ops, wants = _res4_blocks(rng, 9, 14, 14, 2)          # batch 9: an image per XCD needs <= 8
+    chains = [S.SaberConvChain(ca, cb, conv3x3=c0) for c0, ca, cb in ops]
+    with pytest.raises(RuntimeError):
+        S.SaberChainStage(chains)
+    x, res, ops, wants = _res4_blocks(rng, 2, 6, 40, 2, Cc=128)   # width 40: three column tiles (arrivals per edge not a power of two)
+    chains = [S.SaberConvChain(ca, cb, conv3x3=c0) for c0, ca, cb in ops]
+    with pytest.raises(RuntimeError):
+        S.SaberChainStage(chains)
+    x, res, ops, wants = _res4_blocks(rng, 2, 6, 14, 1, Cc=128)   # C = 128: a stage is at least two blocks
     chains = [S.SaberConvChain(ca, cb, conv3x3=c0) for c0, ca, cb in ops]
     with pytest.raises(RuntimeError):
         S.SaberChainStage(chains)
