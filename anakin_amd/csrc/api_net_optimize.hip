@@ -400,8 +400,9 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
                     ops[i].stage_n = (int)run.size();
                     int before = 0;
                     for (size_t k = 0; k < run.size(); ++k) before += 3 - (ops[i + 3 * k].skip + ops[i + 3 * k + 1].skip + ops[i + 3 * k + 2].skip);
-                    // default until the autotuner has timed both forms: on from batch 4 (an image per XCD: fewer images leave XCDs idle)
-                    const bool on = run[0]->a->d.n >= 4;
+                    // default until the autotuner has timed both forms: the res4 stage (C = 256) on from batch 4 (an image per XCD: fewer
+                    // images leave XCDs idle); the res3 stage (C = 128) off - measured slower than its chain launches
+                    const bool on = run[0]->a->d.n >= 4 && run[0]->c1 == 256;
                     net_set_stage(net, (int)i, on);
                     if (on) removed += before - 1;
                 }
