@@ -18,7 +18,7 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
             const int rc = stage_run(o.stage, T(o.in), T(o.chain3_res), y1, y2, s);
             if (rc == SABER_HIP_RUNTIME_ERROR) {      // an earlier launch of it timed out (conv_stage_coop.hip): block by block from now on
                 net_set_stage(net, (int)(&o - net->ops.data()), false);
-                if (net->exec) {
+                if (net->exec) {      // (the captured graph holds the stage launch)
                     (void)hipGraphExecDestroy(net->exec);
                     (void)hipGraphDestroy(net->graph);
                     net->exec = nullptr;
@@ -509,6 +509,52 @@ int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id) {
     for (const NetOp& o : net->ops)
         if (o.chain3 && o.use_chain3 && o.out == id) return 1;
     return 0;
+}
+// After a pass has COMPLETED (the caller has synchronised): did one of its cooperative launches - a stage launch, a two-workgroup
+// chain - find its workgroups on different XCDs or time out in a hand-off (its outputs are then not valid)? The pinned error
+// words are read and cleared, the affected sites fall back to their single-workgroup launches for good, a captured graph is dropped.
+// SABER_HIP_RUNTIME_ERROR tells the caller to run the pass again. (Without this call the next launch of the site reports it.)
+static void net_drop_graph(saber_hip_net* net) {
+    if (!net->exec) return;
+    (void)hipGraphExecDestroy(net->exec);
+    (void)hipGraphDestroy(net->graph);
+    net->exec = nullptr;
+    net->graph = nullptr;
+}
+int saber_hip_net_status(saber_hip_net_t* net) {
+    if (!net || !net->finalized) return fail(SABER_HIP_INVALID_VALUE, "net not finalized");
+    int bad = 0;
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        NetOp& o = net->ops[i];
+        if (o.stage && o.stage->h_err && *(volatile unsigned*)o.stage->h_err) {
+            *(volatile unsigned*)o.stage->h_err = 0u;
+            if (o.use_stage) net_set_stage(net, (int)i, false);
+            ++bad;
+        }
+        saber_hip_chain* ch = o.chain3;
+        if (ch) {
+            unsigned* words[2] = {ch->h_coop_err, ch->stage1 ? ch->stage1->h_err : nullptr};
+            for (unsigned* w : words)
+                if (w && *(volatile unsigned*)w) {
+                    *(volatile unsigned*)w = 0u;
+                    if (ch->tn == 7 || ch->tn == 15) (void)saber_hip_conv2d_chain_set_tile(ch, 3);
+                    ++bad;
+                }
+        }
+    }
+    if (!bad) return SABER_HIP_OK;
+    net_drop_graph(net);
+    return fail(SABER_HIP_RUNTIME_ERROR, "a cooperative launch of the last pass did not complete (workgroups on different XCDs, or a hand-off "
+                "timed out: another kernel held the CUs); its outputs are not valid - those sites now launch block by block: run the pass again");
+}
+// testing aid: makes the next saber_hip_net_status report a failed cooperative launch at the first site that has an error word
+int saber_hip_net_inject_coop_error(saber_hip_net_t* net) {
+    if (!net) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    for (NetOp& o : net->ops) {
+        if (o.stage && o.stage->h_err) { *(volatile unsigned*)o.stage->h_err = 1u; return SABER_HIP_OK; }
+        if (o.chain3 && o.chain3->h_coop_err) { *(volatile unsigned*)o.chain3->h_coop_err = 1u; return SABER_HIP_OK; }
+    }
+    return fail(SABER_HIP_INVALID_VALUE, "the net has no cooperative launch site");
 }
 int saber_hip_net_num_launches(const saber_hip_net_t* net) {
     int n = 0;

@@ -722,6 +722,11 @@ class Net:
         for i, c in enumerate(choices):
             L.check(lib.saber_hip_net_set_choice(self.h, i, int(c)))
 
+    def status(self):
+        """after a completed pass: raises SaberHipError when one of its cooperative launches failed (those sites then launch block by
+        block: run the pass again) - saber_hip_net_status"""
+        L.check(L.load().saber_hip_net_status(self.h))
+
     def stages(self):
         """[(op index, blocks, selected)] of the ops that head a stage (saber_hip_net_optimize flag 256)"""
         lib = L.load()

@@ -396,6 +396,13 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * the next run returns SABER_HIP_RUNTIME_ERROR and the chains launch one by one from then on).
  * Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
+/* After a forward pass has COMPLETED (the caller synchronised the stream): SABER_HIP_RUNTIME_ERROR when one of its cooperative
+ * launches (a stage launch, a two-workgroup chain launch) found its workgroups on different XCDs or timed out in a hand-off - its
+ * outputs are not valid; those sites launch block by block from then on (a captured graph is dropped): run the pass again.
+ * Without this call the site's NEXT launch returns the error. saber_hip_net_inject_coop_error: a testing aid that makes the next
+ * saber_hip_net_status report such a failure at the net's first cooperative site. */
+int saber_hip_net_status(saber_hip_net_t* net);
+int saber_hip_net_inject_coop_error(saber_hip_net_t* net);
 /* > 0: op `index` heads a stage of that many blocks (flag 256); bit 30 of its saber_hip_net_get_choice / _set_choice value says
  * whether the stage launch is selected */
 int saber_hip_net_stage_blocks(const saber_hip_net_t* net, int index);
