@@ -333,7 +333,7 @@ struct ColdScope {
 
 // op-list executor
 namespace saber_api {
-enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_FC_Q, OP_SOFTMAX, OP_RELU_F32 };
+enum OpKind { OP_CONV, OP_CONV_PAIR, OP_FC, OP_QUANT, OP_DEQUANT, OP_TRANSPOSE_IN, OP_ELT_I8, OP_ELT_F32, OP_POOL_I8, OP_POOL_F32, OP_POOL_F32_I8, OP_FC_Q, OP_SOFTMAX, OP_RELU_F32, OP_ACT_F32 };
 struct NetOp {
     OpKind kind;
     std::string name;

@@ -62,6 +62,7 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     case OP_FC_Q: return saber_hip_fc_run_q(o.fc, (const int8_t*)T(o.in), (float*)T(o.out), s);
     case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
     case OP_RELU_F32: return saber_hip_relu_f32(o.count, (const float*)T(o.in), (float*)T(o.out), s);
+    case OP_ACT_F32: return saber_hip_activation_f32(o.p[0], o.count, o.f[0], o.f[1], (const float*)T(o.in), (float*)T(o.out), s);
     }
     return SABER_HIP_UNIMPL;
 }
@@ -211,6 +212,12 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
 int saber_hip_net_add_relu_f32(saber_hip_net_t* net, size_t count, int in_id, int out_id) {
     NetOp o;
     o.kind = OP_RELU_F32; o.in = in_id; o.out = out_id; o.count = count; o.name = "relu_f32";
+    return push(net, std::move(o));
+}
+int saber_hip_net_add_activation_f32(saber_hip_net_t* net, int active, size_t count, float negative_slope, float coef, int in_id, int out_id) {
+    NetOp o;
+    o.kind = OP_ACT_F32; o.in = in_id; o.out = out_id; o.count = count; o.name = "activation_f32";
+    o.p[0] = active; o.f[0] = negative_slope; o.f[1] = coef;
     return push(net, std::move(o));
 }
 int saber_hip_net_add_softmax(saber_hip_net_t* net, int rows, int cols, int in_id, int out_id) {

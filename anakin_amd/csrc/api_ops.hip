@@ -266,6 +266,29 @@ int saber_hip_relu_f32(size_t count, const float* x, float* y, saber_hip_stream_
     HIP_TRY(launch_relu_f32(count, x, y, (hipStream_t)s));
     return SABER_HIP_OK;
 }
+static bool activation_kind_ok(int active) { return active == 1 || active == 3 || active == 4 || active == 5 || active == 9 || active == 11 || active == 12; }
+int saber_hip_activation_f32(int active, size_t count, float negative_slope, float coef, const float* x, float* y, saber_hip_stream_t s) {
+    if (active == 2) {      // Active_relu: the standalone operator ignores negative_slope (saber_activation.cpp:136-154)
+        return saber_hip_relu_f32(count, x, y, s);
+    }
+    if (!activation_kind_ok(active)) return fail(SABER_HIP_UNIMPL, "activation: sigmoid 1, relu 2, tanh 3, clipped relu 4, elu 5, stanh 9, gelu 11, swish 12 (prelu: saber_hip_prelu_f32)");
+    if (!count) return SABER_HIP_OK;
+    if (!x || !y) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (g_capture) {
+        const float f[2] = {negative_slope, coef};
+        return capture_stream_op(OP_ACT_F32, "activation_f32", &active, 1, f, 2, count, x, count * 4, nullptr, 0, y, count * 4, nullptr, 0);
+    }
+    HIP_TRY(launch_activation_f32(active, count, negative_slope, coef, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
+int saber_hip_prelu_f32(size_t count, int channels, int inner, int channel_shared, const float* slope, const float* x, float* y,
+                        saber_hip_stream_t s) {
+    if (g_capture) return capture_unsupported("saber_hip_prelu_f32 (its slope tensor has no op-list form)");
+    if (!count) return SABER_HIP_OK;
+    if (!slope || !x || !y || channels <= 0 || inner <= 0) return fail(SABER_HIP_INVALID_VALUE, "prelu: bad argument");
+    HIP_TRY(launch_prelu_f32(count, channels, inner, channel_shared, slope, x, y, (hipStream_t)s));
+    return SABER_HIP_OK;
+}
 int saber_hip_pool_out_dim2(int in, int pad, int window, int stride, int floor_mode, int any_pad) {
     int o;  // Pooling<>::compute_output_shape, saber/funcs/pooling.h:92-121
     if (floor_mode) {

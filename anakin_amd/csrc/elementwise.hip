@@ -303,6 +303,59 @@ hipError_t launch_relu_f32(size_t count, const float* x, float* y, hipStream_t s
     return hipGetLastError();
 }
 
+// ---- the other activation types of SaberActivation<X86, AK_FLOAT> (saber_activation.cpp:156-262; the scalar formulas of
+// test/saber/test_saber_activation.cpp:17-115): elementwise, HBM-bound, in place allowed. `active` = the reference's ActiveType value.
+template <int ACTIVE>
+__device__ __forceinline__ float act_f32(float v, float slope, float coef) {
+    if constexpr (ACTIVE == 1) return 1.0f / (1.0f + expf(-v));                         // sigmoid
+    else if constexpr (ACTIVE == 3) return tanhf(v);                                    // tanh
+    else if constexpr (ACTIVE == 4) { const float r = v > 0.f ? v : 0.f; return r < coef ? r : coef; }   // clipped relu
+    else if constexpr (ACTIVE == 5) return v > 0.f ? v : coef * (expf(v) - 1.f);        // elu
+    else if constexpr (ACTIVE == 9) return coef * tanhf(slope * v);                     // stanh
+    else if constexpr (ACTIVE == 11) return v * (0.5f * (erff(v / sqrtf(2.f)) + 1.f));  // gelu
+    else return v / (1.0f + expf(-v * coef));                                           // swish (12)
+}
+template <int ACTIVE>
+__global__ __launch_bounds__(256) void activation_f32_kernel(size_t count, float slope, float coef, const float* __restrict__ x,
+                                                             float* __restrict__ y) {
+    const size_t vec = count >> 2;
+    for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < vec; gid += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)x)[gid];
+        ((float4*)y)[gid] = make_float4(act_f32<ACTIVE>(v.x, slope, coef), act_f32<ACTIVE>(v.y, slope, coef),
+                                        act_f32<ACTIVE>(v.z, slope, coef), act_f32<ACTIVE>(v.w, slope, coef));
+    }
+    for (size_t i = (vec << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+        y[i] = act_f32<ACTIVE>(x[i], slope, coef);
+}
+hipError_t launch_activation_f32(int active, size_t count, float slope, float coef, const float* x, float* y, hipStream_t s) {
+    const dim3 grid(grid_for((count + 3) / 4)), block(256);
+    switch (active) {
+    case 1: hipLaunchKernelGGL(activation_f32_kernel<1>, grid, block, 0, s, count, slope, coef, x, y); break;
+    case 3: hipLaunchKernelGGL(activation_f32_kernel<3>, grid, block, 0, s, count, slope, coef, x, y); break;
+    case 4: hipLaunchKernelGGL(activation_f32_kernel<4>, grid, block, 0, s, count, slope, coef, x, y); break;
+    case 5: hipLaunchKernelGGL(activation_f32_kernel<5>, grid, block, 0, s, count, slope, coef, x, y); break;
+    case 9: hipLaunchKernelGGL(activation_f32_kernel<9>, grid, block, 0, s, count, slope, coef, x, y); break;
+    case 11: hipLaunchKernelGGL(activation_f32_kernel<11>, grid, block, 0, s, count, slope, coef, x, y); break;
+    case 12: hipLaunchKernelGGL(activation_f32_kernel<12>, grid, block, 0, s, count, slope, coef, x, y); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// PReLU (excute_prelu, saber_activation.cpp:38-132): y = x > 0 ? x : x * slope[channel]; channel = (i / inner) % channels
+// (NCHW: inner = H * W, NHWC: inner = 1); channel_shared: slope[0]
+__global__ __launch_bounds__(256) void prelu_f32_kernel(size_t count, int channels, int inner, int shared, const float* __restrict__ slope,
+                                                        const float* __restrict__ x, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        const float sl = shared ? slope[0] : slope[(i / (size_t)inner) % (size_t)channels];
+        y[i] = v > 0.f ? v : v * sl;
+    }
+}
+hipError_t launch_prelu_f32(size_t count, int channels, int inner, int shared, const float* slope, const float* x, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(prelu_f32_kernel, dim3(grid_for(count)), dim3(256), 0, s, count, channels, inner, shared, slope, x, y);
+    return hipGetLastError();
+}
+
 // ---- 8-bit NHWC pooling -----------------------------------------------------------------------
 // One lane per (output pixel, 4-channel dword). JIT semantics: int32 window sum, (float)sum * idivider,
 // round-to-nearest-even, saturate; max by signed/unsigned compare.

@@ -291,6 +291,8 @@ hipError_t launch_eltwise_sum_i8(size_t count, const int8_t* a, const int8_t* b,
 hipError_t launch_eltwise_sum_f32(size_t count, const float* a, const float* b, float c0, float c1, int relu,
                                   float* y, hipStream_t s);
 hipError_t launch_relu_f32(size_t count, const float* x, float* y, hipStream_t s);
+hipError_t launch_activation_f32(int active, size_t count, float slope, float coef, const float* x, float* y, hipStream_t s);
+hipError_t launch_prelu_f32(size_t count, int channels, int inner, int shared, const float* slope, const float* x, float* y, hipStream_t s);
 hipError_t launch_pool2d_i8_nhwc(int n, int h, int w, int c, int oh, int ow, int kh, int kw, int sh, int sw,
                                  int ph, int pw, int type, int in_dtype, int out_dtype, const void* x, void* y,
                                  hipStream_t s);

@@ -36,7 +36,7 @@ SYMBOLS = [
     "saber_hip_gemm_i8_create", "saber_hip_gemm_i8_workspace_bytes", "saber_hip_gemm_i8_run", "saber_hip_gemm_i8_destroy",
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
-    "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32", "saber_hip_relu_f32",
+    "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32", "saber_hip_relu_f32", "saber_hip_activation_f32", "saber_hip_prelu_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool_out_dim2", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
     "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice", "saber_hip_net_stage_blocks", "saber_hip_net_time_op_in_pass", "saber_hip_net_status", "saber_hip_net_inject_coop_error",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
@@ -46,7 +46,7 @@ SYMBOLS = [
     "saber_hip_net_arena_bytes", "saber_hip_net_num_ops", "saber_hip_net_run", "saber_hip_net_run_op",
     "saber_hip_net_capture", "saber_hip_net_replay", "saber_hip_net_time_ops", "saber_hip_net_time_pass", "saber_hip_net_op_work", "saber_hip_net_op_name",
     "saber_hip_net_autotune", "saber_hip_net_destroy",
-    "saber_hip_net_add_relu_f32", "saber_hip_net_bind_tensor", "saber_hip_net_num_tensors", "saber_hip_net_tensor_bytes",
+    "saber_hip_net_add_relu_f32", "saber_hip_net_add_activation_f32", "saber_hip_net_bind_tensor", "saber_hip_net_num_tensors", "saber_hip_net_tensor_bytes",
     "saber_hip_capture_begin", "saber_hip_capture_end", "saber_hip_capture_active", "saber_hip_net_tensor_of_ptr",
 ]
 
@@ -178,6 +178,8 @@ def load():
     lib.saber_hip_net_add_fc_q.argtypes = [P, P, I, I]
     lib.saber_hip_softmax_f32.argtypes = [I, I, P, P, P]
     lib.saber_hip_relu_f32.argtypes = [Z, P, P, P]
+    lib.saber_hip_activation_f32.argtypes = [I, Z, F, F, P, P, P]
+    lib.saber_hip_prelu_f32.argtypes = [Z, I, I, I, P, P, P, P]
     lib.saber_hip_net_create.argtypes = [C.POINTER(P)]
     lib.saber_hip_net_add_tensor.argtypes = [P, Z]
     lib.saber_hip_net_add_conv.argtypes = [P, P, I, I, I]
@@ -211,6 +213,7 @@ def load():
     lib.saber_hip_net_destroy.argtypes = [P]
     lib.saber_hip_net_destroy.restype = None
     lib.saber_hip_net_add_relu_f32.argtypes = [P, Z, I, I]
+    lib.saber_hip_net_add_activation_f32.argtypes = [P, I, Z, F, F, I, I]
     lib.saber_hip_net_bind_tensor.argtypes = [P, I, P]
     lib.saber_hip_net_num_tensors.argtypes = [P]
     lib.saber_hip_net_tensor_bytes.argtypes = [P, I]

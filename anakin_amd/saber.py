@@ -53,6 +53,9 @@ class ConvParam:
         self.scale_res = 1.0
         self.res_stride = 0           # RES_ELTWISE: (stride, res_h, res_w) of a 1x1 / stride-s shortcut pooling folded into the
         self.res_hw = (0, 0)          # residual read (saber_hip_conv_desc::res_stride)
+        # an activation other than relu behind an FP32 conv: (ActiveType value, negative_slope, coef) - the conv runs without one and
+        # the activation follows in place (include/saber_mi355x_impl.h: _post_act; the NV impl's _saber_act)
+        self.post_act = None
 
 
 class SaberConv2D:
@@ -95,6 +98,10 @@ class SaberConv2D:
         if getattr(param, "res_stride", 0) > 1:
             d.res_stride, (d.res_h, d.res_w) = int(param.res_stride), param.res_hw
         self.desc = d
+        self.post_act = getattr(param, "post_act", None)
+        if self.post_act is not None and (self.int8 or param.res_mode != L.RES_NONE or param.relu or out_dtype != L.F32):
+            # (the adaptor's rule: SaberUnImplError - the x86 impls know only relu there)
+            raise L.SaberHipError("an activation other than relu needs an FP32 conv with f32 output and no eltwise")
         L.check(lib.saber_hip_conv2d_create(C.byref(d), C.byref(self.h)))
         w_np = np.ascontiguousarray(param.weight)
         w_dt = L.F32 if w_np.dtype == np.float32 else L.S8
@@ -120,6 +127,9 @@ class SaberConv2D:
 
     def dispatch(self, x, y, res=None):
         L.check(L.load().saber_hip_conv2d_run(self.h, _p(x), _p(y), _p(res), _p(self.ws), _stream()))
+        if getattr(self, "post_act", None) is not None:
+            active, slope, coef = self.post_act
+            activation(active, y, y, slope, coef)
         return y
 
     def algo(self):
@@ -250,6 +260,30 @@ class SaberConvPair:
                 L.load().saber_hip_conv2d_destroy(self.h)
         except Exception:
             pass
+
+
+# ActiveType values (saber/saber_types.h:283-293)
+ACTIVE_SIGMOID, ACTIVE_RELU, ACTIVE_TANH, ACTIVE_CLIPPED_RELU, ACTIVE_ELU, ACTIVE_STANH, ACTIVE_PRELU, ACTIVE_GELU, ACTIVE_SWISH = \
+    1, 2, 3, 4, 5, 9, 10, 11, 12
+
+
+def activation(active, x, y=None, negative_slope=0.0, coef=1.0):
+    """Activation<MI355X, AK_FLOAT>::dispatch for every type but prelu (saber_hip_activation_f32); y defaults to a new tensor, y = x:
+    in place."""
+    import torch
+    if y is None:
+        y = torch.empty_like(x)
+    L.check(L.load().saber_hip_activation_f32(int(active), x.numel(), float(negative_slope), float(coef), _p(x), _p(y), _stream()))
+    return y
+
+
+def prelu(x, slope, channels, inner, channel_shared=False, y=None):
+    """Active_prelu (saber_hip_prelu_f32): channel = (i / inner) % channels; slope: a device f32 tensor"""
+    import torch
+    if y is None:
+        y = torch.empty_like(x)
+    L.check(L.load().saber_hip_prelu_f32(x.numel(), int(channels), int(inner), int(bool(channel_shared)), _p(slope), _p(x), _p(y), _stream()))
+    return y
 
 
 class SaberConvChain:

@@ -317,6 +317,17 @@ int saber_hip_eltwise_sum_f32(size_t count, const float* a, const float* b, floa
 /* standalone ReLU op (framework/operators/relu.cpp -> Activation<T,D>, Active_relu; saber_activation.cpp:136-154):
  * y = x > 0 ? x : 0 over `count` f32 elements; x == y (in place) is allowed */
 int saber_hip_relu_f32(size_t count, const float* x, float* y, saber_hip_stream_t stream);
+/* The other activation types of the standalone Activation operator (Activation<T, AK_FLOAT>: saber/funcs/activation.h,
+ * x86: saber/funcs/impl/x86/saber_activation.cpp:156-262), elementwise on f32, in place allowed. `active` is the reference's
+ * ActiveType value (saber/saber_types.h:283-293): sigmoid 1, relu 2 (= saber_hip_relu_f32), tanh 3, clipped relu 4 (threshold =
+ * coef), elu 5 (coef), stanh 9 (coef * tanh(negative_slope * x)), gelu 11, swish 12 (beta = coef); anything else: UNIMPL.
+ * PReLU (Active_prelu 10; excute_prelu :38-132): y = x > 0 ? x : x * slope[channel], channel = (i / inner) % channels
+ * (NCHW: inner = H * W; NHWC: inner = 1), channel_shared: slope[0]; `slope` is device memory. Also what a Conv with a non-relu
+ * activation runs after the convolution (the adaptor, as the NV impl does: saber/funcs/impl/cuda/saber_conv.cpp _saber_act). */
+int saber_hip_activation_f32(int active, size_t count, float negative_slope, float coef, const float* x, float* y,
+                             saber_hip_stream_t stream);
+int saber_hip_prelu_f32(size_t count, int channels, int inner, int channel_shared, const float* slope, const float* x, float* y,
+                        saber_hip_stream_t stream);
 /* Pooling<>::compute_output_shape (pooling.h:69-130) */
 int saber_hip_pool_out_dim(int in, int pad, int window, int stride, int floor_mode);
 /* The same for one dimension of a pooling whose OTHER dimension may be padded: the reference clips the last window of
@@ -452,6 +463,8 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
 void saber_hip_net_destroy(saber_hip_net_t* net);
 /* standalone ReLU operator inside an op list (Activation<T,D>, Active_relu; VGG16's fc6 / fc7) */
 int saber_hip_net_add_relu_f32(saber_hip_net_t* net, size_t count, int in_id, int out_id);
+int saber_hip_net_add_activation_f32(saber_hip_net_t* net, int active, size_t count, float negative_slope, float coef, int in_id,
+                                     int out_id);
 /* Caller-owned storage for tensor `id` instead of a slot of the net's arena (the net's inputs and outputs when the caller
  * has buffers of its own: the reference's Net owns its edge tensors). Before finalize any tensor can be bound (ptr != NULL)
  * or returned to the arena (NULL); after finalize only the address of an already external tensor can change. A captured

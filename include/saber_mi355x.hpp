@@ -34,7 +34,8 @@ enum SaberStatus { SaberSuccess = -1, SaberNotInitialized = 1, SaberInvalidValue
 enum DataType { AK_INVALID = 0, AK_HALF = 1, AK_FLOAT = 2, AK_DOUBLE = 3, AK_INT8 = 4, AK_INT16 = 5, AK_INT32 = 6,
                 AK_INT64 = 7, AK_UINT8 = 8 };
 enum LayoutType { Layout_invalid = 0, Layout_NCHW = 2, Layout_NHWC = 3 };
-enum ActiveType { Active_unknow = 0, Active_relu = 2 };
+enum ActiveType { Active_unknow = 0, Active_sigmoid = 1, Active_relu = 2, Active_tanh = 3, Active_clipped_relu = 4, Active_elu = 5,
+                  Active_identity = 6, Active_stanh = 9, Active_prelu = 10, Active_gelu = 11, Active_swish = 12 };   // saber_types.h:283-293
 enum EltwiseType { Eltwise_unknow = 0, Eltwise_prod = 1, Eltwise_sum = 2, Eltwise_max = 3 };
 enum PoolingType { Pooling_unknow = 0, Pooling_max = 1, Pooling_average_include_padding = 2,
                    Pooling_average_exclude_padding = 3 };   // saber_types.h:305-311
@@ -175,12 +176,22 @@ protected:
 };
 
 template <typename TargetType>
-struct ActivationParam {
-    ActivationParam() : active(Active_unknow), negative_slope(0.f), has_active(false) {}
-    explicit ActivationParam(ActiveType a, float slope = 0.f) : active(a), negative_slope(slope), has_active(true) {}
+struct PreluParam {                     // saber_funcs_param.h: channel_shared + the slope tensor (non-owning)
+    PreluParam() : channel_shared(false), slope(nullptr) {}
+    PreluParam(bool shared, Tensor<TargetType>* slope_in) : channel_shared(shared), slope(slope_in) {}
+    bool channel_shared;
+    Tensor<TargetType>* slope;
+};
+template <typename TargetType>
+struct ActivationParam {                // saber_funcs_param.h:47-110
+    ActivationParam() : active(Active_unknow), negative_slope(0.f), coef(1.f), has_active(false) {}
+    explicit ActivationParam(ActiveType a, float slope = 0.f, float co = 1.f, PreluParam<TargetType> prelu = PreluParam<TargetType>())
+        : active(a), negative_slope(slope), coef(co), has_active(true), prelu_param(prelu) {}
     ActiveType active;
     float negative_slope;
+    float coef;
     bool has_active;
+    PreluParam<TargetType> prelu_param;
 };
 
 template <typename TargetType>

@@ -67,6 +67,28 @@ inline bool mi355x_conv_sum_scale(float beta, DataType beta_type, DataType out_d
     return true;
 }
 
+// The activation types the target runs on f32 tensors (saber_hip_activation_f32 / saber_hip_prelu_f32)
+inline bool mi355x_activation_supported(ActiveType a) {
+    return a == Active_sigmoid || a == Active_relu || a == Active_tanh || a == Active_clipped_relu || a == Active_elu ||
+           a == Active_stanh || a == Active_prelu || a == Active_gelu || a == Active_swish;
+}
+// one Activation<AK_FLOAT> on `in` -> `out` (the same tensor: in place); PReLU reads its slope tensor (device memory) and the
+// channel position from the tensor's layout
+template <typename TargetType>
+inline int mi355x_run_activation(ActivationParam<TargetType>& p, Tensor<TargetType>& in, Tensor<TargetType>& out,
+                                 saber_hip_stream_t stream) {
+    const size_t count = (size_t)in.valid_size();
+    if (p.active == Active_prelu) {
+        PreluParam<TargetType> pr = p.prelu_param;
+        if (!pr.slope) return SABER_HIP_INVALID_VALUE;
+        const int inner = in.get_layout() == Layout_NHWC ? 1 : in.height() * in.width();
+        return saber_hip_prelu_f32(count, in.channel(), inner, pr.channel_shared ? 1 : 0, (const float*)pr.slope->data(),
+                                   (const float*)in.data(), (float*)out.mutable_data(), stream);
+    }
+    return saber_hip_activation_f32((int)p.active, count, p.negative_slope, p.coef, (const float*)in.data(),
+                                    (float*)out.mutable_data(), stream);
+}
+
 // SaberConv2D<MI355X, OpDtype> and SaberConvEltwise<MI355X, OpDtype> share this body
 // (ConvEltwiseParam = ConvParam + EltwiseParam, saber_funcs_param.h:586-615).
 template <typename TargetType, DataType OpDtype>
@@ -113,7 +135,14 @@ public:
         d.act = (cp.activation_param.has_active && cp.activation_param.active == Active_relu) ? SABER_HIP_ACT_RELU
                                                                                               : SABER_HIP_ACT_NONE;
         d.act_negative_slope = d.act == SABER_HIP_ACT_RELU ? cp.activation_param.negative_slope : 0.f;
-        if (cp.activation_param.has_active && cp.activation_param.active != Active_relu) return SaberUnImplError;
+        // Any other activation type behind an FP32 conv without an eltwise: the convolution runs without one and the activation
+        // follows in place on its output - the structure of the NV impl (saber/funcs/impl/cuda/saber_conv.cpp: `_saber_act` after
+        // the conv kernel). INT8 / with an eltwise: the x86 impls know only relu there.
+        _post_act = cp.activation_param.has_active && cp.activation_param.active != Active_relu;
+        if (_post_act && (OpDtype != AK_FLOAT || ep.has_eltwise || out->get_dtype() != AK_FLOAT ||
+                          !mi355x_activation_supported(cp.activation_param.active)))
+            return SaberUnImplError;
+        _act = cp.activation_param;
         if (ep.has_eltwise && ep.operation == Eltwise_sum && _elt_input && inputs.size() > 1) {
             d.res_mode = SABER_HIP_RES_ELTWISE;
             d.res_act = (ep.activation_param.has_active && ep.activation_param.active == Active_relu)
@@ -168,7 +197,9 @@ public:
         saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
         void* ws = saber_hip_conv2d_workspace_bytes(_op) ? _ws.mutable_data() : nullptr;
         const void* res = (_elt_input && inputs.size() > 1) ? inputs[1]->data() : nullptr;
-        return mi355x_status(saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), res, ws, stream));
+        int rc = saber_hip_conv2d_run(_op, inputs[0]->data(), outputs[0]->mutable_data(), res, ws, stream);
+        if (rc == SABER_HIP_OK && _post_act) rc = mi355x_run_activation(_act, *outputs[0], *outputs[0], stream);
+        return mi355x_status(rc);
     }
 
     // Conv<>::trans_weights static_casts to this (conv.h:103-119): the repack already happened in create()
@@ -180,6 +211,8 @@ public:
 private:
     saber_hip_conv_t* _op;
     bool _elt_input;
+    bool _post_act = false;
+    ActivationParam<TargetType> _act;
     Tensor<TargetType> _ws;
 };
 
@@ -460,8 +493,8 @@ private:
     int _rows, _cols;
 };
 
-// Activation<MI355X, AK_FLOAT>, Active_relu (the standalone ReLU operator, framework/operators/relu.cpp; x86:
-// saber_activation.cpp:136-154). Every other activation type: SaberUnImplError.
+// Activation<MI355X, AK_FLOAT> (saber/funcs/activation.h; x86: saber_activation.cpp:136-262): relu (the standalone ReLU operator,
+// framework/operators/relu.cpp), sigmoid, tanh, clipped relu, elu, stanh, swish, gelu, prelu. INT8 tensors: SaberUnImplError.
 template <typename TargetType, DataType OpDtype>
 class SaberActivationMI355X : public ImplBase<TargetType, OpDtype, ActivationParam<TargetType> > {
 public:
@@ -473,7 +506,7 @@ public:
     virtual SaberStatus create(const std::vector<Tensor<TargetType>*>& inputs, std::vector<Tensor<TargetType>*>& outputs,
                                ActivationParam<TargetType>& param, Context<TargetType>& ctx) {
         this->_ctx = &ctx;
-        if (OpDtype != AK_FLOAT || param.active != Active_relu || param.negative_slope != 0.f) return SaberUnImplError;
+        if (OpDtype != AK_FLOAT || !mi355x_activation_supported(param.active)) return SaberUnImplError;
         if (inputs[0]->get_dtype() != AK_FLOAT || outputs[0]->get_dtype() != AK_FLOAT) return SaberUnImplError;
         return SaberSuccess;
     }
@@ -481,8 +514,7 @@ public:
                                  ActivationParam<TargetType>& param) {
         saber_hip_stream_t stream = (saber_hip_stream_t)this->_ctx->get_compute_stream();
         for (size_t i = 0; i < inputs.size(); ++i) {
-            int rc = saber_hip_relu_f32((size_t)inputs[i]->valid_size(), (const float*)inputs[i]->data(),
-                                        (float*)outputs[i]->mutable_data(), stream);
+            int rc = mi355x_run_activation(param, *inputs[i], *outputs[i], stream);
             if (rc) return mi355x_status(rc);
         }
         return SaberSuccess;

@@ -19,6 +19,7 @@
 #include "saber/core/tensor_op.h"
 #include "saber/funcs/conv.h"
 #include "saber/funcs/conv_eltwise.h"
+#include "saber/funcs/activation.h"
 #include "saber/funcs/timer.h"
 
 #include <cstdio>
@@ -192,6 +193,41 @@ int main() {
         printf("SaberTimer<MI355X>: %.1f us average, %.1f us best per dispatch (event pair included)\n", t.get_average_ms() * 1e3f,
                t.get_best_ms() * 1e3f);
         if (!(t.get_average_ms() > 0.f)) { printf("FAIL timer\n"); ++g_fail; }
+    }
+    {   // Activation<MI355X, AK_FLOAT> beyond relu, under the reference's own BaseFunc (saber/funcs/activation.h): sigmoid, swish,
+        // prelu with per-channel slopes - against the scalar formulas of test/saber/test_saber_activation.cpp:17-115
+        const int n = 2, c = 5, h = 7, w = 9, count = n * c * h * w;
+        Tensor<X86> hx(Shape({n, c, h, w}, Layout_NCHW), AK_FLOAT), hslope(Shape({1, c, 1, 1}, Layout_NCHW), AK_FLOAT);
+        float* px = (float*)hx.mutable_data();
+        for (int i = 0; i < count; ++i) px[i] = ((i * 37) % 101 - 50) * 0.07f;
+        float* ps = (float*)hslope.mutable_data();
+        for (int i = 0; i < c; ++i) ps[i] = 0.1f * (i + 1);
+        Tensor<MI355X> dx(hx.valid_shape(), AK_FLOAT), dy(hx.valid_shape(), AK_FLOAT), dslope(hslope.valid_shape(), AK_FLOAT);
+        dx.copy_from(hx);
+        dslope.copy_from(hslope);
+        std::vector<Tensor<MI355X>*> ins{&dx}, outs{&dy};
+        struct { ActiveType a; const char* name; } kinds[] = {{Active_sigmoid, "sigmoid"}, {Active_swish, "swish"}, {Active_prelu, "prelu"}};
+        for (auto& k : kinds) {
+            PreluParam<MI355X> prelu(false, &dslope);
+            ActivationParam<MI355X> param(k.a, 0.f, 1.3f, prelu);
+            Activation<MI355X, AK_FLOAT> act;
+            SaberStatus st = act.init(ins, outs, param, SPECIFY, SABER_IMPL, ctx);
+            if (st == SaberSuccess) st = act(ins, outs, param, ctx);
+            Tensor<X86> hy(hx.valid_shape(), AK_FLOAT);
+            hy.copy_from(dy);
+            const float* py = (const float*)hy.data();
+            double worst = 0;
+            for (int i = 0; i < count; ++i) {
+                const float v = px[i];
+                const int ch = (i / (h * w)) % c;
+                const float want = k.a == Active_sigmoid ? 1.0f / (expf(-v) + 1.0f)
+                                   : (k.a == Active_swish ? v / (1.0f + expf(-(v * 1.3f))) : (v > 0 ? v : v * ps[ch]));
+                worst = std::max(worst, (double)fabsf(py[i] - want));
+            }
+            ++g_run;
+            if (st != SaberSuccess || worst > 1e-5) { printf("FAIL Activation<MI355X,AK_FLOAT> %s: status %d, max error %.3g\n", k.name, (int)st, worst); ++g_fail; }
+            else printf("ok   Activation<MI355X,AK_FLOAT> %s under BaseFunc, max error %.2g\n", k.name, worst);
+        }
     }
     printf("%d cases, %d failed\n", g_run, g_fail);
     return g_fail ? 1 : 0;

@@ -283,6 +283,48 @@ def bn_fold(w, bias, bn_scale, eps, mean, var, scale_w, scale_b):
     return w, b
 
 
+def activation_f32(x, active, negative_slope=0.0, coef=1.0):
+    """SaberActivation<X86, AK_FLOAT>::dispatch (saber/funcs/impl/x86/saber_activation.cpp:136-262) and the scalar formulas the
+    reference's own test checks it against (test/saber/test_saber_activation.cpp:17-115), per ActiveType value (saber_types.h:283-
+    293). PARITY UNPINNED for these types: saber_activation.cpp needs xbyak (jit_generator.h) and cannot be compiled into
+    oracle/_ref here; this is the published formula in f32 with numpy's libm."""
+    x = np.asarray(x, np.float32)
+    one = np.float32(1.0)
+    if active == 2:       # relu (the standalone operator ignores negative_slope)
+        return np.where(x > 0, x, np.float32(0)).astype(np.float32)
+    if active == 1:       # sigmoid
+        return (one / (one + np.exp(-x))).astype(np.float32)
+    if active == 3:       # tanh
+        return np.tanh(x).astype(np.float32)
+    if active == 4:       # clipped relu, threshold = coef
+        r = np.where(x > 0, x, np.float32(0))
+        return np.where(r < np.float32(coef), r, np.float32(coef)).astype(np.float32)
+    if active == 5:       # elu
+        return np.where(x > 0, x, np.float32(coef) * (np.exp(x) - one)).astype(np.float32)
+    if active == 9:       # stanh
+        return (np.float32(coef) * np.tanh(np.float32(negative_slope) * x)).astype(np.float32)
+    if active == 11:      # gelu: x * 0.5 * (erf(x / sqrt(2)) + 1)
+        from math import erf, sqrt
+        e = np.vectorize(lambda v: erf(float(v) / sqrt(2.0)))(x).astype(np.float32)
+        return (x * (np.float32(0.5) * (e + one))).astype(np.float32)
+    if active == 12:      # swish, beta = coef
+        return (x / (one + np.exp(-x * np.float32(coef)))).astype(np.float32)
+    raise ValueError("activation type %d" % active)
+
+
+def prelu_f32(x, slope, channel_axis, channel_shared=False):
+    """excute_prelu (saber_activation.cpp:38-132): y = x > 0 ? x : x * slope[channel] (slope[0] when channel_shared)"""
+    x = np.asarray(x, np.float32)
+    slope = np.asarray(slope, np.float32)
+    if channel_shared:
+        sl = slope.ravel()[0]
+    else:
+        shape = [1] * x.ndim
+        shape[channel_axis] = x.shape[channel_axis]
+        sl = slope.reshape(shape)
+    return np.where(x > 0, x, x * sl).astype(np.float32)
+
+
 def softmax_f32(x):
     x = np.ascontiguousarray(x, np.float32)
     outer, Cn = x.shape[0], x.shape[1]

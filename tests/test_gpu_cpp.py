@@ -42,6 +42,8 @@ def test_mi355x_target_inside_the_reference_operator_stack(tmp_path):
     p = subprocess.run([MI355X_BIN], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))   # (the reference's logger writes ./log/)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 failed" in p.stdout and "bit-exact" in p.stdout and "SaberTimer<MI355X>" in p.stdout
+    for kind in ("sigmoid", "swish", "prelu"):       # Activation<MI355X, AK_FLOAT> beyond relu, under the reference's BaseFunc
+        assert "ok   Activation<MI355X,AK_FLOAT> %s" % kind in p.stdout, p.stdout[-2000:]
 
 
 def test_mi355x_target_test_binary_is_built():
