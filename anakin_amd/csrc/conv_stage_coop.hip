@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512) void conv_stage4_c256_kernel(const Stage4KArgs
     __shared__ v4i prm0[P0C];
     __shared__ v4i prm1[P1C];
     __shared__ v4i prm2[P2C];
+    __shared__ int dma_off[((HCH / 64 + NW - 1) / NW + (YCH / 64 + NW - 1) / NW) * 512];
     SABER_TL_DECL;
     SABER_TL(0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -93,17 +94,42 @@ __global__ __launch_bounds__(512) void conv_stage4_c256_kernel(const Stage4KArgs
     const int tpx = tid / CPRW, tc = (tid % CPRW) ^ (tpx & 15);          // this thread's chunk of the quarter's y1 tile
     const int pt = pix(tpx, okt);
 
-    auto dma_halo = [&](const void* x, bool l2) {            // 4 rows x 18 columns x 256 channels, zero page for the padding
+    // This lane's source offsets of the two per-block DMA copies, computed ONCE (the instruction mix of the launch was 10 VALU per MFMA
+    // instruction, a third of it the index arithmetic of these copies repeated every block): the input halo - 4 rows x 18 columns x 256
+    // channels, -1 = the zero page (padding) - and the partners' part of the y1 tile (slot L = pixel * 49 + partner chunk, chunk 48 of
+    // every pixel is padding).
+    // (kept in LDS, one word per thread and copy instruction: in registers they pushed the kernel over 256 VGPRs)
+    constexpr int HIT = (HCH / 64 + NW - 1) / NW, YIT = (YCH / 64 + NW - 1) / NW;
+    int* const halo_off = dma_off + tid;               // [it * 512]
+    int* const pt_off = dma_off + HIT * 512 + tid;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int L = (wave + it * NW) * 64 + lane;
+        const int hp = L / PCH, cc = L - hp * PCH;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool in = hp < HP && cc < CH1 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        halo_off[it * 512] = in ? ((n * H + gy) * W + gx) * C1 + cc * 16 : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < YIT; ++it) {
+        const int L = (wave + it * NW) * 64 + lane;
+        const int px = L / YPC, j = L - px * YPC;
+        bool okp;
+        const int pp_ = pix(px & 31, okp);
+        const int pc = j < q * 16 ? j : j + 16;      // the partners' chunks in channel order, this quarter's 16 skipped
+        pt_off[it * 512] = (px < 32 && j < YPC - 1) ? pp_ * K1 + pc * 16 : -1;
+    }
+    auto dma_halo = [&](const void* x, bool l2) {
         const char* xg = (const char*)x;
-        for (int i = wave; i < HCH / 64; i += NW) {
-            const int L = i * 64 + lane;
-            const int hp = L / PCH, cc = L - hp * PCH;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool in = hp < HP && cc < CH1 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const char* src = in ? xg + ((size_t)((n * H + gy) * W + gx) * C1 + cc * 16) : (const char*)ka.zero;
-            if (l2 && in) lds_dma16_l2(src, halo + i * 64);
-            else lds_dma16(src, halo + i * 64);
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int i = wave + it * NW;
+            if (i >= HCH / 64) break;
+            const int off = halo_off[it * 512];
+            if (off < 0) lds_dma16(ka.zero, halo + i * 64);
+            else if (l2) lds_dma16_l2(xg + off, halo + i * 64);
+            else lds_dma16(xg + off, halo + i * 64);
         }
     };
     auto dma_prm = [&](const StageBlk& B) {
@@ -274,15 +300,13 @@ __global__ __launch_bounds__(512) void conv_stage4_c256_kernel(const Stage4KArgs
             }
             coop_wait<31ull>(ctr + 16, ka.err);              // the partners' quarters of the y1 tile are in the L2
             SABER_TL(5);
-            // ... into LDS, once per workgroup: slot L = pixel * 49 + partner chunk (chunk 48 of every pixel is padding)
-            for (int i = wave; i < YCH / 64; i += NW) {
-                const int L = i * 64 + lane;
-                const int px = L / YPC, j = L - px * YPC;
-                bool okp;
-                const int pp_ = pix(px & 31, okp);
-                const int pc = j < q * 16 ? j : j + 16;      // the partners' chunks in channel order, this quarter's 16 skipped
-                const bool in = px < 32 && j < YPC - 1;
-                if (in) lds_dma16_l2((const char*)ka.y1[k] + (size_t)pp_ * K1 + pc * 16, ptile + i * 64);
+            // ... into LDS, once per workgroup (offsets: pt_off above)
+#pragma unroll
+            for (int it = 0; it < YIT; ++it) {
+                const int i = wave + it * NW;
+                if (i >= YCH / 64) break;
+                const int off = pt_off[it * 512];
+                if (off >= 0) lds_dma16_l2((const char*)ka.y1[k] + off, ptile + i * 64);
                 else lds_dma16(ka.zero, ptile + i * 64);
             }
             wait_vm_older_than<0>();
