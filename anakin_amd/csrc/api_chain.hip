@@ -109,6 +109,66 @@ static void pack_stage1_c128_stream(const saber_hip_conv* c3, const saber_hip_co
         for (int ks = 0; ks < 8; ++ks) pack_frag1(b->wq_oihw.data(), K1, w * 16, 1, 0, ks, out);
     }
 }
+// ------------------------------------------------------------------------------------------------
+// stem conv + max pooling + the sibling pair of 1x1 convs on the pooled tensor in ONE launch (conv_stem.h)
+// ------------------------------------------------------------------------------------------------
+int saber_hip_conv2d_stem_pair_create(saber_hip_conv_t* stem, const saber_hip_conv_t* a, const saber_hip_conv_t* b, saber_hip_stem_pair_t** out) {
+    if (!stem || !a || !b || !out) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const saber_hip_conv_desc& ds = stem->d;
+    if (!stem->pool_fused || !stem->weights_set || ds.k != 64 || (ds.out_dtype != SABER_HIP_U8 && ds.out_dtype != SABER_HIP_S8))
+        return fail(SABER_HIP_INVALID_VALUE, "stem pair: the head must be the fused stem conv + max pooling with 64 output channels (8-bit)");
+    auto plain1x1 = [&](const saber_hip_conv* o) {
+        const saber_hip_conv_desc& d = o->d;
+        return o->is_i8 && o->weights_set && o->algo == ALGO_IGEMM_I8 && o->epi == EPI_I8_CONV && d.res_mode == SABER_HIP_RES_NONE &&
+               !o->pair_k2 && !o->pool_fused && !o->pool2 && !o->pre_quant && !o->pre_pad && d.kh == 1 && d.kw == 1 && d.stride_h == 1 &&
+               d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && d.group == 1 && d.c == 64 && o->c_eff == 64 && d.k % 32 == 0 &&
+               d.in_layout == SABER_HIP_NHWC && d.out_layout == SABER_HIP_NHWC && d.act_negative_slope == 0.f &&
+               (d.out_dtype == SABER_HIP_S8 || d.out_dtype == SABER_HIP_U8) && d.n == ds.n && d.h == stem->pool_oh && d.w == stem->pool_ow &&
+               (o->x_dtype == DT_U8) == (ds.out_dtype == SABER_HIP_U8) && (int)o->wq_oihw.size() == d.k * 64;
+    };
+    if (!plain1x1(a) || !plain1x1(b) || a->d.k + b->d.k > 320)
+        return fail(SABER_HIP_INVALID_VALUE, "stem pair: two plain 1x1 / stride-1 INT8 convs (64 -> k, k % 32 == 0, k_a + k_b <= 320, 8-bit NHWC outputs) "
+                                              "on the pooled tensor");
+    auto* sp = new saber_hip_stem_pair();
+    sp->stem = stem; sp->a = a; sp->b = b;
+    const int K1 = a->d.k, Kt = K1 + b->d.k;
+    std::vector<int8_t> wcat((size_t)Kt * 64);
+    std::memcpy(wcat.data(), a->wq_oihw.data(), (size_t)K1 * 64);
+    std::memcpy(wcat.data() + (size_t)K1 * 64, b->wq_oihw.data(), (size_t)b->d.k * 64);
+    std::vector<uint8_t> w, pa, pb, prm(256 * 16, 0);
+    w.reserve((size_t)Kt * 64);
+    for (int g = 0; g < Kt / 32; ++g)
+        for (int mf = 0; mf < 2; ++mf) pack_frag1(wcat.data(), 64, g * 32, 2, mf, 0, w);
+    pack_chain_params(a, (size_t)K1 / 4 * 3, pa);
+    pack_chain_params(b, (size_t)b->d.k / 4 * 3, pb);
+    std::memcpy(prm.data(), pa.data(), pa.size());
+    std::memcpy(prm.data() + pa.size(), pb.data(), pb.size());
+    hipError_t e = sp->d_w.upload(w);
+    if (e == hipSuccess) e = sp->d_prm.upload(prm);
+    if (e != hipSuccess) {
+        delete sp;
+        return hip_fail(e, "stem pair: device copies");
+    }
+    *out = sp;
+    return SABER_HIP_OK;
+}
+void saber_hip_conv2d_stem_pair_destroy(saber_hip_stem_pair_t* sp) { delete sp; }
+int saber_hip_conv2d_stem_pair_run(saber_hip_stem_pair_t* sp, const void* x, void* y_pool, void* y_a, void* y_b, void* workspace,
+                                   saber_hip_stream_t stream) {
+    if (g_capture) return capture_unsupported("saber_hip_conv2d_stem_pair_run (an executor-level object: saber_hip_net_optimize forms it itself)");
+    if (!sp || !x || !y_a || !y_b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    saber_hip_conv* op = sp->stem;
+    if (op->ws_bytes && !workspace) return fail(SABER_HIP_INVALID_VALUE, "workspace required");
+    saber_mi355x::StemPairKArgs ka;
+    const int rc = stem_pool_args(op, x, y_pool, workspace, (hipStream_t)stream, &ka.c);
+    if (rc) return rc;
+    ka.t.w = sp->d_w.p; ka.t.prm = sp->d_prm.p; ka.t.y1 = y_a; ka.t.y2 = y_b;
+    ka.t.K1 = sp->a->d.k; ka.t.K2 = sp->b->d.k;
+    ka.t.relu1 = sp->a->d.act == SABER_HIP_ACT_RELU; ka.t.relu2 = sp->b->d.act == SABER_HIP_ACT_RELU;
+    ka.t.u8_1 = sp->a->d.out_dtype == SABER_HIP_U8; ka.t.u8_2 = sp->b->d.out_dtype == SABER_HIP_U8;
+    HIP_TRY(saber_mi355x::launch_conv_stem_pool_pair(op->pre_quant ? 1 : 0, ka, (hipStream_t)stream));
+    return SABER_HIP_OK;
+}
 saber_hip_chain::~saber_hip_chain() {
     if (h_coop_err) (void)hipHostFree(h_coop_err);
     delete stage1;

@@ -672,6 +672,21 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     }
 }
 
+// the fused stem conv + pooling's argument block (and its channel-padding pre-pass); shared with saber_hip_conv2d_stem_pair_run
+int stem_pool_args(const saber_hip_conv* op, const void* x, void* y, void* workspace, hipStream_t s, saber_mi355x::ConvKArgs* a) {
+    const saber_hip_conv_desc& d = op->d;
+    const void* xin = x;
+    if (op->pre_pad) {
+        HIP_TRY(launch_pad_channels_i8((size_t)d.n * d.h * d.w, d.c, 4, x, workspace, s));
+        xin = workspace;
+    }
+    fill_args(op, *a, xin, y, nullptr);
+    a->pool_oh = op->pool_oh; a->pool_ow = op->pool_ow;
+    a->Cin = d.c;
+    a->qinv = 1.f / op->in_scale;
+    return SABER_HIP_OK;
+}
+
 int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
                          saber_hip_stream_t stream) {
     if (g_capture) return capture_conv(op, x, y, res);
@@ -687,14 +702,8 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     if (op->img1) return img_conv_run(op, x, y, res, nullptr, s);
     if (op->pool_fused) {
         ConvKArgs a;
-        if (op->pre_pad) {
-            HIP_TRY(launch_pad_channels_i8((size_t)d.n * d.h * d.w, d.c, 4, x, workspace, s));
-            xin = workspace;
-        }
-        fill_args(op, a, xin, y, res);
-        a.pool_oh = op->pool_oh; a.pool_ow = op->pool_ow;
-        a.Cin = d.c;
-        a.qinv = 1.f / op->in_scale;
+        const int rc = stem_pool_args(op, x, y, workspace, s, &a);
+        if (rc) return rc;
         HIP_TRY(launch_conv_stem_pool(op->pre_quant ? 1 : 0, a, s));
         return SABER_HIP_OK;
     }
@@ -804,6 +813,7 @@ int saber_hip_conv2d_create_pair(const saber_hip_conv_t* a, const saber_hip_conv
     op->Kg = a->Kg; op->Kg_pad = a->Kg_pad;
     op->in_scale = a->in_scale; op->out_scale = a->out_scale;
     op->pair_k1 = da.k; op->pair_k2 = db.k;
+    op->pair_src_a = a; op->pair_src_b = b;
     op->pair_relu2 = db.act == SABER_HIP_ACT_RELU;
     op->pair_dtype2 = db.out_dtype;
     const size_t k2_pad = round_up(db.k, 128), rows = (size_t)da.k + k2_pad;

@@ -138,6 +138,17 @@ struct saber_hip_conv {
     std::string algo_name;
     // sibling pair (saber_hip_conv2d_create_pair): d.k = k1 + k2, rows >= k1 belong to the second conv
     int pair_k1 = 0, pair_k2 = 0, pair_relu2 = 0, pair_dtype2 = 0;
+    const saber_hip_conv* pair_src_a = nullptr;   // the two ops the pair was made of (not owned; saber_hip_net_optimize flag 512 packs
+    const saber_hip_conv* pair_src_b = nullptr;   // their weights again for the stem kernel's tail)
+};
+
+// the fused stem conv + max pooling with the sibling pair of 1x1 convs reading the pooled tensor in the same launch
+// (conv_stem.h: conv_stem_pool_pair_kernel); refers to the three ops, owns the pair's weights in fragment order and its constants
+struct saber_hip_stem_pair {
+    saber_hip_conv* stem = nullptr;
+    const saber_hip_conv* a = nullptr;
+    const saber_hip_conv* b = nullptr;
+    DevBuf<uint8_t> d_w, d_prm;
 };
 
 // two 1x1 INT8 convs in one launch (conv1x1_chain.hip); refers to the two ops, owns the repacked stream
@@ -355,6 +366,10 @@ struct NetOp {
     saber_hip_chain_stage* stage = nullptr;
     int stage_n = 0;
     bool use_stage = false;
+    // the fused stem conv + pooling with the sibling pair that reads the pooled tensor (flag 512): THIS op is the stem conv, the next
+    // op (the pair, `skip`) launches nothing; stem_y1 / stem_y2 are the pair's outputs and this op's own output edge is not written
+    saber_hip_stem_pair* stem_pair = nullptr;
+    int stem_y1 = -1, stem_y2 = -1;
     int lane = 0;            // 0: caller's stream, 1: the net's side stream (graph::Lane, operator_func.h:103-114)
     bool record = false;     // an op on the other lane consumes this op's output: record an event after it
     int p[16] = {0};
@@ -388,6 +403,7 @@ struct saber_hip_net {
     std::vector<saber_hip_conv*> owned;   // ops created by saber_hip_net_optimize (destroyed with the net)
     std::vector<saber_hip_chain*> owned_chains;
     std::vector<saber_hip_chain_stage*> owned_stages;
+    std::vector<saber_hip_stem_pair*> owned_stem_pairs;
 };
 
 // Op-list capture (api_capture.hip; saber_hip_capture_begin / _end): while g_capture is set on the calling thread every
@@ -408,6 +424,8 @@ bool halo_ok(const saber_hip_conv* op);      // api_conv.hip
 bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb);      // api_conv.hip
 bool stem_ok(const saber_hip_conv* op);      // api_conv.hip
 void name_algo(saber_hip_conv* op);      // api_conv.hip
+std::string stem_pair_name(const saber_api::NetOp& o);      // api_net_optimize.hip
+int stem_pool_args(const saber_hip_conv* op, const void* x, void* y, void* workspace, hipStream_t s, saber_mi355x::ConvKArgs* a);   // api_conv.hip
 // FP32 split-K (b3 kernels): 2^sh workgroups per tile; needs >= 2 stages per split, a bounded partial buffer, and the
 // workgroup -> XCD placement the hand-off relies on (checked once per device). split_prepare allocates the buffers.
 bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh);      // api_conv.hip

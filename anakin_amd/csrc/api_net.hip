@@ -27,12 +27,15 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
             }
             return rc;
         }
+        if (o.stem_pair) return saber_hip_conv2d_stem_pair_run(o.stem_pair, T(o.in), nullptr, T(o.stem_y1), T(o.stem_y2), ws, s);
         if (o.chain3 && o.use_chain3)
             return saber_hip_conv2d_chain_run(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), s);
         if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
         if (o.conv->gpool) return saber_hip_conv2d_run_gpool(o.conv, T(o.in), T(o.out), T(o.in2), T(o.out2), s);
         return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
-    case OP_CONV_PAIR: return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
+    case OP_CONV_PAIR:
+        if (o.skip) return SABER_HIP_OK;      // written by the stem launch in front of it (flag 512)
+        return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
     case OP_FC: return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
     case OP_QUANT:
         return saber_hip_quantize_nchw_to_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.f[0],
@@ -343,7 +346,7 @@ int saber_hip_net_set_lane(saber_hip_net_t* net, int index, int lane) {
     if (index < 0 || index >= (int)net->ops.size() || lane < 0 || lane > 1) return fail(SABER_HIP_INVALID_VALUE, "bad op index / lane");
     if (net->lanes_ready) return fail(SABER_HIP_INVALID_VALUE, "lanes are fixed after the first run");
     for (const NetOp& o : net->ops)
-        if (lane && (o.chain || o.chain3))
+        if (lane && (o.chain || o.chain3 || o.stem_pair))
             return fail(SABER_HIP_INVALID_VALUE, "the net has conv1x1 chain launches: lanes must be assigned before saber_hip_net_optimize (a chain launch spans several ops' tensors)");
     if (lane) {   // both lanes share the arena's single workspace: an op that uses it stays on the main lane
         const NetOp& o = net->ops[index];
@@ -402,13 +405,17 @@ int saber_hip_net_op_work(const saber_hip_net_t* net, int index, double* bytes, 
     case OP_CONV:
         if (o.skip) return SABER_HIP_OK;
         conv_work(o.conv, *bytes, *flops);
-        if (o.chain3 && o.use_chain3) {
+        if (o.stem_pair) {      // + the pair's work (the algorithmic bytes of the separate ops, like the chains')
+            conv_work(net->ops[index + 1].conv, *bytes, *flops);
+        } else if (o.chain3 && o.use_chain3) {
             for (int j = index + 1; j < (int)net->ops.size() && net->ops[j].skip; ++j) conv_work(net->ops[j].conv, *bytes, *flops);
         } else if (o.chain && o.use_chain) {
             if (index + 1 < (int)net->ops.size() && net->ops[index + 1].skip) conv_work(net->ops[index + 1].conv, *bytes, *flops);
         }
         return SABER_HIP_OK;
-    case OP_CONV_PAIR: conv_work(o.conv, *bytes, *flops); return SABER_HIP_OK;
+    case OP_CONV_PAIR:
+        if (!o.skip) conv_work(o.conv, *bytes, *flops);
+        return SABER_HIP_OK;
     case OP_FC:
     case OP_FC_Q: {
         const saber_hip_fc_desc& d = o.fc->d;
@@ -448,7 +455,7 @@ int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int
             int rc = net_launch(net, o, s);
             if (rc) return rc;
             prev[i] = last;
-            if (o.kind == OP_CONV && o.skip) continue;     // launches nothing: no event (a marker packet costs ~2.5 us itself)
+            if (o.skip) continue;     // launches nothing: no event (a marker packet costs ~2.5 us itself)
             HIP_TRY(hipEventRecord(ev[i + 1], s));
             last = i + 1;
         }
@@ -456,7 +463,7 @@ int saber_hip_net_time_pass(saber_hip_net_t* net, saber_hip_stream_t stream, int
         if (!it) continue;
         for (size_t i = 0; i < n; ++i) {
             const NetOp& o = net->ops[i];
-            if (o.kind == OP_CONV && o.skip) continue;
+            if (o.skip) continue;
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev[prev[i]], ev[i + 1]));
             acc[i] += ms;
@@ -514,7 +521,7 @@ int saber_hip_net_tensor_unwritten(const saber_hip_net_t* net, int id) {
     if (id < 0 || id >= (int)net->tensor_bytes.size()) return 0;
     if (net->tensor_bytes[id] == 0) return 1;      // the edge was removed by saber_hip_net_optimize (it has no storage)
     for (const NetOp& o : net->ops)
-        if (o.chain3 && o.use_chain3 && o.out == id) return 1;
+        if (((o.chain3 && o.use_chain3) || o.stem_pair) && o.out == id) return 1;
     return 0;
 }
 // After a pass has COMPLETED (the caller has synchronised): did one of its cooperative launches - a stage launch, a two-workgroup
@@ -573,6 +580,7 @@ void saber_hip_net_destroy(saber_hip_net_t* net) {
     if (net->exec) (void)hipGraphExecDestroy(net->exec);
     if (net->graph) (void)hipGraphDestroy(net->graph);
     if (net->arena) (void)hipFree(net->arena);
+    for (saber_hip_stem_pair* sp : net->owned_stem_pairs) saber_hip_conv2d_stem_pair_destroy(sp);
     for (saber_hip_chain_stage* st : net->owned_stages) saber_hip_conv2d_stage_destroy(st);
     for (saber_hip_chain* c : net->owned_chains) saber_hip_conv2d_chain_destroy(c);
     for (saber_hip_conv* c : net->owned) saber_hip_conv2d_destroy(c);

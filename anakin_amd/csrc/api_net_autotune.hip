@@ -28,6 +28,7 @@ int saber_hip_net_stage_blocks(const saber_hip_net_t* net, int index) {
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     saber_hip_conv* c = net_op_conv(net, index);
     if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
+    if (net->ops[index].kind == OP_CONV_PAIR && net->ops[index].skip) return SABER_HIP_OK;      // no kernel of its own (flag 512)
     const int chain_bits = (choice >> 24) & 63;
     const bool stage_on = (choice >> 30) & 1;
     choice &= 0xffffff;
@@ -47,6 +48,8 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     }
     if (o.stage) net_set_stage(net, index, stage_on);      // (a stage head comes before its blocks: set_choices runs in op order)
     if (o.skip) o.name = (o.chain3 && o.use_chain3) ? "conv:(in the stage launch)" : "conv:(in the chain launch)";
+    if (o.skip && o.kind == OP_CONV_PAIR) o.name = "conv:(in the stem launch)";
+    if (o.stem_pair) o.name = stem_pair_name(o);
     if (net->exec) {
         (void)hipGraphExecDestroy(net->exec);
         (void)hipGraphDestroy(net->graph);
@@ -153,6 +156,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         ~UsedScope() { g_used_kernels = nullptr; }
     } used_scope(&used_kernels);
     for (NetOp& o : net->ops) {
+        if (o.kind == OP_CONV_PAIR && o.skip) continue;      // runs inside the stem launch (flag 512): no kernel of its own
         if (o.kind == OP_CONV_PAIR) {
             int rc = saber_hip_conv2d_autotune_pair(o.conv, T(o.in), T(o.out), T(o.out2), stream, iters);
             if (rc) return rc;
@@ -170,6 +174,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         int rc = saber_hip_conv2d_autotune(c, xin, T(o.out), T(o.in2), net->arena + net->ws_off, stream, iters);
         if (rc) return rc;
         o.name = std::string(o.kind == OP_CONV ? "conv:" : "fc:") + c->algo_name;
+        if (o.stem_pair) o.name = stem_pair_name(o);
     }
     // conv1x1 chains: the tuned separate launches against the chain launch (every pixel-tile size) and, where the block's
     // 3x3 conv can lead the chain, against that single launch too - on the real tensors

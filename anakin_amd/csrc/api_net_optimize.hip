@@ -59,6 +59,9 @@ void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
 }
 // The stage headed by ops[i0] on / off. On: every block runs its 3x3-led chain form (mode 2), ops[i0] launches them all and the
 // other blocks' 3x3 convs carry `skip` too. Off: the blocks' chains launch one by one again (mode 2, their own tile codes).
+std::string stem_pair_name(const NetOp& o) {
+    return std::string("conv:") + o.conv->algo_name + "+pair1x1_" + std::to_string(o.stem_pair->a->d.k) + "+" + std::to_string(o.stem_pair->b->d.k);
+}
 void net_set_stage(saber_hip_net* net, int i0, bool on) {
     NetOp& H0 = net->ops[i0];
     if (!H0.stage) return;
@@ -309,6 +312,30 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
     for (size_t i = 0; i < ops.size(); ++i)
         if (!dead[i]) live.push_back(std::move(ops[i]));
     ops.swap(live);
+    // ---- 512: the fused stem conv + pooling runs the sibling pair that reads the pooled tensor (on the compacted list) --------
+    bool side_lane = false;      // (like the chains: a launch that writes other ops' tensors is not ordered across lanes)
+    for (const NetOp& o : ops) side_lane |= o.lane != 0;
+    if ((flags & 512) && !side_lane) {
+        for (size_t i = 0; i + 1 < ops.size(); ++i) {
+            NetOp& S = ops[i];
+            NetOp& P = ops[i + 1];
+            if (S.kind != OP_CONV || !S.conv || !S.conv->pool_fused || S.lane || S.in2 >= 0 || S.out2 >= 0 || S.stem_pair) continue;
+            if (P.kind != OP_CONV_PAIR || !P.conv || P.lane || P.in != S.out || !P.conv->pair_src_a || !P.conv->pair_src_b) continue;
+            int readers = 0;
+            for (const NetOp& o : ops) readers += (o.in == S.out) + (o.in2 == S.out);
+            if (readers != 1) continue;
+            saber_hip_stem_pair* sp = nullptr;
+            if (saber_hip_conv2d_stem_pair_create(S.conv, P.conv->pair_src_a, P.conv->pair_src_b, &sp) != SABER_HIP_OK) continue;
+            net->owned_stem_pairs.push_back(sp);
+            S.stem_pair = sp;
+            S.stem_y1 = P.out;
+            S.stem_y2 = P.out2;
+            S.name = stem_pair_name(S);
+            P.skip = true;
+            P.name = "conv:(in the stem launch)";
+            ++removed;
+        }
+    }
     // A chain launch reads and writes the tensors of SEVERAL ops (chain3_res / chain_out / chain3_y1 / chain3_y2), while the
     // cross-lane event ordering of saber_hip_net_run only follows the launching op's own in / in2 / out / out2: in a
     // two-lane net a chained launch could read a residual produced on the other lane before its event. The two executor

@@ -11,7 +11,7 @@
 // B fragments are 16 contiguous LDS bytes at (2*py + i, 2*px + j). Same arithmetic and epilogues as
 // conv_igemm_impl.h; weights use the first-layer repack [K][kh][8][4].
 #pragma once
-#include "conv_igemm_impl.h"
+#include "epilogue_pack.h"
 
 namespace saber_mi355x {
 
@@ -203,8 +203,15 @@ static hipError_t launch_conv_stem_inst(int f32_in, const ConvKArgs& a, hipStrea
 // window maxima from there. The 112x112x64 conv tensor is never written. Max pooling of the requantised bytes is
 // exact, so the result equals pool(conv(x)) byte for byte; windows are clipped at the image border as
 // SaberPooling does (ceil-mode output shape).
-template <bool F32IN>
-__global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs a) {
+//
+// TAIL (conv_stem_pool_pair_kernel): the two 1x1 / stride-1 convolutions that read the pooled tensor (ResNet res2a's `branch1`
+// and `branch2a`, a sibling pair) run in the same launch on the workgroup's 32 pooled pixels: the pooled bytes go to LDS as the
+// MFMA B operand (K = 64 = one i8 MFMA step), the pair's weights come straight from memory in A-fragment order (20 KB, packed by
+// the host: saber_hip_conv2d_stem_pair_create), its per-channel constants by LDS-DMA at kernel entry. 20 units of 32 channels x 16
+// pixels, five per wave; the epilogue is chain_out_pack = epilogue_i8_pair's arithmetic, so both outputs are the bits of the
+// separate launch. The pooled tensor itself is written only when a.y is given.
+template <bool F32IN, bool TAIL>
+__device__ __forceinline__ void conv_stem_pool_body(const ConvKArgs& a, const StemPairTail& t) {
     constexpr int PH = 4, PW = 8;
     constexpr int CR = 2 * PH + 1, CC = 2 * PW + 1, NPX = CR * CC;      // 9 x 17 = 153 conv outputs
     constexpr int NG = (NPX + 15) / 16, TN = NG / 2;                    // 10 MFMA pixel groups, 5 per wave column
@@ -213,12 +220,15 @@ __global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs 
     static_assert(NG % 2 == 0, "pixel groups split over two wave columns");
 
     __shared__ v4i lds_w[WCH];
-    __shared__ unsigned lds_x[IR * ICP];
+    __shared__ __attribute__((aligned(16))) unsigned lds_x[IR * ICP];
     __shared__ uint2 lds_c[NG * 16 * 8];       // conv tile [pixel][64 channels], bytes in unsigned order
+    constexpr int TPC = 256;                   // the pair's constants: 48 bytes per 4 channels, <= 320 channels (+ padding: 4 x 64 chunks)
+    __shared__ v4i lds_tp[TAIL ? TPC : 1];
     SABER_TL_DECL;
     SABER_TL(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (TAIL) lds_dma16((const v4i*)t.prm + tid, lds_tp + wave * 64);   // landed long before the tail (loads return in order)
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fq = lane >> 4;
 
@@ -335,6 +345,20 @@ __global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs 
     __syncthreads();
 
     SABER_TL(4);
+    // the pair's weights, requested now (the accumulators are dead; any earlier and the kernel spills): wave w owns units u = w + 4 i,
+    // unit = (32-channel group u >> 1, pixel group u & 1 - the same for all of a wave's units), 2 A fragments each
+    constexpr int MAXU = 5;
+    v4i taf[TAIL ? MAXU : 1][2];
+    const int tng = TAIL ? (t.K1 + t.K2) >> 5 : 0;
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            int g = (wave + 4 * i) >> 1;
+            g = g < tng ? g : tng - 1;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) taf[i][mf] = ((const v4i*)t.w)[(g * 2 + mf) * 64 + lane];
+        }
+    }
     // 3x3 / stride 2 window maxima: one lane per (pooled pixel, 8 channels)
     const int pp = tid >> 3, cg = tid & 7;
     const int ppy = pp / PW, ppx = pp - ppy * PW;
@@ -354,12 +378,58 @@ __global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs 
             }
         const unsigned flip = u8 ? 0u : 0x80808080u;
         const uint2 o = make_uint2((ev[0] | (od[0] << 8)) ^ flip, (ev[1] | (od[1] << 8)) ^ flip);
-        uint8_t* y = (uint8_t*)a.y + (((size_t)n * a.pool_oh + poy) * a.pool_ow + pox) * a.K + kc;
-        if (kc + 8 <= a.K) *(uint2*)y = o;
-        else for (int t = 0; t < a.K - kc; ++t) y[t] = (uint8_t)((t < 4 ? o.x : o.y) >> (8 * (t & 3)));
+        if constexpr (TAIL) {
+            // B operand of the pair: the pooled bytes as s8 (unsigned order ^ 0x80: u8 shifted by 128 - compensated through the
+            // pair's comp - or the s8 value itself); pixel pitch 80 bytes: the 16 lanes of a fragment column hit 16 bank groups
+            *(uint2*)&lds_x[pp * 20 + cg * 2] = make_uint2(o.x ^ flip ^ 0x80808080u, o.y ^ flip ^ 0x80808080u);
+        }
+        if (!TAIL || a.y) {
+            uint8_t* y = (uint8_t*)a.y + (((size_t)n * a.pool_oh + poy) * a.pool_ow + pox) * a.K + kc;
+            if (kc + 8 <= a.K) *(uint2*)y = o;
+            else for (int t = 0; t < a.K - kc; ++t) y[t] = (uint8_t)((t < 4 ? o.x : o.y) >> (8 * (t & 3)));
+        }
     }
     SABER_TL(5);
+    if constexpr (TAIL) {
+        __syncthreads();
+        const int pg = wave & 1;
+        const v4i bfr = *(const v4i*)&lds_x[(pg * 16 + frow) * 20 + fq * 4];
+        const int tp = pg * 16 + frow;                        // this lane's pooled pixel of the tile
+        const int toy = py0 + (tp >> 3), tox = px0 + (tp & 7);
+        const bool tok = toy < a.pool_oh && tox < a.pool_ow;
+        const size_t tpix = ((size_t)n * a.pool_oh + toy) * a.pool_ow + tox;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int g = (wave + 4 * i) >> 1;
+            if (g >= tng) break;                              // wave-uniform
+            const v4i z = {0, 0, 0, 0};
+            const v4i c0 = mma_step(taf[i][0], bfr, z), c1 = mma_step(taf[i][1], bfr, z);
+            const int kb = g * 32 + fq * 8;                   // 8 consecutive channels of the concatenated pair
+            const bool second = kb >= t.K1;
+            const bool ou8 = second ? t.u8_2 : t.u8_1;
+            const float lo = (second ? t.relu2 : t.relu1) ? 0.f : -3.0e38f;
+            const float off = ou8 ? 0.f : 128.f;
+            const unsigned xm = ou8 ? 0u : 0x80808080u;
+            const v4i* pc = lds_tp + (kb >> 2) * 3;
+            const unsigned w0 = chain_out_pack(c0, pc[2], __builtin_bit_cast(v4f, pc[1]), __builtin_bit_cast(v4f, pc[0]), lo, off, xm);
+            const unsigned w1 = chain_out_pack(c1, pc[5], __builtin_bit_cast(v4f, pc[4]), __builtin_bit_cast(v4f, pc[3]), lo, off, xm);
+            if (tok) {
+                uint8_t* y = second ? (uint8_t*)t.y2 + tpix * t.K2 + (kb - t.K1) : (uint8_t*)t.y1 + tpix * t.K1 + kb;
+                *(uint2*)y = make_uint2(w0, w1);
+            }
+        }
+        SABER_TL(6);
+    }
     SABER_TL_FLUSH();
+}
+
+template <bool F32IN>
+__global__ __launch_bounds__(256, 4) void conv_stem_pool_kernel(const ConvKArgs a) {
+    conv_stem_pool_body<F32IN, false>(a, StemPairTail{});
+}
+template <bool F32IN>
+__global__ __launch_bounds__(256, 4) void conv_stem_pool_pair_kernel(const StemPairKArgs ka) {
+    conv_stem_pool_body<F32IN, true>(ka.c, ka.t);
 }
 
 static hipError_t launch_conv_stem_pool_inst(int f32_in, const ConvKArgs& a, hipStream_t s) {
@@ -370,6 +440,16 @@ static hipError_t launch_conv_stem_pool_inst(int f32_in, const ConvKArgs& a, hip
     dim3 grid(b.npx * b.nky), block(256);
     if (f32_in) hipLaunchKernelGGL((conv_stem_pool_kernel<true>), grid, block, 0, s, b);
     else hipLaunchKernelGGL((conv_stem_pool_kernel<false>), grid, block, 0, s, b);
+    return hipGetLastError();
+}
+static hipError_t launch_conv_stem_pool_pair_inst(int f32_in, const StemPairKArgs& ka, hipStream_t s) {
+    StemPairKArgs b = ka;
+    b.c.npx = ka.c.N * ((ka.c.pool_ow + 7) / 8) * ((ka.c.pool_oh + 3) / 4);
+    b.c.nky = 1;                                   // K == 64 (checked by saber_hip_conv2d_stem_pair_create)
+    b.c.mg_npx = magic_div(b.c.npx, (long long)b.c.npx);
+    dim3 grid(b.c.npx), block(256);
+    if (f32_in) hipLaunchKernelGGL((conv_stem_pool_pair_kernel<true>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((conv_stem_pool_pair_kernel<false>), grid, block, 0, s, b);
     return hipGetLastError();
 }
 

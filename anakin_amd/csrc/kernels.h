@@ -109,6 +109,23 @@ struct ImgKArgs {
 };
 static_assert(offsetof(ConvKArgs, y) == 128, "hot kernel arguments fill exactly the first two 64-byte lines");
 
+// conv_stem_pool_pair_kernel (conv_stem.h): the fused stem conv + max pooling with the sibling pair of 1x1 convs that reads the pooled
+// tensor in the same launch. t.w: the pair's weights (first conv's rows, then the second's) in MFMA A-fragment order, per 32-channel
+// group two fragments of 1 KB (row rho of fragment mf = channel base + (rho >> 2) * 8 + mf * 4 + (rho & 3)); t.prm: per 4 channels
+// {scale[4], bias'[4], comp[4]}, padded to 256 x 16 bytes. c.y: the pooled tensor, or null when nothing else reads it.
+struct StemPairTail {
+    const void* w;
+    const void* prm;
+    void* y1;             // [pooled pixels][K1]
+    void* y2;             // [pooled pixels][K2]
+    int K1, K2;           // multiples of 32, K1 + K2 <= 320
+    int relu1, relu2, u8_1, u8_2;
+};
+struct StemPairKArgs {
+    ConvKArgs c;
+    StemPairTail t;
+};
+
 // conv1x1_chain_kernel (conv1x1_chain.hip): a 1x1 conv with the fused eltwise epilogue (ResNet branch2c + sum + relu)
 // followed by the next block's 1x1 branch2a conv on the same pixels, one launch.
 constexpr int STAGE_MAX_TENSORS = 24;
@@ -266,6 +283,7 @@ bool fc_f32_small_ok(int m, int c, int kg_pad);
 hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s);
 // ... followed by the 3x3 / stride-2 / pad-0 max pooling in the same kernel (s8 / u8 outputs only)
 hipError_t launch_conv_stem_pool(int f32_in, const ConvKArgs& a, hipStream_t s);
+hipError_t launch_conv_stem_pool_pair(int f32_in, const StemPairKArgs& a, hipStream_t s);
 // Generic fallback: any C / group. w is OIHW-like repack [K][kh][kw][Cg]. mode 0 int8, 2 f32
 hipError_t launch_conv_direct(int is_f32, const ConvKArgs& a, int group, hipStream_t s);
 

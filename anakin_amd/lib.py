@@ -29,6 +29,7 @@ SYMBOLS = [
     "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_create3", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
     "saber_hip_conv2d_chain_set_tile", "saber_hip_conv2d_chain_get_tile",
     "saber_hip_conv2d_stage_create", "saber_hip_conv2d_stage_destroy", "saber_hip_conv2d_stage_run",
+    "saber_hip_conv2d_stem_pair_create", "saber_hip_conv2d_stem_pair_destroy", "saber_hip_conv2d_stem_pair_run",
     "saber_hip_conv2d_set_global_pooling", "saber_hip_conv2d_run_gpool",
     "saber_hip_stage_create", "saber_hip_stage_num_tensors", "saber_hip_stage_run", "saber_hip_stage_status", "saber_hip_stage_trace", "saber_hip_stage_destroy",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
@@ -127,6 +128,10 @@ def load():
     lib.saber_hip_conv2d_stage_destroy.argtypes = [P]
     lib.saber_hip_conv2d_stage_destroy.restype = None
     lib.saber_hip_conv2d_stage_run.argtypes = [P, P, P, C.POINTER(P), C.POINTER(P), P]
+    lib.saber_hip_conv2d_stem_pair_create.argtypes = [P, P, P, C.POINTER(P)]
+    lib.saber_hip_conv2d_stem_pair_destroy.argtypes = [P]
+    lib.saber_hip_conv2d_stem_pair_destroy.restype = None
+    lib.saber_hip_conv2d_stem_pair_run.argtypes = [P, P, P, P, P, P, P]
     lib.saber_hip_conv2d_set_global_pooling.argtypes = [P]
     lib.saber_hip_conv2d_run_gpool.argtypes = [P, P, P, P, P, P]
     lib.saber_hip_stage_create.argtypes = [C.POINTER(StagePhase), I, C.POINTER(P)]

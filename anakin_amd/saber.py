@@ -344,6 +344,29 @@ class SaberChainStage:
             pass
 
 
+class SaberStemPair:
+    """The fused stem conv + max pooling (SaberConv2DPooling, INT8, 64 channels) with the two 1x1 convs `a` and `b` that read the pooled
+    tensor in ONE launch (saber_hip_conv2d_stem_pair_create). dispatch(x, y_a, y_b, y_pool=None): y_pool only when something else reads
+    the pooled tensor. The outputs hold the bits of dispatching the three operators one after the other (net.cpp:417-509)."""
+
+    def __init__(self, stem, a, b):
+        self.ops = (stem, a, b)                      # keep them alive: the object borrows their weights
+        self.h = C.c_void_p()
+        L.check(L.load().saber_hip_conv2d_stem_pair_create(stem.h, a.h, b.h, C.byref(self.h)))
+
+    def dispatch(self, x, y_a, y_b, y_pool=None):
+        stem = self.ops[0]
+        ws = stem.ws if hasattr(stem, "ws") else stem.conv.ws      # (a SaberConv2D with a fused pooling, or SaberConv2DPooling)
+        L.check(L.load().saber_hip_conv2d_stem_pair_run(self.h, _p(x), _p(y_pool), _p(y_a), _p(y_b), _p(ws), _stream()))
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.load().saber_hip_conv2d_stem_pair_destroy(self.h)
+        except Exception:
+            pass
+
+
 class SaberStage:
     """XCD-resident stage (saber_hip_stage_create): `phases` = [(conv, in_slot, out_slot, res_slot | -1), ...] run as ONE
     persistent launch, image i on XCD i % 8; dispatch(tensors) takes the device tensors by slot. Every output slot holds

@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    ap.add_argument("--no-stem-pair", action="store_true",
+                    help="INT8: conv1 + pool1 and the sibling pair reading pool1 stay two launches (saber_hip_net_optimize flag 512 off)")
     ap.add_argument("--no-stage", action="store_true",
                     help="INT8: do not let runs of res4 block chains run as one persistent stage launch (saber_hip_net_optimize flag 256)")
     ap.add_argument("--timed-only", action="store_true",
@@ -86,14 +88,15 @@ def build_net(W, model, scales, batch, args, stage=True):
     if args.precision == "int8":
         cxx = not (args.py_fuse or args.no_fuse or args.lanes)      # the C++ host side finds the fusions (the north star's "host side stays C++")
         return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx,
-                                stage=stage and not args.no_stage)
+                                stage=stage and not args.no_stage, stem_pair=not args.no_stem_pair)
     return W.build_fp32_net(model, batch)
 
 
 def tune_key(args, batch, L):
     """a cached selection is only valid for the sources and executor options it was tuned on"""
-    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
+    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_sp%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
                                                                   int(args.lanes), args.chain, int(args.py_fuse), int(not args.no_stage),
+                                                                  int(not args.no_stem_pair),
                                                                   L.source_sha())
 
 
@@ -315,7 +318,7 @@ def main():
         peak_ops = MFMA_I8_PEAK_TOPS if args.precision == "int8" else MFMA_F32_PEAK_TFLOPS
         kern = {}
         for i, (nm, t) in enumerate(zip(names, pass_us)):
-            if "(in the chain launch)" in nm or "(in the stage launch)" in nm:
+            if "(in the chain launch)" in nm or "(in the stage launch)" in nm or "(in the stem launch)" in nm:
                 continue
             by, fl = net.op_work(i)
             k = kern.setdefault(nm, dict(kernel=nm, launches=0, us=0.0, bytes=0.0, flops=0.0))

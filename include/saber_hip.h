@@ -214,6 +214,18 @@ void saber_hip_conv2d_stage_destroy(saber_hip_chain_stage_t* stage);
 int saber_hip_conv2d_stage_run(saber_hip_chain_stage_t* stage, const void* x, const void* res, void* const* y1, void* const* y2,
                                saber_hip_stream_t stream);
 
+/* The ResNet stem with its first two consumers in ONE launch: `stem` (an INT8 conv with saber_hip_conv2d_set_pooling's fused 3x3 /
+ * stride-2 max pooling, 64 output channels: SaberConv2DPooling<AK_INT8>, saber_conv_pooling.cpp:60-160) followed, on the workgroup's
+ * pooled pixels, by the two 1x1 / stride-1 INT8 convs `a` and `b` that read the pooled tensor (res2a's branch1 and branch2a; 64 -> k,
+ * k % 32 == 0, k_a + k_b <= 320, 8-bit NHWC outputs; GemmX8S8S32XConv::dispatch, gemm_x8s8s32x_conv.cpp:184-257) - an executor-level
+ * fusion like the chains, results bit-identical to the three launches. y_pool may be null when nothing else reads the pooled tensor.
+ * The ops are not owned and must outlive the object. */
+typedef struct saber_hip_stem_pair saber_hip_stem_pair_t;
+int saber_hip_conv2d_stem_pair_create(saber_hip_conv_t* stem, const saber_hip_conv_t* a, const saber_hip_conv_t* b, saber_hip_stem_pair_t** out);
+void saber_hip_conv2d_stem_pair_destroy(saber_hip_stem_pair_t* sp);
+int saber_hip_conv2d_stem_pair_run(saber_hip_stem_pair_t* sp, const void* x, void* y_pool, void* y_a, void* y_b, void* workspace,
+                                   saber_hip_stream_t stream);
+
 /* XCD-resident stage: a run of INT8 convolutions over SMALL feature maps (h * w <= 64 pixels per image: ResNet's res5) as
  * ONE persistent launch. Image i is computed entirely on XCD i % 8 (32 CUs, one workgroup each); the convolutions
  * ("phases") follow each other inside the kernel, separated by an XCD-local barrier where one reads what an earlier one
@@ -405,6 +417,9 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * faster form. Only for a net that has the GPU to itself while it runs: the launch needs all workgroups of an image resident on
  * one XCD together, and two such launches in flight on different streams can starve each other (they time out after ~20 ms,
  * the next run returns SABER_HIP_RUNTIME_ERROR and the chains launch one by one from then on).
+ * 512 (with 2 | 4; NOT in 255): the fused stem conv + max pooling whose pooled tensor is read by one sibling pair of 1x1 convs only
+ * (ResNet's conv1 + pool1 -> res2a_branch1 / res2a_branch2a) runs that pair in its own launch (saber_hip_conv2d_stem_pair_create);
+ * the pooled edge is then not written (saber_hip_net_tensor_unwritten), the pair stays in the list and launches nothing.
  * Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 /* After a forward pass has COMPLETED (the caller synchronised the stream): SABER_HIP_RUNTIME_ERROR when one of its cooperative

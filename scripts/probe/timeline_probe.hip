@@ -204,6 +204,7 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    const bool stem_only = argc > 1 && !strcmp(argv[1], "stem");
     if (argc > 1 && !strcmp(argv[1], "chain")) {
         // conv1x1 chain: phases 0 entry, 1 loads / DMA issued, 2 first group's MFMAs done + DMA barrier, 3 first conv done,
         // 4 tile stored / second conv's operand in registers, 5 done
@@ -239,7 +240,7 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    {   // ---- fc1000 of ResNet50, batch 8: phases 0 entry, 1 loads issued, 2 MFMAs done, 3 after the reduce barrier, 4 stored
+    if (!stem_only) {   // ---- fc1000 of ResNet50, batch 8: phases 0 entry, 1 loads issued, 2 MFMAs done, 3 after the reduce barrier, 4 stored
         ConvKArgs a;
         memset(&a, 0, sizeof a);
         a.M = 8; a.C = 2048; a.K = 1000; a.Kg_pad = 2048; a.N = 8; a.H = a.W = a.OH = a.OW = 1; a.kh = a.kw = 1;
@@ -259,6 +260,7 @@ int main(int argc, char** argv) {
     };
     // phases: 0 entry, 1 weights requested + table built, 2 DMA issued, 3 own DMA landed, 4 everyone's landed, 5 MFMAs done, 6 stored
     for (const Img& g : imgs) {
+        if (stem_only) break;
         ConvKArgs a;
         memset(&a, 0, sizeof a);
         const int kg = 9 * g.C, kgp = (kg + 1023) / 1024 * 1024;
@@ -283,7 +285,18 @@ int main(int argc, char** argv) {
         a.scale = (const float*)dalloc(2048 * 4, 0); a.bias = (const float*)dalloc(2048 * 4, 0);
         run(P, nb == 8 ? "stem 7x7/2 + maxpool 3x3/2, f32 image in, batch 8" : "stem 7x7/2 + maxpool 3x3/2, batch 1", nb * 98, 6,
             [&] { launch_conv_stem_pool(1, a, P.st); });
+        // ... with the sibling pair reading the pooled tensor in the same launch (phase 6: the pair's outputs stored)
+        StemPairKArgs ka;
+        memset(&ka, 0, sizeof ka);
+        ka.c = a;
+        ka.c.y = nullptr;
+        ka.t.w = dalloc(320 * 64, -1); ka.t.prm = dalloc(256 * 16, 0);
+        ka.t.y1 = dalloc((size_t)nb * 56 * 56 * 256, 0); ka.t.y2 = dalloc((size_t)nb * 56 * 56 * 64, 0);
+        ka.t.K1 = 256; ka.t.K2 = 64; ka.t.relu2 = 1; ka.t.u8_2 = 1;
+        run(P, nb == 8 ? "stem + maxpool + pair 64 -> 256 | 64, batch 8" : "stem + maxpool + pair, batch 1", nb * 98, 7,
+            [&] { launch_conv_stem_pool_pair(1, ka, P.st); });
     }
+    if (stem_only) return 0;
     // ---- the implicit-GEMM / halo kernels on typical ResNet50 layers (batch 8 and batch 1) -----------------------------
     // phases: 0 entry, 1 gather state set up, 2 first stage in LDS (dma: ring prefetch issued), 3 reduction done, 4 stored
     struct Lay { const char* name; int N, HW, C, K, k, stride, pad, elt, kind, tile, ks, wg, early; };   // kind 0 reg, 1 dma, 2 halo(th=tile)

@@ -366,6 +366,82 @@ def test_conv_pooling_stem_fused_vs_oracle(case, odt):
     assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), cp.algo()
 
 
+@pytest.mark.parametrize("case", [(2, 224, 224, "f32"), (1, 61, 47, "f32"), (2, 33, 40, "s8"), (1, 30, 30, "u8"), (3, 18, 23, "f32")])
+@pytest.mark.parametrize("combo", [(O.U8, 256, 64), (O.S8, 64, 256), (O.U8, 32, 96)])
+def test_stem_pool_pair_equals_the_three_ops(case, combo):
+    """saber_hip_conv2d_stem_pair_create: conv1 + pool1 and the two 1x1 convs reading pool1 (res2a_branch1 / res2a_branch2a) in ONE
+    launch == oracle conv -> pooling -> the two convs, byte for byte (ragged pooled sizes, every input form of the stem, s8 / u8 pooled
+    tensors, both output types on either side); the pooled tensor itself is written only on request."""
+    N, H, W, kind = case
+    odt, K1, K2 = combo
+    rng = np.random.default_rng(abs(hash((case, combo))) % 2**31)
+    w = (rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    in_scale, pool_scale = 1 / 127.0, 0.02
+    if kind == "f32":
+        xf = rng.uniform(-1, 1, (N, 3, H, W)).astype(np.float32)
+        xq = O.quant_nchw_to_nhwc(xf, in_scale, O.S8)
+        x_dev, idt, in_layout = dev(xf), L.F32, L.NCHW
+    else:
+        xq = (rng.integers(0, 256, (N, H, W, 3)).astype(np.uint8) if kind == "u8" else rng.integers(-128, 128, (N, H, W, 3)).astype(np.int8))
+        x_dev, idt, in_layout = dev(xq), O.code_of(xq), L.NHWC
+    ws = O.weight_scales(w)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, pool_scale, O.code_of(xq), odt)
+    pooled = O.pool_i8_nhwc(O.conv_i8(xq, O.quant_weights(w, ws), bp, sc, odt, odt == O.U8, (3, 3), (2, 2)), (3, 3), (2, 2), (0, 0), 0)
+    stem = S.SaberConv2DPooling().init((N, 3, H, W), S.ConvParam(w, b, 1, (3, 3), (2, 2), (1, 1), odt == O.U8), L.POOL_MAX, (3, 3), (2, 2),
+                                       (0, 0), idt, odt, in_scale, pool_scale, in_layout=in_layout)
+    assert stem.fused
+    ph, pw = pooled.shape[1:3]
+    convs, wants = [], []
+    for K, kdt, relu, out_scale in ((K1, O.S8, 0, 0.05), (K2, O.U8, 1, 0.031)):
+        wk = (rng.standard_normal((K, 64, 1, 1)) * np.sqrt(2.0 / 64)).astype(np.float32)
+        bk = (rng.standard_normal(K) * 0.5).astype(np.float32)
+        wsk = O.weight_scales(wk)
+        bpk, sck = O.conv_i8_prepare(wsk, bk, pool_scale, out_scale, odt, kdt)
+        wants.append(O.conv_i8(pooled, O.quant_weights(wk, wsk), bpk, sck, kdt, relu))
+        convs.append(S.SaberConv2D(True).init((N, 64, ph, pw), S.ConvParam(wk, bk, 1, (0, 0), (1, 1), (1, 1), bool(relu)), odt, kdt,
+                                              pool_scale, out_scale))
+    sp = S.SaberStemPair(stem, convs[0], convs[1])
+    for with_pool in (True, False):
+        ya, yb, yp = convs[0].new_output(), convs[1].new_output(), stem.new_output()
+        ya.fill_(77)
+        yb.fill_(77)
+        yp.fill_(9)
+        sp.dispatch(x_dev, ya, yb, yp if with_pool else None)
+        assert np.array_equal(host(ya), wants[0]) and np.array_equal(host(yb), wants[1]), (case, combo, with_pool)
+        assert np.array_equal(host(yp), pooled) if with_pool else bool((host(yp) == 9).all())
+    # the three operators stay usable on their own
+    yp = stem.new_output()
+    stem.dispatch(x_dev, yp)
+    ya = convs[0].new_output()
+    convs[0].dispatch(yp, ya)
+    assert np.array_equal(host(yp), pooled) and np.array_equal(host(ya), wants[0])
+
+
+def test_stem_pool_pair_rejects_what_it_cannot_run():
+    rng = np.random.default_rng(5)
+
+    def stem(k):
+        w = (rng.standard_normal((k, 3, 7, 7)) * 0.1).astype(np.float32)
+        return S.SaberConv2DPooling().init((1, 3, 64, 64), S.ConvParam(w, None, 1, (3, 3), (2, 2), (1, 1), True), L.POOL_MAX, (3, 3), (2, 2),
+                                           (0, 0), L.F32, O.U8, 1 / 127.0, 0.02, in_layout=L.NCHW)
+
+    def conv(k, c=64, hw=16, idt=O.U8, kk=1):
+        w = (rng.standard_normal((k, c, kk, kk)) * 0.1).astype(np.float32)
+        return S.SaberConv2D(True).init((1, c, hw, hw), S.ConvParam(w, None, 1, (kk // 2, kk // 2), (1, 1), (1, 1), True), idt, O.U8, 0.02, 0.05)
+
+    st = stem(64)
+    S.SaberStemPair(st, conv(256), conv(64))
+    for bad in (lambda: S.SaberStemPair(st, conv(256), conv(48)),              # k % 32
+                lambda: S.SaberStemPair(st, conv(256), conv(96)),              # k_a + k_b > 320
+                lambda: S.SaberStemPair(st, conv(256), conv(64, hw=15)),       # not the pooled tensor's shape
+                lambda: S.SaberStemPair(st, conv(256), conv(64, idt=O.S8)),    # reads s8, the stem writes u8
+                lambda: S.SaberStemPair(st, conv(256), conv(64, kk=3)),        # not 1x1
+                lambda: S.SaberStemPair(conv(64), conv(256), conv(64))):       # the head is not a fused conv + pooling
+        with pytest.raises(L.SaberHipError):
+            bad()
+
+
 def test_conv_pooling_unfused_fallback_is_two_ops():
     """No fused kernel for this combination: conv into an inner tensor, then pooling (SaberConv2DPooling<X86,AK_FLOAT>
     structure); same bytes as the oracle."""
