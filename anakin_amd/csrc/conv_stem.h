@@ -402,17 +402,17 @@ __device__ __forceinline__ void conv_stem_pool_body(const ConvKArgs& a, const St
         for (int i = 0; i < MAXU; ++i) {
             const int g = (wave + 4 * i) >> 1;
             if (g >= tng) break;                              // wave-uniform
-            const v4i z = {0, 0, 0, 0};
-            const v4i c0 = mma_step(taf[i][0], bfr, z), c1 = mma_step(taf[i][1], bfr, z);
             const int kb = g * 32 + fq * 8;                   // 8 consecutive channels of the concatenated pair
+            const v4i* pc = lds_tp + (kb >> 2) * 3;
+            const v4i z = {0, 0, 0, 0};
+            const v4i c0 = mma_step(taf[i][0], bfr, pc[2]), c1 = mma_step(taf[i][1], bfr, pc[5]);   // accumulate onto the compensation
             const bool second = kb >= t.K1;
             const bool ou8 = second ? t.u8_2 : t.u8_1;
             const float lo = (second ? t.relu2 : t.relu1) ? 0.f : -3.0e38f;
             const float off = ou8 ? 0.f : 128.f;
             const unsigned xm = ou8 ? 0u : 0x80808080u;
-            const v4i* pc = lds_tp + (kb >> 2) * 3;
-            const unsigned w0 = chain_out_pack(c0, pc[2], __builtin_bit_cast(v4f, pc[1]), __builtin_bit_cast(v4f, pc[0]), lo, off, xm);
-            const unsigned w1 = chain_out_pack(c1, pc[5], __builtin_bit_cast(v4f, pc[4]), __builtin_bit_cast(v4f, pc[3]), lo, off, xm);
+            const unsigned w0 = chain_out_pack(c0, z, __builtin_bit_cast(v4f, pc[1]), __builtin_bit_cast(v4f, pc[0]), lo, off, xm);
+            const unsigned w1 = chain_out_pack(c1, z, __builtin_bit_cast(v4f, pc[4]), __builtin_bit_cast(v4f, pc[3]), lo, off, xm);
             if (tok) {
                 uint8_t* y = second ? (uint8_t*)t.y2 + tpix * t.K2 + (kb - t.K1) : (uint8_t*)t.y1 + tpix * t.K1 + kb;
                 *(uint2*)y = make_uint2(w0, w1);
