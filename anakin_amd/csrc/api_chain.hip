@@ -270,12 +270,15 @@ int saber_hip_conv2d_stage_run(saber_hip_chain_stage_t* st, const void* x, const
         if (!y1[i] || !y2[i]) return fail(SABER_HIP_INVALID_VALUE, "stage: an output pointer per block");
     return stage_run(st, x, res, y1, y2, (hipStream_t)stream);
 }
-static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out) {
-    // b == nullptr (with c3): conv3x3 + first 1x1 conv only
-    if (!a || !out || (!b && !c3)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b, saber_hip_chain_t** out, saber_hip_conv* b2 = nullptr) {
+    // b == nullptr (with c3): conv3x3 + first 1x1 conv only; b2 (with c3 / stride 2 and b): b and b2 are the sibling pair that reads a's output
+    if (!a || !out || (!b && !c3) || (b2 && (!b || !c3))) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    const bool pair2 = b2 != nullptr;
     // a sub-sampled shortcut (saber_hip_conv_desc::res_stride) is read by the conv3x3 + conv1x1 form with a strided head only
-    const bool strided = c3 && !b && c3->d.stride_h == 2 && c3->d.stride_w == 2;
-    if (!chain_1x1(a, strided) || (b && !chain_1x1(b))) return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
+    const bool strided = c3 && (!b || pair2) && c3->d.stride_h == 2 && c3->d.stride_w == 2;
+    if (pair2 && !strided) return fail(SABER_HIP_INVALID_VALUE, "chain: a sibling pair follows the strided head (conv3x3 / stride 2 + conv1x1 + eltwise) only");
+    if (!chain_1x1(a, strided) || (b && !chain_1x1(b)) || (b2 && !chain_1x1(b2)))
+        return fail(SABER_HIP_INVALID_VALUE, "chain: both ops must be plain 1x1 stride-1 INT8 NHWC convs with weights set");
     if (strided != (a->d.res_stride > 1) || (strided && a->d.res_stride != 2))
         return fail(SABER_HIP_INVALID_VALUE, "chain: a stride-2 head goes with a shortcut sub-sampled by 2 (and only with one)");
     const saber_hip_conv_desc& da = a->d;
@@ -285,8 +288,14 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         const saber_hip_conv_desc& db = b->d;
         if (db.res_mode != SABER_HIP_RES_NONE || b->x_dtype != DT_S8 || (db.out_dtype != SABER_HIP_S8 && db.out_dtype != SABER_HIP_U8))
             return fail(SABER_HIP_INVALID_VALUE, "chain: the second conv must be a plain s8-input conv with an 8-bit output");
-        if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || db.k != da.c)
+        if (db.n != da.n || db.h != a->oh || db.w != a->ow || db.c != da.k || (!pair2 && db.k != da.c))
             return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
+    }
+    if (pair2) {
+        const saber_hip_conv_desc &db = b->d, &d2 = b2->d;
+        if (d2.res_mode != SABER_HIP_RES_NONE || b2->x_dtype != DT_S8 || (d2.out_dtype != SABER_HIP_S8 && d2.out_dtype != SABER_HIP_U8) || d2.n != da.n ||
+            d2.h != a->oh || d2.w != a->ow || d2.c != da.k || da.c != 64 || db.k % 32 || db.k + d2.k != 640 || d2.k <= 0)
+            return fail(SABER_HIP_INVALID_VALUE, "chain: the sibling pair after a strided head: 64 -> 256 (+ eltwise) -> k_b | k_b2 with k_b + k_b2 = 640, k_b % 32 == 0, 8-bit outputs");
     }
     if (!conv1x1_chain_ok(da.c, da.k, da.c))
         return fail(SABER_HIP_INVALID_VALUE, "chain: shapes must be C -> 4C -> C with C in {64,128,256,512} on the same pixels");
@@ -303,20 +312,30 @@ static int chain_build(saber_hip_conv* c3, saber_hip_conv* a, saber_hip_conv* b,
         if (!ok) return fail(SABER_HIP_INVALID_VALUE, "chain: the head must be the 3x3 pad-1 INT8 conv (C -> C, C <= 256; stride 1, or 2 in front of a lone 1x1 conv) whose 8-bit output the first 1x1 conv reads");
     }
     saber_hip_chain* ch = new saber_hip_chain();
-    const int k2 = b ? b->d.k : 0, c2 = b ? b->d.c : 0;
-    ch->c3 = c3; ch->a = a; ch->b = b; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = k2;
+    const int k2 = b ? b->d.k + (pair2 ? b2->d.k : 0) : 0, c2 = b ? b->d.c : 0;
+    ch->c3 = c3; ch->a = a; ch->b = b; ch->b2 = b2; ch->c1 = da.c; ch->k1 = da.k; ch->k2 = k2;
     ch->tn = conv1x1_chain_tn(da.c, da.n * a->oh * a->ow);
-    const int mfg2 = (k2 / 4) / 16 >= 4 ? 4 : (k2 / 4) / 16;
+    const int mfg2 = pair2 ? 2 : ((k2 / 4) / 16 >= 4 ? 4 : (k2 / 4) / 16);      // (pair: 160 channels per wave = 5 groups of 32)
+    std::vector<int8_t> wcat;       // the pair's rows one after the other
+    if (pair2) {
+        wcat.assign(b->wq_oihw.begin(), b->wq_oihw.end());
+        wcat.insert(wcat.end(), b2->wq_oihw.begin(), b2->wq_oihw.end());
+    }
     std::vector<uint8_t> stream, p0, p1, p2;
     stream.reserve((size_t)da.k * da.c + (size_t)k2 * c2 + (c3 ? (size_t)9 * da.c * da.c : 0));
     for (int w = 0; w < 4; ++w) {
         if (c3) pack_chain_weights3(c3->wq_oihw.data(), da.c, w, stream);
         pack_chain_weights(a->wq_oihw.data(), da.k, da.c, 4, w, stream);
-        if (b) pack_chain_weights(b->wq_oihw.data(), k2, c2, mfg2, w, stream);
+        if (b) pack_chain_weights(pair2 ? wcat.data() : b->wq_oihw.data(), k2, c2, mfg2, w, stream);
     }
     pack_chain_params(a, (size_t)da.k / 4 * 3, p1);
     if (b) pack_chain_params(b, ((size_t)k2 / 4 * 3 + 63) / 64 * 64 + 64, p2);      // (+ 64 chunks of slack: the cooperative kernel
                                                                                      // DMAs whole 64-chunk blocks from a half's offset)
+    if (pair2) {                    // b2's constants behind b's (48 bytes per 4 channels)
+        std::vector<uint8_t> pb2;
+        pack_chain_params(b2, (size_t)b2->d.k / 4 * 3, pb2);
+        std::memcpy(p2.data() + (size_t)b->d.k / 4 * 48, pb2.data(), pb2.size());
+    }
     hipError_t e = ch->d_stream.upload(stream);
     if (e == hipSuccess && !c3 && da.c >= 256) {
         std::vector<uint8_t> sp;
@@ -411,9 +430,15 @@ int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* 
     if (!conv3x3) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     return chain_build(conv3x3, a, b, out);
 }
+int saber_hip_conv2d_chain_create3_pair(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* pair_a, saber_hip_conv_t* pair_b,
+                                        saber_hip_chain_t** out) {
+    if (!conv3x3 || !pair_a || !pair_b) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    return chain_build(conv3x3, a, pair_a, out, pair_b);
+}
 void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* ch) { delete ch; }
 int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
     if (!ch) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (ch->b2 && tn != 4 && tn != 2) return fail(SABER_HIP_INVALID_VALUE, "chain: the strided head + pair form has 2 or 4 tile rows");
     const bool ok = (ch->c1 == 64 && (tn == 4 || tn == 2)) || (ch->c1 == 128 && (tn == 2 || tn == 1)) || (ch->c1 >= 256 && tn == 1) ||
                     (ch->c1 == 128 && (tn == 6 || tn == 5) && ch->d_stream_w8.p) || (ch->c1 == 256 && tn == 3 && ch->c3 && ch->d_stream_w8.p) ||
                     (ch->c1 >= 256 && tn == 9 && ch->d_stream_split.p && ch->b) || (tn == 11 && ch->d_stream_split8.p && ch->b) ||
@@ -425,8 +450,12 @@ int saber_hip_conv2d_chain_set_tile(saber_hip_chain_t* ch, int tn) {
 int saber_hip_conv2d_chain_get_tile(const saber_hip_chain_t* ch) { return ch ? ch->tn : 0; }
 int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void* res, void* y_a, void* y_b,
                                saber_hip_stream_t stream) {
+    return saber_hip_conv2d_chain_run3(ch, x, res, y_a, y_b, nullptr, stream);
+}
+int saber_hip_conv2d_chain_run3(saber_hip_chain_t* ch, const void* x, const void* res, void* y_a, void* y_b, void* y_c,
+                                saber_hip_stream_t stream) {
     if (g_capture) return capture_unsupported("saber_hip_conv2d_chain_run (saber_hip_net_optimize forms chains itself)");
-    if (!ch || !x || !res || !y_a || (ch->b && !y_b)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!ch || !x || !res || !y_a || (ch->b && !y_b) || (ch->b2 && !y_c)) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     const saber_hip_conv* a = ch->a;
     const saber_hip_conv* b = ch->b;
     ChainKArgs k;
@@ -445,6 +474,12 @@ int saber_hip_conv2d_chain_run(saber_hip_chain_t* ch, const void* x, const void*
     if (b) {
         k.relu2 = b->d.act == SABER_HIP_ACT_RELU;
         k.out_u8_2 = b->d.out_dtype == SABER_HIP_U8;
+    }
+    if (ch->b2) {
+        k.y2b = y_c;
+        k.k2_split = b->d.k;
+        k.relu2b = ch->b2->d.act == SABER_HIP_ACT_RELU;
+        k.out_u8_2b = ch->b2->d.out_dtype == SABER_HIP_U8;
     }
     if (ch->c3) {   // x is the 3x3 conv's input; tiles of tn rows x 16 columns
         auto magic = [](int d) { return d >= 2 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; };

@@ -156,6 +156,7 @@ struct saber_hip_chain {
     saber_hip_conv* c3 = nullptr;   // the block's 3x3 conv in front of `a` (saber_hip_conv2d_chain_create3), or null
     saber_hip_conv* a = nullptr;
     saber_hip_conv* b = nullptr;
+    saber_hip_conv* b2 = nullptr;   // strided head + sibling pair (saber_hip_conv2d_chain_create3_pair): b and b2 both read a's output
     int c1 = 0, k1 = 0, k2 = 0, tn = 0;
     DevBuf<uint8_t> d_stream, d_prm0, d_prm1, d_prm2;
     DevBuf<uint8_t> d_stream_split;   // 1x1 chains with C >= 256: [half][wave] streams for the split second conv (tile | 8)
@@ -360,6 +361,7 @@ struct NetOp {
     // is set it launches all three (its own output edge is then not written) and both followers carry `skip`
     saber_hip_chain* chain3 = nullptr;
     int chain3_res = -1, chain3_y1 = -1, chain3_y2 = -1;
+    int chain3_y3 = -1;      // strided head + sibling pair (flag 1024): the pair's second output; the pair op (ops[i + 2]) carries `skip`
     bool use_chain3 = false;
     // ... and a RUN of such 3x3-led C = 256 chains (flag 256): THIS op is the first block's 3x3 conv; while use_stage is set it launches
     // all stage_n chains (3 * stage_n ops, the others carry `skip`) as one persistent launch (saber_hip_conv2d_stage_run)

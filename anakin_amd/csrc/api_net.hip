@@ -29,7 +29,7 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
         }
         if (o.stem_pair) return saber_hip_conv2d_stem_pair_run(o.stem_pair, T(o.in), nullptr, T(o.stem_y1), T(o.stem_y2), ws, s);
         if (o.chain3 && o.use_chain3)
-            return saber_hip_conv2d_chain_run(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), s);
+            return saber_hip_conv2d_chain_run3(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), T(o.chain3_y3), s);
         if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
         if (o.conv->gpool) return saber_hip_conv2d_run_gpool(o.conv, T(o.in), T(o.out), T(o.in2), T(o.out2), s);
         return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);

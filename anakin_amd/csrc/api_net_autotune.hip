@@ -28,7 +28,7 @@ int saber_hip_net_stage_blocks(const saber_hip_net_t* net, int index) {
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     saber_hip_conv* c = net_op_conv(net, index);
     if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
-    if (net->ops[index].kind == OP_CONV_PAIR && net->ops[index].skip) return SABER_HIP_OK;      // no kernel of its own (flag 512)
+    if (net->ops[index].kind == OP_CONV_PAIR && index > 0 && net->ops[index - 1].stem_pair) return SABER_HIP_OK;      // no kernel of its own (flag 512)
     const int chain_bits = (choice >> 24) & 63;
     const bool stage_on = (choice >> 30) & 1;
     choice &= 0xffffff;
@@ -48,7 +48,7 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     }
     if (o.stage) net_set_stage(net, index, stage_on);      // (a stage head comes before its blocks: set_choices runs in op order)
     if (o.skip) o.name = (o.chain3 && o.use_chain3) ? "conv:(in the stage launch)" : "conv:(in the chain launch)";
-    if (o.skip && o.kind == OP_CONV_PAIR) o.name = "conv:(in the stem launch)";
+    if (o.skip && o.kind == OP_CONV_PAIR) o.name = (index > 0 && net->ops[index - 1].stem_pair) ? "conv:(in the stem launch)" : "conv:(in the chain launch)";
     if (o.stem_pair) o.name = stem_pair_name(o);
     if (net->exec) {
         (void)hipGraphExecDestroy(net->exec);
@@ -156,7 +156,9 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         ~UsedScope() { g_used_kernels = nullptr; }
     } used_scope(&used_kernels);
     for (NetOp& o : net->ops) {
-        if (o.kind == OP_CONV_PAIR && o.skip) continue;      // runs inside the stem launch (flag 512): no kernel of its own
+        // a pair that runs inside the stem launch (flag 512) has no kernel of its own (one absorbed by a chain launch - flag 1024 -
+        // keeps its own for the mode in which the chain is off: it is tuned like any other)
+        if (o.kind == OP_CONV_PAIR && o.skip && &o != net->ops.data() && (&o)[-1].stem_pair) continue;
         if (o.kind == OP_CONV_PAIR) {
             int rc = saber_hip_conv2d_autotune_pair(o.conv, T(o.in), T(o.out), T(o.out2), stream, iters);
             if (rc) return rc;
@@ -186,7 +188,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         NetOp* H = (ia > 0 && net->ops[ia - 1].chain3) ? &net->ops[ia - 1] : nullptr;
         if (!A.chain && !H) continue;
         const int first = H ? ia - 1 : ia;
-        const int last = A.chain ? ia + 1 : ia;
+        const int last = (A.chain || (H && H->chain3->b2)) ? ia + 1 : ia;      // (a head + pair chain also replaces the pair op behind A)
         hipStream_t s = (hipStream_t)stream;
         auto run_all = [&]() -> int {
             int rc = 0;

@@ -41,12 +41,17 @@ void net_set_chain_mode(saber_hip_net* net, int ia, int mode) {
     if (mode == 2 && !H) mode = 1;
     if (mode == 1 && !A.chain) mode = 0;
     NetOp* B = A.chain ? &net->ops[ia + 1] : nullptr;
-    A.use_chain = mode == 1 || (mode == 2 && H->chain3->b);
+    A.use_chain = mode == 1 || (mode == 2 && H->chain3->b && !H->chain3->b2);
     if (B) B->skip = mode == 1 || (mode == 2 && H->chain3->b);
     A.skip = mode == 2;
+    if (H && H->chain3->b2) {      // strided head + sibling pair: the pair op behind A launches nothing while the chain runs
+        NetOp& P = net->ops[ia + 1];
+        P.skip = mode == 2;
+        P.name = mode == 2 ? "conv:(in the chain launch)" : std::string("conv:") + P.conv->algo_name;
+    }
     if (H) {
         H->use_chain3 = mode == 2;
-        H->name = mode == 2 ? std::string("conv:conv3x3+") + (H->chain3->b ? "chain1x1_c" : "conv1x1_c") + std::to_string(H->chain3->c1) +
+        H->name = mode == 2 ? std::string("conv:conv3x3+") + (H->chain3->b2 ? "conv1x1+pair1x1_c" : (H->chain3->b ? "chain1x1_c" : "conv1x1_c")) + std::to_string(H->chain3->c1) +
                                   "_" + std::to_string(H->chain3->c1 == 128 ? H->chain3->tn & 3 : (H->chain3->c1 == 256 ? (H->chain3->tn == 15 ? 2 : 1) : H->chain3->tn)) + "x16" +
                                   ((H->chain3->c1 == 128 && (H->chain3->tn & 4)) || (H->chain3->c1 == 256 && H->chain3->tn == 3) ? "_w8" : "") +
                                   (H->chain3->c1 == 256 && H->chain3->tn == 7 ? "_coop2" : "") + (H->chain3->c1 == 256 && H->chain3->tn == 15 ? "_coop4" : "")
@@ -394,12 +399,22 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             for (const NetOp& o : ops) readers += (o.in == Hd.out) + (o.in2 == Hd.out);
             if (readers != 1) continue;
             saber_hip_chain* ch = nullptr;
-            if (saber_hip_conv2d_chain_create3(Hd.conv, A.conv, nullptr, &ch) != SABER_HIP_OK) continue;
+            // 1024: ... and the sibling pair that is the only reader of A's output (the next stage's branch1 / branch2a) joins the launch
+            NetOp* P = (flags & 1024) && i + 2 < ops.size() ? &ops[i + 2] : nullptr;
+            if (P && (P->kind != OP_CONV_PAIR || P->lane || P->skip || P->in != A.out || !P->conv || !P->conv->pair_src_a || !P->conv->pair_src_b)) P = nullptr;
+            if (P) {
+                int rd = 0;
+                for (const NetOp& o : ops) rd += (o.in == A.out) + (o.in2 == A.out);
+                if (rd != 1 || saber_hip_conv2d_chain_create3_pair(Hd.conv, A.conv, const_cast<saber_hip_conv*>(P->conv->pair_src_a),
+                                                                   const_cast<saber_hip_conv*>(P->conv->pair_src_b), &ch) != SABER_HIP_OK)
+                    P = nullptr;
+            }
+            if (!P && saber_hip_conv2d_chain_create3(Hd.conv, A.conv, nullptr, &ch) != SABER_HIP_OK) continue;
             net->owned_chains.push_back(ch);
             Hd.chain3 = ch;
-            Hd.chain3_res = A.in2; Hd.chain3_y1 = A.out; Hd.chain3_y2 = -1;
+            Hd.chain3_res = A.in2; Hd.chain3_y1 = A.out; Hd.chain3_y2 = P ? P->out : -1; Hd.chain3_y3 = P ? P->out2 : -1;
             net_set_chain_mode(net, (int)i + 1, ch->c1 <= 128 ? 2 : 0);
-            if (Hd.use_chain3) ++removed;
+            if (Hd.use_chain3) removed += P ? 2 : 1;
         }
     }
     // ---- 256: runs of 3x3-led C = 256 (or C = 128) chains whose blocks feed each other (ResNet's res4 / res3 stage) -> one persistent launch

@@ -43,7 +43,7 @@ namespace saber_mi355x {
 template <int KS1, int G1, int MFG2, int G2, int TN, int R, bool C3, int SP, bool HAS2 = true, int NW = 4, int S0 = 1>
 __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs a) {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-    static_assert(S0 == 1 || (C3 && !HAS2 && S0 == 2), "a strided head exists for conv3x3 + conv1x1 only");
+    static_assert(S0 == 1 || (C3 && S0 == 2), "a strided head is led by its 3x3 conv");
     constexpr int KS2 = NW * G1;                      // K1 / 64
     constexpr int K1 = 64 * NW * G1, C1 = 64 * KS1, K2W = NW * G2 * 16 * MFG2, K2 = K2W * SP;   // K2W: this workgroup's share
     constexpr int NPX = 16 * TN;
@@ -312,13 +312,18 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
     SABER_TL(4);
 
     // ================= second 1x1 conv ==============================================================================
-    const float lo2 = a.relu2 ? 0.f : -3.0e38f;
-    const float off2 = a.out_u8_2 ? 0.f : 128.f;
-    const unsigned xm2 = a.out_u8_2 ? 0u : 0x80808080u;
+    // a.k2_split > 0: the "second conv" is a sibling PAIR (two 1x1 convs over the tile, rows [0, k2_split) -> y2, the rest -> y2b with
+    // their own relu / output type; k2_split is a multiple of a group's 16 * MFG2 channels, so the side is wave-uniform per group)
 #pragma unroll 1
     for (int g = 0; g < G2; ++g) {
         v4i acc[MFG2][TN];
         const int cg = half * K2W + wave * (K2W / NW) + g * (16 * MFG2) + fq * (4 * MFG2);
+        const bool side_b = a.k2_split > 0 && wave * (K2W / NW) + g * (16 * MFG2) >= a.k2_split;
+        const float lo2 = (side_b ? a.relu2b : a.relu2) ? 0.f : -3.0e38f;
+        const float off2 = (side_b ? a.out_u8_2b : a.out_u8_2) ? 0.f : 128.f;
+        const unsigned xm2 = (side_b ? a.out_u8_2b : a.out_u8_2) ? 0u : 0x80808080u;
+        const int kout = a.k2_split > 0 ? (side_b ? K2 - a.k2_split : a.k2_split) : K2;
+        char* yout = side_b ? (char*)a.y2b - a.k2_split : (char*)a.y2;      // (- k2_split: cg counts from the pair's first row)
         const v4i* pp = prm2 + (cg / 4) * 3;
 #pragma unroll
         for (int mf = 0; mf < MFG2; ++mf)
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_chain_kernel(const ChainKArgs
             bool ok;
             const int p = pix(j * 16 + frow, ok);
             if (ok) {
-                char* y = (char*)a.y2 + (size_t)p * K2 + cg;
+                char* y = yout + (size_t)p * kout + cg;
                 if constexpr (MFG2 == 1) *(unsigned*)y = o[0];
                 else if constexpr (MFG2 == 2) *(uint2*)y = make_uint2(o[0], o[1]);
                 else *(uint4*)y = make_uint4(o[0], o[1], o[2], o[3]);
@@ -373,7 +378,9 @@ int conv1x1_chain_tn(int c1, int m) {
 // conv's output channels are split over two workgroups (wstream then holds [half][wave] streams, api.hip)
 hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int tile, int with3x3, hipStream_t s) {
     const bool has2 = k2 != 0;          // k2 == 0: conv3x3 + first 1x1 conv only (with3x3 required)
-    if (!conv1x1_chain_ok(c1, k1, has2 ? k2 : c1) || a.M <= 0 || (!has2 && !with3x3)) return hipErrorInvalidValue;
+    const bool pair2 = has2 && a.k2_split > 0;      // the strided head followed by the next stage's sibling pair: 64 -> 256 (+ sum) -> 512 | 128
+    if (pair2 && !(a.s0 == 2 && with3x3 && c1 == 64 && k1 == 256 && k2 == 640 && a.k2_split % 32 == 0 && a.k2_split < 640)) return hipErrorInvalidValue;
+    if (!conv1x1_chain_ok(c1, k1, (has2 && !pair2) ? k2 : c1) || a.M <= 0 || (!has2 && !with3x3)) return hipErrorInvalidValue;
     // C >= 256 codes: 1 = one fragment, 9 = second conv split over two workgroups, 11 = split + 8 waves per workgroup
     // C = 128 codes: 2 | 1 fragments, + 4 = 8 waves per workgroup
     const bool w8 = (c1 >= 256 && (tile & 7) == 3) || (c1 == 128 && (tile & 4));
@@ -385,6 +392,14 @@ hipError_t launch_conv1x1_chain(const ChainKArgs& a, int c1, int k1, int k2, int
     // ring depths: measured with scripts/probe/timeline_probe.hip (chain): deeper rings (32 / 64 steps, or the whole
     // stream in registers) only move the wait into the prologue - the stream is bound by the CU's vector-memory path
     // (~43 B/clk measured for these 1 KB-per-instruction loads), not by the latency of one round trip
+    if (pair2) {
+        switch (tile) {
+        case 4: SABER_CHAIN(1, 1, 2, 5, 4, 4, true, 1, true, 4, 2); break;
+        case 2: SABER_CHAIN(1, 1, 2, 5, 2, 4, true, 1, true, 4, 2); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (!has2 && a.s0 == 2) {      // strided head (the last block of a stage after the reference's stride-up)
         switch (c1 * 32 + tile) {
         case 64 * 32 + 4: SABER_CHAIN(1, 1, 1, 1, 4, 4, true, 1, false, 4, 2); break;

@@ -150,6 +150,9 @@ struct ChainKArgs {
     int in0_u8, relu0;                 // the 3x3 conv's input dtype / relu (its output dtype is in_u8)
     int s0, H0, W0;                    // stride of the leading 3x3 conv (1 | 2) and, for 2, its input dims (H, W are the output's)
     int res_sub, res_H, res_W;         // s0 == 2: the shortcut is [N][res_H][res_W][K1], read at (y * res_sub, x * res_sub)
+    // the second conv as a sibling pair (strided head + the next stage's branch1 / branch2a): rows >= k2_split -> y2b [M][K2 - k2_split]
+    void* y2b;
+    int k2_split, relu2b, out_u8_2b;
 };
 // cooperative form (conv_chain_coop.hip): TWO workgroups of one XCD per pixel tile, each computing half of every conv's output
 // channels; the 3x3 conv's tile and the first 1x1 conv's tile are handed over through that XCD's L2. (Its own block: every byte of

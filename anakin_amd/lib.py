@@ -26,7 +26,8 @@ SYMBOLS = [
     "saber_hip_conv2d_get_tile", "saber_hip_conv2d_autotune", "saber_hip_conv2d_set_pooling",
     "saber_hip_conv2d_create_pair", "saber_hip_conv2d_run_pair", "saber_hip_conv2d_autotune_pair",
     "saber_hip_net_add_conv_pair",
-    "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_create3", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
+    "saber_hip_conv2d_chain_create", "saber_hip_conv2d_chain_create3", "saber_hip_conv2d_chain_create3_pair", "saber_hip_conv2d_chain_destroy", "saber_hip_conv2d_chain_run",
+    "saber_hip_conv2d_chain_run3",
     "saber_hip_conv2d_chain_set_tile", "saber_hip_conv2d_chain_get_tile",
     "saber_hip_conv2d_stage_create", "saber_hip_conv2d_stage_destroy", "saber_hip_conv2d_stage_run",
     "saber_hip_conv2d_stem_pair_create", "saber_hip_conv2d_stem_pair_destroy", "saber_hip_conv2d_stem_pair_run",
@@ -122,6 +123,8 @@ def load():
     lib.saber_hip_conv2d_chain_destroy.argtypes = [P]
     lib.saber_hip_conv2d_chain_destroy.restype = None
     lib.saber_hip_conv2d_chain_run.argtypes = [P, P, P, P, P, P]
+    lib.saber_hip_conv2d_chain_create3_pair.argtypes = [P, P, P, P, C.POINTER(P)]
+    lib.saber_hip_conv2d_chain_run3.argtypes = [P, P, P, P, P, P, P]
     lib.saber_hip_conv2d_chain_set_tile.argtypes = [P, I]
     lib.saber_hip_conv2d_chain_get_tile.argtypes = [P]
     lib.saber_hip_conv2d_stage_create.argtypes = [C.POINTER(P), I, C.POINTER(P)]

@@ -291,18 +291,21 @@ class SaberConvChain:
     (saber_hip_conv2d_chain_create): ResNet's `branch2c + sum + relu -> next branch2a`. Both outputs hold the bits of
     dispatching `a` and then `b`, which is what the reference does (net.cpp:417-509)."""
 
-    def __init__(self, a, b, conv3x3=None):
+    def __init__(self, a, b, conv3x3=None, pair_b=None):
         """conv3x3: the block's 3x3 conv in front of `a` joins the launch (saber_hip_conv2d_chain_create3); dispatch() then
-        takes ITS input as x and its own output edge is not written."""
-        self.a, self.b, self.c3 = a, b, conv3x3
+        takes ITS input as x and its own output edge is not written. pair_b (with a stride-2 conv3x3): `b` and `pair_b` are the
+        sibling pair reading a's output (saber_hip_conv2d_chain_create3_pair); dispatch() then also takes yc."""
+        self.a, self.b, self.c3, self.b2 = a, b, conv3x3, pair_b
         self.h = C.c_void_p()
-        if conv3x3 is None:
+        if pair_b is not None:
+            L.check(L.load().saber_hip_conv2d_chain_create3_pair(conv3x3.h, a.h, b.h, pair_b.h, C.byref(self.h)))
+        elif conv3x3 is None:
             L.check(L.load().saber_hip_conv2d_chain_create(a.h, b.h, C.byref(self.h)))
         else:   # b may be None: conv3x3 + `a` only
             L.check(L.load().saber_hip_conv2d_chain_create3(conv3x3.h, a.h, None if b is None else b.h, C.byref(self.h)))
 
-    def dispatch(self, x, res, ya, yb=None):
-        L.check(L.load().saber_hip_conv2d_chain_run(self.h, _p(x), _p(res), _p(ya), _p(yb), _stream()))
+    def dispatch(self, x, res, ya, yb=None, yc=None):
+        L.check(L.load().saber_hip_conv2d_chain_run3(self.h, _p(x), _p(res), _p(ya), _p(yb), _p(yc), _stream()))
         return ya, yb
 
     def set_tile(self, tn):

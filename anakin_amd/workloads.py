@@ -259,7 +259,7 @@ def _out_hw(h, k, s, p):
 
 
 def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
-                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True):
+                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True, head_pair=False):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
@@ -278,7 +278,10 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     launch (flag 256; saber_hip_conv2d_stage_create) - for a net that has the GPU to itself; pass False for nets that run
     concurrently with others on their own streams.
     stem_pair: the fused conv1 + pool1 launch also runs the sibling pair that reads pool1 (res2a_branch1 / res2a_branch2a; flag 512;
-    saber_hip_conv2d_stem_pair_create); pool1's edge is then not written."""
+    saber_hip_conv2d_stem_pair_create); pool1's edge is then not written.
+    head_pair (with chain = 2): the strided head of a stage (conv3x3 / stride 2 + conv1x1 + eltwise, C = 64: res2c) also runs the next
+    stage's sibling pair (res3a_branch1 / res3a_branch2a) that reads its output (flag 1024; saber_hip_conv2d_chain_create3_pair).
+    Off by default: measured no faster than the two launches."""
     from . import lib as L
     from . import saber as S
     if chain is None:
@@ -420,7 +423,8 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     # the last block's conv (+ fused eltwise) also writes the global average pooling of its output (flag 128): pool5's launch goes
     net.gpooled = net.optimize(128) if (fuse_eltwise or cxx_optimize) and absorb_pool else 0
     net.stem_paired = net.optimize(512) if stem_pair and not lanes and (fuse_eltwise or cxx_optimize) else 0
-    net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0) | (256 if int(chain) >= 2 and stage else 0)) if chain else 0
+    net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0) | (256 if int(chain) >= 2 and stage else 0) |
+                               (1024 if int(chain) >= 2 and head_pair else 0)) if chain else 0
     net.finalize()
     return net
 

@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     ap.add_argument("--no-stem-pair", action="store_true",
                     help="INT8: conv1 + pool1 and the sibling pair reading pool1 stay two launches (saber_hip_net_optimize flag 512 off)")
+    ap.add_argument("--head-pair", action="store_true",
+                    help="INT8: res2c's strided-head chain launch also runs the res3a sibling pair (saber_hip_net_optimize flag 1024; measured no faster)")
     ap.add_argument("--no-stage", action="store_true",
                     help="INT8: do not let runs of res4 block chains run as one persistent stage launch (saber_hip_net_optimize flag 256)")
     ap.add_argument("--timed-only", action="store_true",
@@ -88,15 +90,15 @@ def build_net(W, model, scales, batch, args, stage=True):
     if args.precision == "int8":
         cxx = not (args.py_fuse or args.no_fuse or args.lanes)      # the C++ host side finds the fusions (the north star's "host side stays C++")
         return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx,
-                                stage=stage and not args.no_stage, stem_pair=not args.no_stem_pair)
+                                stage=stage and not args.no_stage, stem_pair=not args.no_stem_pair, head_pair=args.head_pair)
     return W.build_fp32_net(model, batch)
 
 
 def tune_key(args, batch, L):
     """a cached selection is only valid for the sources and executor options it was tuned on"""
-    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_sp%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
+    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_sp%d_hp%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
                                                                   int(args.lanes), args.chain, int(args.py_fuse), int(not args.no_stage),
-                                                                  int(not args.no_stem_pair),
+                                                                  int(not args.no_stem_pair), int(args.head_pair),
                                                                   L.source_sha())
 
 

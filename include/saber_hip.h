@@ -191,9 +191,17 @@ int saber_hip_conv2d_chain_create(saber_hip_conv_t* a, saber_hip_conv_t* b, sabe
  * is not written (it lives in LDS), y_a / y_b hold the bits of running the three ops one after the other. The pixel
  * tile is `tn` rows x 16 columns (set_tile: 4 | 2 for C = 64, 2 | 1 for C = 128, 1 for C = 256). */
 int saber_hip_conv2d_chain_create3(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* b, saber_hip_chain_t** out);
+/* ... and the last block of a stage after the reference's stride-up (conv3x3 / stride 2 + conv1x1 + eltwise on a sub-sampled
+ * shortcut, C = 64: ResNet's res2c) followed in the SAME launch by the next stage's sibling pair `pair_a` / `pair_b` - the two 1x1
+ * stride-1 convs that read a's output (res3a_branch1 / res3a_branch2a; 256 -> k_a | k_b, k_a + k_b = 640, k_a % 32 == 0, 8-bit
+ * outputs): four operators, one launch. saber_hip_conv2d_chain_run3 writes y_a (a's output), y_b / y_c (the pair's). */
+int saber_hip_conv2d_chain_create3_pair(saber_hip_conv_t* conv3x3, saber_hip_conv_t* a, saber_hip_conv_t* pair_a, saber_hip_conv_t* pair_b,
+                                        saber_hip_chain_t** out);
 void saber_hip_conv2d_chain_destroy(saber_hip_chain_t* chain);
 int saber_hip_conv2d_chain_run(saber_hip_chain_t* chain, const void* x, const void* res, void* y_a, void* y_b,
                                saber_hip_stream_t stream);
+int saber_hip_conv2d_chain_run3(saber_hip_chain_t* chain, const void* x, const void* res, void* y_a, void* y_b, void* y_c,
+                                saber_hip_stream_t stream);
 /* pixel fragments (16 pixels each) per workgroup: 4 | 2 for C = 64, 2 | 1 for C = 128, 1 otherwise; C >= 256 also takes
  * 9 = 1 fragment with the second conv's output channels split over two workgroups (both run the first conv);
  * C = 256 also 11 = the same with 8 waves per workgroup; C = 128 also 6 | 5 = 2 | 1 fragments with 8 waves */
@@ -420,6 +428,9 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * 512 (with 2 | 4; NOT in 255): the fused stem conv + max pooling whose pooled tensor is read by one sibling pair of 1x1 convs only
  * (ResNet's conv1 + pool1 -> res2a_branch1 / res2a_branch2a) runs that pair in its own launch (saber_hip_conv2d_stem_pair_create);
  * the pooled edge is then not written (saber_hip_net_tensor_unwritten), the pair stays in the list and launches nothing.
+ * 1024 (with 2 | 16 | 32; NOT in 255): the strided head of a stage at C = 64 (conv3x3 / stride 2 + conv1x1 + eltwise: ResNet's res2c)
+ * whose output is read by one sibling pair only (res3a_branch1 / res3a_branch2a) runs that pair in its chain launch
+ * (saber_hip_conv2d_chain_create3_pair); the pair stays in the list and launches nothing while the chain form is selected.
  * Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 /* After a forward pass has COMPLETED (the caller synchronised the stream): SABER_HIP_RUNTIME_ERROR when one of its cooperative

@@ -85,7 +85,9 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
         const bool stage = env_on("SABER_MI355X_NET_STAGE", plan.own_stream == nullptr);
         // 512: conv1 + pool1 also run the sibling pair reading pool1 (one launch fewer; pool1's own tensor is not written by the plan)
         const bool stem_pair = env_on("SABER_MI355X_NET_STEM_PAIR", true);
-        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0)) >= 0;
+        // 1024: res2c's strided-head chain launch also runs the res3a sibling pair (opt-in: measured no faster than the two launches)
+        const bool head_pair = env_on("SABER_MI355X_NET_HEAD_PAIR", false);
+        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0) | (head_pair ? 1024 : 0)) >= 0;
         if (ok) ok = saber_hip_net_finalize(n) == SABER_HIP_OK;
         if (ok && plan.builds == 0 && env_on("SABER_MI355X_NET_PLAN_TUNE", true))
             ok = saber_hip_net_autotune(n, plan.stream, 9) == SABER_HIP_OK;

@@ -1778,6 +1778,61 @@ STRIDED_HEAD_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(2, 56, 56, O.U8, O.U8, 1, 512, None), (1, 27, 41, O.U8, O.U8, 1, 512, 2), (2, 30, 22, O.S8, O.S8, 0, 128, 4),
+                                  (1, 56, 56, O.U8, O.U8, 1, 608, 2)])
+def test_strided_head_chain_runs_the_next_stages_sibling_pair(case):
+    """saber_hip_conv2d_chain_create3_pair: res2c as the reference's stride-up leaves it (3x3 / stride 2, 1x1 + eltwise on the sub-sampled
+    shortcut, C = 64) AND the two 1x1 convs that read its output (res3a_branch1 / res3a_branch2a) in ONE launch: all three written tensors
+    are the bits of the four operators one after the other (ragged tiles, both pixel-tile heights, either split of the 640 channels)."""
+    N, H, Wd, idt, mdt, res_relu, Kb, tn = case
+    Cc, K1, Kc = 64, 256, 640 - Kb
+    rng = np.random.default_rng(4100 + H + Kb)
+    x = (rng.integers(0, 256, (N, H, Wd, Cc)).astype(np.uint8) if idt == O.U8 else rng.integers(-128, 128, (N, H, Wd, Cc)).astype(np.int8))
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (Wd + 2 - 3) // 2 + 1
+    Hs, Ws = 2 * Ho - (1 if H % 2 else 0), 2 * Wo - (1 if Wd % 2 else 0)
+    res_full = rng.integers(-128, 128, (N, Hs, Ws, K1)).astype(np.int8)
+    w0 = (rng.standard_normal((Cc, Cc, 3, 3)) * np.sqrt(2.0 / (9 * Cc))).astype(np.float32)
+    b0 = (rng.standard_normal(Cc) * 0.5).astype(np.float32)
+    w1 = (rng.standard_normal((K1, Cc, 1, 1)) * np.sqrt(2.0 / Cc)).astype(np.float32)
+    b1 = (rng.standard_normal(K1) * 0.5).astype(np.float32)
+    s_x, s_in, s_mid, s_res, s_sum = 0.023, 0.02, 0.05, 0.043, 0.06
+    c = 1.0 / s_sum
+    relu0 = mdt == O.U8
+    ws0 = O.weight_scales(w0)
+    bp0, sc0 = O.conv_i8_prepare(ws0, b0, s_x, s_in, idt, mdt)
+    t0 = O.conv_i8(x, O.quant_weights(w0, ws0), bp0, sc0, mdt, int(relu0), (1, 1), (2, 2))
+    ws1 = O.weight_scales(w1)
+    bp1, sc1 = O.conv_i8_prepare(ws1, b1, s_in, s_mid, mdt, O.S8)
+    t1 = O.conv_i8(t0, O.quant_weights(w1, ws1), bp1, sc1, O.S8, 0)
+    y1_want = O.eltwise_i8(t1, O.pool_i8_nhwc(res_full, (1, 1), (2, 2), (0, 0), 0, floor_mode=True), s_mid, s_res, c, c, bool(res_relu))
+    c0 = S.SaberConv2D(int8=True).init((N, Cc, H, Wd), S.ConvParam(w0, b0, 1, (1, 1), (2, 2), (1, 1), bool(relu0)), idt, mdt, s_x, s_in)
+    pa = S.ConvParam(w1, b1, 1, (0, 0), (1, 1), (1, 1), False)
+    pa.res_mode, pa.res_relu, pa.sum_scale, pa.coeff, pa.scale_res = L.RES_ELTWISE, bool(res_relu), 1.0, (c, c), s_res
+    pa.res_stride, pa.res_hw = 2, (Hs, Ws)
+    ca = S.SaberConv2D(int8=True).init((N, Cc, Ho, Wo), pa, mdt, O.S8, s_in, s_mid)
+    pair, wants = [], []
+    for K, kdt, relu, out_scale in ((Kb, O.S8, 0, 0.045), (Kc, O.U8, 1, 0.033)):
+        wk = (rng.standard_normal((K, K1, 1, 1)) * np.sqrt(2.0 / K1)).astype(np.float32)
+        bk = (rng.standard_normal(K) * 0.5).astype(np.float32)
+        wsk = O.weight_scales(wk)
+        bpk, sck = O.conv_i8_prepare(wsk, bk, s_sum, out_scale, O.S8, kdt)
+        wants.append(O.conv_i8(y1_want, O.quant_weights(wk, wsk), bpk, sck, kdt, relu))
+        pair.append(S.SaberConv2D(True).init((N, K1, Ho, Wo), S.ConvParam(wk, bk, 1, (0, 0), (1, 1), (1, 1), bool(relu)), O.S8, kdt, s_sum, out_scale))
+    chain = S.SaberConvChain(ca, pair[0], conv3x3=c0, pair_b=pair[1])
+    for t in ([tn] if tn is not None else [4, 2]):
+        chain.set_tile(t)
+        z1, zb, zc = ca.new_output(), pair[0].new_output(), pair[1].new_output()
+        for z in (z1, zb, zc):
+            z.fill_(77)
+        chain.dispatch(dev(x), dev(res_full), z1, zb, zc)
+        assert np.array_equal(host(z1), y1_want), ("head", t)
+        assert np.array_equal(host(zb), wants[0]) and np.array_equal(host(zc), wants[1]), ("pair", t)
+    with pytest.raises(L.SaberHipError):
+        chain.set_tile(1)
+    with pytest.raises(L.SaberHipError):       # not 640 channels in total
+        S.SaberConvChain(ca, pair[0], conv3x3=c0, pair_b=pair[0])
+
+
 @pytest.mark.parametrize("case", STRIDED_HEAD_CASES)
 def test_strided_conv3x3_conv1x1_chain_with_subsampled_shortcut(case):
     """The last block of a stage as the reference's stride-up leaves it: 3x3 / stride 2 (C -> C), then 1x1 (C -> 4C) + eltwise

@@ -263,6 +263,44 @@ def test_cxx_net_optimize_equals_python_fused_list(setup):
     assert checked >= 39, checked
 
 
+def test_strided_head_chain_with_the_next_pair_in_the_net():
+    """saber_hip_net_optimize flag 1024 (opt-in: measured no faster): res2c's strided-head chain launch also runs the res3a
+    sibling pair. One launch fewer, every written edge and the logits bit-identical to the default list's and to the oracle's - eager,
+    after autotuning (which may switch the site back to separate launches) and through the saved selection."""
+    model = W.framework_model(W.build_model("resnet50"), "int8")      # the reference optimiser's list: the stride moved up into res2c's 3x3
+    x = W.make_input(2, hw=224)
+    scales = W.calibrate(model, x)
+    ref = NO.run_int8(model, dict(scales), x)
+    a = W.build_int8_net(model, dict(scales), 2)
+    b = W.build_int8_net(model, dict(scales), 2, head_pair=True)
+    assert b.chained == a.chained + 1 and b.num_launches() == a.num_launches() - 1, (a.chained, b.chained, a.num_launches(), b.num_launches())
+    assert sum("conv3x3+conv1x1+pair1x1_c64" in b.op_name(i) for i in range(b.num_ops())) == 1
+    for net in (a, b):
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+
+    def same():
+        for name in a.tensors:
+            if name == "data" or a.unwritten(name) or b.unwritten(name):
+                continue
+            assert np.array_equal(_h(a.tensor(name)), _h(b.tensor(name))), name
+        assert np.array_equal(_h(b.tensor("fc1000")), ref["fc1000"].reshape(2, -1))
+    same()
+    b.autotune(iters=3)
+    for name in b.tensors:
+        if name != "data" and not b.unwritten(name):
+            b.tensor(name).zero_()
+    b.tensor("data").copy_(torch.from_numpy(x).cuda())
+    b.run()
+    same()
+    c = W.build_int8_net(model, dict(scales), 2, head_pair=True)
+    c.set_choices(b.choices())
+    assert [b.op_name(i) for i in range(b.num_ops())] == [c.op_name(i) for i in range(c.num_ops())]
+    c.tensor("data").copy_(torch.from_numpy(x).cuda())
+    c.run()
+    assert np.array_equal(_h(c.tensor("fc1000")), ref["fc1000"].reshape(2, -1))
+
+
 def test_autotuned_selection_round_trips_through_choices(setup):
     """Net.choices() / set_choices() (the bench's --tune-cache) carry the whole autotuned selection - kernel variant per op
     AND the chain decisions (separate launches / conv1x1 chain / chain led by the 3x3 conv, with their tile sizes) - into a
