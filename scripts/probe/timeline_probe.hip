@@ -21,6 +21,7 @@ __device__ unsigned long long* saber_tl_buf = nullptr;
 #include "../../anakin_amd/csrc/igemm_m0_e1.hip"
 #include "../../anakin_amd/csrc/igemm_m0_e2.hip"
 #include "../../anakin_amd/csrc/igemm_m3_e3.hip"
+#include "../../anakin_amd/csrc/igemm_m2_e3.hip"
 #include "../../anakin_amd/csrc/igemm_dma_m0_e1.hip"
 #include "../../anakin_amd/csrc/halo_e1.hip"
 #include "../../anakin_amd/csrc/stem_pool.hip"
@@ -201,6 +202,44 @@ int main(int argc, char** argv) {
             unsigned errs = 0;
             CK(hipMemcpy(&errs, ck.coop_err, 4, hipMemcpyDeviceToHost));
             printf("    coop error word: %u\n", errs);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "f32pw")) {
+        // FP32 pointwise layers of ResNet50's res2 / res3 at batch 8 (2.4 TB/s where streaming reaches 4 - 6.5): the implicit-GEMM kernel on the
+        // f32 MFMA (MODE 2) and on the bf16 planes (MODE 3), with and without the in-place sum. phases: 0 entry, 1 gather state set up, 2 first stage in LDS,
+        // 5 reduction loop done, 4 stored
+        struct P2 { const char* name; int mode, HW, C, K, tile, ks, sum; };
+        const P2 ps[] = {
+            {"f32 mfma   res2 64->256 @56 + sum in place  32x32 k2", 2, 56, 64, 256, TILE_32x32, 2, 1},
+            {"f32 mfma   res2 64->256 @56                 32x32 k2", 2, 56, 64, 256, TILE_32x32, 2, 0},
+            {"f32 mfma   res2 64->256 @56 + sum in place  64x64 k2", 2, 56, 64, 256, TILE_64x64, 2, 1},
+            {"f32 planes res2 64->256 @56 + sum in place  64x64 k1", 3, 56, 64, 256, TILE_64x64, 1, 1},
+            {"f32 mfma   res2 256->64 @56                 32x32 k2", 2, 56, 256, 64, TILE_32x32, 2, 0},
+            {"f32 planes res3 128->512 @28 + sum in place 64x64 k1", 3, 28, 128, 512, TILE_64x64, 1, 1},
+        };
+        for (const P2& g : ps) {
+            ConvKArgs a;
+            memset(&a, 0, sizeof a);
+            const int N = 8, kg = g.C, kgp = (kg + 63) / 64 * 64, kpad = (g.K + 127) / 128 * 128;
+            a.N = N; a.H = a.W = a.OH = a.OW = g.HW; a.C = g.C; a.K = g.K; a.kh = a.kw = 1;
+            a.stride_h = a.stride_w = a.dil_h = a.dil_w = 1;
+            a.M = N * g.HW * g.HW; a.Kg = kg; a.Kg_pad = kgp; a.epi = EPI_F32; a.out_dtype = DT_F32; a.relu = 1;
+            a.inv_ohw = 1.f / (g.HW * g.HW); a.inv_ow = 1.f / g.HW;
+            a.x = dalloc((size_t)a.M * g.C * 4, 0);
+            a.w = dalloc((size_t)(g.mode == 3 ? 3 * 2 : 4) * kpad * kgp + 65536, 0);
+            a.w_plane_chunks = (int)((size_t)kpad * kgp / 8);
+            a.zero = zero;
+            a.y = dalloc((size_t)a.M * g.K * 4, 0);
+            a.bias = (const float*)dalloc(2048 * 4, 0);
+            a.res_mode = g.sum ? RES_SUM_INPLACE : RES_NONE;
+            int bmk, bnp;
+            tile_dims(g.tile, &bmk, &bnp);
+            const int blocks = ((a.M + bnp - 1) / bnp) * ((g.K + bmk - 1) / bmk);
+            const int estage = (g.mode == 3 ? 32 : 16) * g.ks;
+            a.steps = (kg + estage - 1) / estage;
+            if (g.mode == 3) run(P, g.name, blocks, 6, [&] { launch_igemm_m3_e3(g.tile, g.ks, a, P.st); });
+            else run(P, g.name, blocks, 6, [&] { launch_igemm_m2_e3(g.tile, g.ks, a, P.st); });
         }
         return 0;
     }
