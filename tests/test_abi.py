@@ -55,6 +55,24 @@ def test_create_validates_without_gpu(built):
     assert built.saber_hip_pool_out_dim(224, 1, 3, 2, 0) == 113 - 0
 
 
+def test_executor_level_objects_validate_their_arguments_without_gpu(built):
+    """the fused-launch objects of round 4 (stem + pair, strided head + pair) refuse null / unset operators with a status, no device needed"""
+    import ctypes as C
+    h = C.c_void_p()
+    assert built.saber_hip_conv2d_stem_pair_create(None, None, None, C.byref(h)) == -2
+    assert built.saber_hip_conv2d_chain_create3_pair(None, None, None, None, C.byref(h)) == -2
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.c, d.k, d.kh, d.kw = 1, 16, 16, 64, 64, 1, 1
+    d.stride_h = d.stride_w = d.dil_h = d.dil_w = d.group = 1
+    d.in_dtype, d.out_dtype, d.in_layout, d.out_layout, d.int8_weights = L.U8, L.U8, L.NHWC, L.NHWC, 1
+    c = C.c_void_p()
+    assert built.saber_hip_conv2d_create(C.byref(d), C.byref(c)) == 0
+    assert built.saber_hip_conv2d_stem_pair_create(c, c, c, C.byref(h)) == -2      # not a fused stem conv + pooling, no weights
+    assert b"stem pair" in built.saber_hip_last_error()
+    assert built.saber_hip_conv2d_stem_pair_run(None, None, None, None, None, None, None) == -2
+    built.saber_hip_conv2d_destroy(c)
+
+
 def test_algorithm_selection_is_host_side(built):
     """create() picks the kernel family from shapes alone (no device needed)."""
     import ctypes as C
