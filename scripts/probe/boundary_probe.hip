@@ -13,6 +13,10 @@
 //      then READS the 4 KB of its right-hand neighbour on the same XCD with sc1 (L1-bypassing) loads and checks EVERY word.
 //      Reported: us per phase (host-paired over 200 phases), and the number of stale words seen (must be 0 to be usable).
 //      Variants: hand-off 0 / 4 KB / 32 KB; 'fenced' = the placement-independent protocol (release fence + acquire fence, agent).
+//  (3) round 4: the same persistent kernel with a DEVICE-wide barrier (what a weight-stationary res5 kernel would need between
+//      its convolutions): mode 3 = two levels (arrival on the XCD's counter, the XCD's first workgroup forwards one arrival to
+//      a global counter, polls it and releases its XCD through a local "go" word), mode 4 = flat (all 256 workgroups on one counter);
+//      release fence before the arrival, acquire after the release, and the 4 KB read is the buffer of a workgroup on the NEXT XCD.
 // Every spin is bounded (a stuck barrier sets a timeout word and the kernel ends).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/probe/boundary_probe.hip -o scripts/probe/boundary_probe.bin
@@ -126,9 +130,44 @@ __global__ __launch_bounds__(256) void xcd_barrier_kernel(const BarArgs a) {
     }
     __syncthreads();
     const unsigned n = s_n;
+    const bool dev = a.mode >= 3;       // device-wide barrier: read across XCDs (every XCD holds the same number of workgroups here)
     unsigned* mine = a.data + ((size_t)x * 64 + me) * a.words;
-    const unsigned* theirs = a.data + ((size_t)x * 64 + (me + 1) % n) * a.words;
+    const unsigned* theirs = dev ? a.data + ((size_t)((x + 1) & 7) * 64 + me % n) * a.words : a.data + ((size_t)x * 64 + (me + 1) % n) * a.words;
     unsigned* ctr = a.counters + x * 32;
+    unsigned* gctr = a.counters + 8 * 32;           // the global lines (modes 3, 4)
+    // one device-wide barrier (thread 0): `which` selects the counter set (0: data published, 1: readers done)
+    auto dev_barrier = [&](int ph, int which) {
+        unsigned* lc = ctr + which * 16;
+        unsigned* gc = gctr + which * 32;
+        unsigned* go = ctr + 8 + which * 16;
+        int spin = 0;
+        if (a.mode == 4) {
+            __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (load_sc1(gc) < (unsigned)ph * gridDim.x) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > 4000000) { atomicExch(a.timeout, 1u); break; }
+            }
+            return;
+        }
+        __hip_atomic_fetch_add(lc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (me == 0) {
+            while (load_sc1(lc) < (unsigned)ph * n) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > 4000000) { atomicExch(a.timeout, 1u); break; }
+            }
+            __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (load_sc1(gc) < (unsigned)ph * 8u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > 4000000) { atomicExch(a.timeout, 1u); break; }
+            }
+            __hip_atomic_store(go, (unsigned)ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (load_sc1(go) < (unsigned)ph) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > 4000000) { atomicExch(a.timeout, 1u); break; }
+            }
+        }
+    };
     unsigned bad = 0;
     __shared__ unsigned s_abort;
     if (me >= 64) {      // more workgroups on one XCD than the hand-off area holds: give up cleanly (the others time out)
@@ -145,12 +184,25 @@ __global__ __launch_bounds__(256) void xcd_barrier_kernel(const BarArgs a) {
             if (a.mode == 1) __hip_atomic_store(&mine[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else mine[w] = v;
         }
-        if (a.mode == 2) {
+        if (a.mode >= 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (dev) {
+            if (threadIdx.x == 0) {
+                dev_barrier(ph, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            for (int w = threadIdx.x; w < a.words; w += 256) bad += theirs[w] != (unsigned)ph * 0x10001u + (unsigned)w;
+            __syncthreads();
+            if (threadIdx.x == 0) dev_barrier(ph, 1);
+            __syncthreads();
+            continue;
+        }
         // arrive + wait: monotonic counter, n arrivals per phase
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -226,10 +278,11 @@ int main() {
     // (2) XCD-local barrier
     printf("# (2) XCD-local barrier + hand-off, persistent kernel, one 256-thread workgroup per CU (grid %d), 200 phases\n", prop.multiProcessorCount);
     const int grid = prop.multiProcessorCount;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
+        if (mode == 3) printf("# (3) DEVICE-wide barrier + hand-off across XCDs, same kernel: two-level / flat\n");
         for (int words : {0, 1024, 8192}) {
             BarArgs a;
-            CK(hipMalloc(&a.counters, 8 * 32 * 4));
+            CK(hipMalloc(&a.counters, 10 * 32 * 4));
             CK(hipMalloc(&a.slot, 32));
             CK(hipMalloc(&a.stale, 4));
             CK(hipMalloc(&a.timeout, 4));
@@ -242,7 +295,7 @@ int main() {
             const int phases[2] = {20, 220};
             for (int r = 0; r < 2; ++r) {        // host-paired: (220 phases) - (20 phases) = 200 phases
                 a.phases = phases[r];
-                CK(hipMemsetAsync(a.counters, 0, 8 * 32 * 4, st));
+                CK(hipMemsetAsync(a.counters, 0, 10 * 32 * 4, st));
                 CK(hipMemsetAsync(a.slot, 0, 32, st));
                 CK(hipMemsetAsync(a.stale, 0, 4, st));
                 CK(hipMemsetAsync(a.timeout, 0, 4, st));
@@ -265,7 +318,8 @@ int main() {
                 CK(hipMemcpy(hist, a.xcd_hist, 32, hipMemcpyDeviceToHost));
             }
             printf("%-34s hand-off %5d B: %.2f us per phase (two arrivals per phase), stale words %u%s; workgroups per XCD %u %u %u %u %u %u %u %u\n",
-                   mode == 0 ? "plain stores + vmcnt(0), sc1 loads" : (mode == 1 ? "sc1 stores, sc1 loads" : "release / acquire fences (agent)"),
+                   mode == 0 ? "plain stores + vmcnt(0), sc1 loads" : (mode == 1 ? "sc1 stores, sc1 loads" : (mode == 2 ? "release / acquire fences (agent)" :
+                   (mode == 3 ? "device-wide, two levels, fences" : "device-wide, one counter, fences"))),
                    words * 4, (us[1] - us[0]) / 200.0, stale, tmo ? "  [TIMEOUT]" : "", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
             CK(hipFree(a.counters)); CK(hipFree(a.slot)); CK(hipFree(a.stale)); CK(hipFree(a.timeout)); CK(hipFree(a.xcd_hist)); CK(hipFree(a.data));
         }
