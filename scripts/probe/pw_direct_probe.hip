@@ -593,7 +593,7 @@ static void run_case(const char* name, int M, int K, double product_us, hipStrea
     // tiles 9: the LDS form (pw_lds) with d groups in flight
     // tiles 8: pw_asm (C = 64 only)
     // tiles 7: pw_tr (full-line accesses through wave-private LDS, C = 64 only)
-    const V vs[] = {{0, 0, 0}, {4, 1, 1}, {8, 1, 1}, {7, 1, 1}, {7, 2, 1}, {7, 1, 2}, {7, 2, 2}};
+    const V vs[] = {{0, 0, 0}, {4, 1, 1}, {4, 1, 2}, {2, 2, 1}, {2, 2, 2}, {9, 1, 1}, {9, 2, 1}, {8, 1, 1}, {8, 2, 1}, {7, 1, 1}, {7, 2, 1}, {7, 1, 2}, {7, 2, 2}};
     for (const V& v : vs)
     for (int sum = 1; sum >= 0; --sum) {
         if (C == 128 && (v.tiles == 4 || v.tiles == 8 || v.tiles == 7)) continue;       // (192 weight registers)
