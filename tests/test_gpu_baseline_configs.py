@@ -4,10 +4,12 @@ at batch 4 / 8 - img3x3_i8_2img_x_4rows, 128x128 w8 split4, 256x128 tiles ...).
 
 The OpenMP C oracle (oracle/saber_oracle.c through oracle/net_oracle.py) evaluates a whole batch-8 ResNet50 INT8 pass in a few
 seconds, so these are plain oracle comparisons of the FULL batch, not batch-invariance properties:
-  * ResNet50 INT8, the list the reference's optimiser emits (workloads.framework_spec), batch 4 and 8: every edge the executor
-    materialises, every image, bit-exact; eager and hipGraph replay;
+  * ResNet50 INT8, the list the reference's optimiser emits (workloads.framework_spec), batch 1 / 2 / 4 / 8: every edge the executor
+    materialises, every image, bit-exact; eager and hipGraph replay - once Python-fused with a fresh autotune, once EXACTLY as the
+    driver's `python bench.py` runs it (round-4 verdict, weak 1): the unfused list fused by the C++ host side (cxx_optimize) with the
+    committed profiles/tune.json selection for this source hash (bench.tune_key), stage launch and stem pair on;
   * ResNet101 INT8 batch 8: the same;
-  * ResNet50 FP32 batch 4 / 8 and VGG16 FP32 batch 8: every logical edge of every image within 1e-4 on both criteria of
+  * ResNet50 FP32 batch 1 / 2 / 4 / 8 and VGG16 FP32 batch 8: every logical edge of every image within 1e-4 on both criteria of
     tests/test_gpu_resnet.py (max-norm and element-wise with the tensor's mean magnitude as the floor).
 Reference contracts: saber/funcs/impl/x86/gemm_x8s8s32x_conv.cpp:187-288 (INT8), test/saber/conv_func_helper.h:196-264 (FP32)."""
 import numpy as np
@@ -28,16 +30,52 @@ def _h(t):
     return t.cpu().numpy()
 
 
-def _int8_every_edge(name, batch, min_edges):
+def _bench_args(model="resnet50", precision="int8"):
+    """bench.py's defaults as the namespace its tune_key() reads: the key of the configuration the driver's plain `python bench.py` times"""
+    import types
+    return types.SimpleNamespace(model=model, precision=precision, graph="framework", no_fuse=False, lanes=False, chain=None, py_fuse=False,
+                                 no_stage=False, no_stem_pair=False, head_pair=False)
+
+
+def _apply_committed_selection(net, name, batch):
+    """profiles/tune.json's entry for this configuration AND these sources (bench.tune_key), applied the way bench.tune() does;
+    returns "cache", or "autotune" after tuning here when the committed file has no entry for the current source hash"""
+    import json
+    import os
+    import warnings
+    import bench
+    key = bench.tune_key(_bench_args(name), batch, L)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tune.json")
+    cache = json.load(open(path)) if os.path.exists(path) else {}
+    if cache.get(key) and len(cache[key]) == net.num_ops():
+        net.set_choices(cache[key])
+        return "cache"
+    warnings.warn("profiles/tune.json holds NO selection for %s (source hash %s): csrc/ or workloads.py changed after the last "
+                  "`scripts/profile_r05.sh` - the driver's bench will autotune instead of applying the committed selection; "
+                  "this test autotunes too" % (key, L.source_sha()))
+    net.autotune(iters=3)
+    return "autotune"
+
+
+def _int8_every_edge(name, batch, min_edges, driver_config=False):
     L.require_device()
     model = W.framework_model(W.build_model(name), "int8")
     x = W.make_input(batch, hw=224)
-    scales = W.calibrate(model, x[:2])
+    scales = W.calibrate(model, W.make_input(2) if driver_config else x[:2])      # (bench.py calibrates on make_input(2))
     ref = NO.run_int8(model, dict(scales), x)
-    net = W.build_int8_net(model, dict(scales), batch)
+    if driver_config:
+        # exactly bench.build_net's call: the list handed over UNFUSED, fused by the C++ host side (saber_hip_net_optimize), the res4
+        # stage launch and the stem pair on
+        net = W.build_int8_net(model, dict(scales), batch, fuse_eltwise=True, lanes=False, chain=None, cxx_optimize=True, stage=True,
+                               stem_pair=True, head_pair=False)
+    else:
+        net = W.build_int8_net(model, dict(scales), batch)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
-    net.autotune(iters=3)                      # RUNTIME strategy on the real tensors: what bench.py times
+    if driver_config:
+        net.selection = _apply_committed_selection(net, name, batch)
+    else:
+        net.autotune(iters=3)                  # RUNTIME strategy on the real tensors: what bench.py times
     names = [net.op_name(i) for i in range(net.num_ops())]
     for form in ("eager", "graph"):
         for nm in net.tensors:
@@ -98,11 +136,22 @@ def _int8_every_edge(name, batch, min_edges):
     return net
 
 
-@pytest.mark.parametrize("batch", [4, 8])
+@pytest.mark.parametrize("batch", [1, 2, 4, 8])
 def test_resnet50_int8_framework_list_autotuned_every_edge_every_image(batch):
     net = _int8_every_edge("resnet50", batch, 40)
     print("ResNet50 INT8 batch %d: %d ops in %d launches, bit-exact on every materialised edge" % (batch, net.num_ops(), net.num_launches()))
     assert net.stage_count == 2      # res3: three 3x3-led chains feeding each other (C = 128), res4: five (C = 256)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 4, 8])
+def test_resnet50_int8_exactly_what_the_driver_times(batch):
+    """Round-4 verdict, weak 1: BENCH runs the C++-fused list (cxx_optimize) with the COMMITTED profiles/tune.json selection
+    (kernel_selection "cache"), and the batch-1 leg with ITS entry (the stage launch on one XCD); this is that configuration, every
+    materialised edge of every image against the oracle, eager and hipGraph, stage on and off."""
+    net = _int8_every_edge("resnet50", batch, 40, driver_config=True)
+    print("ResNet50 INT8 batch %d, C++-fused, selection: %s: %d ops in %d launches, bit-exact on every materialised edge"
+          % (batch, net.selection, net.num_ops(), net.num_launches()))
+    assert net.stage_count == 2
 
 
 def test_resnet101_int8_batch8_autotuned_every_edge_every_image():
@@ -146,7 +195,7 @@ def _fp32_every_edge_autotuned(name, batch, min_edges):
     print("%s FP32 batch %d autotuned: %d edges, worst max-norm %.2e, worst element-wise %.2e" % (name, batch, checked, worst_max, worst_el))
 
 
-@pytest.mark.parametrize("batch", [4, 8])
+@pytest.mark.parametrize("batch", [1, 2, 4, 8])
 def test_resnet50_fp32_autotuned_every_edge_every_image(batch):
     _fp32_every_edge_autotuned("resnet50", batch, 56)
 
