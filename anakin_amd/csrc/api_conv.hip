@@ -120,6 +120,7 @@ bool xcd_round_robin() {
 bool split_ok(const saber_hip_conv* op, int tile, int ks, int sh) {
     if (sh == 0) return true;
     if (sh < 0 || sh > 3 || !b3_tile_ok(op, tile, ks)) return false;
+    if (op->no_placement) return false;      // a net that shares its device: the splits' common XCD is a dispatch property of an idle GPU
     const int steps = (op->Kg + 32 * ks - 1) / (32 * ks);
     if ((steps >> sh) < 2) return false;
     const size_t m = (size_t)op->d.n * op->oh * op->ow;

@@ -136,6 +136,7 @@ struct GemmPlan {
     saber_hip_conv* op = nullptr;
     DevBuf<float> a_t;           // trans_a: A transposed to [m][k]
     unsigned long long stamp = 0;
+    bool pinned = false;         // a hipGraph captured on `stream` holds this plan's buffers: never evicted, never matched by eager calls
     ~GemmPlan() {
         if (op) saber_hip_conv2d_destroy(op);
     }
@@ -193,22 +194,40 @@ int build_plan(GemmPlan* p) {
     return SABER_HIP_OK;
 }
 
-GemmPlan* find_plan(int dev, hipStream_t s, int ta, int tb, int m, int n, int k, int sum, int* rc) {
+// A plan's device buffers (weight planes, transpose scratch) are what a launch reads, so their lifetime is the caller-visible part of
+// this "stateless" entry point (round-4 advisor finding):
+//   * a call made while `s` is CAPTURING takes the plan an earlier eager call of the same key built and PINS it: the graph keeps the
+//     pointers, so the plan is never evicted and no eager call uses it again (an eager call of that key builds a fresh one - a replay
+//     and an eager launch would otherwise race on the plane buffer). With no such plan the call does not fail: *stateless = true and the
+//     caller records the f32-MFMA kernel, which owns nothing (nothing may be allocated under capture);
+//   * eviction (least recently used, unpinned only) drains the plan's stream first;
+//   * saber_hip_gemm_f32_release_plans() frees the calling thread's plans (pinned ones too: the caller says its graphs are gone).
+GemmPlan* find_plan(int dev, hipStream_t s, int ta, int tb, int m, int n, int k, int sum, int* rc, bool* stateless) {
     if (!g_plans) g_plans = new std::vector<GemmPlan*>();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    GemmPlan* pinned_match = nullptr;
     for (GemmPlan* p : *g_plans)
         if (p->dev == dev && p->stream == s && p->ta == ta && p->tb == tb && p->m == m && p->n == n && p->k == k && p->sum == sum) {
+            if (p->pinned) {
+                pinned_match = p;
+                continue;
+            }
+            if (capturing) p->pinned = true;
             p->stamp = ++g_stamp;
             return p;
         }
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-        *rc = fail(SABER_HIP_INVALID_VALUE, "saber_hip_gemm_f32: the first call of a shape allocates its plan - run it once outside stream capture");
+    if (capturing) {
+        if (pinned_match) return pinned_match;      // a second capture of the same key on this stream: the same graph-owned plan
+        *stateless = true;
         return nullptr;
     }
-    if (g_plans->size() >= kMaxPlans) {      // evict the least recently used (its device buffers are idle: the stream is drained first)
-        size_t lru = 0;
-        for (size_t i = 1; i < g_plans->size(); ++i)
-            if ((*g_plans)[i]->stamp < (*g_plans)[lru]->stamp) lru = i;
+    size_t unpinned = 0;
+    for (GemmPlan* p : *g_plans) unpinned += p->pinned ? 0 : 1;
+    if (unpinned >= kMaxPlans) {      // evict the least recently used (its device buffers are idle: the stream is drained first)
+        size_t lru = g_plans->size();
+        for (size_t i = 0; i < g_plans->size(); ++i)
+            if (!(*g_plans)[i]->pinned && (lru == g_plans->size() || (*g_plans)[i]->stamp < (*g_plans)[lru]->stamp)) lru = i;
         (void)hipStreamSynchronize((*g_plans)[lru]->stream);
         delete (*g_plans)[lru];
         g_plans->erase(g_plans->begin() + lru);
@@ -251,7 +270,12 @@ int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const f
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     int rc = SABER_HIP_OK;
-    GemmPlan* p = find_plan(dev, s, ta, tb, m, n, k, beta != 0.f ? 1 : 0, &rc);
+    bool stateless = false;
+    GemmPlan* p = find_plan(dev, s, ta, tb, m, n, k, beta != 0.f ? 1 : 0, &rc, &stateless);
+    if (stateless) {      // first sight of this shape while the stream is capturing: the kernel that owns no device state
+        HIP_TRY(launch_gemm_f32(ta, tb, m, n, k, alpha, a, b, beta, c, s));
+        return SABER_HIP_OK;
+    }
     if (!p) return rc;
     saber_hip_conv* op = p->op;
     // W = alpha * op(B)^T as three bf16 planes [3][K_pad][Kg_pad] (the padding stays zero from the plan's allocation)
@@ -269,4 +293,16 @@ int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const f
     }
     if (beta != 0.f && beta != 1.f) HIP_TRY(launch_eltwise_sum_f32((size_t)m * n, c, c, 0.5f * beta, 0.5f * beta, 0, c, s));
     return saber_hip_conv2d_run(op, x, c, nullptr, nullptr, s);
+}
+
+int saber_hip_gemm_f32_release_plans(void) {
+    if (!g_plans) return 0;
+    int n = 0;
+    for (GemmPlan* p : *g_plans) {
+        (void)hipStreamSynchronize(p->stream);
+        delete p;
+        ++n;
+    }
+    g_plans->clear();
+    return n;
 }

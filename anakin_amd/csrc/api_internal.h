@@ -107,6 +107,7 @@ struct saber_hip_conv {
     int gpool = 0;           // ... with the global average pooling of its output fused (saber_hip_net_optimize flag 128): img1 only
     struct saber_hip_stage* img_stage = nullptr;   // the single-phase descriptor + repacked weights of that kernel (img_conv_prepare)
     int ksplit = 0;          // b3 only: log2 of the split-K factor (conv_igemm_impl.h: splits of one tile share an XCD), 0: none
+    bool no_placement = false;   // the op belongs to a net that does NOT own the device (saber_hip_net_optimize flag 2048): no split-K through one XCD's L2
     int b3 = 0;              // FP32: 1 = the implicit GEMM runs on the bf16 matrix cores (three bf16 operand planes, conv_igemm_impl.h
                              // MODE 3): needs c_eff % 8 == 0 and the pre-split weight planes d_w3
     int img_ib = 0, img_rb = 0, img_nw = 4;   // img_rb > 0: small-image 3x3 kernel (conv3x3_img.h): images / output rows
@@ -396,6 +397,12 @@ struct saber_hip_net {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool finalized = false;
+    // saber_hip_net_optimize flag 2048: other streams / processes run kernels on this device while the net does. Kernel variants whose
+    // SPEED or completion depends on where the hardware places workgroups relative to each other - the persistent stage launch (needs
+    // every workgroup of an image resident on its XCD at once), the cooperating-workgroup chains (tile codes 7 / 15), FP32 split-K
+    // through one XCD's L2 - are then never selected: not statically, not by the autotuner, not from a restored selection.
+    bool shared_device = false;
+    int coop_fallbacks = 0;   // cooperative launches that reported a failed pass (saber_hip_net_status), since the net was created
     // two-lane execution: independent branches (ResNet branch1 vs branch2a/2b) run on a side stream
     hipStream_t side = nullptr;
     hipEvent_t ev_start = nullptr, ev_join = nullptr;

@@ -1,6 +1,9 @@
 // anakin_amd/csrc/api_net.hip - the op-list executor (saber_hip_net_*): arena, two lanes, hipGraph capture / replay, timing.
 #include "api_internal.h"
 
+#include <atomic>
+static std::atomic<int> g_coop_fallbacks_total{0};      // every net of the process (saber_hip_coop_fallbacks_total)
+
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     auto T = [&](int id) -> void* { return net->ptr(id); };
     void* ws = net->arena + net->ws_off;
@@ -17,6 +20,8 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
             }
             const int rc = stage_run(o.stage, T(o.in), T(o.chain3_res), y1, y2, s);
             if (rc == SABER_HIP_RUNTIME_ERROR) {      // an earlier launch of it timed out (conv_stage_coop.hip): block by block from now on
+                ++net->coop_fallbacks;
+                ++g_coop_fallbacks_total;
                 net_set_stage(net, (int)(&o - net->ops.data()), false);
                 if (net->exec) {      // (the captured graph holds the stage launch)
                     (void)hipGraphExecDestroy(net->exec);
@@ -28,8 +33,14 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
             return rc;
         }
         if (o.stem_pair) return saber_hip_conv2d_stem_pair_run(o.stem_pair, T(o.in), nullptr, T(o.stem_y1), T(o.stem_y2), ws, s);
-        if (o.chain3 && o.use_chain3)
-            return saber_hip_conv2d_chain_run3(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), T(o.chain3_y3), s);
+        if (o.chain3 && o.use_chain3) {
+            const int rc = saber_hip_conv2d_chain_run3(o.chain3, T(o.in), T(o.chain3_res), T(o.chain3_y1), T(o.chain3_y2), T(o.chain3_y3), s);
+            if (rc == SABER_HIP_RUNTIME_ERROR) {      // (a cooperating-workgroup chain reporting its failed earlier launch)
+                ++net->coop_fallbacks;
+                ++g_coop_fallbacks_total;
+            }
+            return rc;
+        }
         if (o.chain && o.use_chain) return saber_hip_conv2d_chain_run(o.chain, T(o.in), T(o.in2), T(o.out), T(o.chain_out), s);
         if (o.conv->gpool) return saber_hip_conv2d_run_gpool(o.conv, T(o.in), T(o.out), T(o.in2), T(o.out2), s);
         return saber_hip_conv2d_run(o.conv, T(o.in), T(o.out), T(o.in2), ws, s);
@@ -360,27 +371,47 @@ int saber_hip_net_run_op(saber_hip_net_t* net, int index, saber_hip_stream_t str
     if (!net->finalized || index < 0 || index >= (int)net->ops.size()) return fail(SABER_HIP_INVALID_VALUE, "bad op index");
     return net_launch(net, net->ops[index], (hipStream_t)stream);
 }
+static bool net_coop_error_pending(const saber_hip_net* net) {      // host reads of the sites' pinned error words: a few nanoseconds each
+    for (const NetOp& o : net->ops) {
+        if (o.stage && o.stage->h_err && *(volatile unsigned*)o.stage->h_err) return true;
+        if (const saber_hip_chain* ch = o.chain3)
+            if ((ch->h_coop_err && *(volatile unsigned*)ch->h_coop_err) || (ch->stage1 && ch->stage1->h_err && *(volatile unsigned*)ch->stage1->h_err))
+                return true;
+    }
+    return false;
+}
 int saber_hip_net_capture(saber_hip_net_t* net, saber_hip_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (net->exec) {
-        (void)hipGraphExecDestroy(net->exec);
-        (void)hipGraphDestroy(net->graph);
-        net->exec = nullptr;
-        net->graph = nullptr;
-    }
+    if (net->exec) (void)hipGraphExecDestroy(net->exec);
+    if (net->graph) (void)hipGraphDestroy(net->graph);
+    net->exec = nullptr;
+    net->graph = nullptr;
+    // a cooperative launch of an EARLIER pass that failed is dealt with before anything is recorded (the sites fall back, the caller
+    // hears about it): inside the capture the site's own check would switch kernels while the stream is capturing
+    if (net_coop_error_pending(net)) return saber_hip_net_status(net);
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = saber_hip_net_run(net, stream);
     hipError_t e = hipStreamEndCapture(s, &net->graph);
-    if (rc) return rc;
-    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-    HIP_TRY(hipGraphInstantiate(&net->exec, net->graph, nullptr, nullptr, 0));
-    return SABER_HIP_OK;
+    if (rc == SABER_HIP_OK && e != hipSuccess) rc = hip_fail(e, "hipStreamEndCapture");
+    if (rc == SABER_HIP_OK && (e = hipGraphInstantiate(&net->exec, net->graph, nullptr, nullptr, 0)) != hipSuccess) rc = hip_fail(e, "hipGraphInstantiate");
+    if (rc != SABER_HIP_OK) {      // no half-built graph survives a failed capture
+        if (net->exec) (void)hipGraphExecDestroy(net->exec);
+        if (net->graph) (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
+    return rc;
 }
 int saber_hip_net_replay(saber_hip_net_t* net, saber_hip_stream_t stream) {
     if (!net->exec) return fail(SABER_HIP_INVALID_VALUE, "net not captured");
+    // an eager launch of a cooperative site checks its error word itself (stage_run, chain_run3); a graph node cannot: a failed earlier
+    // pass is reported here, before the next one is launched (saber_hip_net_status: the sites fall back, the graph is dropped)
+    if (net_coop_error_pending(net)) return saber_hip_net_status(net);
     HIP_TRY(hipGraphLaunch(net->exec, (hipStream_t)stream));
     return SABER_HIP_OK;
 }
+int saber_hip_net_coop_fallbacks(const saber_hip_net_t* net) { return net ? net->coop_fallbacks : 0; }
+int saber_hip_coop_fallbacks_total(void) { return g_coop_fallbacks_total.load(); }
 // Algorithmic work of ONE launch of op `index` (every tensor touched once — input, output, residual — plus the
 // weights once; MACs x 2), summed over the operators the launch covers (a chain head reports its followers' work too, the
 // followers report 0). Streaming ops: bytes only.
@@ -557,6 +588,8 @@ int saber_hip_net_status(saber_hip_net_t* net) {
         }
     }
     if (!bad) return SABER_HIP_OK;
+    net->coop_fallbacks += bad;
+    g_coop_fallbacks_total += bad;
     net_drop_graph(net);
     return fail(SABER_HIP_RUNTIME_ERROR, "a cooperative launch of the last pass did not complete (workgroups on different XCDs, or a hand-off "
                 "timed out: another kernel held the CUs); its outputs are not valid - those sites now launch block by block: run the pass again");

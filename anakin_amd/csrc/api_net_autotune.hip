@@ -29,9 +29,13 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     saber_hip_conv* c = net_op_conv(net, index);
     if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
     if (net->ops[index].kind == OP_CONV_PAIR && index > 0 && net->ops[index - 1].stem_pair) return SABER_HIP_OK;      // no kernel of its own (flag 512)
-    const int chain_bits = (choice >> 24) & 63;
-    const bool stage_on = (choice >> 30) & 1;
+    int chain_bits = (choice >> 24) & 63;
+    const bool stage_on = ((choice >> 30) & 1) && !net->shared_device;
     choice &= 0xffffff;
+    if (net->shared_device) {      // a selection tuned on a net that owned its device: placement-dependent variants are mapped to their plain forms
+        if (((choice >> 16) & 0xff) == 11) choice &= ~(0xf << 12);                           // bf16-plane kernel: split-K off
+        if ((chain_bits & 15) == 7 || (chain_bits & 15) == 15) chain_bits = (chain_bits & ~15) | 3;   // cooperating chains -> one workgroup per tile, 8 waves
+    }
     int rc = choice ? saber_hip_conv2d_set_tile(c, choice) : SABER_HIP_OK;
     if (rc) return rc;
     NetOp& o = net->ops[index];
@@ -225,6 +229,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
             saber_hip_chain* ch = mode == 2 ? H->chain3 : A.chain;
             for (int tn : tns) {
                 if (!tn) continue;
+                if (net->shared_device && (tn == 7 || tn == 15)) continue;      // cooperating workgroups: not on a shared device
                 float ms = 0.f;
                 if (saber_hip_conv2d_chain_set_tile(ch, tn) != SABER_HIP_OK) continue;
                 net_set_chain_mode(net, ia, mode);
@@ -240,7 +245,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
     // stages: the blocks' tuned launches one after the other against the one persistent launch
     for (size_t i = 0; i < net->ops.size(); ++i) {
         NetOp& H0 = net->ops[i];
-        if (!H0.stage) continue;
+        if (!H0.stage || net->shared_device) continue;
         const int first = (int)i, last = first + 3 * H0.stage_n - 1;
         hipStream_t s = (hipStream_t)stream;
         auto run_all = [&]() -> int {

@@ -100,6 +100,11 @@ static int clone_conv_i8(const saber_hip_conv* src, const saber_hip_conv_desc& d
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
     if (!net) return fail(SABER_HIP_INVALID_VALUE, "null argument");
     if (net->finalized) return fail(SABER_HIP_INVALID_VALUE, "optimize must run before finalize");
+    if (flags & 2048) {      // the net does not own the device: decided HERE, at selection time, not when a launch has failed
+        net->shared_device = true;
+        flags &= ~256;       // no persistent stage launch
+    }
+    if (net->shared_device) flags &= ~256;
     std::vector<NetOp>& ops = net->ops;
     const int nt = (int)net->tensor_bytes.size();
     std::vector<char> dead(ops.size(), 0);
@@ -450,6 +455,17 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
                 }
             }
             i += 3 * run.size();
+        }
+    }
+    if (net->shared_device) {      // no variant that relies on workgroup placement: split-K off, cooperating chains back to one workgroup per tile
+        for (NetOp& o : ops) {
+            saber_hip_conv* c = (o.kind == OP_FC || o.kind == OP_FC_Q) ? (o.fc ? o.fc->conv : nullptr) : o.conv;
+            if (c) {
+                c->no_placement = true;
+                if (c->ksplit) { c->ksplit = 0; name_algo(c); }
+            }
+            for (saber_hip_chain* ch : {o.chain, o.chain3})
+                if (ch && (ch->tn == 7 || ch->tn == 15)) (void)saber_hip_conv2d_chain_set_tile(ch, 3);
         }
     }
     // the shared workspace only has to cover the surviving ops

@@ -14,9 +14,11 @@
 // (each half's weight stream is packed with its own k-steps first; integer sums: the order cannot change a bit)
 // The two workgroups of a tile are 8 apart in the grid = the same XCD (the placement api_conv.hip: xcd_round_robin verifies once
 // per device; each half also publishes its XCC_ID and the pair compares them), so the hand-off needs no L2 write-back: plain
-// stores, s_waitcnt vmcnt(0), one relaxed agent-scope atomic on the pair's counter, a spin on SCALAR loads (they do not queue
-// behind the wave's weight loads), buffer_inv sc1, plain loads - the protocol profiles/r03/boundary_probe.txt measured at 0.9 us
-// for 32 workgroups. Every tile's counters (and XCC words) sit in 128-byte lines of their own - tiles t .. t + 7 of a group run on
+// stores, s_waitcnt vmcnt(0), one relaxed WORKGROUP-scope atomic on the pair's counter (it executes in this XCD's L2; an agent-scope
+// one is performed beyond it: 1.6 us per arrival), a spin on SCALAR loads (they do not queue behind the wave's weight loads), then
+// sc1 LOADS of the partner's data (they miss the L1 and hit the L2) - NOT `buffer_inv sc1` + plain loads as in round 3: that
+// device-scope invalidate also drops the XCD's L2 (coop_sync.h). The barrier itself is the protocol profiles/r03/boundary_probe.txt
+// measured at 0.9 us for 32 workgroups. Every tile's counters (and XCC words) sit in 128-byte lines of their own - tiles t .. t + 7 of a group run on
 // eight different XCDs, whose L2s are not coherent with each other: with the counters packed, eight L2s fought over one line and the
 // launch took 37 us instead of 12. Counters are never reset: an arrival adds 1, the first of a pair waits for the value to become even again.
 // Both workgroups of a pair are dispatched back to back on one XCD, so a waiting workgroup's partner always gets a slot; a spin

@@ -343,20 +343,23 @@ __global__ __launch_bounds__(512) void conv_stage4_c256_kernel(const Stage4KArgs
             // ============= between two blocks: the next halo = the y2 rows of this tile and of the tiles above and below it ==============
             // One counter per EDGE between two tile rows of the image (tiles_x = 1): every workgroup of the two tiles at an edge arrives there
             // when its y2 stores are in the L2 (8 arrivals; 4 at the image's top and bottom edge, where one tile takes part), and its
-            // wave 0 waits at the tile's two edges - a barrier among participants only (the counters are never reset: multiples of 8 / 4),
+            // wave 0 waits at the tile's two edges (both polled in ONE loop) - a barrier among participants only (the counters are never reset: multiples of 8 / 4),
             // no image-wide skew. (One arrival and one poller per WORKGROUP: with every wave arriving and polling, 64 waves spinning on
             // the line the atomics go to made the five-block launch 71 us instead of 54.) Then the halo by sc1 DMA.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                // (every wave is also done with this block's constants)
+            // The counter of an edge alternates with the block's PARITY (two words of the edge's line): arrival is unconditional and comes before
+            // the wait, so with ONE word a tile row running a block ahead - the dependency structure allows rows two apart to be two blocks
+            // apart - could re-arrive at a shared edge before this row had sampled it at its multiple of 8, and the mask test would never pass
+            // (round-4 advisor finding). A row cannot reach block k + 2's arrival before its neighbour has PASSED block k's wait (its block
+            // k + 1 needs the neighbour's block-k + 1 rows), so the word of block k's parity stays at its multiple until everybody has seen it.
+            unsigned long long* const e_k = e_up + (k & 1);
             if (wave == 0 && lane == 0) {
-                (void)__hip_atomic_fetch_add(e_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                (void)__hip_atomic_fetch_add(e_up + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(e_k, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(e_k + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             dma_prm(Bn);                                                 // (the next block's: nothing to wait for)
-            if (wave == 0) {
-                coop_wait_mask(e_up, ty > 0 ? 7ull : 3ull, ka.err);
-                coop_wait_mask(e_up + 16, ty + 1 < ka.tiles_per_img ? 7ull : 3ull, ka.err);
-            }
+            if (wave == 0) coop_wait_mask2(e_k, ty > 0 ? 7ull : 3ull, e_k + 16, ty + 1 < ka.tiles_per_img ? 7ull : 3ull, ka.err);
             __builtin_amdgcn_s_barrier();
             dma_halo(ka.y2[k], true);
             wait_vm_older_than<0>();
@@ -601,15 +604,15 @@ __global__ __launch_bounds__(512) void conv_stage1_c128_kernel(const Stage4KArgs
             // ============= between two blocks: the edge barriers of conv_stage4_c256_kernel, tiles_x workgroups per tile row ================
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                // (every wave is also done with this block's constants)
+            unsigned long long* const e_k = e_up + (k & 1);              // (one word per block parity: see conv_stage4_c256_kernel)
             if (wave == 0 && lane == 0) {
-                (void)__hip_atomic_fetch_add(e_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                (void)__hip_atomic_fetch_add(e_up + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(e_k, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(e_k + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             dma_prm(Bn);
             if (wave == 0) {
                 const unsigned long long one = (unsigned long long)ka.tiles_x;     // arrivals at an edge: tiles_x per tile row
-                coop_wait_mask(e_up, (ty > 0 ? 2 * one : one) - 1, ka.err);
-                coop_wait_mask(e_up + 16, (ty + 1 < tile_rows ? 2 * one : one) - 1, ka.err);
+                coop_wait_mask2(e_k, (ty > 0 ? 2 * one : one) - 1, e_k + 16, (ty + 1 < tile_rows ? 2 * one : one) - 1, ka.err);
             }
             __builtin_amdgcn_s_barrier();
             dma_halo(ka.y2[k], true);

@@ -64,6 +64,25 @@ __device__ __forceinline__ void coop_wait_mask(const unsigned long long* ctr, un
     }
 }
 
+// Two counters in one loop (the stage kernels' edge barriers: the edge above and the edge below a tile row): each is latched when it is
+// first seen at its multiple, so neither sample can be missed while the other is still being waited for.
+__device__ __forceinline__ void coop_wait_mask2(const unsigned long long* a, unsigned long long mask_a, const unsigned long long* b,
+                                                unsigned long long mask_b, unsigned* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's own arrivals have been PERFORMED before it looks at the counters
+    int spins = 0;
+    bool da = false, db = false;
+    for (;;) {
+        if (!da) da = (coop_sload(a) & mask_a) == 0ull;
+        if (!db) db = (coop_sload(b) & mask_b) == 0ull;
+        if (da && db) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 200000) {                          // ~20 ms: give up loudly (see the file header)
+            if (err && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
 // LDS-DMA of 16 bytes per lane with sc1: misses this CU's L1 and reads the XCD's L2 - what another workgroup of the XCD stored earlier
 __device__ __forceinline__ void lds_dma16_l2(const void* src, void* dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

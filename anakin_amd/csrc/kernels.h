@@ -190,7 +190,7 @@ struct Stage4KArgs {
     const void* zero;                  // >= 16 zero bytes
     const StageBlk* blk;
     unsigned long long* grp_ctr;       // [tiles][32]: a tile's two hand-off counters (words 0 and 16), a 256-byte pair of lines per tile
-    unsigned long long* img_ctr;       // [images][tiles per image + 1][16]: one counter (its own 128-byte line) per edge between two tile rows
+    unsigned long long* img_ctr;       // [images][tiles per image + 1][16]: one 128-byte line per edge between two tile rows; words 0 / 1 = the counters of even / odd blocks
     void* xch;                         // [tiles][32 pixels][256]: the 3x3 conv's 8-bit output tile
     unsigned* xcc;                     // [tiles][32]: words 0..3 = the XCD each quarter ran on
     unsigned* err;                     // host-visible word: placement violations / barrier time-outs are counted here

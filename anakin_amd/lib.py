@@ -34,13 +34,13 @@ SYMBOLS = [
     "saber_hip_conv2d_set_global_pooling", "saber_hip_conv2d_run_gpool",
     "saber_hip_stage_create", "saber_hip_stage_num_tensors", "saber_hip_stage_run", "saber_hip_stage_status", "saber_hip_stage_trace", "saber_hip_stage_destroy",
     "saber_hip_fc_create", "saber_hip_fc_set_weights", "saber_hip_fc_workspace_bytes", "saber_hip_fc_run",
-    "saber_hip_fc_destroy", "saber_hip_fc_algo", "saber_hip_fc_set_tile", "saber_hip_gemm_f32",
+    "saber_hip_fc_destroy", "saber_hip_fc_algo", "saber_hip_fc_set_tile", "saber_hip_gemm_f32", "saber_hip_gemm_f32_release_plans",
     "saber_hip_gemm_i8_create", "saber_hip_gemm_i8_workspace_bytes", "saber_hip_gemm_i8_run", "saber_hip_gemm_i8_destroy",
     "saber_hip_quantize_nchw_to_nhwc", "saber_hip_dequantize_nhwc_to_nchw",
     "saber_hip_transpose_nchw_to_nhwc_f32", "saber_hip_transpose_nhwc_to_nchw_f32",
     "saber_hip_quantize_flat_s8", "saber_hip_eltwise_sum_i8", "saber_hip_eltwise_sum_f32", "saber_hip_relu_f32", "saber_hip_activation_f32", "saber_hip_prelu_f32",
     "saber_hip_pool_out_dim", "saber_hip_pool_out_dim2", "saber_hip_pool2d_i8_nhwc", "saber_hip_pool2d_f32", "saber_hip_pool2d_f32_from_i8", "saber_hip_pool2d_f32_from_i8_q", "saber_hip_fc_run_q", "saber_hip_softmax_f32",
-    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice", "saber_hip_net_stage_blocks", "saber_hip_net_time_op_in_pass", "saber_hip_net_status", "saber_hip_net_inject_coop_error",
+    "saber_hip_net_add_pool_f32_from_i8_q", "saber_hip_net_add_fc_q", "saber_hip_net_optimize", "saber_hip_net_num_launches", "saber_hip_net_tensor_unwritten", "saber_hip_net_get_choice", "saber_hip_net_set_choice", "saber_hip_net_stage_blocks", "saber_hip_net_time_op_in_pass", "saber_hip_net_status", "saber_hip_net_inject_coop_error", "saber_hip_net_coop_fallbacks", "saber_hip_coop_fallbacks_total",
     "saber_hip_net_create", "saber_hip_net_add_tensor", "saber_hip_net_add_conv", "saber_hip_net_add_fc",
     "saber_hip_net_add_quantize", "saber_hip_net_add_dequantize", "saber_hip_net_add_transpose_in_f32", "saber_hip_net_add_eltwise_i8",
     "saber_hip_net_add_eltwise_f32", "saber_hip_net_add_pool_i8", "saber_hip_net_add_pool_f32",
@@ -154,6 +154,8 @@ def load():
     lib.saber_hip_net_stage_blocks.argtypes = [P, I]
     lib.saber_hip_net_status.argtypes = [P]
     lib.saber_hip_net_inject_coop_error.argtypes = [P]
+    lib.saber_hip_net_coop_fallbacks.argtypes = [P]
+    lib.saber_hip_coop_fallbacks_total.argtypes = []
     lib.saber_hip_net_time_op_in_pass.argtypes = [P, P, I, I, C.POINTER(C.c_float)]
     lib.saber_hip_net_get_choice.argtypes = [P, I]
     lib.saber_hip_net_set_choice.argtypes = [P, I, I]
@@ -162,6 +164,8 @@ def load():
     lib.saber_hip_fc_set_tile.argtypes = [P, I]
     lib.saber_hip_fc_destroy.restype = None
     lib.saber_hip_gemm_f32.argtypes = [I, I, I, I, I, F, P, P, F, P, P]
+    lib.saber_hip_gemm_f32_release_plans.argtypes = []
+    lib.saber_hip_gemm_f32_release_plans.restype = I
     lib.saber_hip_gemm_i8_create.argtypes = [I, I, I, I, I, I, P, C.POINTER(P)]
     lib.saber_hip_gemm_i8_workspace_bytes.argtypes = [P]
     lib.saber_hip_gemm_i8_workspace_bytes.restype = Z

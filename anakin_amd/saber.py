@@ -787,6 +787,10 @@ class Net:
         block: run the pass again) - saber_hip_net_status"""
         L.check(L.load().saber_hip_net_status(self.h))
 
+    def coop_fallbacks(self):
+        """cooperative launches of this net that reported a failed pass so far (saber_hip_net_coop_fallbacks)"""
+        return L.load().saber_hip_net_coop_fallbacks(self.h)
+
     def stages(self):
         """[(op index, blocks, selected)] of the ops that head a stage (saber_hip_net_optimize flag 256)"""
         lib = L.load()

@@ -259,7 +259,7 @@ def _out_hw(h, k, s, p):
 
 
 def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
-                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True, head_pair=False):
+                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True, head_pair=False, shared_device=False):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
@@ -281,7 +281,10 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     saber_hip_conv2d_stem_pair_create); pool1's edge is then not written.
     head_pair (with chain = 2): the strided head of a stage (conv3x3 / stride 2 + conv1x1 + eltwise, C = 64: res2c) also runs the next
     stage's sibling pair (res3a_branch1 / res3a_branch2a) that reads its output (flag 1024; saber_hip_conv2d_chain_create3_pair).
-    Off by default: measured no faster than the two launches."""
+    Off by default: measured no faster than the two launches.
+    shared_device: the net runs beside other nets / streams / processes on its GPU (saber_hip_net_optimize flag
+    SABER_HIP_NET_SHARED_DEVICE = 2048): no stage launch, no cooperating-workgroup chains, no split-K through one XCD's L2 - excluded
+    from the static selection, the autotuner and restored selections."""
     from . import lib as L
     from . import saber as S
     if chain is None:
@@ -415,6 +418,9 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
         elif kd == "softmax":
             net.add_tensor(nm, (B, 1000), F32)
             net.add_softmax(B, 1000, l["src"], nm)
+    if shared_device:
+        net.optimize(2048)           # (sticks to the net: every later optimize / autotune / set_choices call honours it)
+        stage = False
     if cxx_optimize:
         net.unfused_ops = net.num_ops()
         net.removed = net.optimize(15)
@@ -429,9 +435,10 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     return net
 
 
-def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True):
+def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False):
     """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
-    does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132)."""
+    does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132).
+    shared_device: see build_int8_net (here: no split-K through one XCD's L2)."""
     from . import lib as L
     from . import saber as S
     net = S.Net()
@@ -547,6 +554,8 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True):
             mark(nm)
     net.alias = alias
     net.produced = produced
+    if shared_device:
+        net.optimize(2048)
     net.finalize()
     return net
 

@@ -86,12 +86,15 @@ def parse():
     return ap.parse_args()
 
 
-def build_net(W, model, scales, batch, args, stage=True):
+def build_net(W, model, scales, batch, args, stage=True, shared_device=False):
+    """shared_device: the net will run BESIDE other nets on this GPU (the multi-stream leg, ranks sharing a device): declared to the
+    executor (saber_hip_net_optimize flag SABER_HIP_NET_SHARED_DEVICE), which then never selects a placement-dependent kernel variant"""
     if args.precision == "int8":
         cxx = not (args.py_fuse or args.no_fuse or args.lanes)      # the C++ host side finds the fusions (the north star's "host side stays C++")
         return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx,
-                                stage=stage and not args.no_stage, stem_pair=not args.no_stem_pair, head_pair=args.head_pair)
-    return W.build_fp32_net(model, batch)
+                                stage=stage and not args.no_stage and not shared_device, stem_pair=not args.no_stem_pair, head_pair=args.head_pair,
+                                shared_device=shared_device)
+    return W.build_fp32_net(model, batch, shared_device=shared_device)
 
 
 def tune_key(args, batch, L):
@@ -142,12 +145,11 @@ def timed_steps(net, steps, use_graph, gather=None, flush=None):
 
 
 def pick_launch_mode(net, steps=60, gather=None, flush=None):
-    """hipGraph replay against eager launches (the C++ op loop of saber_hip_net_run) of the same op list, timed once
-    before the timed region — with the per-step logits gather when there is one, since the eager loop costs ~275 us of
-    host time per step (graph: ~30 us) and leaves little room for anything else on the launching thread; the faster
-    one is used. On this host, single GPU, the eager loop keeps the GPU fed and is ~1 % faster than the graph; and
-    occasionally (2 of ~30 runs) a process gets a graph whose replay is 25-30 % slower than the sum of its kernels
-    while eager per-op times are normal."""
+    """hipGraph replay against eager launches (the C++ op loop of saber_hip_net_run) of the same op list, timed once before the
+    timed region (with the per-step logits gather when there is one); the faster one is used. Both forms are GPU-bound on this
+    workload: the eager loop enqueues a batch-8 pass in ~60 us of host time (scripts/enqueue_cost.py; 24 launches x ~2.5 us) against
+    ~216 us of GPU time, so the launching thread stays ahead as long as it has a core to itself, and a graph has no launch cost to
+    save; what differs is what the command processor does between two dependent kernels (profiles/r05/graph_vs_eager.txt)."""
     import torch
     t = {}
     for mode in ("graph", "eager", "graph", "eager"):
@@ -216,7 +218,8 @@ def main():
     scales = W.calibrate(model, W.make_input(2)) if args.precision == "int8" else {}
     # (ranks sharing one GPU - the 2-rank test of tests/test_gpu_dist.py - run concurrently on it: no persistent stage launches there,
     # two of them in flight can starve each other of CUs; one rank per GPU: the stage has its GPU to itself)
-    net = build_net(W, model, scales, B, args, stage=os.environ.get("BENCH_SHARE_GPU") != "1")
+    shared = os.environ.get("BENCH_SHARE_GPU") == "1"
+    net = build_net(W, model, scales, B, args, stage=not shared, shared_device=shared)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     torch.cuda.synchronize()
@@ -286,6 +289,24 @@ def main():
     dt = shard.max_over_ranks(dt, "cuda")
     ms_per_step = dt * 1000.0 / args.steps
     value = n_gpus * B * args.steps / dt
+
+    # N > 1: the same steps with the logits exchanged PER REQUEST (one all-gather per step, --gather-every 1): what a batch-64 request
+    # split 8 ways pays when its answer must be complete before the next request starts; the headline amortises the exchange over
+    # --gather-every steps (a request's logits then arrive up to that many steps late). Every rank takes part; reported beside it.
+    per_request = None
+    if world > 1 and gather is not None and args.gather_every != 1:
+        ag1 = shard.BatchedLogitGather(logits, world, every=1)
+        n1 = max(20, min(args.steps, 200))
+        timed_steps(net, 10, use_graph, lambda: ag1.step(logits), ag1.finish)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        timed_steps(net, n1, use_graph, lambda: ag1.step(logits), ag1.finish)
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt1 = shard.max_over_ranks(time.perf_counter() - t1, "cuda")
+        per_request = {"every_steps": 1, "steps": n1, "ms_per_step": round(dt1 * 1000.0 / n1, 4),
+                       "images_per_s": round(n_gpus * B * n1 / dt1, 1)}
 
     out = None
     if args.timed_only:
@@ -430,22 +451,26 @@ def main():
             try:
                 multi = {}
                 extra, streams = [], []
-                for i in range(2):
+                for i in range(3):
                     st = torch.cuda.Stream()
                     with torch.cuda.stream(st):
-                        # (stage=False: a persistent stage launch needs its image's workgroups resident together - one such
-                        # launch at a time; these nets run their res4 blocks as the chain launches)
-                        ne = build_net(W, model, scales, B, args, stage=False)
-                        ne.set_choices(net.choices())
+                        # every net of this leg runs BESIDE the others: built with SABER_HIP_NET_SHARED_DEVICE (no persistent stage launch,
+                        # no cooperating-workgroup chains, no split-K through an XCD's L2 - selected out, not found out by a time-out)
+                        ne = build_net(W, model, scales, B, args, shared_device=True)
                         ne.tensor("data").copy_(torch.from_numpy(W.make_input(B, seed=11 + i)).cuda())
+                        ne.run()
+                        if i == 0:
+                            ne.autotune(iters=7)
+                            shared_choices = ne.choices()
+                        else:
+                            ne.set_choices(shared_choices)
                         ne.run()
                         ne.capture()
                     extra.append(ne)
                     streams.append(st)
                 torch.cuda.synchronize()
-                net.capture()      # (again: the launch-mode probe may have kept or dropped its graph)
                 for k in (2, 3):
-                    group = [(net, torch.cuda.current_stream())] + list(zip(extra[:k - 1], streams[:k - 1]))
+                    group = list(zip(extra[:k], streams[:k]))
 
                     def round_():
                         for n_, s_ in group:
@@ -461,6 +486,8 @@ def main():
                     dt = (time.perf_counter() - t0) / 200
                     multi["streams_%d" % k] = {"images_per_s": round(k * B / dt, 1), "ms_per_round": round(dt * 1e3, 4),
                                                "batches_in_flight": k, "batch": B}
+                multi["coop_fallbacks"] = sum(n_.coop_fallbacks() for n_ in extra)
+                multi["launches_per_net"] = extra[0].num_launches()
                 multi["note"] = "independent batch-%d forward passes in flight on separate streams; each batch's latency is ms_per_round" % B
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
                 multi = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -519,18 +546,25 @@ def main():
                             # the reference's serving shape on the same model file: Worker<MI355X, INT8> (framework/core/net/
                             # worker.h:38-60), 3 pool threads = 3 Nets, each replaying its own plan on its own stream; requests
                             # and answers are HOST tensors (4.8 MB of f32 image per batch-8 request over PCIe - an inclusive rate)
-                            rw = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, "worker", "3", "300"],
-                                                capture_output=True, text=True, errors="replace", timeout=300, cwd=td,
-                                                env=dict(os.environ, SABER_MI355X_NET_PLAN_STREAM="own"))
-                            if rw.returncode == 0:
+                            def worker_run(mode, threads, requests=300):
+                                rw = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, mode, str(threads), str(requests)],
+                                                    capture_output=True, text=True, errors="replace", timeout=300, cwd=td)
+                                if rw.returncode != 0:
+                                    return {"error": "rc %d" % rw.returncode}
                                 wt = open(os.path.join(td, "worker.txt")).read().split()
-                                ref_list["worker"] = dict(
-                                    threads=3, requests=int(wt[wt.index("requests") + 1]), mismatches=int(wt[wt.index("mismatches") + 1]),
-                                    images_per_s=round(float(wt[wt.index("images_per_s") + 1]), 1),
-                                    what="Worker<MI355X, INT8>::sync_prediction, batch-%d requests from host memory (PCIe-inclusive), "
-                                         "3 threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan)" % B)
-                            else:
-                                ref_list["worker"] = {"error": "rc %d" % rw.returncode}
+                                f = {wt[i]: wt[i + 1] for i in range(0, len(wt) - 1, 2)}
+                                return dict(threads=threads, requests=int(f["requests"]), mismatches=int(f["mismatches"]),
+                                            images_per_s=round(float(f["images_per_s"]), 1), median_ms=float(f["median_ms"]),
+                                            max_ms=float(f["max_ms"]), coop_fallbacks=int(f["coop_fallbacks"]))
+                            ref_list["worker"] = worker_run("worker", 3)
+                            ref_list["worker"]["what"] = (
+                                "Worker<MI355X, INT8>::sync_prediction, batch-%d requests from PAGEABLE host memory (PCIe-inclusive: 4.8 MB of "
+                                "f32 image per request through the calling thread's pinned staging ring + copy stream, mi355x_impl.cpp), "
+                                "3 threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan on its own stream, "
+                                "SABER_HIP_NET_SHARED_DEVICE); median / max = submit -> answer with at most 2 x threads requests outstanding" % B)
+                            ref_list["worker_6_threads"] = worker_run("worker", 6)
+                            ref_list["worker_pinned_requests"] = worker_run("worker_pinned", 3)
+                            ref_list["worker_async_prediction"] = worker_run("worker_async", 3, 96)
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
                 ref_list = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -668,14 +702,18 @@ def main():
                        "dist_backend": dist.get_backend() if world > 1 else None,
                        # ranks of an RCCL communicator that really exists (0 under the gloo dry run of the multi-rank control flow)
                        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
-                       "kernel_selection": selection, "coop_fallback": coop_fallback, "fused_by": "saber_hip_net_optimize (C++)" if (args.precision == "int8" and not (args.py_fuse or args.no_fuse or args.lanes)) else "workloads.py",
+                       "kernel_selection": selection, "coop_fallback": coop_fallback,
+                       "coop_fallbacks": net.coop_fallbacks() if hasattr(net, "coop_fallbacks") else 0, "shared_device": shared, "fused_by": "saber_hip_net_optimize (C++)" if (args.precision == "int8" and not (args.py_fuse or args.no_fuse or args.lanes)) else "workloads.py",
                        "gather": None if (world == 1 or gather is None) else {"every_steps": args.gather_every, "backend": dist.get_backend(),
                                                           "host_us_per_step": round(gather_host_us, 1),
+                                                          "per_request": per_request,
                                                           "what": "every step's logits -> device ring (async copy); one asynchronous "
                                                                   "all-gather of the ring per every_steps steps, all inside the timed region"}},
-            "parity_scope": "tests/test_gpu_baseline_configs.py: this workload at THIS batch size with the autotuned selection - every edge "
-                            "the executor materialises, every image, bit-exact (INT8) / within 1e-4 on two criteria (FP32) against the CPU "
-                            "oracle, eager and hipGraph (ResNet50 INT8 b4/b8, ResNet101 INT8 b8, ResNet50 FP32 b4/b8, VGG16 FP32 b8); "
+            "parity_scope": "tests/test_gpu_baseline_configs.py::test_resnet50_int8_exactly_what_the_driver_times: the cached selection "
+                            "(profiles/tune.json for this source hash), C++-fused list, stage launch + stem pair on, b1/2/4/8 - every edge "
+                            "the executor materialises, every image, bit-exact against the CPU oracle, eager and hipGraph, stage on and off; "
+                            "the same file: fresh autotune, Python-fused, ResNet50 INT8 b1/2/4/8, ResNet101 INT8 b8, ResNet50 FP32 b1/2/4/8 and "
+                            "VGG16 FP32 b8 within 1e-4 on two criteria; "
                             "tests/test_gpu_net.py: the same through the reference's own Net<MI355X> (every edge at batch 2, every image's "
                             "output at batch 8, plan == operator loop)",
             "latency_ms": {"batch": B, "p50": round(p50, 4), "p99": round(p99, 4)},

@@ -297,6 +297,13 @@ void saber_hip_fc_destroy(saber_hip_fc_t* op);
 /* ------------------------------------------------------------------------------------------- */
 int saber_hip_gemm_f32(int trans_a, int trans_b, int m, int n, int k, float alpha, const float* a,
                        const float* b, float beta, float* c, saber_hip_stream_t stream);
+/* The entry point above is stateless for the caller, its device scratch (weight planes, transpose buffer = Gemm<>::init's state) is
+ * not: it lives in plans cached per calling thread, keyed by (device, stream, transposes, m, n, k, beta class), at most 16 unpinned
+ * ones (least recently used evicted after draining its stream). A call recorded into a hipGraph (the stream is capturing) pins the
+ * plan it uses - never evicted, not shared with eager calls - or, when the shape was never run eagerly on that stream, records the
+ * f32-MFMA kernel that owns no state. This frees the calling thread's plans (pinned ones included: the caller's graphs over them
+ * must be gone) after draining their streams; returns how many. */
+int saber_hip_gemm_f32_release_plans(void);
 
 /* INT8 GEMM (MklDnnGemm<int8_t | uint8_t, int8_t, int>, saber/funcs/impl/x86/mkl_gemm.cpp:138-256; its test
  * test/saber/test_saber_gemm_int8.cpp): row-major C[m,n] (int32) = op(A)[m,k] x op(B)[k,n], exact integer
@@ -431,8 +438,22 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * 1024 (with 2 | 16 | 32; NOT in 255): the strided head of a stage at C = 64 (conv3x3 / stride 2 + conv1x1 + eltwise: ResNet's res2c)
  * whose output is read by one sibling pair only (res3a_branch1 / res3a_branch2a) runs that pair in its chain launch
  * (saber_hip_conv2d_chain_create3_pair); the pair stays in the list and launches nothing while the chain form is selected.
+ * 2048 (SABER_HIP_NET_SHARED_DEVICE; NOT in 255; may be passed on its own, sticks to the net): the net does NOT have the device to
+ * itself - other streams, Worker threads or processes run kernels there while it does (framework/core/net/worker.h:38-60: one Net
+ * per pool thread). Every kernel variant whose completion or speed depends on where the hardware places workgroups relative to
+ * each other is then excluded AT SELECTION TIME - flag 256 is ignored, the cooperating-workgroup chains (tile codes 7 / 15) and
+ * FP32 split-K through one XCD's L2 are neither chosen statically, nor offered to saber_hip_net_autotune, nor accepted from a
+ * restored selection (saber_hip_net_set_choice maps them to their plain forms) - instead of being found out by a timed-out
+ * hand-off (~20 ms) at run time.
  * Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
+#define SABER_HIP_NET_SHARED_DEVICE 2048
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
+/* How many cooperative launches of this net have reported a failed pass since it was created (each made saber_hip_net_status /
+ * the site's next launch return SABER_HIP_RUNTIME_ERROR once and its site fall back to single-workgroup launches): 0 on a net that
+ * owns its device or was optimised with SABER_HIP_NET_SHARED_DEVICE. */
+int saber_hip_net_coop_fallbacks(const saber_hip_net_t* net);
+/* ... summed over every net this process has created (a Worker's Nets live inside its pool threads): what a serving loop reports. */
+int saber_hip_coop_fallbacks_total(void);
 /* After a forward pass has COMPLETED (the caller synchronised the stream): SABER_HIP_RUNTIME_ERROR when one of its cooperative
  * launches (a stage launch, a two-workgroup chain launch) found its workgroups on different XCDs or timed out in a hand-off - its
  * outputs are not valid; those sites launch block by block from then on (a captured graph is dropped): run the pass again.

@@ -100,6 +100,16 @@ def patch_framework(ref, dst):
     # Worker<MI355X, P, R> (the multi-instance serving shape: one Net per thread, framework/core/net/worker.h:38-60) and the
     # calibration-table generator (EntropyCalibrator / BatchStream, framework/core/net/entropy_calibrator.cpp, calibrator.h)
     instantiate(os.path.join(net, "worker.cpp"), r"template class Worker<X86, [^;]*;")
+    # a Worker with several pool threads = several Nets in flight on one GPU: its constructor declares that to the MI355X plans BEFORE
+    # the pool threads initialise their Nets (a stream per Net, SABER_HIP_NET_SHARED_DEVICE: no placement-dependent kernel variants) -
+    # mi355x_net_plan.h: MI355XNetPlanDefaults. Other targets: a no-op.
+    insert(os.path.join(net, "worker.cpp"), "namespace anakin {\n",
+           "\ntemplate <typename T> static inline void mi355x_worker_defaults(int) {}\n"
+           "#ifdef USE_MI355X_PLACE\n"
+           "template <> inline void mi355x_worker_defaults<saber::MI355X>(int threads) { MI355XNetPlanDefaults::worker_threads(threads); }\n"
+           "#endif\n")
+    sub(os.path.join(net, "worker.cpp"), "_model_path(model_path), ThreadPool(num_thread) {}",
+        "_model_path(model_path), ThreadPool(num_thread) { mi355x_worker_defaults<Ttype>(num_thread); }")
     instantiate(os.path.join(net, "entropy_calibrator.cpp"), r"template class EntropyCalibrator<X86>;")
     instantiate(os.path.join(net, "batch_stream.cpp"), r"template class BatchStream<X86>;")
     instantiate(os.path.join(F, "graph", "graph.cpp"), r"template class Graph<X86, [^;]*;")

@@ -24,6 +24,13 @@
 // SABER_MI355X_NET_PLAN_TUNE=0 keeps the static kernel selection, SABER_MI355X_NET_PLAN_GRAPH=0|1 forces eager / hipGraph,
 // SABER_MI355X_NET_PLAN_STREAM=own gives every Net's plan a stream of its own (all Nets of a device otherwise share the
 // Context's compute stream `lane`, as on every target of the reference: Worker threads would serialise on the GPU).
+// WHO OWNS THE DEVICE is a property of the plan, decided before kernels are selected (round-4 verdict item 5), not an environment
+// variable read at failure time: MI355XNetPlan::shared_device says that other Nets run on the GPU at the same time. It is passed to
+// saber_hip_net_optimize as SABER_HIP_NET_SHARED_DEVICE, which keeps every placement-dependent kernel variant (the persistent res4
+// stage launch, cooperating-workgroup chains, FP32 split-K through one XCD's L2) out of the static selection, the autotuner and a
+// restored selection. Worker<MI355X, ...> (one Net per pool thread) sets the process default from its constructor
+// (MI355XNetPlanDefaults::worker_threads: more than one thread -> a stream per Net + shared_device); a single Net on the context's
+// compute stream owns the device. The environment variable above remains as an A/B aid and implies shared_device.
 // New code of this repository (reference-side glue of the MI355X target).
 #ifndef ANAKIN_FRAMEWORK_CORE_NET_MI355X_NET_PLAN_H
 #define ANAKIN_FRAMEWORK_CORE_NET_MI355X_NET_PLAN_H
@@ -36,8 +43,21 @@
 
 namespace anakin {
 
+// Process-wide defaults a plan takes when it is built (function-local statics: header-only). Set BEFORE the Nets are initialised.
+struct MI355XNetPlanDefaults {
+    static int& shared_device() { static int v = 0; return v; }   // other Nets / streams run on the device concurrently
+    static int& own_stream() { static int v = 0; return v; }      // every plan gets a non-blocking stream of its own
+    // Worker<MI355X, P, R>(model, n): n pool threads = n Nets in flight on one GPU (framework/core/net/worker.cpp:59)
+    static void worker_threads(int n) {
+        if (n > 1) { shared_device() = 1; own_stream() = 1; }
+    }
+};
+
 struct MI355XNetPlan {
     saber_hip_net_t* net = nullptr;
+    bool shared_device = MI355XNetPlanDefaults::shared_device() != 0;   // see the header comment; may be set on net.mi355x_plan() before init()
+    bool want_own_stream = MI355XNetPlanDefaults::own_stream() != 0;
+    int coop_fallbacks = 0;      // cooperative launches that failed a pass and fell back (saber_hip_net_coop_fallbacks); 0 expected
     bool tried = false;          // a build was attempted for the current shapes (successful or not)
     bool enabled = true;
     bool use_graph = false;

@@ -66,8 +66,12 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
         }
         plan.stream = (void*)net._exec_funcs[0].ctx_p->get_compute_stream();
         {
+            // a stream of this plan's own: the Worker shape (MI355XNetPlanDefaults::worker_threads) - or the A/B switch in the environment.
+            // A plan that does not run on the context's shared compute stream runs BESIDE other plans: it does not own the device.
             const char* own = std::getenv("SABER_MI355X_NET_PLAN_STREAM");
-            if (own && std::string(own) == "own" && !plan.own_stream) {
+            if (own && std::string(own) == "own") plan.want_own_stream = true;
+            if (plan.want_own_stream) plan.shared_device = true;
+            if (plan.want_own_stream && !plan.own_stream) {
                 API::stream_t s;
                 API::event_t e;
                 API::create_stream_with_flag(&s, 1);
@@ -79,15 +83,16 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
         void* const ctx_stream = plan.stream;
         if (plan.own_stream) plan.stream = plan.own_stream;
         plan.ctx_stream = ctx_stream;
-        // 256 (a run of res4 blocks as one persistent launch) only for a plan on the context's own compute stream, which every Net of
-        // the process shares: with a stream of its own per Net (Worker threads serving concurrently) two such launches could each
-        // hold half of the CUs and wait for the other half (saber_hip.h: saber_hip_conv2d_stage_create)
-        const bool stage = env_on("SABER_MI355X_NET_STAGE", plan.own_stream == nullptr);
+        // 256 (a run of res4 blocks as one persistent launch) only for a plan that owns the device; a shared device is declared to the
+        // executor (SABER_HIP_NET_SHARED_DEVICE), which then excludes every placement-dependent variant when kernels are SELECTED
+        // (SABER_MI355X_NET_STAGE=0 remains as an A/B switch for the owning case)
+        const bool stage = !plan.shared_device && env_on("SABER_MI355X_NET_STAGE", true);
         // 512: conv1 + pool1 also run the sibling pair reading pool1 (one launch fewer; pool1's own tensor is not written by the plan)
         const bool stem_pair = env_on("SABER_MI355X_NET_STEM_PAIR", true);
         // 1024: res2c's strided-head chain launch also runs the res3a sibling pair (opt-in: measured no faster than the two launches)
         const bool head_pair = env_on("SABER_MI355X_NET_HEAD_PAIR", false);
-        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0) | (head_pair ? 1024 : 0)) >= 0;
+        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0) | (head_pair ? 1024 : 0) |
+                                               (plan.shared_device ? SABER_HIP_NET_SHARED_DEVICE : 0)) >= 0;
         if (ok) ok = saber_hip_net_finalize(n) == SABER_HIP_OK;
         if (ok && plan.builds == 0 && env_on("SABER_MI355X_NET_PLAN_TUNE", true))
             ok = saber_hip_net_autotune(n, plan.stream, 9) == SABER_HIP_OK;
@@ -172,6 +177,7 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
             // the pass has completed: a cooperative launch that could not (another kernel held the CUs its workgroups wait for) reports
             // itself here, those sites now launch block by block, and the pass runs once more - the caller never sees its outputs
             if (saber_hip_net_status(plan.net) == SABER_HIP_OK) break;
+            plan.coop_fallbacks = saber_hip_net_coop_fallbacks(plan.net);
             LOG(WARNING) << "MI355X net plan: " << saber_hip_last_error();
             CHECK_EQ(attempt, 0) << "MI355X net plan: the fallback launches failed as well";
             plan.use_graph = false;

@@ -45,6 +45,11 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemcpyPeer(void* d, int, const void* s, int, size_t n) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t*, const void*) { return hipErrorInvalidValue; }      // everything is "pageable"
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
+
 hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
@@ -74,5 +79,9 @@ hipError_t __hipPopCallConfiguration(dim3* g, dim3* b, size_t* shm, hipStream_t*
     return hipSuccess;
 }
 hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipLaunchCooperativeKernel(const void*, dim3, dim3, void**, unsigned int, hipStream_t) { return hipSuccess; }
+hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void*) { return hipSuccess; }
 
 }  // extern "C"

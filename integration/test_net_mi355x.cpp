@@ -15,7 +15,9 @@
 //
 // The program is a file-driven harness (the Python test writes the model and checks the dumps against the oracle):
 //     test_net_mi355x.bin <model.txt> <weights.bin (unused: named by the model)> <input.bin> <outdir> [iters | dry]
-//     ... <outdir> worker <threads> [requests]      Worker<MI355X, FP32>: one Net per pool thread (worker.txt, out_worker.bin)
+//     ... <outdir> worker[_async][_pinned] <threads> [requests]   Worker<MI355X, P>: one Net per pool thread, sync_prediction (or
+//                                                   async_prediction / async_get_result; _pinned: the request buffer is hipHostRegister'ed)
+//                                                   -> worker.txt (throughput, median / max request latency, cooperative-launch fallbacks), out_worker.bin
 //     ... <outdir> calibrate <batches>              EntropyCalibrator<MI355X> over `batches` inputs (calibration_table.txt)
 // model.txt: the TEXT model format of integration/mi355x/framework/text_model_parser.cpp (this build's model parser: the network
 // BEFORE any fusion as original operators + raw weight blobs, per-node precisions and per-variable scales or the two calibrator
@@ -44,6 +46,9 @@
 #include <mutex>
 #include <thread>
 #include <algorithm>
+#include <chrono>
+#include <deque>
+#include <future>
 
 #include "saber/core/context.h"
 #include "saber/core/tensor.h"
@@ -195,8 +200,10 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
 // serving shape: `threads` pool threads, each loads the model (Graph::load -> the text model parser), optimises it and owns a
 // Net; requests are host tensors, answers futures of host tensors. Every answer must equal the first; requests / s reported.
 template <Precision P>
-static int run_worker(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int threads, int requests) {
+static int run_worker(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int threads, int requests,
+                      const std::string& mode) {
     typedef Worker<MI355X, P, OpRunType::ASYNC> worker_t;
+    const bool use_async = mode.find("async") != std::string::npos, pinned = mode.find("pinned") != std::string::npos;
     std::string in_name, out_name;
     std::vector<int> shape;
     {
@@ -208,7 +215,7 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
         auto sh = g[in_name]->template get_attr<PTuple<int> >("input_shape");
         for (int i = 0; i < 4; ++i) shape.push_back(sh[i]);
     }
-    worker_t worker(model_path, threads);
+    worker_t worker(model_path, threads);      // (several threads: the constructor declares the shared device to the plans - worker.cpp)
     worker.register_inputs({in_name});
     worker.register_outputs({out_name});
     worker.Reshape(in_name, shape);
@@ -216,27 +223,71 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
     Tensor4d<X86> host_in(Shape(shape), AK_FLOAT);
     if ((size_t)host_in.valid_size() != input.size()) { fprintf(stderr, "input.bin does not match the model's input\n"); return 2; }
     memcpy(host_in.mutable_data(), input.data(), input.size() * sizeof(float));
+    // `pinned`: a client that registers its request buffer with the HIP runtime (what target_host<NV> = NVHX86's cudaHostAlloc gives the
+    // reference's NV Worker for free): the copy lane then skips its staging ring (mi355x_impl.cpp)
+    if (pinned) MI355X_CHECK(hipHostRegister(host_in.mutable_data(), input.size() * sizeof(float), hipHostRegisterDefault));
     std::vector<Tensor4d<X86> > ins(1, host_in);
     auto first = worker.sync_prediction(ins).get();      // also: every pool thread has finished its init by the time the queue drains
     for (int w = 0; w < 2 * threads; ++w) worker.sync_prediction(ins).get();
-    const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::future<std::vector<Tensor4d<X86> > > > fut;
-    for (int r = 0; r < requests; ++r) fut.push_back(worker.sync_prediction(ins));
+    typedef std::chrono::steady_clock clk;
     int bad = 0;
-    for (auto& f : fut) {
-        auto out = f.get();
-        if (out.size() != 1 || out[0].valid_size() != first[0].valid_size() ||
-            memcmp(out[0].data(), first[0].data(), first[0].valid_size() * sizeof(float)) != 0) ++bad;
+    std::vector<double> lat_ms;
+    const auto t0 = clk::now();
+    if (!use_async) {
+        // at most 2 x threads requests outstanding: every request's submit -> answer time is observed (queueing included)
+        std::deque<std::pair<std::future<std::vector<Tensor4d<X86> > >, clk::time_point> > fly;
+        auto reap = [&]() {
+            auto out = fly.front().first.get();
+            lat_ms.push_back(std::chrono::duration<double, std::milli>(clk::now() - fly.front().second).count());
+            fly.pop_front();
+            if (out.size() != 1 || out[0].valid_size() != first[0].valid_size() ||
+                memcmp(out[0].data(), first[0].data(), first[0].valid_size() * sizeof(float)) != 0) ++bad;
+        };
+        for (int r = 0; r < requests; ++r) {
+            if ((int)fly.size() >= 2 * threads) reap();
+            const auto ts = clk::now();
+            fly.emplace_back(worker.sync_prediction(ins), ts);
+        }
+        while (!fly.empty()) reap();
+    } else {
+        // Worker::async_prediction / async_get_result (worker.h:52-60, worker.cpp:176-207): requests queue up, the answers are the
+        // pool thread's OWN device tensors (the reference's contract: valid until that thread's next request) - copied out and compared
+        std::vector<Tensor4dPtr<X86> > in_ptrs(1, &host_in);
+        int outstanding = 0;
+        auto reap = [&]() {
+            auto outs = worker.async_get_result();
+            --outstanding;
+            Tensor4d<X86> h(outs[0]->valid_shape(), AK_FLOAT);
+            h.copy_from(*outs[0]);
+            if (outs.size() != 1 || h.valid_size() != first[0].valid_size() ||
+                memcmp(h.data(), first[0].data(), first[0].valid_size() * sizeof(float)) != 0) ++bad;
+        };
+        for (int r = 0; r < requests; ++r) {
+            if (outstanding >= threads) reap();          // (the answer is a tensor of the Net that served it: do not let a thread lap it)
+            worker.async_prediction(in_ptrs);
+            ++outstanding;
+        }
+        while (outstanding) reap();
     }
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double sec = std::chrono::duration<double>(clk::now() - t0).count();
+    if (pinned) MI355X_CHECK(hipHostUnregister(host_in.mutable_data()));
+    double med = 0, mx = 0;
+    if (!lat_ms.empty()) {
+        std::vector<double> v = lat_ms;
+        std::sort(v.begin(), v.end());
+        med = v[v.size() / 2];
+        mx = v.back();
+    }
     FILE* f = fopen((outdir + "/out_worker.bin").c_str(), "wb");
     fwrite(first[0].data(), sizeof(float), first[0].valid_size(), f);
     fclose(f);
     f = fopen((outdir + "/worker.txt").c_str(), "w");
-    fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f\n", threads, requests, bad, sec,
-            requests / sec, requests * (double)shape[0] / sec);
+    fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f median_ms %.4f max_ms %.4f "
+            "coop_fallbacks %d async %d pinned %d\n", threads, requests, bad, sec, requests / sec, requests * (double)shape[0] / sec, med, mx,
+            saber_hip_coop_fallbacks_total(), (int)use_async, (int)pinned);
     fclose(f);
-    printf("worker ok: %d threads, %d requests, %d mismatches, %.1f requests/s\n", threads, requests, bad, requests / sec);
+    printf("worker ok: %d threads, %d requests (%s), %d mismatches, %.1f requests/s, median %.3f ms, max %.3f ms, %d cooperative-launch fallbacks\n",
+           threads, requests, mode.c_str(), bad, requests / sec, med, mx, saber_hip_coop_fallbacks_total());
     return bad ? 3 : 0;
 }
 
@@ -293,11 +344,11 @@ int main(int argc, char** argv) {
         return v;
     };
     std::vector<float> input = slurp(argv[3]);
-    if (argc > 6 && std::string(argv[5]) == "worker") {
+    if (argc > 6 && std::string(argv[5]).compare(0, 6, "worker") == 0) {      // worker | worker_async | worker_pinned | worker_async_pinned
         Env<MI355X>::env_init();
         const int th = atoi(argv[6]), rq = argc > 7 ? atoi(argv[7]) : 64;
-        if (precision == "int8") return run_worker<Precision::INT8>(argv[1], input, argv[4], th, rq);
-        return run_worker<Precision::FP32>(argv[1], input, argv[4], th, rq);
+        if (precision == "int8") return run_worker<Precision::INT8>(argv[1], input, argv[4], th, rq, argv[5]);
+        return run_worker<Precision::FP32>(argv[1], input, argv[4], th, rq, argv[5]);
     }
     if (argc > 6 && std::string(argv[5]) == "calibrate") {
         Env<MI355X>::env_init();

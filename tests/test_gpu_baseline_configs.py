@@ -202,3 +202,67 @@ def test_resnet50_fp32_autotuned_every_edge_every_image(batch):
 
 def test_vgg16_fp32_batch8_autotuned_every_edge_every_image():
     _fp32_every_edge_autotuned("vgg16", 8, 17)
+
+
+def test_shared_device_nets_never_select_placement_dependent_variants():
+    """Round-4 verdict item 5: a net that does NOT own its device (Worker threads, ranks sharing a GPU, the multi-stream leg) declares it to
+    saber_hip_net_optimize (SABER_HIP_NET_SHARED_DEVICE = 2048); the persistent stage launch, the cooperating-workgroup chains (names
+    *_coop2 / *_coop4) and FP32 split-K through one XCD's L2 (*_split2/4/8) are then excluded at SELECTION time - static choice, autotuner,
+    and a selection restored from a net that owned its device - and the outputs stay the oracle's bits."""
+    L.require_device()
+    batch = 8
+    model = W.framework_model(W.build_model("resnet50"), "int8")
+    x = W.make_input(batch, hw=224)
+    scales = W.calibrate(model, W.make_input(2))
+    ref = NO.run_int8(model, dict(scales), x)
+    owner = W.build_int8_net(model, dict(scales), batch, cxx_optimize=True)
+    owner.tensor("data").copy_(torch.from_numpy(x).cuda())
+    owner.run()
+    _apply_committed_selection(owner, "resnet50", batch)
+    assert owner.stages()
+
+    def placement_free(net, what):
+        assert not net.stages(), what
+        for i in range(net.num_ops()):
+            nm = net.op_name(i)
+            assert "coop" not in nm and "_split" not in nm and not nm.startswith("conv:stage_"), (what, i, nm)
+
+    def exact(net, what):
+        for nm in net.tensors:
+            if nm != "data" and not net.unwritten(nm):
+                net.tensor(nm).zero_()
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+        for nm in net.tensors:
+            if nm == "data" or nm not in ref or net.unwritten(nm) or nm == "prob":
+                continue
+            got = _h(net.tensor(nm))
+            assert np.array_equal(got, ref[nm].reshape(got.shape)), (what, nm)
+        assert net.coop_fallbacks() == 0
+
+    shared = W.build_int8_net(model, dict(scales), batch, cxx_optimize=True, shared_device=True)
+    assert shared.num_ops() == owner.num_ops()
+    placement_free(shared, "static selection")
+    exact(shared, "static selection")
+    shared.set_choices(owner.choices())           # the owner's selection carries the stage bit (and possibly cooperating chains)
+    placement_free(shared, "restored selection")
+    exact(shared, "restored selection")
+    shared.autotune(iters=3)
+    placement_free(shared, "autotuned")
+    exact(shared, "autotuned")
+    print("shared-device ResNet50 INT8 b8: %d launches (the owning net: %d)" % (shared.num_launches(), owner.num_launches()))
+
+    # FP32: split-K is the placement-dependent variant there
+    fmodel = W.build_model("resnet50")
+    fref = NO.run_fp32(fmodel, x[:2])
+    fnet = W.build_fp32_net(fmodel, 2, hw=224, shared_device=True)
+    fnet.tensor("data").copy_(torch.from_numpy(x[:2]).cuda())
+    fnet.run()
+    fnet.autotune(iters=3)
+    for i in range(fnet.num_ops()):
+        assert "_split" not in fnet.op_name(i), fnet.op_name(i)
+    fnet.tensor("data").copy_(torch.from_numpy(x[:2]).cuda())
+    fnet.run()
+    got = _h(fnet.tensor("fc1000"))
+    want = fref["fc1000"].reshape(got.shape)
+    assert np.abs(got - want).max() <= FP32_RTOL * np.abs(want).max()

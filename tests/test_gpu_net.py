@@ -209,10 +209,11 @@ def test_worker_mi355x_fp32_serves_requests_from_a_thread_pool(tmp_path):
     within 1e-4 of the CPU oracle."""
     batch = 8
     x = W.make_input(batch)
-    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["worker", "3", "48"], {"SABER_MI355X_NET_PLAN_STREAM": "own"})
+    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["worker", "3", "48"])      # (the Worker's constructor asks for a stream per Net)
     assert "worker ok" in r.stdout
     t = open(os.path.join(d, "worker.txt")).read().split()
     assert int(t[t.index("mismatches") + 1]) == 0 and int(t[t.index("requests") + 1]) == 48
+    assert int(t[t.index("coop_fallbacks") + 1]) == 0
     prob = np.fromfile(os.path.join(d, "out_worker.bin"), np.float32)
     ref = NO.run_fp32(W.framework_model(model, "fp32"), x)
     _fp32_check(prob, ref["prob"], "prob (Worker<MI355X>::sync_prediction)")
@@ -228,17 +229,45 @@ def test_worker_mi355x_int8_serves_the_headline_model(tmp_path):
     x = W.make_input(batch)
     model = W.build_model("resnet50")
     scales = W.calibrate(model, x)
-    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["worker", "3", "64"], {"SABER_MI355X_NET_PLAN_STREAM": "own"},
-                            precision="int8", scales=scales)
+    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["worker", "3", "300"], precision="int8", scales=scales)
     assert "worker ok" in r.stdout
     t = open(os.path.join(d, "worker.txt")).read().split()
-    assert int(t[t.index("mismatches") + 1]) == 0 and int(t[t.index("requests") + 1]) == 64
+    f = {t[i]: t[i + 1] for i in range(0, len(t) - 1, 2)}
+    assert int(f["mismatches"]) == 0 and int(f["requests"]) == 300
+    # round-4 verdict item 5: three Nets in flight on one GPU - the Worker's constructor declares the shared device to the plans
+    # (MI355XNetPlanDefaults::worker_threads -> SABER_HIP_NET_SHARED_DEVICE), so no placement-dependent kernel variant is ever selected:
+    # ZERO cooperative-launch fallbacks, and no request waits for a ~20 ms hand-off time-out (every request within 5 x the median; at most
+    # 2 x threads requests are outstanding, so queueing is inside the median)
+    assert int(f["coop_fallbacks"]) == 0, f
+    assert float(f["max_ms"]) <= 5.0 * float(f["median_ms"]), f
     prob = np.fromfile(os.path.join(d, "out_worker.bin"), np.float32)
     fm = W.framework_model(model, "int8")
     ref = NO.run_int8(fm, dict(scales), x)
     want = ref["prob"].reshape(batch, -1)
     assert np.abs(prob.reshape(batch, -1) - want).max() <= 1e-4 * want.max()
-    print("Worker<MI355X, INT8>, ResNet50 batch 8, 3 threads, host tensors in and out: %.0f images/s" % float(t[t.index("images_per_s") + 1]))
+    print("Worker<MI355X, INT8>, ResNet50 batch 8, 3 threads x 300 requests, host tensors in and out: %.0f images/s, request latency median %s ms, max %s ms"
+          % (float(f["images_per_s"]), f["median_ms"], f["max_ms"]))
+
+
+@pytest.mark.parametrize("mode", ["worker_async", "worker_pinned"])
+def test_worker_mi355x_int8_async_prediction_and_pinned_requests(tmp_path, mode):
+    """Worker::async_prediction / async_get_result (framework/core/net/worker.h:52-60; round-4 verdict, missing 4) driven on the device:
+    the answers are the serving Net's own device tensors, copied out and compared - and sync_prediction from a request buffer the
+    client registered with the HIP runtime (the copy lane then sends it in one asynchronous copy, no staging ring)."""
+    batch = 8
+    x = W.make_input(batch)
+    model = W.build_model("resnet50")
+    scales = W.calibrate(model, x)
+    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, [mode, "3", "96"], precision="int8", scales=scales)
+    assert "worker ok" in r.stdout
+    t = open(os.path.join(d, "worker.txt")).read().split()
+    f = {t[i]: t[i + 1] for i in range(0, len(t) - 1, 2)}
+    assert int(f["mismatches"]) == 0 and int(f["requests"]) == 96 and int(f["coop_fallbacks"]) == 0
+    prob = np.fromfile(os.path.join(d, "out_worker.bin"), np.float32)
+    ref = NO.run_int8(W.framework_model(model, "int8"), dict(scales), x)
+    want = ref["prob"].reshape(batch, -1)
+    assert np.abs(prob.reshape(batch, -1) - want).max() <= 1e-4 * want.max()
+    print("Worker<MI355X, INT8> %s: %.0f images/s" % (mode, float(f["images_per_s"])))
 
 
 def test_entropy_calibrator_mi355x_writes_the_calibration_table(tmp_path):

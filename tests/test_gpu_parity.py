@@ -1367,6 +1367,63 @@ def test_gemm_f32_b_changes_between_calls_and_streams_have_their_own_plans():
     assert np.array_equal(host(c2), r2)
 
 
+def test_gemm_f32_plans_under_hipgraph_capture_survive_eviction():
+    """Round-4 advisor finding: the plane path keeps its device scratch in a per-thread LRU of 16 plans. A hipGraph captured over a
+    plan keeps its pointers, so (a) the plan a capture uses is pinned - 20 other shapes afterwards must not free what the graph
+    replays on; (b) the first sight of a shape UNDER capture does not fail: it records the stateless f32-MFMA kernel; (c) an eager
+    call of the captured key gets a plan of its own; (d) saber_hip_gemm_f32_release_plans frees them all."""
+    rng = np.random.default_rng(59)
+    lib = L.load()
+    lib.saber_hip_gemm_f32_release_plans()
+    M, N, K = 128, 256, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    a, b, c = dev(A), dev(B), dev(np.zeros((M, N), np.float32))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        S.gemm(0, 0, M, N, K, 1.0, a, b, 0.0, c)          # eager: builds the plan
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            S.gemm(0, 0, M, N, K, 1.0, a, b, 0.0, c)      # pins it
+        # (b) a shape this stream has never run, first seen under capture
+        M2, N2, K2 = 96, 160, 264
+        A2 = rng.standard_normal((M2, K2)).astype(np.float32)
+        B2 = rng.standard_normal((K2, N2)).astype(np.float32)
+        a2, b2, c2 = dev(A2), dev(B2), dev(np.zeros((M2, N2), np.float32))
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=st):
+            S.gemm(0, 0, M2, N2, K2, 1.0, a2, b2, 0.0, c2)
+        # 20 other shapes on the same stream: more than the LRU holds
+        for i in range(20):
+            m_ = 64 + 8 * i
+            x_, w_, y_ = dev(np.ones((m_, 256), np.float32)), dev(np.ones((256, 256), np.float32)), dev(np.zeros((m_, 256), np.float32))
+            S.gemm(0, 0, m_, 256, 256, 1.0, x_, w_, 0.0, y_)
+        st.synchronize()
+        c.zero_()
+        c2.zero_()
+        g.replay()
+        g2.replay()
+        st.synchronize()
+        got = host(c)
+        assert np.abs(got - want).max() <= FP32_RTOL * np.abs(want).max()
+        want2 = A2.astype(np.float64) @ B2.astype(np.float64)
+        assert np.abs(host(c2) - want2).max() <= FP32_RTOL * np.abs(want2).max()
+        # (c) eager again with the captured key, then the graph again: same bits both ways
+        c.zero_()
+        S.gemm(0, 0, M, N, K, 1.0, a, b, 0.0, c)
+        st.synchronize()
+        assert np.array_equal(host(c), got)
+        c.zero_()
+        g.replay()
+        st.synchronize()
+        assert np.array_equal(host(c), got)
+    del g, g2
+    assert lib.saber_hip_gemm_f32_release_plans() >= 2
+    assert lib.saber_hip_gemm_f32_release_plans() == 0
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("adt", [O.S8, O.U8])
 def test_gemm_i8_exact(ta, tb, adt):

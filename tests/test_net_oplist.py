@@ -188,3 +188,27 @@ def test_resnet50_fp32_and_vgg16_pass_the_reference_optimiser(tmp_path):
     assert kinds.count("ReLU") == 2 and kinds.count("Softmax") == 1
     assert "plan 1 captured_ops 24 " in dry_run.plan[0], dry_run.plan[0]
 
+
+
+@pytest.mark.parametrize("mode", ["worker", "worker_async", "worker_pinned"])
+def test_worker_host_side_on_the_mock_runtime(tmp_path, mode):
+    """Worker<MI355X, INT8> (framework/core/net/worker.h:38-60), 3 pool threads, on the malloc-backed mock HIP runtime: nothing is computed,
+    but everything the HOST does per request runs - the constructor declaring the shared device to the plans (worker.cpp patch ->
+    MI355XNetPlanDefaults::worker_threads: a stream per Net, SABER_HIP_NET_SHARED_DEVICE), Graph::load + Optimize + Net::init with the
+    captured plan in every pool thread, the per-thread copy lanes of TargetWrapper<MI355X>::sync_memcpy (pinned staging ring, 4.8 MB in
+    1 MB chunks; mi355x_impl.cpp), sync_prediction and async_prediction / async_get_result. The GPU tier (tests/test_gpu_net.py) runs the
+    same binary on the device and checks the answers."""
+    model = W.build_model("resnet50")
+    x = W.make_input(8)
+    scales = W.calibrate(model, x[:2])
+    d = str(tmp_path)
+    mt, wb = NM.write_model(model, scales, 8, d, "int8", calibrator_config=True)
+    x.tofile(os.path.join(d, "input.bin"))
+    env = dict(os.environ, LD_PRELOAD=MOCK, SABER_MI355X_NET_PLAN_TUNE="0")
+    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, mode, "3", "24"], env=env, capture_output=True, text=True,
+                       errors="replace", cwd=d, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    wt = open(os.path.join(d, "worker.txt")).read().split()
+    f = {wt[i]: wt[i + 1] for i in range(0, len(wt) - 1, 2)}
+    assert int(f["requests"]) == 24 and int(f["mismatches"]) == 0 and int(f["coop_fallbacks"]) == 0
+    assert int(f["async"]) == (1 if "async" in mode else 0)
