@@ -87,6 +87,10 @@ struct Capture {
         return id;
     }
     int readwrite(void* p, size_t bytes) {     // in place: the operator reads the tensor it then overwrites
+        // A target nobody has written earlier in the pass becomes an INPUT bound to the caller's memory that every run of the list
+        // accumulates into: legitimate for a caller who refills it per run (a single captured ConvEltwise), fatal for anything that runs
+        // the list repeatedly on its own - saber_hip_net_autotune refuses such a net (saber_hip_net::inplace_external).
+        if (p && live.find((uintptr_t)p) == live.end()) net->inplace_external = true;
         return read(p, bytes);
     }
     void note(const void* p, int id) {
@@ -115,7 +119,8 @@ int capture_conv(saber_hip_conv* op, const void* x, void* y, const void* res) {
     const int in = c.read(x, in_b);
     int r = -1;
     if (d.res_mode == SABER_HIP_RES_ELTWISE) {
-        const size_t res_b = d.res_stride > 1 ? (size_t)d.n * d.res_h * d.res_w * d.k : (size_t)d.n * op->oh * op->ow * d.k;
+        const size_t res_b = (d.res_stride > 1 ? (size_t)d.n * d.res_h * d.res_w * d.k : (size_t)d.n * op->oh * op->ow * d.k) *
+                             esz(d.out_dtype);      // (the eltwise operands have the output's element size: s8 | s8 -> s8, f32 | f32 -> f32)
         r = c.read(res, res_b);
     }
     const int out = d.res_mode == SABER_HIP_RES_SUM_INPLACE ? c.readwrite(y, out_b) : c.write(y, out_b);

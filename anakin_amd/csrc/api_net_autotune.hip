@@ -143,6 +143,9 @@ static int net_consolidate_kernels(saber_hip_net* net, hipStream_t s) {
 }
 
 int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int iters) {
+    if (net->inplace_external)
+        return fail(SABER_HIP_INVALID_VALUE, "autotune: an in-place sum of this captured list accumulates into a tensor of the caller's that the "
+                    "list itself never writes - timing passes would change it (run the pass that writes it inside the capture)");
     if (net->exec) {   // a captured graph holds the OLD kernel selections: drop it, the caller captures again
         (void)hipGraphExecDestroy(net->exec);
         (void)hipGraphDestroy(net->graph);

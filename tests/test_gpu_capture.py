@@ -169,3 +169,7 @@ def test_captured_fp32_inplace_sum_keeps_one_tensor():
     net.run()
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy(), want)
+    # the in-place target is the caller's tensor, never written by the list itself: every run accumulates into it, so the autotuner
+    # (which runs passes on its own) refuses the net instead of letting its result drift (round-4 advisor finding)
+    with pytest.raises(L.SaberHipError):
+        net.autotune(iters=3)

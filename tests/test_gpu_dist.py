@@ -30,6 +30,31 @@ def test_bench_two_ranks_share_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_four_ranks_share_one_gpu_and_report_the_per_request_exchange():
+    """Four ranks (round-4 verdict item 8) on the one GPU of the box: nets declared SABER_HIP_NET_SHARED_DEVICE (no stage launch / no
+    cooperating chains: four processes' kernels interleave on the CUs), logits through gloo; the line carries both exchange cadences -
+    amortised over --gather-every steps (the headline) and per request (config.gather.per_request) - and zero cooperative fallbacks."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "40", "--warmup", "5", "--no-cpu-baseline",
+                        "--no-b1"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 4 and cfg["global_batch"] == 32 and cfg["parallelism"] == "batch-shard x4"
+    assert cfg["shared_device"] is True and cfg["coop_fallbacks"] == 0 and cfg["coop_fallback"] is False
+    assert cfg["rccl_ranks"] == 0 and cfg["dist_backend"] == "gloo"
+    g = cfg["gather"]
+    assert g["every_steps"] == 16 and g["per_request"]["every_steps"] == 1 and g["per_request"]["ms_per_step"] > 0
+    print("4 ranks sharing the GPU: %.4f ms/step amortised gather, %.4f ms/step with a gather per request"
+          % (out["ms_per_step"], g["per_request"]["ms_per_step"]))
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_spawns_its_own_ranks_and_the_gather_is_cheap():
     """`python bench.py --gpus 2` called PLAINLY (no torchrun): the script re-executes itself under torch.distributed.run,
     shards the batch over two ranks (here sharing the one GPU of the test box, logits through gloo), asserts n_gpus == --gpus
