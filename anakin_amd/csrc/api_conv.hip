@@ -673,6 +673,8 @@ static void fill_args(const saber_hip_conv* op, ConvKArgs& a, const void* x, voi
     }
 }
 
+void conv_fill_args(const saber_hip_conv* op, saber_mi355x::ConvKArgs& a, const void* x, void* y, const void* res) { fill_args(op, a, x, y, res); }
+
 // the fused stem conv + pooling's argument block (and its channel-padding pre-pass); shared with saber_hip_conv2d_stem_pair_run
 int stem_pool_args(const saber_hip_conv* op, const void* x, void* y, void* workspace, hipStream_t s, saber_mi355x::ConvKArgs* a) {
     const saber_hip_conv_desc& d = op->d;

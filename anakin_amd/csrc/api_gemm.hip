@@ -255,7 +255,13 @@ int saber_hip_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const f
     ta = ta ? 1 : 0;
     tb = tb ? 1 : 0;
     if (m <= 16 && tb && !ta && k % 4 == 0 && (size_t)n * k >= ((size_t)1 << 20) && !std::getenv("SABER_HIP_GEMM_F32_PLANES")) {
-        // a few rows against [n][k] weights: one pass over B (gemm_f32_rows_kernel)
+        // a few rows against [n][k] weights: one pass over B on the f32 MFMA (fc_small.hip: fc_f32_stream_kernel, the kernel VenderFc's
+        // FP32 role runs inside a net; SABER_HIP_GEMM_ROWS_VALU=1: round 4's VALU kernel, kept for A/B)
+        const char* valu = std::getenv("SABER_HIP_GEMM_ROWS_VALU");
+        if (!(valu && valu[0] == '1') && gemm_f32_rows_ok(m, k)) {
+            HIP_TRY(launch_gemm_f32_rows(m, n, k, alpha, a, b, beta, c, zero_page(), s));
+            return SABER_HIP_OK;
+        }
         const dim3 grid((n + 7) / 8), block(256);
         if (m <= 4) hipLaunchKernelGGL(gemm_f32_rows_kernel<4>, grid, block, 0, s, m, n, k, alpha, a, b, beta, c);
         else if (m <= 8) hipLaunchKernelGGL(gemm_f32_rows_kernel<8>, grid, block, 0, s, m, n, k, alpha, a, b, beta, c);

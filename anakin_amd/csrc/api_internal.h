@@ -135,6 +135,7 @@ struct saber_hip_conv {
     DevBuf<uint8_t> d_w3;    // FP32 convs: the repacked weights split into three bf16 planes [3][K_pad][Kg_pad] (b3 variant)
     DevBuf<float> d_bias, d_scale;
     DevBuf<int> d_comp;
+    DevBuf<unsigned> d_sm_ctr;   // INT8 fc + softmax in one launch (fc_small.hip): the arrival counter, zero between launches
     bool has_bias = false, has_comp = false;
     std::string algo_name;
     // sibling pair (saber_hip_conv2d_create_pair): d.k = k1 + k2, rows >= k1 belong to the second conv
@@ -435,6 +436,7 @@ bool img_ok(const saber_hip_conv* op, int nw, int ib, int rb);      // api_conv.
 bool stem_ok(const saber_hip_conv* op);      // api_conv.hip
 void name_algo(saber_hip_conv* op);      // api_conv.hip
 std::string stem_pair_name(const saber_api::NetOp& o);      // api_net_optimize.hip
+void conv_fill_args(const saber_hip_conv* op, saber_mi355x::ConvKArgs& a, const void* x, void* y, const void* res);   // api_conv.hip
 int stem_pool_args(const saber_hip_conv* op, const void* x, void* y, void* workspace, hipStream_t s, saber_mi355x::ConvKArgs* a);   // api_conv.hip
 // FP32 split-K (b3 kernels): 2^sh workgroups per tile; needs >= 2 stages per split, a bounded partial buffer, and the
 // workgroup -> XCD placement the hand-off relies on (checked once per device). split_prepare allocates the buffers.
@@ -447,6 +449,9 @@ int img_conv_prepare(saber_hip_conv* op);
 int img_conv_run(saber_hip_conv* op, const void* x, void* y, const void* res, void* y_pool, hipStream_t stream);
 void img_conv_release(saber_hip_conv* op);
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s);      // api_net.hip
+bool fc_softmax_ok(const saber_hip_fc* fc, bool quantised_input = false);      // api_ops.hip: the INT8 small-batch fc kernel can normalise its own logits (fc_small.hip)
+int fc_run_softmax(saber_hip_fc* fc, const void* x, float* y, float* prob, void* workspace, hipStream_t s, bool quantised_input);
+int fc_softmax_prepare(saber_hip_fc* fc);        // ... allocates the arrival counter (not under stream capture)
 void net_set_chain_mode(saber_hip_net* net, int ia, int mode);      // api_net_optimize.hip
 int net_chain_mode(const saber_hip_net* net, int ia);      // api_net_optimize.hip
 // the stage headed by ops[i0] (NetOp::stage) on / off: on forces every block's 3x3-led chain form and makes ops[i0] launch them all

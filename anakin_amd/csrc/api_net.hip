@@ -47,7 +47,9 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
     case OP_CONV_PAIR:
         if (o.skip) return SABER_HIP_OK;      // written by the stem launch in front of it (flag 512)
         return saber_hip_conv2d_run_pair(o.conv, T(o.in), T(o.out), T(o.out2), s);
-    case OP_FC: return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
+    case OP_FC:
+        if (o.out2 >= 0) return fc_run_softmax(o.fc, T(o.in), (float*)T(o.out), (float*)T(o.out2), ws, s, false);      // flag 4096
+        return saber_hip_fc_run(o.fc, T(o.in), (float*)T(o.out), ws, s);
     case OP_QUANT:
         return saber_hip_quantize_nchw_to_nhwc(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.f[0],
                                                (const float*)T(o.in), T(o.out), s);
@@ -73,8 +75,12 @@ int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s) {
         return saber_hip_pool2d_f32_from_i8_q(o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8],
                                               o.p[9], o.p[10], o.p[11], o.p[12], o.p[13], o.f[0], T(o.in),
                                               (float*)T(o.out), o.f[1], (int8_t*)T(o.out2), s);
-    case OP_FC_Q: return saber_hip_fc_run_q(o.fc, (const int8_t*)T(o.in), (float*)T(o.out), s);
-    case OP_SOFTMAX: return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
+    case OP_FC_Q:
+        if (o.out2 >= 0) return fc_run_softmax(o.fc, T(o.in), (float*)T(o.out), (float*)T(o.out2), ws, s, true);
+        return saber_hip_fc_run_q(o.fc, (const int8_t*)T(o.in), (float*)T(o.out), s);
+    case OP_SOFTMAX:
+        if (o.skip) return SABER_HIP_OK;      // normalised by the fc launch in front of it (flag 4096)
+        return saber_hip_softmax_f32(o.p[0], o.p[1], (const float*)T(o.in), (float*)T(o.out), s);
     case OP_RELU_F32: return saber_hip_relu_f32(o.count, (const float*)T(o.in), (float*)T(o.out), s);
     case OP_ACT_F32: return saber_hip_activation_f32(o.p[0], o.count, o.f[0], o.f[1], (const float*)T(o.in), (float*)T(o.out), s);
     }
@@ -453,9 +459,13 @@ int saber_hip_net_op_work(const saber_hip_net_t* net, int index, double* bytes, 
         const double esz = d.int8_weights ? 1 : 4;
         *bytes = (double)d.m * d.k * (o.kind == OP_FC_Q || d.in_dtype != SABER_HIP_F32 ? 1 : 4) + (double)d.m * d.n * 4 + (double)d.n * d.k * esz;
         *flops = 2.0 * d.m * d.n * d.k;
+        if (o.out2 >= 0) *bytes += 2.0 * tb(o.out2);      // + the softmax it runs (flag 4096): the logits read back, the probabilities written
         return SABER_HIP_OK;
     }
-    default: *bytes = tb(o.in) + tb(o.in2) + tb(o.out) + tb(o.out2); return SABER_HIP_OK;
+    default:
+        if (o.skip) return SABER_HIP_OK;
+        *bytes = tb(o.in) + tb(o.in2) + tb(o.out) + tb(o.out2);
+        return SABER_HIP_OK;
     }
 }
 // Per-op time INSIDE a forward pass: one event after every launch of an eager pass, averaged over `iters` passes

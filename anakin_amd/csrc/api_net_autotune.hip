@@ -40,6 +40,7 @@ int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     if (rc) return rc;
     NetOp& o = net->ops[index];
     o.name = std::string(o.kind == OP_FC || o.kind == OP_FC_Q ? "fc:" : "conv:") + c->algo_name;
+    if ((o.kind == OP_FC || o.kind == OP_FC_Q) && o.out2 >= 0) o.name += fc_softmax_ok(o.fc, o.kind == OP_FC_Q) ? "+softmax" : " | softmax_f32";
     // chain decisions: a 3x3 head (bit 29) is restored before its chain head (bit 28, the next op): set_choices runs in op order
     if (o.chain3 && (chain_bits & 32) && index + 1 < (int)net->ops.size()) {
         const int tn = chain_bits & 15;
@@ -183,6 +184,7 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         int rc = saber_hip_conv2d_autotune(c, xin, T(o.out), T(o.in2), net->arena + net->ws_off, stream, iters);
         if (rc) return rc;
         o.name = std::string(o.kind == OP_CONV ? "conv:" : "fc:") + c->algo_name;
+        if ((o.kind == OP_FC || o.kind == OP_FC_Q) && o.out2 >= 0) o.name += fc_softmax_ok(o.fc, o.kind == OP_FC_Q) ? "+softmax" : " | softmax_f32";
         if (o.stem_pair) o.name = stem_pair_name(o);
     }
     // conv1x1 chains: the tuned separate launches against the chain launch (every pixel-tile size) and, where the block's

@@ -457,6 +457,25 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
             i += 3 * run.size();
         }
     }
+    // ---- 4096: fc + the softmax over its output -> one launch (fc_small.hip: the last-arriving workgroup normalises) ----------------
+    if (flags & 4096) {
+        for (size_t i = 0; i + 1 < ops.size(); ++i) {
+            NetOp& F = ops[i];
+            if (dead[i] || (F.kind != OP_FC && F.kind != OP_FC_Q) || !F.fc || F.out2 >= 0 || F.lane) continue;
+            size_t j = i + 1;
+            while (j < ops.size() && dead[j]) ++j;
+            if (j >= ops.size()) break;
+            NetOp& S = ops[j];
+            if (S.kind != OP_SOFTMAX || S.in != F.out || S.skip || S.lane || S.p[0] != F.fc->d.m || S.p[1] != F.fc->d.n) continue;
+            if (F.kind == OP_FC && F.fc->pre_quant) continue;      // (a quantise-on-entry pre-pass: two launches already)
+            if (!fc_softmax_ok(F.fc, F.kind == OP_FC_Q) || fc_softmax_prepare(F.fc) != SABER_HIP_OK) continue;
+            F.out2 = S.out;
+            F.name = std::string("fc:") + F.fc->conv->algo_name + "+softmax";
+            S.skip = true;
+            S.name = "softmax_f32 (in the fc launch)";
+            ++removed;
+        }
+    }
     if (net->shared_device) {      // no variant that relies on workgroup placement: split-K off, cooperating chains back to one workgroup per tile
         for (NetOp& o : ops) {
             saber_hip_conv* c = (o.kind == OP_FC || o.kind == OP_FC_Q) ? (o.fc ? o.fc->conv : nullptr) : o.conv;

@@ -121,6 +121,47 @@ int saber_hip_fc_run_q(saber_hip_fc_t* fc, const int8_t* xq, float* y, saber_hip
     return saber_hip_conv2d_run(fc->conv, xq, y, nullptr, nullptr, stream);
 }
 
+// fc + Softmax in ONE launch (fc_small.hip: the last-arriving workgroup normalises the rows). Eligible: an INT8 fc whose small-batch
+// weight-streaming kernel is selected, reading an 8-bit operand as it lies (no quantise-on-entry pre-pass), <= 1024 outputs, a
+// reduction of 512 / 1024 / 2048 / 4096. Anything else - also a later change of the fc's kernel selection - runs the two launches:
+// the entry point is always correct, the fusion is an optimisation.
+bool fc_softmax_ok(const saber_hip_fc* fc, bool quantised_input) {
+    if (!fc || !fc->conv || (fc->pre_quant && !quantised_input)) return false;
+    const saber_hip_conv* c = fc->conv;
+    const int ksw = (c->c_eff + 255) / 256;
+    return c->fc_small && c->algo == ALGO_IGEMM_I8 && (ksw == 2 || ksw == 4 || ksw == 8 || ksw == 16) &&
+           fc_i8_small_softmax_ok(c->d.n, c->c_eff, c->Kg_pad, c->d.k);
+}
+int fc_softmax_prepare(saber_hip_fc* fc) {
+    if (!fc || !fc->conv) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!fc->conv->d_sm_ctr.p) HIP_TRY(fc->conv->d_sm_ctr.alloc_zero(32));
+    return SABER_HIP_OK;
+}
+// quantised_input: x is the s8 operand an f32-input INT8 fc would have computed on entry (saber_hip_fc_run_q's contract)
+int fc_run_softmax(saber_hip_fc* fc, const void* x, float* y, float* prob, void* workspace, hipStream_t s, bool quantised_input) {
+    if (!fc || !x || !y || !prob) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (!g_capture && fc_softmax_ok(fc, quantised_input) && !fc->conv->d_sm_ctr.p) {
+        // first use outside a net: the counter (nothing may be allocated under stream capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)fc_softmax_prepare(fc);
+    }
+    if (!g_capture && fc_softmax_ok(fc, quantised_input) && fc->conv->d_sm_ctr.p) {
+        saber_hip_conv* op = fc->conv;
+        if (!op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "set_weights not called");
+        ConvKArgs a;
+        conv_fill_args(op, a, x, y, nullptr);
+        HIP_TRY(launch_fc_i8_small_softmax(a, prob, op->d_sm_ctr.p, s));
+        return SABER_HIP_OK;
+    }
+    // the two operators one after the other (under an op-list capture: recorded as the two operators they are)
+    const int rc = quantised_input ? saber_hip_fc_run_q(fc, (const int8_t*)x, y, (saber_hip_stream_t)s)
+                                   : saber_hip_fc_run(fc, x, y, workspace, (saber_hip_stream_t)s);
+    return rc ? rc : saber_hip_softmax_f32(fc->d.m, fc->d.n, y, prob, (saber_hip_stream_t)s);
+}
+int saber_hip_fc_run_softmax(saber_hip_fc_t* fc, const void* x, float* y, float* prob, void* workspace, saber_hip_stream_t stream) {
+    return fc_run_softmax(fc, x, y, prob, workspace, (hipStream_t)stream, false);
+}
+
 const char* saber_hip_fc_algo(const saber_hip_fc_t* fc) { return fc ? fc->conv->algo_name.c_str() : ""; }
 int saber_hip_fc_set_tile(saber_hip_fc_t* fc, int tile) {
     if (!fc) return fail(SABER_HIP_INVALID_VALUE, "null argument");

@@ -15,9 +15,23 @@
 namespace saber_mi355x {
 
 // KSW: 64-byte k-steps per wave (reduction = 4 waves x KSW x 64, zero padded weights beyond Kg)
-template <int KSW>
-__global__ __launch_bounds__(256) void fc_i8_small_kernel(const ConvKArgs a) {
+// SM (round 5, round-4 verdict item 2 ii): the Softmax operator that follows the fc (saber_softmax.cpp role; softmax_f32_kernel's
+// arithmetic per row: max, exp(x - max), sum, divide) in the SAME launch - the fc's 63 workgroups each hold 16 of an image's 1000 logits,
+// so the workgroup that arrives LAST on a device-wide counter normalises the rows (one wave per row, 16 logits per lane, wave shuffles).
+// Round 1 tried this with an agent-scope RELEASE fence per workgroup (an L2 write-back: 33.9 us against 8.7 for the two launches); here
+// the hand-off is the one the guide measures at ~1 us: the logits leave as agent-scope (write-through) stores, `s_waitcnt vmcnt(0)`,
+// one returning agent-scope atomic on the counter, and the last workgroup reads them back with SYSTEM-scope loads (sc0 sc1: served from
+// beyond its XCD's L2, whatever that L2 holds of the lines its own 64-byte stores touched). The counter is put back to zero by the last
+// workgroup. The logits tensor is written as before (it is an edge of the op list); a row's sum runs lane-major instead of
+// softmax_f32_kernel's thread-major order: same values within the 1e-4 the softmax output is held to everywhere.
+struct FcSoftmaxTail {
+    float* prob;        // [M][K]
+    unsigned* ctr;      // one word, zero between launches
+};
+template <int KSW, bool SM>
+__device__ __forceinline__ void fc_i8_small_body(const ConvKArgs& a, const FcSoftmaxTail& t) {
     __shared__ v4i red[3][64];
+    __shared__ unsigned last_flag;
     SABER_TL_DECL;
     SABER_TL(0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -52,87 +66,221 @@ __global__ __launch_bounds__(256) void fc_i8_small_kernel(const ConvKArgs a) {
     if (wave > 0) red[wave - 1][lane] = acc;
     __syncthreads();
     SABER_TL(3);
-    if (wave > 0) return;
-    acc += red[0][lane];
-    acc += red[1][lane];
-    acc += red[2][lane];
-    // lane: output channels kb..kb+3 of batch row frow
-    if (frow >= a.M || kb >= a.K) return;
-    float out[4];
+    if (wave == 0) {
+        acc += red[0][lane];
+        acc += red[1][lane];
+        acc += red[2][lane];
+        // lane: output channels kb..kb+3 of batch row frow
+        if (frow < a.M && kb < a.K) {
+            float out[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int v = acc[r] + cp.comp[r];
-        const float d = (float)v;
-        if (a.epi == EPI_I8_FC_S8) out[r] = __fadd_rn(__fmul_rn(d, cp.scale[r]), cp.bias[r]);
-        else out[r] = (cp.scale[r] == 1.f) ? d : __fmul_rn(cp.scale[r], d);     // EPI_I8_FC_U8
-    }
-    float* y = (float*)a.y + (size_t)frow * a.K + kb;
-    if (kb + 4 <= a.K && (a.K & 3) == 0) {
-        *(float4*)y = make_float4(out[0], out[1], out[2], out[3]);
-    } else {
-        for (int r = 0; r < 4; ++r)
-            if (kb + r < a.K) y[r] = out[r];
+            for (int r = 0; r < 4; ++r) {
+                const int v = acc[r] + cp.comp[r];
+                const float d = (float)v;
+                if (a.epi == EPI_I8_FC_S8) out[r] = __fadd_rn(__fmul_rn(d, cp.scale[r]), cp.bias[r]);
+                else out[r] = (cp.scale[r] == 1.f) ? d : __fmul_rn(cp.scale[r], d);     // EPI_I8_FC_U8
+            }
+            float* y = (float*)a.y + (size_t)frow * a.K + kb;
+            if constexpr (SM) {
+                for (int r = 0; r < 4; ++r)
+                    if (kb + r < a.K) __hip_atomic_store(y + r, out[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through
+            } else if (kb + 4 <= a.K && (a.K & 3) == 0) {
+                *(float4*)y = make_float4(out[0], out[1], out[2], out[3]);
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (kb + r < a.K) y[r] = out[r];
+            }
+        }
     }
     SABER_TL(4);
-    SABER_TL_FLUSH();
+    if constexpr (!SM) {
+        SABER_TL_FLUSH();
+        return;
+    } else {
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's logits are at the device's coherence point
+            if (lane == 0) last_flag = __hip_atomic_fetch_add(t.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!last_flag) {
+            SABER_TL_FLUSH();
+            return;
+        }
+        SABER_TL(5);
+        if (tid == 0) __hip_atomic_store(t.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch
+        constexpr int PER = 16;                                   // logits per lane: rows of up to 1024 (checked by the launcher)
+        for (int row = wave; row < a.M; row += 4) {
+            const float* yr = (const float*)a.y + (size_t)row * a.K;
+            float v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = lane + 64 * i;
+                v[i] = c < a.K ? __hip_atomic_load(yr + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : -3.4e38f;
+            }
+            float mx = v[0];
+#pragma unroll
+            for (int i = 1; i < PER; ++i) mx = fmaxf(mx, v[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                v[i] = lane + 64 * i < a.K ? expf(v[i] - mx) : 0.f;
+                sum += v[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            float* pr = t.prob + (size_t)row * a.K;
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                if (lane + 64 * i < a.K) pr[lane + 64 * i] = v[i] / sum;
+        }
+        SABER_TL(6);
+        SABER_TL_FLUSH();
+    }
+}
+template <int KSW>
+__global__ __launch_bounds__(256) void fc_i8_small_kernel(const ConvKArgs a) {
+    fc_i8_small_body<KSW, false>(a, FcSoftmaxTail{nullptr, nullptr});
+}
+template <int KSW>
+__global__ __launch_bounds__(256) void fc_i8_small_softmax_kernel(const ConvKArgs a, const FcSoftmaxTail t) {
+    fc_i8_small_body<KSW, true>(a, t);
 }
 
-// FP32 fc (VenderFc<X86,AK_FLOAT>, vender_fc.cpp:154-212: out = in W^T + bias) at <= 16 batch rows: the same shape of
-// kernel on v_mfma_f32_16x16x4_f32 - 16 outputs per workgroup, the 4 waves split the reduction, weight and activation chunks
-// (16 floats per row per step) go straight into MFMA operand registers sixteen steps at a time, partial sums meet in LDS.
-// ResNet50's fc (8 x 2048 -> 1000, an 8 MB weight stream): 15.4 us through the implicit-GEMM kernel's 32 workgroups.
-__global__ __launch_bounds__(256) void fc_f32_small_kernel(const ConvKArgs a, int ksw) {
+// FP32 fc (VenderFc<X86,AK_FLOAT>, vender_fc.cpp:154-212: out = in W^T + bias) at <= 16 batch rows, and Gemm<float> with a few rows
+// against [n][k] weights (saber/funcs/gemm.h:27-66): ONE pass over the weights - VGG16's fc6 is a 411 MB stream for 1.6 GFLOP - on
+// v_mfma_f32_16x16x4_f32. 16 outputs per workgroup, the 4 waves split the reduction; weight and activation chunks (16 floats per row per
+// step) go straight into MFMA operand registers.
+// Round 5 (round-4 verdict item 7: fc6 at 3.08 TB/s = 38 % of HBM, asked >= 60 %): the round-2 kernel loaded 16 + 16 chunks, waited for
+// ALL of them, ran 64 MFMAs that all accumulate into ONE register quad (each waits out its predecessor's 8 passes) and only then asked for
+// the next batch - load latency and MFMA time added up, 24 times per wave at fc6. Now:
+//   * two register buffers of NS steps: the loads of buffer b ^ 1 are issued BEFORE the MFMAs of buffer b (the compiler's counted
+//     s_waitcnt vmcnt leaves exactly those in flight) - 2 x NS KB of weights per wave in flight, 96 KB per CU at NS = 12;
+//   * every load is unconditional (conditional loads make the wait-count pass drain the queue): beyond the reduction's end the weight
+//     ADDRESS falls back to the row's start (finite values) and the activation address to the zero page;
+//   * four independent accumulators (one per k-group of a chunk), summed once at the end;
+//   * the weights are requested non-temporal (read once per pass; the activations, re-read by every workgroup, are not).
+// Summation order differs from MKL's and from the round-2 kernel's - inside the 1e-4 FP32 tolerance like every FP32 path.
+struct FcStreamArgs {
+    const float* w;      // [n (padded or not)][w_pitch]
+    const float* x;      // [m][c]
+    float* y;            // [m][n]
+    const float* bias;   // [n] or null
+    const void* zero;    // >= 16 zero bytes
+    int m, n, c, w_pitch;
+    int w_rows;          // rows of w that may be read (rows beyond fall back to the last one; their outputs are not stored)
+    int relu;
+    float neg_slope, alpha, beta;      // y = act(alpha * acc + bias) (+ beta * y_old when beta != 0)
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void fc_f32_stream_kernel(const FcStreamArgs a) {
     __shared__ v4f redf[3][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int m = frow < a.M ? frow : a.M - 1;
+    const int m = frow < a.m ? frow : a.m - 1;               // rows beyond the batch re-read the last one (results dropped)
+    const int wr = n0 + frow < a.w_rows ? n0 + frow : a.w_rows - 1;
+    const int ksw = (a.c + 63) / 64;                         // 16-float steps per wave
     const int k0 = wave * ksw * 16 + fq * 4;                 // this lane's first reduction index
-    const float* wp = (const float*)a.w + (size_t)(n0 + frow) * a.Kg_pad + k0;
-    const float* xp = (const float*)a.x + (size_t)m * a.C + k0;
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < ksw; s0 += 16) {
-        v4i wf[16], xf[16];
+    const float* const wrow = a.w + (size_t)wr * a.w_pitch;
+    const float* const xrow = a.x + (size_t)m * a.c;
+    const float* const zero = (const float*)a.zero;
+    v4f acc[4];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const bool in = s0 + s < ksw && k0 + (s0 + s) * 16 < a.C;      // the activation row is C floats; weights are zero padded
-            wf[s] = in ? *(const v4i*)(wp + (s0 + s) * 16) : v4i{0, 0, 0, 0};
-            xf[s] = in ? *(const v4i*)(xp + (s0 + s) * 16) : v4i{0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4i wf[2][NS], xf[2][NS];
+    auto request = [&](int b, int s0) {                      // steps s0 .. s0 + NS - 1 of this wave into buffer b
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k = k0 + (s0 + s) * 16;
+            const bool in = s0 + s < ksw && k < a.c;
+            const float* wp = in ? wrow + k : wrow;          // (address select, not a branch: the load itself is unconditional)
+            const float* xp = in ? xrow + k : zero;
+            wf[b][s] = __builtin_nontemporal_load((const v4i*)wp);
+            xf[b][s] = *(const v4i*)xp;
         }
+    };
+    auto multiply = [&](int b) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = mma_step(wf[s], xf[s], acc);
+        for (int s = 0; s < NS; ++s) {
+            const v4f wv = __builtin_bit_cast(v4f, wf[b][s]);
+            const v4f xv = __builtin_bit_cast(v4f, xf[b][s]);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[3], 0, 0, 0);
+        }
+    };
+    // (scheduling barriers: left alone, the scheduler sinks every load next to its MFMA to save registers - one load in flight,
+    // s_waitcnt vmcnt(0) in front of every MFMA group; with them the wait-count pass emits vmcnt(2 * NS) in front of a buffer's MFMAs)
+    request(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < ksw; s0 += 2 * NS) {
+        request(1, s0 + NS);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(0);
+        __builtin_amdgcn_sched_barrier(0);
+        request(0, s0 + 2 * NS);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (wave > 0) redf[wave - 1][lane] = acc;
+    v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (wave > 0) redf[wave - 1][lane] = sum;
     __syncthreads();
     if (wave > 0) return;
-    acc += redf[0][lane];
-    acc += redf[1][lane];
-    acc += redf[2][lane];
-    const int kb = n0 + fq * 4;
-    if (frow >= a.M || kb >= a.K) return;
+    sum += redf[0][lane];
+    sum += redf[1][lane];
+    sum += redf[2][lane];
+    const int kb = n0 + fq * 4;                              // lane: outputs kb .. kb + 3 of batch row frow
+    if (frow >= a.m || kb >= a.n) return;
+    float* y = a.y + (size_t)frow * a.n + kb;
     float out[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float d = acc[r];
-        if (a.bias && kb + r < a.K) d = __fadd_rn(d, a.bias[kb + r]);
+        float d = a.alpha == 1.f ? sum[r] : __fmul_rn(a.alpha, sum[r]);
+        if (a.bias && kb + r < a.n) d = __fadd_rn(d, a.bias[kb + r]);
         if (a.relu) d = d > 0.f ? d : (a.neg_slope == 0.f ? 0.f : __fmul_rn(d, a.neg_slope));
+        if (a.beta != 0.f && kb + r < a.n) d = __fadd_rn(d, __fmul_rn(a.beta, y[r]));
         out[r] = d;
     }
-    float* y = (float*)a.y + (size_t)frow * a.K + kb;
-    if (kb + 4 <= a.K && (a.K & 3) == 0) {
+    if (kb + 4 <= a.n && (a.n & 3) == 0) {
         *(float4*)y = make_float4(out[0], out[1], out[2], out[3]);
     } else {
         for (int r = 0; r < 4; ++r)
-            if (kb + r < a.K) y[r] = out[r];
+            if (kb + r < a.n) y[r] = out[r];
     }
 }
 bool fc_f32_small_ok(int m, int c, int kg_pad) { return m >= 1 && m <= 16 && c % 4 == 0 && c <= 65536 && kg_pad >= (c + 63) / 64 * 64; }
+static hipError_t launch_fc_f32_stream(const FcStreamArgs& f, hipStream_t s) {
+    const dim3 grid((f.n + 15) / 16), block(256);
+    // long reductions: 12 steps per buffer (96 KB of weights in flight per CU); short ones: 4 (less to drain at the end)
+    if ((f.c + 63) / 64 >= 48) hipLaunchKernelGGL((fc_f32_stream_kernel<12>), grid, block, 0, s, f);
+    else hipLaunchKernelGGL((fc_f32_stream_kernel<4>), grid, block, 0, s, f);
+    return hipGetLastError();
+}
 hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s) {
     if (!fc_f32_small_ok(a.M, a.C, a.Kg_pad)) return hipErrorInvalidValue;
-    const int ksw = (a.C + 63) / 64;       // 16-float k-steps per wave
-    hipLaunchKernelGGL(fc_f32_small_kernel, dim3((a.K + 15) / 16), dim3(256), 0, s, a, ksw);
-    return hipGetLastError();
+    FcStreamArgs f;
+    f.w = (const float*)a.w; f.x = (const float*)a.x; f.y = (float*)a.y; f.bias = a.bias; f.zero = a.zero;
+    f.m = a.M; f.n = a.K; f.c = a.C; f.w_pitch = a.Kg_pad;
+    f.w_rows = (a.K + 15) / 16 * 16;        // (the repacked weights are padded to multiples of 128 rows)
+    f.relu = a.relu; f.neg_slope = a.neg_slope; f.alpha = 1.f; f.beta = 0.f;
+    return launch_fc_f32_stream(f, s);
+}
+// Gemm<float> with m <= 16 rows of A against B stored [n][k] (trans_b): C[m][n] = alpha * A B^T + beta * C on raw pointers
+bool gemm_f32_rows_ok(int m, int k) { return m >= 1 && m <= 16 && k % 4 == 0 && k <= (1 << 24); }
+hipError_t launch_gemm_f32_rows(int m, int n, int k, float alpha, const float* A, const float* B, float beta, float* C, const void* zero,
+                                hipStream_t s) {
+    if (!gemm_f32_rows_ok(m, k)) return hipErrorInvalidValue;
+    FcStreamArgs f;
+    f.w = B; f.x = A; f.y = C; f.bias = nullptr; f.zero = zero;
+    f.m = m; f.n = n; f.c = k; f.w_pitch = k; f.w_rows = n;
+    f.relu = 0; f.neg_slope = 0.f; f.alpha = alpha; f.beta = beta;
+    return launch_fc_f32_stream(f, s);
 }
 
 // a.M = batch rows (<= 16), a.C = reduction length (multiple of 16), a.K = outputs, a.Kg_pad = weight row pitch
@@ -147,6 +295,21 @@ hipError_t launch_fc_i8_small(const ConvKArgs& a, hipStream_t s) {
         SABER_FC_CASE(1) SABER_FC_CASE(2) SABER_FC_CASE(3) SABER_FC_CASE(4) SABER_FC_CASE(5) SABER_FC_CASE(6)
         SABER_FC_CASE(7) SABER_FC_CASE(8) SABER_FC_CASE(9) SABER_FC_CASE(10) SABER_FC_CASE(11) SABER_FC_CASE(12)
         SABER_FC_CASE(13) SABER_FC_CASE(14) SABER_FC_CASE(15) SABER_FC_CASE(16)
+    default: return hipErrorInvalidValue;
+    }
+#undef SABER_FC_CASE
+    return hipGetLastError();
+}
+// ... with the Softmax operator over the [M][K] logits in the same launch (K <= 1024: 16 logits per lane of the normalising wave)
+bool fc_i8_small_softmax_ok(int m, int c, int kg_pad, int k) { return fc_i8_small_ok(m, c, kg_pad) && k >= 1 && k <= 1024; }
+hipError_t launch_fc_i8_small_softmax(const ConvKArgs& a, float* prob, unsigned* ctr, hipStream_t s) {
+    if (!fc_i8_small_softmax_ok(a.M, a.C, a.Kg_pad, a.K) || !prob || !ctr) return hipErrorInvalidValue;
+    const int ksw = (a.C + 255) / 256;
+    dim3 grid((a.K + 15) / 16), block(256);
+    const FcSoftmaxTail t{prob, ctr};
+#define SABER_FC_CASE(n) case n: hipLaunchKernelGGL((fc_i8_small_softmax_kernel<n>), grid, block, 0, s, a, t); break;
+    switch (ksw) {      // (ResNet's 2048- and VGG's 4096-long reductions and their neighbours; other lengths run the two launches)
+        SABER_FC_CASE(2) SABER_FC_CASE(4) SABER_FC_CASE(8) SABER_FC_CASE(16)
     default: return hipErrorInvalidValue;
     }
 #undef SABER_FC_CASE

@@ -282,6 +282,11 @@ bool fc_i8_small_ok(int m, int c, int kg_pad);
 // the FP32 counterpart (EPI_F32 epilogue: + bias, optional relu), any a.C % 4 == 0
 hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s);
 bool fc_f32_small_ok(int m, int c, int kg_pad);
+bool fc_i8_small_softmax_ok(int m, int c, int kg_pad, int k);
+hipError_t launch_fc_i8_small_softmax(const ConvKArgs& a, float* prob, unsigned* ctr, hipStream_t s);
+bool gemm_f32_rows_ok(int m, int k);
+hipError_t launch_gemm_f32_rows(int m, int n, int k, float alpha, const float* A, const float* B, float beta, float* C, const void* zero,
+                                hipStream_t s);
 // ResNet stem (7x7 stride 2, <= 4 channels) with the input patch in LDS; f32_in: fuse the quantise-on-entry
 hipError_t launch_conv_stem(int f32_in, const ConvKArgs& a, hipStream_t s);
 // ... followed by the 3x3 / stride-2 / pad-0 max pooling in the same kernel (s8 / u8 outputs only)

@@ -442,6 +442,11 @@ class SaberFc:
     def set_tile(self, tile):
         L.check(L.load().saber_hip_fc_set_tile(self.h, int(tile)))
 
+    def dispatch_softmax(self, x, y, prob):
+        """fc + the Softmax over its output, one launch where the INT8 small-batch kernel runs the fc (saber_hip_fc_run_softmax)."""
+        L.check(L.load().saber_hip_fc_run_softmax(self.h, _p(x), _p(y), _p(prob), _p(self.ws), _stream()))
+        return y, prob
+
     def dispatch_q(self, xq, y):
         """Input already quantised to s8 with in_scale (saber_hip_fc_run_q)."""
         L.check(L.load().saber_hip_fc_run_q(self.h, _p(xq), _p(y), _stream()))

@@ -259,7 +259,8 @@ def _out_hw(h, k, s, p):
 
 
 def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
-                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True, head_pair=False, shared_device=False):
+                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True, head_pair=False, shared_device=False,
+                   fc_softmax=True):
     """ResNet INT8 op list on the device (see module docstring for the dtype rules).
 
     pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
@@ -282,6 +283,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     head_pair (with chain = 2): the strided head of a stage (conv3x3 / stride 2 + conv1x1 + eltwise, C = 64: res2c) also runs the next
     stage's sibling pair (res3a_branch1 / res3a_branch2a) that reads its output (flag 1024; saber_hip_conv2d_chain_create3_pair).
     Off by default: measured no faster than the two launches.
+    fc_softmax: the fc and the Softmax that reads it run as one launch (flag 4096; saber_hip_fc_run_softmax).
     shared_device: the net runs beside other nets / streams / processes on its GPU (saber_hip_net_optimize flag
     SABER_HIP_NET_SHARED_DEVICE = 2048): no stage launch, no cooperating-workgroup chains, no split-K through one XCD's L2 - excluded
     from the static selection, the autotuner and restored selections."""
@@ -431,6 +433,8 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
     net.stem_paired = net.optimize(512) if stem_pair and not lanes and (fuse_eltwise or cxx_optimize) else 0
     net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0) | (256 if int(chain) >= 2 and stage else 0) |
                                (1024 if int(chain) >= 2 and head_pair else 0)) if chain else 0
+    # the fc and the Softmax over its output as one launch (flag 4096: the last-arriving workgroup of the fc kernel normalises the rows)
+    net.fc_softmaxed = net.optimize(4096) if fc_softmax and (fuse_eltwise or cxx_optimize) else 0
     net.finalize()
     return net
 

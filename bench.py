@@ -78,6 +78,8 @@ def parse():
                     help="INT8: conv1 + pool1 and the sibling pair reading pool1 stay two launches (saber_hip_net_optimize flag 512 off)")
     ap.add_argument("--head-pair", action="store_true",
                     help="INT8: res2c's strided-head chain launch also runs the res3a sibling pair (saber_hip_net_optimize flag 1024; measured no faster)")
+    ap.add_argument("--no-fc-softmax", action="store_true",
+                    help="INT8: the fc and the Softmax over its output stay two launches (saber_hip_net_optimize flag 4096 off)")
     ap.add_argument("--no-stage", action="store_true",
                     help="INT8: do not let runs of res4 block chains run as one persistent stage launch (saber_hip_net_optimize flag 256)")
     ap.add_argument("--timed-only", action="store_true",
@@ -93,16 +95,16 @@ def build_net(W, model, scales, batch, args, stage=True, shared_device=False):
         cxx = not (args.py_fuse or args.no_fuse or args.lanes)      # the C++ host side finds the fusions (the north star's "host side stays C++")
         return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx,
                                 stage=stage and not args.no_stage and not shared_device, stem_pair=not args.no_stem_pair, head_pair=args.head_pair,
-                                shared_device=shared_device)
+                                shared_device=shared_device, fc_softmax=not args.no_fc_softmax)
     return W.build_fp32_net(model, batch, shared_device=shared_device)
 
 
 def tune_key(args, batch, L):
     """a cached selection is only valid for the sources and executor options it was tuned on"""
-    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_sp%d_hp%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
-                                                                  int(args.lanes), args.chain, int(args.py_fuse), int(not args.no_stage),
-                                                                  int(not args.no_stem_pair), int(args.head_pair),
-                                                                  L.source_sha())
+    return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_sp%d_hp%d_fs%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
+                                                                       int(args.lanes), args.chain, int(args.py_fuse), int(not args.no_stage),
+                                                                       int(not args.no_stem_pair), int(args.head_pair),
+                                                                       int(not getattr(args, "no_fc_softmax", False)), L.source_sha())
 
 
 def tune(net, args, batch, L, rank, iters=20, refill=None):
@@ -341,7 +343,7 @@ def main():
         peak_ops = MFMA_I8_PEAK_TOPS if args.precision == "int8" else MFMA_F32_PEAK_TFLOPS
         kern = {}
         for i, (nm, t) in enumerate(zip(names, pass_us)):
-            if "(in the chain launch)" in nm or "(in the stage launch)" in nm or "(in the stem launch)" in nm:
+            if "(in the chain launch)" in nm or "(in the stage launch)" in nm or "(in the stem launch)" in nm or "(in the fc launch)" in nm:
                 continue
             by, fl = net.op_work(i)
             k = kern.setdefault(nm, dict(kernel=nm, launches=0, us=0.0, bytes=0.0, flops=0.0))

@@ -286,6 +286,13 @@ int saber_hip_fc_run(saber_hip_fc_t* op, const void* x, float* y, void* workspac
 /* INT8 fc on an input that is ALREADY quantised to s8 with the op's in_scale (e.g. by pool2d_f32_from_i8_q): skips
  * the quantise-on-entry kernel of an f32-input INT8 fc; identical result. */
 int saber_hip_fc_run_q(saber_hip_fc_t* op, const int8_t* xq, float* y, saber_hip_stream_t stream);
+/* Fc followed by Softmax over its [m][n] output (the tail of every classifier: framework/operators/dense.cpp -> softmax.cpp; Saber:
+ * saber/funcs/fc.h:48-127 + saber/funcs/softmax.h) as ONE launch where the INT8 small-batch weight-streaming kernel runs the fc
+ * (m <= 16, n <= 1024, 8-bit operand, reduction 512 / 1024 / 2048 / 4096): the workgroup that arrives last on a device-wide counter
+ * normalises the rows. y (the logits) is written as by saber_hip_fc_run; prob = softmax(y) per row, the arithmetic of
+ * saber_hip_softmax_f32 with the row sum taken lane-major (within the 1e-4 the softmax output is held to). Every other case runs
+ * saber_hip_fc_run + saber_hip_softmax_f32: the result is the same either way. saber_hip_net_optimize flag 4096 forms it. */
+int saber_hip_fc_run_softmax(saber_hip_fc_t* op, const void* x, float* y, float* prob, void* workspace, saber_hip_stream_t stream);
 /* Kernel selection of the INT8 fc, same encoding as saber_hip_conv2d_set_tile: variant 10 (<< 16) = the small-batch
  * weight-streaming kernel (m <= 16, k <= 4096; the STATIC choice when eligible), 1..4 = implicit-GEMM variants. */
 const char* saber_hip_fc_algo(const saber_hip_fc_t* op);
@@ -438,6 +445,8 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * 1024 (with 2 | 16 | 32; NOT in 255): the strided head of a stage at C = 64 (conv3x3 / stride 2 + conv1x1 + eltwise: ResNet's res2c)
  * whose output is read by one sibling pair only (res3a_branch1 / res3a_branch2a) runs that pair in its chain launch
  * (saber_hip_conv2d_chain_create3_pair); the pair stays in the list and launches nothing while the chain form is selected.
+ * 4096 (NOT in 255): an fc (FC / FC on a quantised operand) whose only reader is a Softmax over its output -> saber_hip_fc_run_softmax
+ * (one launch where the small-batch INT8 kernel is selected; the softmax op stays in the list and launches nothing).
  * 2048 (SABER_HIP_NET_SHARED_DEVICE; NOT in 255; may be passed on its own, sticks to the net): the net does NOT have the device to
  * itself - other streams, Worker threads or processes run kernels there while it does (framework/core/net/worker.h:38-60: one Net
  * per pool thread). Every kernel variant whose completion or speed depends on where the hardware places workgroups relative to

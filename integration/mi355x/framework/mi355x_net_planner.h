@@ -91,7 +91,9 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
         const bool stem_pair = env_on("SABER_MI355X_NET_STEM_PAIR", true);
         // 1024: res2c's strided-head chain launch also runs the res3a sibling pair (opt-in: measured no faster than the two launches)
         const bool head_pair = env_on("SABER_MI355X_NET_HEAD_PAIR", false);
-        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0) | (head_pair ? 1024 : 0) |
+        // 4096: the fc and the Softmax over its output as one launch
+        const bool fc_softmax = env_on("SABER_MI355X_NET_FC_SOFTMAX", true);
+        if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0) | (head_pair ? 1024 : 0) | (fc_softmax ? 4096 : 0) |
                                                (plan.shared_device ? SABER_HIP_NET_SHARED_DEVICE : 0)) >= 0;
         if (ok) ok = saber_hip_net_finalize(n) == SABER_HIP_OK;
         if (ok && plan.builds == 0 && env_on("SABER_MI355X_NET_PLAN_TUNE", true))

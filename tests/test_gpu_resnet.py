@@ -243,7 +243,9 @@ def test_cxx_net_optimize_equals_python_fused_list(setup):
     # (+ conv3x3 + conv1x1 in the last blocks of res2 / res3, whose 1x1 conv heads no chain)
     # (+ the stem launch running the res2a sibling pair: flag 512)
     assert a.stem_paired == b.stem_paired == 1
-    assert a.chained == b.chained == 17 and a.num_launches() == b.num_launches() == 34, (a.chained, a.num_launches())
+    # (+ the fc running the Softmax that reads it: flag 4096)
+    assert a.fc_softmaxed == b.fc_softmaxed == 1
+    assert a.chained == b.chained == 17 and a.num_launches() == b.num_launches() == 33, (a.chained, a.num_launches())
     assert [a.op_name(i) for i in range(52)] == [b.op_name(i) for i in range(52)]
     for net in (a, b):
         net.tensor("data").copy_(torch.from_numpy(x).cuda())
