@@ -100,6 +100,11 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
             set_choice(op, chv);
             time_current();
         }
+    if (pw_ok(op)) {      // FP32 1x1, C = 64 / 128: persistent waves with their weights in registers (conv1x1_pw.hip)
+        ConvChoice cp = {op->tile, 1, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 1};
+        set_choice(op, cp);
+        time_current();
+    }
     c = best_c;
     if (fc_small_ok(op)) {
         ConvChoice cf = c;
@@ -169,6 +174,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         op->d_w3h1.release();
         op->d_w3h2.release();
     }
+    if (!op->pw) op->d_wpw.release();
     if (!op->img1 && !op->gpool) img_conv_release(op);
     // leave y holding one clean result of the selected kernel
     return saber_hip_conv2d_run(op, x, y, res, workspace, s);

@@ -156,6 +156,8 @@ void name_algo(saber_hip_conv* op) {
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
+    else if (op->pw) snprintf(buf, sizeof buf, "pw1x1_f32_bf16x3_regs_c%d_%dch_per_wave%s", op->c_eff, op->c_eff == 64 ? 64 : 32,
+                              op->d.res_mode == SABER_HIP_RES_SUM_INPLACE ? "+sum" : "");
     else if (op->b3h) {
         int hb, ht, htm, hthr;
         (void)conv3x3_b3h_variant(op->b3h, &hb, &ht, &htm, &hthr);
@@ -335,7 +337,7 @@ static inline bool tile_arg_ks(int ks) { return ks == 1 || ks == 2 || ks == 4; }
 // starts from here, so a selection made by an earlier autotune / set_tile cannot keep running under the new one's name
 static void clear_selectors(saber_hip_conv* op) {
     if (!op->gpool) op->img1 = 0;      // (conv + fused global pooling exists only as the image-resident kernel)
-    op->b3h = 0; op->b3 = 0; op->ksplit = 0; op->halo = 0; op->stem = 0; op->img_ib = op->img_rb = 0; op->fc_small = 0;
+    op->b3h = 0; op->b3 = 0; op->ksplit = 0; op->halo = 0; op->stem = 0; op->img_ib = op->img_rb = 0; op->fc_small = 0; op->pw = 0;
 }
 
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
@@ -367,6 +369,13 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         }
         clear_selectors(op);
         op->b3 = 1; op->dma = 0; op->ks = ksd ? ksd : 1; op->tile = tile; op->ksplit = sh;
+        name_algo(op);
+        return SABER_HIP_OK;
+    }
+    if (var == 14) {   // FP32 pointwise conv, C = 64 / 128: persistent waves with their weight planes in registers (conv1x1_pw.hip)
+        if (!pw_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "persistent pointwise kernel: FP32 NHWC 1x1 / stride-1 conv with C in {64, 128}, K % 64 == 0");
+        clear_selectors(op);
+        op->pw = 1; op->dma = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
@@ -423,6 +432,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
+    if (op->pw) return 14 << 16;
     if (op->b3h) return op->b3h | (13 << 16);
     if (op->img1) return 12 << 16;
     if (op->fc_small) return 10 << 16;
@@ -600,6 +610,30 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
                     HIP_TRY((tm == 1 ? op->d_w3h1 : op->d_w3h2).upload(fr));
                 }
             }
+            // 1x1 / stride 1 with C = 64 / 128 input channels: the planes once more for the persistent register-weights kernel
+            // (conv1x1_pw.hip): [64-channel block][16-row tile][32-deep slab][plane][lane] x 8 bf16; row = lane & 15 is output channel
+            // block * 64 + 16 tile + row, element j of k-group kg = lane >> 4 is input channel 32 slab + (j < 4 ? 4 kg + j : 16 + 4 kg + j - 4)
+            if (kh == 1 && kw == 1 && d.pad_h == 0 && d.pad_w == 0 && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
+                d.group == 1 && !op->pre_transpose && d.out_layout == SABER_HIP_NHWC && conv1x1_pw_ok(op->c_eff, K) &&
+                (d.res_mode == SABER_HIP_RES_NONE || d.res_mode == SABER_HIP_RES_SUM_INPLACE)) {
+                const int Ce = op->c_eff, NS = Ce / 32;
+                std::vector<uint8_t> fr((size_t)(K / 64) * 4 * NS * 3 * 64 * 16, 0);
+                uint16_t* fp = (uint16_t*)fr.data();
+                for (int kb = 0; kb < K / 64; ++kb)
+                    for (int i = 0; i < 4; ++i)
+                        for (int sl = 0; sl < NS; ++sl)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int r = lane & 15, kg = lane >> 4;
+                                const int ch = kb * 64 + i * 16 + r;
+                                for (int j = 0; j < 8; ++j) {
+                                    const int kk = sl * 32 + (j < 4 ? kg * 4 + j : 16 + kg * 4 + (j - 4));
+                                    const size_t src = (size_t)ch * op->Kg_pad + kk;
+                                    for (int pl3 = 0; pl3 < 3; ++pl3)
+                                        fp[(((((size_t)kb * 4 + i) * NS + sl) * 3 + pl3) * 64 + lane) * 8 + j] = pl[pl3 * n + src];
+                                }
+                            }
+                HIP_TRY(op->d_wpw.upload(fr));
+            }
             // STATIC choice (BaseFunc STATIC strategy): SABER_HIP_F32_BF16X3=1 makes the bf16-plane kernel the default of every
             // eligible FP32 convolution (0 keeps the f32-MFMA kernels); unset: see f32_static_b3()
             const char* e = getenv("SABER_HIP_F32_BF16X3");
@@ -755,6 +789,11 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     case ALGO_IGEMM_F32:
         if (op->fc_small) {
             HIP_TRY(launch_fc_f32_small(a, s));
+            break;
+        }
+        if (op->pw) {
+            a.w = op->d_wpw.p;
+            HIP_TRY(launch_conv1x1_pw(a, s));
             break;
         }
         if (op->b3h) {

@@ -103,6 +103,8 @@ struct saber_hip_conv {
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
     int b3h = 0;             // FP32 3x3: 1..5 = LDS-halo bf16-plane kernel variant (conv3x3_b3h.hip), 0: not used
     DevBuf<uint8_t> d_w3h1, d_w3h2;   // its weight planes in MFMA fragment order for 1 / 2 row tiles per wave
+    int pw = 0;              // FP32 1x1 / stride 1 with C = 64 / 128: 1 = persistent register-weights kernel (conv1x1_pw.hip), 0: not used
+    DevBuf<uint8_t> d_wpw;   // its weight planes in that kernel's fragment order
     int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels
     int gpool = 0;           // ... with the global average pooling of its output fused (saber_hip_net_optimize flag 128): img1 only
     struct saber_hip_stage* img_stage = nullptr;   // the single-phase descriptor + repacked weights of that kernel (img_conv_prepare)
@@ -204,14 +206,17 @@ struct saber_hip_fc {
 namespace saber_api {
 // one selection of kernel variant for an op (what the autotuner saves / restores)
 struct ConvChoice {
-    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit, img1, b3h;
+    int tile, ks, dma, stem, halo, img_ib, img_rb, img_nw, fc_small, b3, ksplit, img1, b3h, pw;
 };
 inline ConvChoice get_choice(const saber_hip_conv* op) {
-    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit, op->img1, op->b3h};
+    return {op->tile, op->ks, op->dma, op->stem, op->halo, op->img_ib, op->img_rb, op->img_nw, op->fc_small, op->b3, op->ksplit, op->img1, op->b3h, op->pw};
 }
 inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
-    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool; op->b3h = c.b3h;
+    op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool; op->b3h = c.b3h; op->pw = c.pw;
+}
+inline bool pw_ok(const saber_hip_conv* op) {      // the persistent pointwise kernel exists for this op (planes packed by set_weights)
+    return op->algo == ALGO_IGEMM_F32 && op->d_wpw.p != nullptr && !op->pair_k2 && !op->pool2;
 }
 inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
     return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr;
@@ -315,6 +320,7 @@ inline unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice&
     else if (op->algo != ALGO_IGEMM_F32 && op->epi == EPI_I8_CONV && d.res_mode != SABER_HIP_RES_SUM_INPLACE && d.k % 16 == 0)
         ek = d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : (d.out_dtype == SABER_HIP_U8 ? 1 : (d.out_dtype == SABER_HIP_S8 ? 0 : 3));
     unsigned long long k = (unsigned long long)op->algo | ((unsigned long long)ek << 4);
+    if (c.pw) return k | (9ull << 8) | ((unsigned long long)op->c_eff << 16) | ((unsigned long long)(d.res_mode == SABER_HIP_RES_SUM_INPLACE) << 32);
     if (c.b3h) return k | (8ull << 8) | ((unsigned long long)c.b3h << 16);
     if (c.img1) return k | (7ull << 8) | ((unsigned long long)(op->d.kh == 3) << 16);      // one function for all image-resident shapes
     if (c.fc_small) return k | (1ull << 8) | ((unsigned long long)((op->c_eff + 255) / 256) << 16);

@@ -216,14 +216,21 @@ __global__ __launch_bounds__(256) void fc_f32_stream_kernel(const FcStreamArgs a
     };
     // (scheduling barriers: left alone, the scheduler sinks every load next to its MFMA to save registers - one load in flight,
     // s_waitcnt vmcnt(0) in front of every MFMA group; with them the wait-count pass emits vmcnt(2 * NS) in front of a buffer's MFMAs)
-    request(0, 0);
+    // Every workgroup walks ITS rows' reduction starting at a different chunk (rotated by its index, wrapping around): all 256 workgroups
+    // start together and run at the same rate, and their rows are a multiple of 16 x c floats apart - with a common starting offset
+    // they all ask the SAME few memory channels for their next lines at any moment (fc6: rows 100 352 bytes apart; both the round-2 and
+    // the round-4 kernel sat at 3.1 - 4.2 TB/s). Order of summation per output: fixed by the workgroup index - deterministic.
+    const int nch = (ksw + NS - 1) / NS;                     // chunks of NS steps per wave
+    const int rot = (int)((blockIdx.x * 7u + wave * 3u) % (unsigned)nch);
+    auto chunk_s0 = [&](int ci) { return ci < nch ? ((ci + rot) % nch) * NS : ksw; };      // (past the end: nothing in range, zeros)
+    request(0, chunk_s0(0));
     __builtin_amdgcn_sched_barrier(0);
-    for (int s0 = 0; s0 < ksw; s0 += 2 * NS) {
-        request(1, s0 + NS);
+    for (int ci = 0; ci < nch; ci += 2) {
+        request(1, chunk_s0(ci + 1));
         __builtin_amdgcn_sched_barrier(0);
         multiply(0);
         __builtin_amdgcn_sched_barrier(0);
-        request(0, s0 + 2 * NS);
+        request(0, chunk_s0(ci + 2));
         __builtin_amdgcn_sched_barrier(0);
         multiply(1);
         __builtin_amdgcn_sched_barrier(0);

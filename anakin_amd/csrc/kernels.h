@@ -274,6 +274,9 @@ bool conv3x3_img_feasible(int C, int OW, int OH, int N, int nw, int ib, int rb);
 // FP32 3x3 / stride 1 / pad 1 on the bf16 matrix cores with an LDS-resident input halo (conv3x3_b3h.hip); variant 1..5 = (output
 // channels per workgroup, tile rows, 16-channel tiles per wave, threads): a.w = the fragment-ordered weight planes for that tm
 bool conv3x3_b3h_variant(int variant, int* bmk, int* th, int* tm, int* threads);
+// FP32 1x1 / stride 1 with C = 64 / 128 input channels: persistent independent waves, weight planes in registers (conv1x1_pw.hip)
+bool conv1x1_pw_ok(int c, int k);
+hipError_t launch_conv1x1_pw(const ConvKArgs& a, hipStream_t s);
 hipError_t launch_conv3x3_b3h(int variant, const ConvKArgs& a, hipStream_t s);
 // INT8 fc for <= 16 batch rows: 16 outputs per workgroup, reduction split over its 4 waves, operands loaded straight
 // into MFMA registers (fc_small.hip). a.M rows, a.C reduction, a.K outputs, FC epilogues only.

@@ -17,6 +17,7 @@
 __device__ unsigned long long* saber_tl_buf = nullptr;
 
 #include "../../anakin_amd/csrc/fc_small.hip"
+#include "../../anakin_amd/csrc/elementwise.hip"
 #include "../../anakin_amd/csrc/img_e1.hip"
 #include "../../anakin_amd/csrc/igemm_m0_e1.hip"
 #include "../../anakin_amd/csrc/igemm_m0_e2.hip"
@@ -37,6 +38,7 @@ void tile_dims(int tile, int* bm_k, int* bn_pix) {
 }  // namespace saber_mi355x
 
 using namespace saber_mi355x;
+static void launch_softmax_rows(int rows, int cols, const float* x, float* y, hipStream_t s) { (void)launch_softmax_f32(rows, cols, x, y, s); }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -287,6 +289,15 @@ int main(int argc, char** argv) {
         a.y = dalloc(8 * 1000 * 4, 0); a.scale = (const float*)dalloc(1024 * 4, 0); a.bias = (const float*)dalloc(1024 * 4, 0);
         a.epi = EPI_I8_FC_S8;
         run(P, "fc_i8_small 8x2048 -> 1000 (63 WGs)", 63, 6, [&] { launch_fc_i8_small(a, P.st); });
+        // round 5: the same fc with the Softmax over its output in the launch (phases 5 = this workgroup arrived LAST and starts to
+        // normalise, 6 = probabilities stored: one sample per launch) and, for the sum of the two launches it replaces, the plain
+        // softmax kernel's chain time (`tail` mode: only this section - the answer to "what is in a 4.2 us launch": profiles/r05/timeline_tail.txt)
+        float* prob = (float*)dalloc(8 * 1000 * 4, 0);
+        unsigned* ctr = (unsigned*)dalloc(128, 0);
+        run(P, "fc_i8_small + softmax 8x2048 -> 1000 (63 WGs)", 63, 7, [&] { launch_fc_i8_small_softmax(a, prob, ctr, P.st); });
+        run(P, "softmax_f32 8 x 1000 (8 WGs; no stamps)", 8, 1, [&] { launch_softmax_rows(8, 1000, (const float*)a.y, prob, P.st); });
+        run(P, "fc_i8_small, then softmax_f32 (two launches)", 63, 1, [&] { launch_fc_i8_small(a, P.st); launch_softmax_rows(8, 1000, (const float*)a.y, prob, P.st); });
+        if (argc > 1 && !strcmp(argv[1], "tail")) return 0;
     }
     struct Img { const char* name; int N, HW, C, K, ib, rb, nw; };
     const Img imgs[] = {

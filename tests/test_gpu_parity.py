@@ -1860,6 +1860,71 @@ def test_conv_f32_bf16x3_pointwise_kernel_vs_oracle(case, variant):
         conv.set_tile(2 | (13 << 16))          # a 3x3 variant on a 1x1 conv
 
 
+F32_PW_REG_CASES = [
+    # N, H, W, C, K, in-place residual sum, relu, bias
+    (2, 56, 56, 64, 256, True, True, True),       # ResNet res2 branch2c + in-place residual sum (round-4 verdict item 3)
+    (8, 56, 56, 64, 256, True, True, True),       # ... at the bench's batch: 25 088 pixels, 1 568 groups over 256 slots
+    (2, 56, 56, 64, 64, False, True, True),       # res2a branch2a
+    (2, 28, 28, 128, 512, True, True, True),      # res3 branch2c + sum
+    (1, 28, 28, 128, 128, False, False, False),   # no relu, no bias
+    (3, 7, 9, 64, 128, True, False, True),        # ragged pixels (189 = 11 groups + 13), sum without relu
+    (1, 5, 5, 128, 1024, False, True, True),      # fewer groups (2) than slots (32): most waves have nothing to do
+]
+
+
+@pytest.mark.parametrize("case", F32_PW_REG_CASES)
+def test_conv_f32_pointwise_register_weights_kernel_vs_oracle(case):
+    """conv1x1_pw.hip (kernel variant 14: persistent independent waves, their output channels' bf16 weight planes in registers, no LDS,
+    no barrier - the productised scripts/probe/pw_direct_probe.hip): the oracle within 1e-4 on both criteria, the implicit-GEMM bf16-plane
+    kernel within rounding, the selection round-trips through get_tile / set_tile, repeated launches give the same bits; a layer the
+    kernel does not take (C = 256, stride 2) refuses the variant."""
+    N, H, W, C, K, elt, relu, bias = case
+    rng = np.random.default_rng(N * 10 + C + K + H)
+    x = (rng.random((N, C, H, W)) * 3.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, 1, 1)) * np.sqrt(2.0 / C)).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32) if bias else None
+    res = (rng.random((N, K, H, W)) * 2.0 - 0.5).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b if bias else np.zeros(K, np.float32), relu and not elt, (0, 0), (1, 1), (1, 1))
+    if elt:
+        want = want + res
+        if relu:
+            want = np.maximum(want, 0.0)
+    p = S.ConvParam(w, b, 1, (0, 0), (1, 1), (1, 1), relu and not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, relu, 1.0
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rin = np.ascontiguousarray(res.transpose(0, 2, 3, 1))
+
+    def run():
+        y = conv.new_output()
+        y.copy_(dev(rin)) if elt else y.fill_(-7.0)
+        conv.dispatch(xin, y)
+        return host(y).transpose(0, 3, 1, 2)
+    conv.set_tile(conv.tile_id() | (1 << 8) | (11 << 16))
+    base = run()
+    conv.set_tile(14 << 16)
+    assert conv.algo().startswith("pw1x1_f32_bf16x3_regs_c%d" % C), conv.algo()
+    assert L.load().saber_hip_conv2d_get_tile(conv.h) == 14 << 16
+    got = run()
+    d = np.abs(got - want)
+    e_max = float(d.max() / np.abs(want).max())
+    e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+    assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (conv.algo(), e_max, e_el)
+    assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
+    assert np.array_equal(run(), got)
+
+
+def test_conv_f32_pointwise_register_weights_kernel_refuses_other_layers():
+    rng = np.random.default_rng(3)
+    for (c, k, stride) in ((256, 64, 1), (64, 256, 2), (64, 72, 1)):
+        w = (rng.standard_normal((k, c, 1, 1)) * 0.1).astype(np.float32)
+        p = S.ConvParam(w, None, 1, (0, 0), (stride, stride), (1, 1), True)
+        conv = S.SaberConv2D(int8=False).init((1, c, 16, 16), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+        with pytest.raises(L.SaberHipError):
+            conv.set_tile(14 << 16)
+
+
 STRIDED_HEAD_CASES = [
     # C, N, Hin, Win, 3x3 input dtype, mid dtype, eltwise relu, tile code (None: default)
     (64, 2, 56, 56, O.U8, O.U8, 1, None),        # res2c after the reference's stride-up: 56 -> 28
