@@ -109,31 +109,43 @@ __device__ __forceinline__ void fc_i8_small_body(const ConvKArgs& a, const FcSof
         SABER_TL(5);
         if (tid == 0) __hip_atomic_store(t.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch
         constexpr int PER = 16;                                   // logits per lane: rows of up to 1024 (checked by the launcher)
-        for (int row = wave; row < a.M; row += 4) {
-            const float* yr = (const float*)a.y + (size_t)row * a.K;
-            float v[PER];
+        // a wave normalises rows wave, wave + 4 (, + 8, + 12): two rows at a time, BOTH rows' 32 loads in flight before the first use - the
+        // tail is one memory round trip per pair (the first version walked its rows one after the other: 4.5 us for two rows per wave,
+        // profiles/r05/timeline_tail.txt)
+        for (int row0 = wave; row0 < a.M; row0 += 8) {
+            const int row1 = row0 + 4;
+            const bool has1 = row1 < a.M;
+            const float* y0 = (const float*)a.y + (size_t)row0 * a.K;
+            const float* y1 = (const float*)a.y + (size_t)(has1 ? row1 : row0) * a.K;
+            float v0[PER], v1[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int c = lane + 64 * i;
-                v[i] = c < a.K ? __hip_atomic_load(yr + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : -3.4e38f;
+                const int cc = c < a.K ? c : a.K - 1;             // (unconditional loads: all in flight together)
+                v0[i] = __hip_atomic_load(y0 + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                v1[i] = __hip_atomic_load(y1 + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            float mx = v[0];
+            auto normalise = [&](float (&v)[PER], int row) {
+                float mx = -3.4e38f;
 #pragma unroll
-            for (int i = 1; i < PER; ++i) mx = fmaxf(mx, v[i]);
+                for (int i = 0; i < PER; ++i) mx = lane + 64 * i < a.K ? fmaxf(mx, v[i]) : mx;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float sum = 0.f;
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                v[i] = lane + 64 * i < a.K ? expf(v[i] - mx) : 0.f;
-                sum += v[i];
-            }
+                for (int i = 0; i < PER; ++i) {
+                    v[i] = lane + 64 * i < a.K ? expf(v[i] - mx) : 0.f;
+                    sum += v[i];
+                }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            float* pr = t.prob + (size_t)row * a.K;
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                float* pr = t.prob + (size_t)row * a.K;
 #pragma unroll
-            for (int i = 0; i < PER; ++i)
-                if (lane + 64 * i < a.K) pr[lane + 64 * i] = v[i] / sum;
+                for (int i = 0; i < PER; ++i)
+                    if (lane + 64 * i < a.K) pr[lane + 64 * i] = v[i] / sum;
+            };
+            normalise(v0, row0);
+            if (has1) normalise(v1, row1);
         }
         SABER_TL(6);
         SABER_TL_FLUSH();
@@ -174,16 +186,16 @@ struct FcStreamArgs {
     float neg_slope, alpha, beta;      // y = act(alpha * acc + bias) (+ beta * y_old when beta != 0)
 };
 
-template <int NS>
-__global__ __launch_bounds__(256) void fc_f32_stream_kernel(const FcStreamArgs a) {
-    __shared__ v4f redf[3][64];
+template <int NS, int NW>
+__global__ __launch_bounds__(NW * 64) void fc_f32_stream_kernel(const FcStreamArgs a) {
+    __shared__ v4f redf[NW - 1][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int m = frow < a.m ? frow : a.m - 1;               // rows beyond the batch re-read the last one (results dropped)
     const int wr = n0 + frow < a.w_rows ? n0 + frow : a.w_rows - 1;
-    const int ksw = (a.c + 63) / 64;                         // 16-float steps per wave
+    const int ksw = (a.c + NW * 16 - 1) / (NW * 16);         // 16-float steps per wave: the NW waves split the reduction
     const int k0 = wave * ksw * 16 + fq * 4;                 // this lane's first reduction index
     const float* const wrow = a.w + (size_t)wr * a.w_pitch;
     const float* const xrow = a.x + (size_t)m * a.c;
@@ -239,9 +251,8 @@ __global__ __launch_bounds__(256) void fc_f32_stream_kernel(const FcStreamArgs a
     if (wave > 0) redf[wave - 1][lane] = sum;
     __syncthreads();
     if (wave > 0) return;
-    sum += redf[0][lane];
-    sum += redf[1][lane];
-    sum += redf[2][lane];
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) sum += redf[w][lane];
     const int kb = n0 + fq * 4;                              // lane: outputs kb .. kb + 3 of batch row frow
     if (frow >= a.m || kb >= a.n) return;
     float* y = a.y + (size_t)frow * a.n + kb;
@@ -263,10 +274,13 @@ __global__ __launch_bounds__(256) void fc_f32_stream_kernel(const FcStreamArgs a
 }
 bool fc_f32_small_ok(int m, int c, int kg_pad) { return m >= 1 && m <= 16 && c % 4 == 0 && c <= 65536 && kg_pad >= (c + 63) / 64 * 64; }
 static hipError_t launch_fc_f32_stream(const FcStreamArgs& f, hipStream_t s) {
-    const dim3 grid((f.n + 15) / 16), block(256);
-    // long reductions: 12 steps per buffer (96 KB of weights in flight per CU); short ones: 4 (less to drain at the end)
-    if ((f.c + 63) / 64 >= 48) hipLaunchKernelGGL((fc_f32_stream_kernel<12>), grid, block, 0, s, f);
-    else hipLaunchKernelGGL((fc_f32_stream_kernel<4>), grid, block, 0, s, f);
+    const dim3 grid((f.n + 15) / 16);
+    // Little's law: 8 TB/s x ~4 us of loaded HBM latency = 32 MB in flight over the chip = 125 KB per CU. Long reductions: 12 steps per
+    // buffer and EIGHT waves per workgroup (two per SIMD, 216 VGPRs each): 192 KB of weights in flight per CU - with four waves (96 KB) the
+    // kernel sat at 3.9 TB/s whatever else was tried (profiles/r05). Short ones: 4 steps, four waves (less to drain at the end).
+    if ((f.c + 63) / 64 >= 96) hipLaunchKernelGGL((fc_f32_stream_kernel<12, 8>), grid, dim3(512), 0, s, f);
+    else if ((f.c + 63) / 64 >= 48) hipLaunchKernelGGL((fc_f32_stream_kernel<12, 4>), grid, dim3(256), 0, s, f);
+    else hipLaunchKernelGGL((fc_f32_stream_kernel<4, 4>), grid, dim3(256), 0, s, f);
     return hipGetLastError();
 }
 hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s) {

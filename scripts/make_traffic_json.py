@@ -26,7 +26,8 @@ try:
         t = line.split()
         if len(t) >= 5 and t[0].isdigit() and t[2] == "us":
             nm = " ".join(t[5:]) if t[4] == "us" else " ".join(t[3:])
-            if "(in the chain launch)" not in nm and "(in the stage launch)" not in nm and "(in the stem launch)" not in nm:
+            if "(in the chain launch)" not in nm and "(in the stage launch)" not in nm and "(in the stem launch)" not in nm \
+                    and "(in the fc launch)" not in nm:
                 names.append(nm)
     fb, wb = f["per_dispatch_bytes_corrected"], w["per_dispatch_bytes_corrected"]
     if len(names) == len(fb) == len(wb):

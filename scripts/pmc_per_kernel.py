@@ -9,7 +9,7 @@ import sys
 
 # conv / fc launches = everything that is not one of the streaming kernels (an inclusion list missed every kernel added after it
 # was written: the cooperative chains, the stage launch, the conv + global-pooling kernel - round-4 finding)
-STREAMING = ("softmax", "pool2d", "quantize", "transpose", "eltwise", "relu_f32", "gemm_pack", "null_kernel")
+STREAMING = ("softmax_f32", "pool2d", "quantize", "transpose", "eltwise", "relu_f32", "gemm_pack", "null_kernel")
 path, counter, nlast = sys.argv[1], sys.argv[2], int(sys.argv[3])
 c = sqlite3.connect(path)
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
