@@ -175,6 +175,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         op->d_w3h2.release();
     }
     if (!op->pw) op->d_wpw.release();
+    if (!op->fc_small) op->d_wfc.release();
     if (!op->img1 && !op->gpool) img_conv_release(op);
     // leave y holding one clean result of the selected kernel
     return saber_hip_conv2d_run(op, x, y, res, workspace, s);

@@ -558,6 +558,24 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
         }
         std::vector<uint8_t> raw((const uint8_t*)wr.data(), (const uint8_t*)wr.data() + wr.size() * sizeof(float));
         HIP_TRY(op->d_w.upload(raw));
+        // an fc at <= 16 batch rows is ONE pass over its weights: the same matrix once more fragment-major, so that every load instruction
+        // of the streaming kernel reads 1 KB contiguous ([16-output tile][16-float step][lane][4]; fc_small.hip). Zero padded.
+        if (op->algo == ALGO_IGEMM_F32 && d.h == 1 && d.w == 1 && kh == 1 && kw == 1 && fc_f32_small_ok(d.n, op->c_eff, op->Kg_pad) &&
+            !getenv("SABER_HIP_FC_F32_ROWMAJOR")) {
+            const int Ce = op->c_eff, tiles = (K + 15) / 16, steps = fc_f32_packed_steps(Ce);
+            std::vector<float> pk((size_t)tiles * steps * 256, 0.f);
+            for (int t = 0; t < tiles; ++t)
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = t * 16 + r;
+                    if (nrow >= K) continue;
+                    const float* src = wr.data() + (size_t)nrow * op->Kg_pad;
+                    for (int k = 0; k < Ce; ++k) {
+                        const int st = k >> 4, g = (k >> 2) & 3, e = k & 3;
+                        pk[(((size_t)t * steps + st) * 64 + g * 16 + r) * 4 + e] = src[k];
+                    }
+                }
+            HIP_TRY(op->d_wfc.upload(pk));
+        }
         // the same matrix as three bf16 planes (w = h + m + l exactly: 3 x 8 mantissa bits) for the bf16-MFMA variant; spatial
         // convolutions only (an fc streams its weights once: 6 bytes per weight instead of 4 would only slow it down)
         if (op->algo == ALGO_IGEMM_F32 && op->c_eff % 8 == 0 && (long)d.h * d.w > 1 && !getenv("SABER_HIP_NO_BF16X3")) {
@@ -788,7 +806,8 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
         break;
     case ALGO_IGEMM_F32:
         if (op->fc_small) {
-            HIP_TRY(launch_fc_f32_small(a, s));
+            if (op->d_wfc.p) a.w = op->d_wfc.p;
+            HIP_TRY(launch_fc_f32_small(a, op->d_wfc.p != nullptr, s));
             break;
         }
         if (op->pw) {

@@ -105,6 +105,7 @@ struct saber_hip_conv {
     DevBuf<uint8_t> d_w3h1, d_w3h2;   // its weight planes in MFMA fragment order for 1 / 2 row tiles per wave
     int pw = 0;              // FP32 1x1 / stride 1 with C = 64 / 128: 1 = persistent register-weights kernel (conv1x1_pw.hip), 0: not used
     DevBuf<uint8_t> d_wpw;   // its weight planes in that kernel's fragment order
+    DevBuf<float> d_wfc;     // FP32 fc at <= 16 rows: the weights fragment-major for the streaming kernel (fc_small.hip: fc_f32_stream_kernel PACKED)
     int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels
     int gpool = 0;           // ... with the global average pooling of its output fused (saber_hip_net_optimize flag 128): img1 only
     struct saber_hip_stage* img_stage = nullptr;   // the single-phase descriptor + repacked weights of that kernel (img_conv_prepare)

@@ -186,7 +186,12 @@ struct FcStreamArgs {
     float neg_slope, alpha, beta;      // y = act(alpha * acc + bias) (+ beta * y_old when beta != 0)
 };
 
-template <int NS, int NW>
+// PACKED: a.w is the fragment-major repack of the weights (api_conv.hip: set_weights, saber_hip_conv::d_wfc): [16-output tile][16-float
+// step][lane][4 floats], lane (r = lane & 15, g = lane >> 4) holding W[tile * 16 + r][step * 16 + 4 g .. + 3], zero padded - one load
+// instruction = 1 KB CONTIGUOUS, a wave's whole share of the reduction one contiguous run. With the weights as they lie ([n][k] rows, the
+// Gemm entry point's raw B) an instruction gathers 16 rows x 64 bytes 100 KB apart: 16 K concurrent 64-byte streams leave HBM at ~50 %
+// (3.9 TB/s on fc6 whether 96 or 192 KB are in flight per CU: profiles/r05/fc_stream.txt).
+template <int NS, int NW, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void fc_f32_stream_kernel(const FcStreamArgs a) {
     __shared__ v4f redf[NW - 1][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void fc_f32_stream_kernel(const FcStreamAr
     const int wr = n0 + frow < a.w_rows ? n0 + frow : a.w_rows - 1;
     const int ksw = (a.c + NW * 16 - 1) / (NW * 16);         // 16-float steps per wave: the NW waves split the reduction
     const int k0 = wave * ksw * 16 + fq * 4;                 // this lane's first reduction index
-    const float* const wrow = a.w + (size_t)wr * a.w_pitch;
+    const float* const wrow = PACKED ? a.w + ((size_t)blockIdx.x * a.w_pitch * 64 + lane) * 4 : a.w + (size_t)wr * a.w_pitch;
     const float* const xrow = a.x + (size_t)m * a.c;
     const float* const zero = (const float*)a.zero;
     v4f acc[4];
@@ -209,7 +214,8 @@ __global__ __launch_bounds__(NW * 64) void fc_f32_stream_kernel(const FcStreamAr
         for (int s = 0; s < NS; ++s) {
             const int k = k0 + (s0 + s) * 16;
             const bool in = s0 + s < ksw && k < a.c;
-            const float* wp = in ? wrow + k : wrow;          // (address select, not a branch: the load itself is unconditional)
+            // (address select, not a branch: the load itself is unconditional; packed weights are zero beyond the reduction's end)
+            const float* wp = PACKED ? wrow + (size_t)(s0 + s < ksw ? wave * ksw + s0 + s : wave * ksw) * 256 : (in ? wrow + k : wrow);
             const float* xp = in ? xrow + k : zero;
             wf[b][s] = __builtin_nontemporal_load((const v4i*)wp);
             xf[b][s] = *(const v4i*)xp;
@@ -273,25 +279,33 @@ __global__ __launch_bounds__(NW * 64) void fc_f32_stream_kernel(const FcStreamAr
     }
 }
 bool fc_f32_small_ok(int m, int c, int kg_pad) { return m >= 1 && m <= 16 && c % 4 == 0 && c <= 65536 && kg_pad >= (c + 63) / 64 * 64; }
-static hipError_t launch_fc_f32_stream(const FcStreamArgs& f, hipStream_t s) {
+static hipError_t launch_fc_f32_stream(const FcStreamArgs& f, bool packed, hipStream_t s) {
     const dim3 grid((f.n + 15) / 16);
-    // Little's law: 8 TB/s x ~4 us of loaded HBM latency = 32 MB in flight over the chip = 125 KB per CU. Long reductions: 12 steps per
-    // buffer and EIGHT waves per workgroup (two per SIMD, 216 VGPRs each): 192 KB of weights in flight per CU - with four waves (96 KB) the
-    // kernel sat at 3.9 TB/s whatever else was tried (profiles/r05). Short ones: 4 steps, four waves (less to drain at the end).
-    if ((f.c + 63) / 64 >= 96) hipLaunchKernelGGL((fc_f32_stream_kernel<12, 8>), grid, dim3(512), 0, s, f);
-    else if ((f.c + 63) / 64 >= 48) hipLaunchKernelGGL((fc_f32_stream_kernel<12, 4>), grid, dim3(256), 0, s, f);
-    else hipLaunchKernelGGL((fc_f32_stream_kernel<4, 4>), grid, dim3(256), 0, s, f);
+    // long reductions: 12 steps per buffer, two buffers (24 KB of weights per wave, 96 KB per CU in flight); short ones: 4 steps (less to
+    // drain at the end). Eight waves per workgroup (192 KB in flight) measured SLOWER on the row-major weights (120 vs 104 us on fc6).
+    const bool deep = (f.c + 63) / 64 >= 48;
+    if (packed) {
+        if (deep) hipLaunchKernelGGL((fc_f32_stream_kernel<12, 4, true>), grid, dim3(256), 0, s, f);
+        else hipLaunchKernelGGL((fc_f32_stream_kernel<4, 4, true>), grid, dim3(256), 0, s, f);
+    } else {
+        if (deep) hipLaunchKernelGGL((fc_f32_stream_kernel<12, 4, false>), grid, dim3(256), 0, s, f);
+        else hipLaunchKernelGGL((fc_f32_stream_kernel<4, 4, false>), grid, dim3(256), 0, s, f);
+    }
     return hipGetLastError();
 }
-hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s) {
+// a.w: the row-major repacked weights [K_pad][Kg_pad] - or, packed = true, their fragment-major form (see fc_f32_stream_kernel)
+hipError_t launch_fc_f32_small(const ConvKArgs& a, bool packed, hipStream_t s) {
     if (!fc_f32_small_ok(a.M, a.C, a.Kg_pad)) return hipErrorInvalidValue;
     FcStreamArgs f;
     f.w = (const float*)a.w; f.x = (const float*)a.x; f.y = (float*)a.y; f.bias = a.bias; f.zero = a.zero;
-    f.m = a.M; f.n = a.K; f.c = a.C; f.w_pitch = a.Kg_pad;
+    f.m = a.M; f.n = a.K; f.c = a.C;
+    f.w_pitch = packed ? fc_f32_packed_steps(a.C) : a.Kg_pad;
     f.w_rows = (a.K + 15) / 16 * 16;        // (the repacked weights are padded to multiples of 128 rows)
     f.relu = a.relu; f.neg_slope = a.neg_slope; f.alpha = 1.f; f.beta = 0.f;
-    return launch_fc_f32_stream(f, s);
+    return launch_fc_f32_stream(f, packed, s);
 }
+// 16-float steps per 16-output tile of the fragment-major weights: four waves x ceil(c / 64) steps each
+int fc_f32_packed_steps(int c) { return 4 * ((c + 63) / 64); }
 // Gemm<float> with m <= 16 rows of A against B stored [n][k] (trans_b): C[m][n] = alpha * A B^T + beta * C on raw pointers
 bool gemm_f32_rows_ok(int m, int k) { return m >= 1 && m <= 16 && k % 4 == 0 && k <= (1 << 24); }
 hipError_t launch_gemm_f32_rows(int m, int n, int k, float alpha, const float* A, const float* B, float beta, float* C, const void* zero,
@@ -301,7 +315,7 @@ hipError_t launch_gemm_f32_rows(int m, int n, int k, float alpha, const float* A
     f.w = B; f.x = A; f.y = C; f.bias = nullptr; f.zero = zero;
     f.m = m; f.n = n; f.c = k; f.w_pitch = k; f.w_rows = n;
     f.relu = 0; f.neg_slope = 0.f; f.alpha = alpha; f.beta = beta;
-    return launch_fc_f32_stream(f, s);
+    return launch_fc_f32_stream(f, false, s);
 }
 
 // a.M = batch rows (<= 16), a.C = reduction length (multiple of 16), a.K = outputs, a.Kg_pad = weight row pitch

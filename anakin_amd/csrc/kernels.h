@@ -283,7 +283,8 @@ hipError_t launch_conv3x3_b3h(int variant, const ConvKArgs& a, hipStream_t s);
 hipError_t launch_fc_i8_small(const ConvKArgs& a, hipStream_t s);
 bool fc_i8_small_ok(int m, int c, int kg_pad);
 // the FP32 counterpart (EPI_F32 epilogue: + bias, optional relu), any a.C % 4 == 0
-hipError_t launch_fc_f32_small(const ConvKArgs& a, hipStream_t s);
+hipError_t launch_fc_f32_small(const ConvKArgs& a, bool packed, hipStream_t s);
+int fc_f32_packed_steps(int c);
 bool fc_f32_small_ok(int m, int c, int kg_pad);
 bool fc_i8_small_softmax_ok(int m, int c, int kg_pad, int k);
 hipError_t launch_fc_i8_small_softmax(const ConvKArgs& a, float* prob, unsigned* ctr, hipStream_t s);

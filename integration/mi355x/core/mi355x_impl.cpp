@@ -4,6 +4,9 @@
 #include "core/tensor.h"
 #include "core/env.h"
 
+#include <atomic>
+#include <chrono>
+
 #ifdef USE_MI355X_PLACE
 namespace anakin {
 namespace saber {
@@ -56,25 +59,24 @@ static inline void mi355x_copy(void* dst, size_t dst_offset, const void* src, si
 // ---- SYNCHRONOUS host <-> device copies: a copy lane per calling thread ------------------------------------------------------
 // Tensor::copy_from between a host tensor (target_host<MI355X> = X86: pageable memory) and a device tensor is how Worker threads
 // hand a request to their Net and take the answer back (framework/core/net/worker.cpp:101-110, 139-142). Round 4 ran both through
-// the legacy null stream - hipMemcpy from pageable memory, and a hipDeviceSynchronize() in front of every device-to-host copy, which
-// made each Worker thread wait for the OTHER threads' forward passes: 18 000 images/s where three plans in flight reach 50 000.
-// Now: every calling thread owns a non-blocking copy stream and a ring of pinned staging chunks (hipHostMalloc).
-//   host -> device  memcpy chunk i into the ring while chunk i - 1 is on the wire (hipMemcpyAsync), wait for the last one: the
-//                   call still returns with the data ON the device (sync_memcpy's contract), never touches the null stream, and
-//                   overlaps other threads' kernels. A source that is already pinned / registered goes out in one asynchronous copy.
+// the legacy null stream - hipMemcpy, and a hipDeviceSynchronize() in front of every device-to-host copy, which made each Worker
+// thread wait for the OTHER threads' forward passes. Now every calling thread owns a non-blocking copy stream:
+//   host -> device  hipMemcpyAsync on the lane + a wait for the lane: the call still returns with the data ON the device
+//                   (sync_memcpy's contract), never touches the null stream, and overlaps other threads' kernels. Pageable sources go
+//                   to the runtime as they are: it pins the pages in place for the transfer and reaches the pinned rate (4.8 MB in
+//                   0.105 ms = 46 GB/s against 47.6 pinned, profiles/r05/pcie_probe.txt) - a staging ring with a CPU copy, tried first
+//                   this round, cost 0.3 - 0.5 ms per request and took Worker<MI355X, INT8> from 18.0k to 14.1k images/s;
 //   device -> host  ordered after the work that produced the tensor, NOT after the whole device: the current device's Env streams
 //                   (the contexts' data + compute streams every Net of the process shares; idle ones return at once) are drained -
 //                   a plan on a stream of its own has synchronised its outputs before prediction() returned
-//                   (mi355x_net_planner.h: run) - then the copy lands in the ring and is copied out.
+//                   (mi355x_net_planner.h: run) - then the copy runs on the lane.
 // The lane is leaked at thread exit on purpose (the HIP runtime may be gone when thread_local destructors run).
+// MI355XCopyStats: nanoseconds this process spent in the two directions (all threads), for the Worker driver's breakdown.
+std::atomic<long long> g_mi355x_h2d_ns{0}, g_mi355x_d2h_ns{0}, g_mi355x_drain_ns{0}, g_mi355x_copies{0};
 namespace {
 struct CopyLane {
-    static constexpr size_t kChunk = (size_t)1 << 20;
-    static constexpr int kSlots = 4;
     int dev = -1;
     hipStream_t stream = nullptr;
-    char* pin[kSlots] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
 };
 thread_local CopyLane* g_lane = nullptr;
 
@@ -85,20 +87,11 @@ CopyLane* copy_lane() {
     CopyLane* l = new CopyLane();      // (a thread that moves to another device gets a new lane; the old one stays with its device)
     l->dev = dev;
     MI355X_CHECK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
-    for (int i = 0; i < CopyLane::kSlots; ++i) {
-        MI355X_CHECK(hipHostMalloc((void**)&l->pin[i], CopyLane::kChunk, hipHostMallocDefault));
-        MI355X_CHECK(hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming));
-    }
     g_lane = l;
     return l;
 }
-bool host_is_pinned(const void* p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();      // plain malloc'ed memory: not an error of the caller's
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
+inline long long now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 void drain_env_streams() {
     const int dev = MI355X_API::get_device_id();
@@ -107,48 +100,10 @@ void drain_env_streams() {
     for (auto s : devs[dev]._compute_stream) MI355X_CHECK(hipStreamSynchronize(s));
     for (auto s : devs[dev]._data_stream) MI355X_CHECK(hipStreamSynchronize(s));
 }
-void staged_h2d(char* dst, const char* src, size_t count) {
+void lane_copy(void* dst, const void* src, size_t count, hipMemcpyKind kind) {
     CopyLane* l = copy_lane();
-    if (count >= CopyLane::kChunk && host_is_pinned(src)) {
-        MI355X_CHECK(hipMemcpyAsync(dst, src, count, hipMemcpyHostToDevice, l->stream));
-        MI355X_CHECK(hipStreamSynchronize(l->stream));
-        return;
-    }
-    size_t off = 0;
-    for (int i = 0; off < count; ++i) {
-        const int slot = i % CopyLane::kSlots;
-        const size_t n = count - off < CopyLane::kChunk ? count - off : CopyLane::kChunk;
-        if (i >= CopyLane::kSlots) MI355X_CHECK(hipEventSynchronize(l->ev[slot]));      // the slot's previous chunk has left
-        memcpy(l->pin[slot], src + off, n);
-        MI355X_CHECK(hipMemcpyAsync(dst + off, l->pin[slot], n, hipMemcpyHostToDevice, l->stream));
-        MI355X_CHECK(hipEventRecord(l->ev[slot], l->stream));
-        off += n;
-    }
+    MI355X_CHECK(hipMemcpyAsync(dst, src, count, kind, l->stream));
     MI355X_CHECK(hipStreamSynchronize(l->stream));
-}
-void staged_d2h(char* dst, const char* src, size_t count) {
-    CopyLane* l = copy_lane();
-    if (count >= CopyLane::kChunk && host_is_pinned(dst)) {
-        MI355X_CHECK(hipMemcpyAsync(dst, src, count, hipMemcpyDeviceToHost, l->stream));
-        MI355X_CHECK(hipStreamSynchronize(l->stream));
-        return;
-    }
-    // chunk i + 1 is on the wire while chunk i is copied out of the ring
-    const size_t chunks = (count + CopyLane::kChunk - 1) / CopyLane::kChunk;
-    auto issue = [&](size_t i) {
-        const size_t off = i * CopyLane::kChunk;
-        const size_t n = count - off < CopyLane::kChunk ? count - off : CopyLane::kChunk;
-        MI355X_CHECK(hipMemcpyAsync(l->pin[i % CopyLane::kSlots], src + off, n, hipMemcpyDeviceToHost, l->stream));
-        MI355X_CHECK(hipEventRecord(l->ev[i % CopyLane::kSlots], l->stream));
-    };
-    for (size_t i = 0; i < chunks && i < (size_t)CopyLane::kSlots - 1; ++i) issue(i);
-    for (size_t i = 0; i < chunks; ++i) {
-        const size_t off = i * CopyLane::kChunk;
-        const size_t n = count - off < CopyLane::kChunk ? count - off : CopyLane::kChunk;
-        MI355X_CHECK(hipEventSynchronize(l->ev[i % CopyLane::kSlots]));
-        memcpy(dst + off, l->pin[i % CopyLane::kSlots], n);
-        if (i + CopyLane::kSlots - 1 < chunks) issue(i + CopyLane::kSlots - 1);      // (into the slot emptied one iteration ago)
-    }
 }
 }  // namespace
 
@@ -160,7 +115,11 @@ void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src
     mi355x_copy(dst, dst_offset, src, src_offset, count, hipMemcpyDeviceToDevice, stream, true);
 }
 void MI355X_API::sync_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count, __HtoD) {
-    if (count) staged_h2d((char*)dst + dst_offset, (const char*)src + src_offset, count);
+    if (!count) return;
+    const long long t0 = now_ns();
+    lane_copy((char*)dst + dst_offset, (const char*)src + src_offset, count, hipMemcpyHostToDevice);
+    g_mi355x_h2d_ns += now_ns() - t0;
+    ++g_mi355x_copies;
 }
 void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count,
                               stream_t stream, __HtoD) {
@@ -172,8 +131,12 @@ void MI355X_API::sync_memcpy(void* dst, size_t dst_offset, int, const void* src,
     // ordering). The target's streams are non-blocking, so the ordering is made explicit - against the streams that can have produced
     // the tensor, not against the whole device (see the copy-lane comment above).
     if (!count) return;
+    const long long t0 = now_ns();
     drain_env_streams();
-    staged_d2h((char*)dst + dst_offset, (const char*)src + src_offset, count);
+    const long long t1 = now_ns();
+    lane_copy((char*)dst + dst_offset, (const char*)src + src_offset, count, hipMemcpyDeviceToHost);
+    g_mi355x_drain_ns += t1 - t0;
+    g_mi355x_d2h_ns += now_ns() - t1;
 }
 void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count,
                               stream_t stream, __DtoH) {

@@ -35,6 +35,8 @@
 #ifndef ANAKIN_FRAMEWORK_CORE_NET_MI355X_NET_PLAN_H
 #define ANAKIN_FRAMEWORK_CORE_NET_MI355X_NET_PLAN_H
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -51,6 +53,13 @@ struct MI355XNetPlanDefaults {
     static void worker_threads(int n) {
         if (n > 1) { shared_device() = 1; own_stream() = 1; }
     }
+};
+
+// nanoseconds this process spent inside plans (all threads): enqueueing a pass, and waiting for its outputs - for the Worker driver's breakdown
+struct MI355XNetPlanStats {
+    static std::atomic<long long>& enqueue_ns() { static std::atomic<long long> v{0}; return v; }
+    static std::atomic<long long>& wait_ns() { static std::atomic<long long> v{0}; return v; }
+    static std::atomic<long long>& runs() { static std::atomic<long long> v{0}; return v; }
 };
 
 struct MI355XNetPlan {

@@ -169,13 +169,18 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
             API::sync_stream((API::event_t)plan.own_event, (API::stream_t)plan.own_stream);
         }
         for (int attempt = 0; attempt < 2; ++attempt) {
+            const auto t0 = std::chrono::steady_clock::now();
             const int rc = plan.use_graph ? saber_hip_net_replay(plan.net, plan.stream) : saber_hip_net_run(plan.net, plan.stream);
             CHECK_EQ(rc, (int)SABER_HIP_OK) << "MI355X net plan: " << saber_hip_last_error();
+            const auto t1 = std::chrono::steady_clock::now();
             for (void* p : plan.out_t) {              // what the Output executors' ins[i]->sync() does (net.cpp:427-432)
                 Tensor4dPtr<saber::MI355X> t = (Tensor4dPtr<saber::MI355X>)p;
                 t->record_event((API::stream_t)plan.stream);
                 t->sync();
             }
+            MI355XNetPlanStats::enqueue_ns() += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            MI355XNetPlanStats::wait_ns() += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
+            ++MI355XNetPlanStats::runs();
             // the pass has completed: a cooperative launch that could not (another kernel held the CUs its workgroups wait for) reports
             // itself here, those sites now launch block by block, and the pass runs once more - the caller never sees its outputs
             if (saber_hip_net_status(plan.net) == SABER_HIP_OK) break;

@@ -46,6 +46,7 @@
 #include <mutex>
 #include <thread>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <future>
@@ -60,6 +61,7 @@
 #include "framework/core/net/net.h"
 #undef private
 #include "framework/core/net/worker.h"
+namespace anakin { namespace saber { extern std::atomic<long long> g_mi355x_h2d_ns, g_mi355x_d2h_ns, g_mi355x_drain_ns, g_mi355x_copies; } }
 #include "framework/core/net/entropy_calibrator.h"
 #include <chrono>
 #include <future>
@@ -271,6 +273,12 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
     }
     const double sec = std::chrono::duration<double>(clk::now() - t0).count();
     if (pinned) MI355X_CHECK(hipHostUnregister(host_in.mutable_data()));
+    {   // where a request's time goes, summed over the pool threads (warm-up requests included): the target's copy lanes and the plan
+        const double n = (double)std::max<long long>(1, MI355XNetPlanStats::runs().load());
+        printf("per request (us, mean over %.0f): host->device %.1f, plan enqueue %.1f, plan wait for outputs %.1f, drain env streams %.1f, device->host %.1f\n", n,
+               anakin::saber::g_mi355x_h2d_ns.load() / n / 1e3, MI355XNetPlanStats::enqueue_ns().load() / n / 1e3, MI355XNetPlanStats::wait_ns().load() / n / 1e3,
+               anakin::saber::g_mi355x_drain_ns.load() / n / 1e3, anakin::saber::g_mi355x_d2h_ns.load() / n / 1e3);
+    }
     double med = 0, mx = 0;
     if (!lat_ms.empty()) {
         std::vector<double> v = lat_ms;
