@@ -549,8 +549,9 @@ def main():
                             # worker.h:38-60), 3 pool threads = 3 Nets, each replaying its own plan on its own stream; requests
                             # and answers are HOST tensors (4.8 MB of f32 image per batch-8 request over PCIe - an inclusive rate)
                             def worker_run(mode, threads, requests=300):
+                                # (stderr discarded: the reference's Worker logs ~22 INFO lines per request, see integration/test_net_mi355x.cpp)
                                 rw = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, mode, str(threads), str(requests)],
-                                                    capture_output=True, text=True, errors="replace", timeout=300, cwd=td)
+                                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", timeout=300, cwd=td)
                                 if rw.returncode != 0:
                                     return {"error": "rc %d" % rw.returncode}
                                 wt = open(os.path.join(td, "worker.txt")).read().split()
@@ -565,6 +566,14 @@ def main():
                                 "3 threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan on its own stream, "
                                 "SABER_HIP_NET_SHARED_DEVICE); median / max = submit -> answer with at most 2 x threads requests outstanding" % B)
                             ref_list["worker_6_threads"] = worker_run("worker", 6)
+                            # the SAME per-thread Graph + Net<MI355X> + request (host tensor -> input, prediction(), output -> host tensor) from
+                            # plain std::threads, without the reference's Worker / ThreadPool shell around it: what the target's side of a
+                            # serving loop sustains (the shell itself does not scale past one thread: profiles/r05/worker_vs_threads.txt)
+                            for nt in (1, 3):
+                                ref_list["net_threads_%d" % nt] = worker_run("threads", nt, 600)
+                            ref_list["net_threads_3"]["what"] = (
+                                "3 std::threads x (Graph::load + Optimize + Net<MI355X, INT8>): Tensor::copy_from(host) -> Net::prediction() -> "
+                                "Tensor::copy_from(device), batch-%d requests from pageable host memory (PCIe-inclusive), no Worker / ThreadPool" % B)
                             ref_list["worker_pinned_requests"] = worker_run("worker_pinned", 3)
                             ref_list["worker_async_prediction"] = worker_run("worker_async", 3, 96)
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line

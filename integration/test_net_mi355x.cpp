@@ -299,6 +299,62 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
     return bad ? 3 : 0;
 }
 
+// ---- `threads <n> <requests>`: the Worker's request (host tensor -> Net input, prediction(), output -> host tensor) from n plain
+// std::threads, each with its own Graph + Net<MI355X> (what NetGraphWrapper::initial builds per pool thread) - WITHOUT the reference's
+// Worker / ThreadPool / per-request logging around it: isolates what the framework's serving shell costs from what the target costs.
+template <Precision P>
+static int run_threads(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int threads, int requests) {
+    MI355XNetPlanDefaults::worker_threads(threads);
+    std::atomic<int> next{0}, bad{0};
+    std::vector<float> first;
+    std::mutex first_mut;
+    std::vector<std::thread> pool;
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    typedef std::chrono::steady_clock clk;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t]() {
+            Graph<MI355X, P> g;
+            Status st = g.load(model_path);
+            if (!st) { ++bad; ++ready; return; }
+            g.Optimize();
+            Net<MI355X, P> net(true);
+            net.init(g, P == Precision::INT8);
+            auto in = net.get_in(g.get_ins()[0]);
+            auto out = net.get_out(g.get_outs()[0]);
+            Tensor4d<X86> hin(in->valid_shape(), AK_FLOAT), hout(out->valid_shape(), AK_FLOAT);
+            memcpy(hin.mutable_data(), input.data(), input.size() * sizeof(float));
+            for (int w = 0; w < 3; ++w) { in->copy_from(hin); net.prediction(); hout.copy_from(*out); }
+            {
+                std::lock_guard<std::mutex> l(first_mut);
+                if (first.empty()) first.assign((const float*)hout.data(), (const float*)hout.data() + hout.valid_size());
+            }
+            ++ready;
+            while (!go.load()) std::this_thread::yield();
+            while (next.fetch_add(1) < requests) {
+                in->copy_from(hin);
+                net.prediction();
+                hout.copy_from(*out);
+                if (memcmp(hout.data(), first.data(), first.size() * sizeof(float)) != 0) ++bad;
+            }
+        });
+    while (ready.load() < threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    const auto t0 = clk::now();
+    go = true;
+    for (auto& th : pool) th.join();
+    const double sec = std::chrono::duration<double>(clk::now() - t0).count();
+    const double n = (double)std::max<long long>(1, MI355XNetPlanStats::runs().load());
+    printf("per request (us, mean over %.0f): host->device %.1f, plan enqueue %.1f, plan wait for outputs %.1f, drain env streams %.1f, device->host %.1f\n", n,
+           anakin::saber::g_mi355x_h2d_ns.load() / n / 1e3, MI355XNetPlanStats::enqueue_ns().load() / n / 1e3, MI355XNetPlanStats::wait_ns().load() / n / 1e3,
+           anakin::saber::g_mi355x_drain_ns.load() / n / 1e3, anakin::saber::g_mi355x_d2h_ns.load() / n / 1e3);
+    FILE* f = fopen((outdir + "/worker.txt").c_str(), "w");
+    fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f median_ms 0 max_ms 0 coop_fallbacks %d async 0 pinned 0\n",
+            threads, requests, bad.load(), sec, requests / sec, requests * 8.0 / sec, saber_hip_coop_fallbacks_total());
+    fclose(f);
+    printf("threads ok: %d plain threads, %d requests, %d mismatches, %.1f requests/s\n", threads, requests, bad.load(), requests / sec);
+    return bad.load() ? 3 : 0;
+}
+
 // ---- `calibrate <batches>`: the reference's calibration-table generator on this target (framework/core/net/entropy_calibrator.cpp,
 // calibrator.h, batch_stream.cpp): a Net<MI355X, FP32, SYNC> runs the calibration batches (input.bin = batches x the model's input),
 // EntropyCalibrator collects per-edge maxima and histograms through the FP32 operators of the MI355X target and writes
@@ -335,7 +391,19 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s model.txt weights.bin input.bin outdir [timing iters]\n", argv[0]);
         return 2;
     }
-    logger::init(argv[0]);
+    // The reference's Worker::sync_prediction logs ~22 INFO lines per request (the first ten input and output floats, the thread id:
+    // worker.cpp:101-105, 143-147); through logger::init's per-severity log FILES (a flush per line, one global mutex) that is 0.3 - 0.7 ms
+    // of every request and the first thing Worker threads serialise on (profiles/r05/worker_breakdown.txt). A serving process does not
+    // log request payloads to disk: in the worker modes the log files are not opened (the lines still go to stderr, which the caller
+    // may discard); SABER_TEST_LOGFILES=1 restores them.
+    const bool worker_mode = argc > 6 && (std::string(argv[5]).compare(0, 6, "worker") == 0 || std::string(argv[5]) == "threads");
+    // SABER_TEST_SYNC=blocking | yield | spin: how host threads wait for the device (hipSetDeviceFlags, before the context exists) - an A/B
+    // aid for the Worker modes: with fewer host cores than pool threads, spinning waiters take the cores the launching threads need
+    if (const char* sy = getenv("SABER_TEST_SYNC")) {
+        const std::string m(sy);
+        (void)hipSetDeviceFlags(m == "blocking" ? hipDeviceScheduleBlockingSync : (m == "yield" ? hipDeviceScheduleYield : hipDeviceScheduleSpin));
+    }
+    if (!worker_mode || getenv("SABER_TEST_LOGFILES")) logger::init(argv[0]);
     std::ifstream fm(argv[1]);
     std::string line, precision = "int8";
     while (std::getline(fm, line)) {
@@ -357,6 +425,12 @@ int main(int argc, char** argv) {
         const int th = atoi(argv[6]), rq = argc > 7 ? atoi(argv[7]) : 64;
         if (precision == "int8") return run_worker<Precision::INT8>(argv[1], input, argv[4], th, rq, argv[5]);
         return run_worker<Precision::FP32>(argv[1], input, argv[4], th, rq, argv[5]);
+    }
+    if (argc > 6 && std::string(argv[5]) == "threads") {
+        Env<MI355X>::env_init();
+        const int th = atoi(argv[6]), rq = argc > 7 ? atoi(argv[7]) : 64;
+        if (precision == "int8") return run_threads<Precision::INT8>(argv[1], input, argv[4], th, rq);
+        return run_threads<Precision::FP32>(argv[1], input, argv[4], th, rq);
     }
     if (argc > 6 && std::string(argv[5]) == "calibrate") {
         Env<MI355X>::env_init();
