@@ -558,10 +558,11 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
         }
         std::vector<uint8_t> raw((const uint8_t*)wr.data(), (const uint8_t*)wr.data() + wr.size() * sizeof(float));
         HIP_TRY(op->d_w.upload(raw));
-        // an fc at <= 16 batch rows is ONE pass over its weights: the same matrix once more fragment-major, so that every load instruction
-        // of the streaming kernel reads 1 KB contiguous ([16-output tile][16-float step][lane][4]; fc_small.hip). Zero padded.
+        // an fc at <= 16 batch rows is ONE pass over its weights. SABER_HIP_FC_F32_PACKED=1 (A/B): the same matrix once more
+        // fragment-major, so that every load instruction of the streaming kernel reads 1 KB contiguous ([16-output tile][16-float step]
+        // [lane][4]; fc_small.hip) - superseded by the kernel that reads the row-major weights in contiguous runs and transposes in LDS.
         if (op->algo == ALGO_IGEMM_F32 && d.h == 1 && d.w == 1 && kh == 1 && kw == 1 && fc_f32_small_ok(d.n, op->c_eff, op->Kg_pad) &&
-            !getenv("SABER_HIP_FC_F32_ROWMAJOR")) {
+            getenv("SABER_HIP_FC_F32_PACKED")) {      // (A/B only since gemm_f32_rows_lds_kernel: the row-major weights stream faster)
             const int Ce = op->c_eff, tiles = (K + 15) / 16, steps = fc_f32_packed_steps(Ce);
             std::vector<float> pk((size_t)tiles * steps * 256, 0.f);
             for (int t = 0; t < tiles; ++t)

@@ -278,6 +278,103 @@ __global__ __launch_bounds__(NW * 64) void fc_f32_stream_kernel(const FcStreamAr
             if (kb + r < a.n) y[r] = out[r];
     }
 }
+// The same product for weights that must be read AS THEY LIE, row-major [n][k] - the raw B of Gemm<float>::dispatch, which may change
+// between calls and cannot be repacked without a second pass: every load instruction reads 1 KB CONTIGUOUS of ONE row (lane l: floats
+// 4 l .. 4 l + 3 of a 256-float super-step), sixteen instructions bring a 16-row x 256-float block into registers, the wave turns it
+// into MFMA operand order through a wave-PRIVATE LDS region (row pitch 1040 bytes: the 16 lanes of a fragment column hit 16 distinct
+// bank quads; no barrier - one wave's LDS operations execute in order), and the activations take the same route (MR contiguous 1 KB
+// loads instead of 16 gathered ones). Two register buffers, unconditional loads, four accumulators, rotated start as above.
+template <int MR>
+__global__ __launch_bounds__(256) void gemm_f32_rows_lds_kernel(const FcStreamArgs a) {
+    constexpr int PITCH = 260;                               // floats per LDS row (256 + 4: see above)
+    __shared__ float lds[4][(16 + MR) * PITCH];
+    __shared__ v4f redf[3][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    float* const wl = lds[wave];
+    float* const xl = lds[wave] + 16 * PITCH;
+    const int nsup = (a.c + 1023) / 1024;                    // 256-float super-steps per wave (the four waves split the reduction)
+    const int kw0 = wave * nsup * 256;                       // this wave's first reduction index
+    const float* const zero = (const float*)a.zero;
+    v4f acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4i wv[2][16], xv[2][MR];
+    auto request = [&](int b, int t) {                       // super-step t of this wave into buffer b
+        const int k = kw0 + t * 256 + lane * 4;
+        const bool in = t < nsup && k < a.c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = n0 + r < a.w_rows ? n0 + r : a.w_rows - 1;
+            const float* wrow = a.w + (size_t)row * a.w_pitch;
+            wv[b][r] = __builtin_nontemporal_load((const v4i*)(in ? wrow + k : wrow));
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int mm = m < a.m ? m : a.m - 1;
+            xv[b][m] = *(const v4i*)(in ? a.x + (size_t)mm * a.c + k : zero);
+        }
+    };
+    auto multiply = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *(v4i*)(wl + r * PITCH + lane * 4) = wv[b][r];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) *(v4i*)(xl + m * PITCH + lane * 4) = xv[b][m];
+        const float* wf = wl + frow * PITCH + fq * 4;
+        const float* xf = xl + (frow < MR ? frow : frow - MR) * PITCH + fq * 4;     // (rows beyond the batch: any finite row, results dropped)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const v4f wq = *(const v4f*)(wf + s * 16);
+            const v4f xq = *(const v4f*)(xf + s * 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.x, xq.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.y, xq.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.z, xq.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.w, xq.w, acc[3], 0, 0, 0);
+        }
+    };
+    const int rot = (int)((blockIdx.x * 7u + wave * 3u) % (unsigned)nsup);
+    auto sup = [&](int ci) { return ci < nsup ? (ci + rot) % nsup : nsup; };      // (past the end: nothing in range, zeros)
+    request(0, sup(0));
+    __builtin_amdgcn_sched_barrier(0);
+    for (int ci = 0; ci < nsup; ci += 2) {
+        request(1, sup(ci + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(0);
+        __builtin_amdgcn_sched_barrier(0);
+        request(0, sup(ci + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (wave > 0) redf[wave - 1][lane] = sum;
+    __syncthreads();
+    if (wave > 0) return;
+    sum += redf[0][lane];
+    sum += redf[1][lane];
+    sum += redf[2][lane];
+    const int kb = n0 + fq * 4;
+    if (frow >= a.m || kb >= a.n) return;
+    float* y = a.y + (size_t)frow * a.n + kb;
+    float out[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float d = a.alpha == 1.f ? sum[r] : __fmul_rn(a.alpha, sum[r]);
+        if (a.bias && kb + r < a.n) d = __fadd_rn(d, a.bias[kb + r]);
+        if (a.relu) d = d > 0.f ? d : (a.neg_slope == 0.f ? 0.f : __fmul_rn(d, a.neg_slope));
+        if (a.beta != 0.f && kb + r < a.n) d = __fadd_rn(d, __fmul_rn(a.beta, y[r]));
+        out[r] = d;
+    }
+    if (kb + 4 <= a.n && (a.n & 3) == 0) {
+        *(float4*)y = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (int r = 0; r < 4; ++r)
+            if (kb + r < a.n) y[r] = out[r];
+    }
+}
+
 bool fc_f32_small_ok(int m, int c, int kg_pad) { return m >= 1 && m <= 16 && c % 4 == 0 && c <= 65536 && kg_pad >= (c + 63) / 64 * 64; }
 static hipError_t launch_fc_f32_stream(const FcStreamArgs& f, bool packed, hipStream_t s) {
     const dim3 grid((f.n + 15) / 16);
@@ -302,6 +399,12 @@ hipError_t launch_fc_f32_small(const ConvKArgs& a, bool packed, hipStream_t s) {
     f.w_pitch = packed ? fc_f32_packed_steps(a.C) : a.Kg_pad;
     f.w_rows = (a.K + 15) / 16 * 16;        // (the repacked weights are padded to multiples of 128 rows)
     f.relu = a.relu; f.neg_slope = a.neg_slope; f.alpha = 1.f; f.beta = 0.f;
+    if (!packed && a.C >= 2048) {      // long reductions on row-major weights: contiguous row reads + the wave-private LDS transpose
+        const dim3 grid((f.n + 15) / 16), block(256);
+        if (f.m <= 8) hipLaunchKernelGGL((gemm_f32_rows_lds_kernel<8>), grid, block, 0, s, f);
+        else hipLaunchKernelGGL((gemm_f32_rows_lds_kernel<16>), grid, block, 0, s, f);
+        return hipGetLastError();
+    }
     return launch_fc_f32_stream(f, packed, s);
 }
 // 16-float steps per 16-output tile of the fragment-major weights: four waves x ceil(c / 64) steps each
@@ -315,6 +418,15 @@ hipError_t launch_gemm_f32_rows(int m, int n, int k, float alpha, const float* A
     f.w = B; f.x = A; f.y = C; f.bias = nullptr; f.zero = zero;
     f.m = m; f.n = n; f.c = k; f.w_pitch = k; f.w_rows = n;
     f.relu = 0; f.neg_slope = 0.f; f.alpha = alpha; f.beta = beta;
+    // long reductions: contiguous row reads turned into operand order through LDS (gemm_f32_rows_lds_kernel; SABER_HIP_GEMM_ROWS_GATHER=1:
+    // the gathering stream kernel, kept for A/B); short ones: the stream kernel
+    static const bool gather = [] { const char* e = std::getenv("SABER_HIP_GEMM_ROWS_GATHER"); return e && e[0] == '1'; }();
+    if (k >= 2048 && !gather) {
+        const dim3 grid((n + 15) / 16), block(256);
+        if (m <= 8) hipLaunchKernelGGL((gemm_f32_rows_lds_kernel<8>), grid, block, 0, s, f);
+        else hipLaunchKernelGGL((gemm_f32_rows_lds_kernel<16>), grid, block, 0, s, f);
+        return hipGetLastError();
+    }
     return launch_fc_f32_stream(f, false, s);
 }
 
