@@ -105,6 +105,12 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         set_choice(op, cp);
         time_current();
     }
+    for (int pv = 1; pv <= 4; ++pv)      // FP32 1x1, C = 256 .. 2048: the reduction split over the waves, no LDS staging (conv1x1_pwk.hip)
+        if (pwk_ok(op, pv)) {
+            ConvChoice cp = {op->tile, 1, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 1 + pv};
+            set_choice(op, cp);
+            time_current();
+        }
     c = best_c;
     if (fc_small_ok(op)) {
         ConvChoice cf = c;

@@ -156,7 +156,12 @@ void name_algo(saber_hip_conv* op) {
     if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
-    else if (op->pw) snprintf(buf, sizeof buf, "pw1x1_f32_bf16x3_regs_c%d_%dch_per_wave%s", op->c_eff, op->c_eff == 64 ? 64 : 32,
+    else if (op->pw > 1) {
+        int ptm = 0, pp = 0, pd = 0, pmb = 0;
+        (void)conv1x1_pwk_variant(op->pw - 1, &ptm, &pp, &pd, &pmb);
+        snprintf(buf, sizeof buf, "pw1x1_f32_bf16x3_ksplit4_%dch_%dpx_d%d%s%s", ptm * 16, pp * 16, pd, pmb > 1 ? "_2wg" : "",
+                 op->d.res_mode == SABER_HIP_RES_SUM_INPLACE ? "+sum" : "");
+    } else if (op->pw) snprintf(buf, sizeof buf, "pw1x1_f32_bf16x3_regs_c%d_%dch_per_wave%s", op->c_eff, op->c_eff == 64 ? 64 : 32,
                               op->d.res_mode == SABER_HIP_RES_SUM_INPLACE ? "+sum" : "");
     else if (op->b3h) {
         int hb, ht, htm, hthr;
@@ -373,9 +378,11 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         return SABER_HIP_OK;
     }
     if (var == 14) {   // FP32 pointwise conv, C = 64 / 128: persistent waves with their weight planes in registers (conv1x1_pw.hip)
-        if (!pw_ok(op)) return fail(SABER_HIP_INVALID_VALUE, "persistent pointwise kernel: FP32 NHWC 1x1 / stride-1 conv with C in {64, 128}, K % 64 == 0");
+        // low byte 0: the register-weights kernel (C = 64 / 128); 1 .. 4: the reduction-split kernel's variants (C = 256 .. 2048)
+        if (tile == 0 ? !pw_ok(op) : !pwk_ok(op, tile))
+            return fail(SABER_HIP_INVALID_VALUE, "pointwise kernels: FP32 NHWC 1x1 / stride-1 conv, K % 64 == 0, C in {64, 128} (variant 0) or C % 128 == 0, C >= 256 (1..4)");
         clear_selectors(op);
-        op->pw = 1; op->dma = 0;
+        op->pw = 1 + tile; op->dma = 0;
         name_algo(op);
         return SABER_HIP_OK;
     }
@@ -432,7 +439,7 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     return SABER_HIP_OK;
 }
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op) {
-    if (op->pw) return 14 << 16;
+    if (op->pw) return (14 << 16) | (op->pw - 1);
     if (op->b3h) return op->b3h | (13 << 16);
     if (op->img1) return 12 << 16;
     if (op->fc_small) return 10 << 16;
@@ -633,7 +640,8 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
             // (conv1x1_pw.hip): [64-channel block][16-row tile][32-deep slab][plane][lane] x 8 bf16; row = lane & 15 is output channel
             // block * 64 + 16 tile + row, element j of k-group kg = lane >> 4 is input channel 32 slab + (j < 4 ? 4 kg + j : 16 + 4 kg + j - 4)
             if (kh == 1 && kw == 1 && d.pad_h == 0 && d.pad_w == 0 && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
-                d.group == 1 && !op->pre_transpose && d.out_layout == SABER_HIP_NHWC && conv1x1_pw_ok(op->c_eff, K) &&
+                d.group == 1 && !op->pre_transpose && d.out_layout == SABER_HIP_NHWC &&
+                (conv1x1_pw_ok(op->c_eff, K) || conv1x1_pwk_ok(d.n * d.h * d.w, op->c_eff, K)) &&
                 (d.res_mode == SABER_HIP_RES_NONE || d.res_mode == SABER_HIP_RES_SUM_INPLACE)) {
                 const int Ce = op->c_eff, NS = Ce / 32;
                 std::vector<uint8_t> fr((size_t)(K / 64) * 4 * NS * 3 * 64 * 16, 0);
@@ -813,7 +821,8 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
         }
         if (op->pw) {
             a.w = op->d_wpw.p;
-            HIP_TRY(launch_conv1x1_pw(a, s));
+            if (op->pw > 1) HIP_TRY(launch_conv1x1_pwk(op->pw - 1, a, s));
+            else HIP_TRY(launch_conv1x1_pw(a, s));
             break;
         }
         if (op->b3h) {

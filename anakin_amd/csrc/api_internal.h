@@ -103,7 +103,8 @@ struct saber_hip_conv {
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
     int b3h = 0;             // FP32 3x3: 1..5 = LDS-halo bf16-plane kernel variant (conv3x3_b3h.hip), 0: not used
     DevBuf<uint8_t> d_w3h1, d_w3h2;   // its weight planes in MFMA fragment order for 1 / 2 row tiles per wave
-    int pw = 0;              // FP32 1x1 / stride 1 with C = 64 / 128: 1 = persistent register-weights kernel (conv1x1_pw.hip), 0: not used
+    int pw = 0;              // FP32 1x1 / stride 1: 1 = persistent register-weights kernel (C = 64 / 128, conv1x1_pw.hip), 2 .. 5 = the
+                             // reduction-split kernel's variants 1 .. 4 (C = 256 .. 2048, conv1x1_pwk.hip), 0: not used
     DevBuf<uint8_t> d_wpw;   // its weight planes in that kernel's fragment order
     DevBuf<float> d_wfc;     // FP32 fc at <= 16 rows: the weights fragment-major for the streaming kernel (fc_small.hip: fc_f32_stream_kernel PACKED)
     int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels
@@ -217,7 +218,12 @@ inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool; op->b3h = c.b3h; op->pw = c.pw;
 }
 inline bool pw_ok(const saber_hip_conv* op) {      // the persistent pointwise kernel exists for this op (planes packed by set_weights)
-    return op->algo == ALGO_IGEMM_F32 && op->d_wpw.p != nullptr && !op->pair_k2 && !op->pool2;
+    return op->algo == ALGO_IGEMM_F32 && op->d_wpw.p != nullptr && !op->pair_k2 && !op->pool2 && conv1x1_pw_ok(op->c_eff, op->d.k);
+}
+inline bool pwk_ok(const saber_hip_conv* op, int variant) {      // ... the reduction-split pointwise kernel, variant 1 .. 4
+    int tm, p, dd, mb;
+    return conv1x1_pwk_variant(variant, &tm, &p, &dd, &mb) && op->algo == ALGO_IGEMM_F32 && op->d_wpw.p != nullptr && !op->pair_k2 &&
+           !op->pool2 && conv1x1_pwk_ok(op->d.n * op->d.h * op->d.w, op->c_eff, op->d.k) && (op->c_eff >> 7) >= dd;      // (slabs in flight <= slabs per wave)
 }
 inline bool b3_ok(const saber_hip_conv* op) {   // the bf16-plane variant exists for this op (planes uploaded by set_weights)
     return op->algo == ALGO_IGEMM_F32 && op->d_w3.p != nullptr;
@@ -321,6 +327,7 @@ inline unsigned long long kernel_key(const saber_hip_conv* op, const ConvChoice&
     else if (op->algo != ALGO_IGEMM_F32 && op->epi == EPI_I8_CONV && d.res_mode != SABER_HIP_RES_SUM_INPLACE && d.k % 16 == 0)
         ek = d.res_mode == SABER_HIP_RES_ELTWISE ? 2 : (d.out_dtype == SABER_HIP_U8 ? 1 : (d.out_dtype == SABER_HIP_S8 ? 0 : 3));
     unsigned long long k = (unsigned long long)op->algo | ((unsigned long long)ek << 4);
+    if (c.pw > 1) return k | (10ull << 8) | ((unsigned long long)c.pw << 16) | ((unsigned long long)(d.res_mode == SABER_HIP_RES_SUM_INPLACE) << 32);
     if (c.pw) return k | (9ull << 8) | ((unsigned long long)op->c_eff << 16) | ((unsigned long long)(d.res_mode == SABER_HIP_RES_SUM_INPLACE) << 32);
     if (c.b3h) return k | (8ull << 8) | ((unsigned long long)c.b3h << 16);
     if (c.img1) return k | (7ull << 8) | ((unsigned long long)(op->d.kh == 3) << 16);      // one function for all image-resident shapes

@@ -1925,6 +1925,77 @@ def test_conv_f32_pointwise_register_weights_kernel_refuses_other_layers():
             conv.set_tile(14 << 16)
 
 
+F32_PWK_CASES = [
+    # N, H, W, C, K, in-place residual sum, relu, bias
+    (8, 14, 14, 1024, 256, False, True, True),    # ResNet res4 branch2a at the bench's batch: 8 slabs per wave
+    (8, 14, 14, 256, 1024, True, True, True),     # res4 branch2c + in-place residual sum: 2 slabs per wave (fewer than slabs in flight)
+    (2, 56, 56, 256, 64, False, True, True),      # res2b branch2a: one channel tile
+    (2, 28, 28, 512, 128, False, True, True),     # res3b branch2a
+    (8, 7, 7, 2048, 512, False, True, True),      # res5b branch2a: 16 slabs per wave, 392 pixels = 24 groups + 8
+    (4, 7, 7, 512, 2048, True, True, True),       # res5 branch2c + sum
+    (3, 7, 9, 384, 192, True, False, True),       # ragged pixels (189), 3 slabs per wave, sum without relu
+    (1, 5, 5, 256, 64, False, False, False),      # 25 pixels: a partial first group row, no relu, no bias
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("case", F32_PWK_CASES)
+def test_conv_f32_pointwise_reduction_split_kernel_vs_oracle(case, variant):
+    """conv1x1_pwk.hip (kernel variant 14, low byte 1 .. 4: the four waves of a workgroup split the reduction by 32-channel slab, weight
+    fragments and activations straight into registers, several slabs in flight per wave, partial sums meet in LDS once): the oracle within
+    1e-4 on both criteria, the implicit-GEMM bf16-plane kernel within rounding, the selection round-trips through get_tile / set_tile,
+    repeated launches give the same bits."""
+    N, H, W, C, K, elt, relu, bias = case
+    rng = np.random.default_rng(N * 10 + C + K + H)
+    x = (rng.random((N, C, H, W)) * 3.0 - 1.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, 1, 1)) * np.sqrt(2.0 / C)).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32) if bias else None
+    res = (rng.random((N, K, H, W)) * 2.0 - 0.5).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b if bias else np.zeros(K, np.float32), relu and not elt, (0, 0), (1, 1), (1, 1))
+    if elt:
+        want = want + res
+        if relu:
+            want = np.maximum(want, 0.0)
+    p = S.ConvParam(w, b, 1, (0, 0), (1, 1), (1, 1), relu and not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, relu, 1.0
+    conv = S.SaberConv2D(int8=False).init((N, C, H, W), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rin = np.ascontiguousarray(res.transpose(0, 2, 3, 1))
+
+    def run():
+        y = conv.new_output()
+        y.copy_(dev(rin)) if elt else y.fill_(-7.0)
+        conv.dispatch(xin, y)
+        return host(y).transpose(0, 3, 1, 2)
+    conv.set_tile(conv.tile_id() | (1 << 8) | (11 << 16))
+    base = run()
+    if C // 128 < {1: 1, 2: 3, 3: 2, 4: 2}[variant]:      # fewer slabs per wave than the variant keeps in flight: refused
+        with pytest.raises(L.SaberHipError):
+            conv.set_tile((14 << 16) | variant)
+        return
+    conv.set_tile((14 << 16) | variant)
+    assert conv.algo().startswith("pw1x1_f32_bf16x3_ksplit4_"), conv.algo()
+    assert L.load().saber_hip_conv2d_get_tile(conv.h) == (14 << 16) | variant
+    got = run()
+    d = np.abs(got - want)
+    e_max = float(d.max() / np.abs(want).max())
+    e_el = float((d / (np.abs(want) + np.abs(want).mean())).max())
+    assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (conv.algo(), e_max, e_el)
+    assert np.abs(got - base).max() <= 2e-5 * np.abs(want).max(), conv.algo()
+    assert np.array_equal(run(), got)
+
+
+def test_conv_f32_pointwise_reduction_split_kernel_refuses_other_layers():
+    rng = np.random.default_rng(4)
+    for (c, k, stride) in ((128, 64, 1), (256, 64, 2), (320, 64, 1), (256, 72, 1)):
+        w = (rng.standard_normal((k, c, 1, 1)) * 0.1).astype(np.float32)
+        p = S.ConvParam(w, None, 1, (0, 0), (stride, stride), (1, 1), True)
+        conv = S.SaberConv2D(int8=False).init((1, c, 16, 16), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+        with pytest.raises(L.SaberHipError):
+            conv.set_tile((14 << 16) | 1)
+
+
 STRIDED_HEAD_CASES = [
     # C, N, Hin, Win, 3x3 input dtype, mid dtype, eltwise relu, tile code (None: default)
     (64, 2, 56, 56, O.U8, O.U8, 1, None),        # res2c after the reference's stride-up: 56 -> 28
