@@ -105,7 +105,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
         set_choice(op, cp);
         time_current();
     }
-    for (int pv = 1; pv <= 4; ++pv)      // FP32 1x1, C = 256 .. 2048: the reduction split over the waves, no LDS staging (conv1x1_pwk.hip)
+    for (int pv = 1; pv <= 4; ++pv)      // FP32 1x1, C = 128 .. 2048: the reduction split over the waves, no LDS staging (conv1x1_pwk.hip)
         if (pwk_ok(op, pv)) {
             ConvChoice cp = {op->tile, 1, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 1 + pv};
             set_choice(op, cp);

@@ -378,9 +378,9 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
         return SABER_HIP_OK;
     }
     if (var == 14) {   // FP32 pointwise conv, C = 64 / 128: persistent waves with their weight planes in registers (conv1x1_pw.hip)
-        // low byte 0: the register-weights kernel (C = 64 / 128); 1 .. 4: the reduction-split kernel's variants (C = 256 .. 2048)
+        // low byte 0: the register-weights kernel (C = 64 / 128); 1 .. 4: the reduction-split kernel's variants (C = 128 .. 2048)
         if (tile == 0 ? !pw_ok(op) : !pwk_ok(op, tile))
-            return fail(SABER_HIP_INVALID_VALUE, "pointwise kernels: FP32 NHWC 1x1 / stride-1 conv, K % 64 == 0, C in {64, 128} (variant 0) or C % 128 == 0, C >= 256 (1..4)");
+            return fail(SABER_HIP_INVALID_VALUE, "pointwise kernels: FP32 NHWC 1x1 / stride-1 conv, K % 64 == 0, C in {64, 128} (variant 0) or C % 128 == 0 (1..4)");
         clear_selectors(op);
         op->pw = 1 + tile; op->dma = 0;
         name_algo(op);

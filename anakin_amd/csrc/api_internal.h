@@ -104,7 +104,7 @@ struct saber_hip_conv {
     int b3h = 0;             // FP32 3x3: 1..5 = LDS-halo bf16-plane kernel variant (conv3x3_b3h.hip), 0: not used
     DevBuf<uint8_t> d_w3h1, d_w3h2;   // its weight planes in MFMA fragment order for 1 / 2 row tiles per wave
     int pw = 0;              // FP32 1x1 / stride 1: 1 = persistent register-weights kernel (C = 64 / 128, conv1x1_pw.hip), 2 .. 5 = the
-                             // reduction-split kernel's variants 1 .. 4 (C = 256 .. 2048, conv1x1_pwk.hip), 0: not used
+                             // reduction-split kernel's variants 1 .. 4 (C = 128 .. 2048, conv1x1_pwk.hip), 0: not used
     DevBuf<uint8_t> d_wpw;   // its weight planes in that kernel's fragment order
     DevBuf<float> d_wfc;     // FP32 fc at <= 16 rows: the weights fragment-major for the streaming kernel (fc_small.hip: fc_f32_stream_kernel PACKED)
     int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels

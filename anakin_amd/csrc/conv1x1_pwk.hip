@@ -1,4 +1,4 @@
-// anakin_amd/csrc/conv1x1_pwk.hip - FP32 pointwise (1x1 / stride 1) convolution with MANY input channels (C = 256 .. 2048) on the bf16
+// anakin_amd/csrc/conv1x1_pwk.hip - FP32 pointwise (1x1 / stride 1) convolution with MANY input channels (C = 128 .. 2048) on the bf16
 // matrix cores without LDS staging and without a barrier in the reduction loop: the four waves of a workgroup split the REDUCTION.
 //
 // Role: SaberConv2D<AK_FLOAT> / SaberConvEltwise<AK_FLOAT> on ResNet's deep pointwise layers - `branch2a` of res2b .. res5c (256 -> 64 ...
@@ -216,9 +216,9 @@ bool conv1x1_pwk_variant(int v, int* tm, int* p, int* d, int* minb) {
     *tm = T[v - 1][0]; *p = T[v - 1][1]; *d = T[v - 1][2]; *minb = T[v - 1][3];
     return true;
 }
-// C % 128 == 0 and >= 256 (every wave has at least two slabs), K % 64 == 0; byte offsets are 32-bit
+// C % 128 == 0 (every wave has at least one slab), K % 64 == 0; byte offsets are 32-bit
 bool conv1x1_pwk_ok(int m, int c, int k) {
-    return c >= 256 && c % 128 == 0 && k >= 64 && k % 64 == 0 && m >= 1 && (long long)m * (c > k ? c : k) * 4 < 0x7fffffffll && (long long)k * c * 6 < 0x7fffffffll;
+    return c >= 128 && c % 128 == 0 && k >= 64 && k % 64 == 0 && m >= 1 && (long long)m * (c > k ? c : k) * 4 < 0x7fffffffll && (long long)k * c * 6 < 0x7fffffffll;
 }
 
 template <int TM, int P, int D, int MINB, int NSW>

@@ -277,7 +277,7 @@ bool conv3x3_b3h_variant(int variant, int* bmk, int* th, int* tm, int* threads);
 // FP32 1x1 / stride 1 with C = 64 / 128 input channels: persistent independent waves, weight planes in registers (conv1x1_pw.hip)
 bool conv1x1_pw_ok(int c, int k);
 hipError_t launch_conv1x1_pw(const ConvKArgs& a, hipStream_t s);
-// FP32 1x1 / stride 1 with C = 256 .. 2048 (C % 128 == 0): the four waves of a workgroup split the reduction, D slabs in flight per wave, no
+// FP32 1x1 / stride 1 with C = 128 .. 2048 (C % 128 == 0): the four waves of a workgroup split the reduction, D slabs in flight per wave, no
 // LDS staging (conv1x1_pwk.hip); variant 1 .. 4 -> (16-channel tiles, 16-pixel groups, slabs in flight, workgroups per CU)
 bool conv1x1_pwk_variant(int v, int* tm, int* p, int* d, int* minb);
 bool conv1x1_pwk_ok(int m, int c, int k);

@@ -1935,6 +1935,7 @@ F32_PWK_CASES = [
     (4, 7, 7, 512, 2048, True, True, True),       # res5 branch2c + sum
     (3, 7, 9, 384, 192, True, False, True),       # ragged pixels (189), 3 slabs per wave, sum without relu
     (1, 5, 5, 256, 64, False, False, False),      # 25 pixels: a partial first group row, no relu, no bias
+    (2, 28, 28, 128, 512, True, True, True),      # res3 branch2c + sum: ONE slab per wave (only the one-slab-in-flight variant takes it)
 ]
 
 
@@ -1988,7 +1989,7 @@ def test_conv_f32_pointwise_reduction_split_kernel_vs_oracle(case, variant):
 
 def test_conv_f32_pointwise_reduction_split_kernel_refuses_other_layers():
     rng = np.random.default_rng(4)
-    for (c, k, stride) in ((128, 64, 1), (256, 64, 2), (320, 64, 1), (256, 72, 1)):
+    for (c, k, stride) in ((64, 64, 1), (256, 64, 2), (320, 64, 1), (256, 72, 1)):
         w = (rng.standard_normal((k, c, 1, 1)) * 0.1).astype(np.float32)
         p = S.ConvParam(w, None, 1, (0, 0), (stride, stride), (1, 1), True)
         conv = S.SaberConv2D(int8=False).init((1, c, 16, 16), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
