@@ -149,8 +149,13 @@ const char* saber_hip_conv2d_algo(const saber_hip_conv_t* op);
  *      bits 8..11 stage depth (1 | 2), bits 12..15 log2 of the split-K factor (2 / 4 / 8 workgroups per tile on one XCD);
  *   13 FP32 3x3 stride-1 pad-1 LDS-halo kernel on the bf16 planes, variant 1..5 in the low byte (channels per workgroup x tile rows x
  *      waves: 128x8x8, 64x8x4, 64x8x8, 64x4x4, 128x4x8); C % 32 == 0, NHWC;
+ *      6..8: the pointwise (1x1) forms of the same kernel, C % 64 == 0;
  *   12 image-resident kernel (INT8 1x1 / 3x3 stride-1 convs on <= 64 pixels per image: workgroup = one image x a channel group,
- *      the image in LDS, the weight slice in registers). */
+ *      the image in LDS, the weight slice in registers);
+ *   14 FP32 pointwise (1x1 / stride 1, NHWC, K % 64 == 0) kernels without LDS staging: low byte 0 = persistent waves with their
+ *      weight planes in registers (C = 64 / 128), 1..4 = the reduction split over the four waves of a workgroup (C % 128 == 0;
+ *      output channels x pixels per workgroup, 32-deep slabs in flight per wave: 64x32 d1 two workgroups per CU, 32x32 d3, 64x32 d2,
+ *      64x64 d2; a variant that keeps more slabs in flight than a wave has - C / 128 - is refused). */
 int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile);
 int saber_hip_conv2d_get_tile(const saber_hip_conv_t* op);
 int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, const void* res, void* workspace,
