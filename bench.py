@@ -551,7 +551,7 @@ def main():
                             def worker_run(mode, threads, requests=300):
                                 # (stderr discarded: the reference's Worker logs ~22 INFO lines per request, see integration/test_net_mi355x.cpp)
                                 rw = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, mode, str(threads), str(requests)],
-                                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", timeout=300, cwd=td)
+                                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", timeout=600, cwd=td)
                                 if rw.returncode != 0:
                                     return {"error": "rc %d" % rw.returncode}
                                 wt = open(os.path.join(td, "worker.txt")).read().split()
@@ -559,23 +559,26 @@ def main():
                                 return dict(threads=threads, requests=int(f["requests"]), mismatches=int(f["mismatches"]),
                                             images_per_s=round(float(f["images_per_s"]), 1), median_ms=float(f["median_ms"]),
                                             max_ms=float(f["max_ms"]), coop_fallbacks=int(f["coop_fallbacks"]))
-                            ref_list["worker"] = worker_run("worker", 3)
+                            # (every run warms up until ALL pool threads serve: each builds its Net inside ThreadPool::launch, one at a time,
+                            # seconds each - rounds 4 / 5 timed right after the first answers = ONE serving thread whatever the pool size,
+                            # profiles/r05/worker_ready.txt)
+                            ref_list["worker"] = worker_run("worker", 3, 600)
                             ref_list["worker"]["what"] = (
                                 "Worker<MI355X, INT8>::sync_prediction, batch-%d requests from PAGEABLE host memory (PCIe-inclusive: 4.8 MB of "
-                                "f32 image per request through the calling thread's pinned staging ring + copy stream, mi355x_impl.cpp), "
-                                "3 threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan on its own stream, "
-                                "SABER_HIP_NET_SHARED_DEVICE); median / max = submit -> answer with at most 2 x threads requests outstanding" % B)
-                            ref_list["worker_6_threads"] = worker_run("worker", 6)
+                                "f32 image per request, hipMemcpyAsync on the calling pool thread's own copy stream, mi355x_impl.cpp), "
+                                "3 pool threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan on its own stream, "
+                                "SABER_HIP_NET_SHARED_DEVICE), timed once every pool thread serves; median / max = submit -> answer with at most "
+                                "2 x threads requests outstanding" % B)
+                            ref_list["worker_6_threads"] = worker_run("worker", 6, 600)
                             # the SAME per-thread Graph + Net<MI355X> + request (host tensor -> input, prediction(), output -> host tensor) from
-                            # plain std::threads, without the reference's Worker / ThreadPool shell around it: what the target's side of a
-                            # serving loop sustains (the shell itself does not scale past one thread: profiles/r05/worker_vs_threads.txt)
+                            # plain std::threads, without the reference's Worker / ThreadPool shell around it
                             for nt in (1, 3):
                                 ref_list["net_threads_%d" % nt] = worker_run("threads", nt, 600)
                             ref_list["net_threads_3"]["what"] = (
                                 "3 std::threads x (Graph::load + Optimize + Net<MI355X, INT8>): Tensor::copy_from(host) -> Net::prediction() -> "
                                 "Tensor::copy_from(device), batch-%d requests from pageable host memory (PCIe-inclusive), no Worker / ThreadPool" % B)
-                            ref_list["worker_pinned_requests"] = worker_run("worker_pinned", 3)
-                            ref_list["worker_async_prediction"] = worker_run("worker_async", 3, 96)
+                            ref_list["worker_pinned_requests"] = worker_run("worker_pinned", 3, 600)
+                            ref_list["worker_async_prediction"] = worker_run("worker_async", 3, 600)
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
                 ref_list = {"error": "%s: %s" % (type(e).__name__, e)}
 

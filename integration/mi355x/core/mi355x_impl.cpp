@@ -73,12 +73,19 @@ static inline void mi355x_copy(void* dst, size_t dst_offset, const void* src, si
 // The lane is leaked at thread exit on purpose (the HIP runtime may be gone when thread_local destructors run).
 // MI355XCopyStats: nanoseconds this process spent in the two directions (all threads), for the Worker driver's breakdown.
 std::atomic<long long> g_mi355x_h2d_ns{0}, g_mi355x_d2h_ns{0}, g_mi355x_drain_ns{0}, g_mi355x_copies{0};
+// ... and BETWEEN a thread's requests: from the end of its device -> host copy to the start of its next host -> device copy (what the
+// serving shell around the target costs per request: task hand-over, result hand-back, whatever the caller does in between), and how the
+// copies spread over the calling threads (the first 16 of them; a request is one device -> host copy)
+std::atomic<long long> g_mi355x_between_ns{0}, g_mi355x_between_n{0}, g_mi355x_thread_h2d[16], g_mi355x_thread_d2h[16];
+std::atomic<int> g_mi355x_threads_seen{0};
 namespace {
 struct CopyLane {
     int dev = -1;
     hipStream_t stream = nullptr;
 };
 thread_local CopyLane* g_lane = nullptr;
+thread_local long long t_last_d2h_end = 0;
+thread_local int t_thread_slot = -1;
 
 CopyLane* copy_lane() {
     int dev = 0;
@@ -117,6 +124,9 @@ void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src
 void MI355X_API::sync_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count, __HtoD) {
     if (!count) return;
     const long long t0 = now_ns();
+    if (t_last_d2h_end) { g_mi355x_between_ns += t0 - t_last_d2h_end; ++g_mi355x_between_n; t_last_d2h_end = 0; }
+    if (t_thread_slot < 0) t_thread_slot = g_mi355x_threads_seen++;
+    if (t_thread_slot < 16) ++g_mi355x_thread_h2d[t_thread_slot];
     lane_copy((char*)dst + dst_offset, (const char*)src + src_offset, count, hipMemcpyHostToDevice);
     g_mi355x_h2d_ns += now_ns() - t0;
     ++g_mi355x_copies;
@@ -136,7 +146,10 @@ void MI355X_API::sync_memcpy(void* dst, size_t dst_offset, int, const void* src,
     const long long t1 = now_ns();
     lane_copy((char*)dst + dst_offset, (const char*)src + src_offset, count, hipMemcpyDeviceToHost);
     g_mi355x_drain_ns += t1 - t0;
-    g_mi355x_d2h_ns += now_ns() - t1;
+    if (t_thread_slot < 0) t_thread_slot = g_mi355x_threads_seen++;
+    if (t_thread_slot < 16) ++g_mi355x_thread_d2h[t_thread_slot];
+    t_last_d2h_end = now_ns();
+    g_mi355x_d2h_ns += t_last_d2h_end - t1;
 }
 void MI355X_API::async_memcpy(void* dst, size_t dst_offset, int, const void* src, size_t src_offset, int, size_t count,
                               stream_t stream, __DtoH) {

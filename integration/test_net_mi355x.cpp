@@ -61,7 +61,7 @@
 #include "framework/core/net/net.h"
 #undef private
 #include "framework/core/net/worker.h"
-namespace anakin { namespace saber { extern std::atomic<long long> g_mi355x_h2d_ns, g_mi355x_d2h_ns, g_mi355x_drain_ns, g_mi355x_copies; } }
+namespace anakin { namespace saber { extern std::atomic<long long> g_mi355x_h2d_ns, g_mi355x_d2h_ns, g_mi355x_drain_ns, g_mi355x_copies, g_mi355x_between_ns, g_mi355x_between_n, g_mi355x_thread_h2d[16], g_mi355x_thread_d2h[16]; extern std::atomic<int> g_mi355x_threads_seen; } }
 #include "framework/core/net/entropy_calibrator.h"
 #include <chrono>
 #include <future>
@@ -198,6 +198,15 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
     return 0;
 }
 
+// between a thread's requests (end of its device -> host copy .. start of its next host -> device copy) and the requests per calling thread
+static void print_between() {
+    const long long bn = std::max<long long>(1, anakin::saber::g_mi355x_between_n.load());
+    printf("    between a thread's requests (us, mean over %lld): %.1f; answers (device -> host copies) per calling thread:", bn, anakin::saber::g_mi355x_between_ns.load() / (double)bn / 1e3);
+    const int seen = std::min(16, anakin::saber::g_mi355x_threads_seen.load());
+    for (int i = 0; i < seen; ++i) printf(" %lld", anakin::saber::g_mi355x_thread_d2h[i].load());
+    printf("\n");
+}
+
 // ---- `worker <threads> <requests>`: Worker<MI355X, FP32> (framework/core/net/worker.h:38-60) - the reference's multi-instance
 // serving shape: `threads` pool threads, each loads the model (Graph::load -> the text model parser), optimises it and owns a
 // Net; requests are host tensors, answers futures of host tensors. Every answer must equal the first; requests / s reported.
@@ -229,8 +238,33 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
     // reference's NV Worker for free): the copy lane then skips its staging ring (mi355x_impl.cpp)
     if (pinned) MI355X_CHECK(hipHostRegister(host_in.mutable_data(), input.size() * sizeof(float), hipHostRegisterDefault));
     std::vector<Tensor4d<X86> > ins(1, host_in);
-    auto first = worker.sync_prediction(ins).get();      // also: every pool thread has finished its init by the time the queue drains
-    for (int w = 0; w < 2 * threads; ++w) worker.sync_prediction(ins).get();
+    auto first = worker.sync_prediction(ins).get();
+    // Warm-up until EVERY pool thread serves requests. Each pool thread builds its Net inside ThreadPool::launch's thread body
+    // (Worker::init -> NetGraphWrapper::initial, worker.cpp:13-39: Graph::load + Optimize + Net::init + the plan's autotune, seconds each,
+    // one thread at a time under NetGraphWrapper::_mut) and there is no readiness signal: the first thread to finish starts serving while the
+    // others are still initialising. Rounds 4 / 5 timed 600 requests (0.25 s) right after the first answers - i.e. ONE serving thread
+    // whatever the pool size, which is what "the Worker shell does not scale" was (profiles/r05/worker_ready.txt). The target's per-thread
+    // copy counters say who has answered.
+    {
+        auto serving = [&]() {
+            int n = 0;
+            const int seen = std::min(16, anakin::saber::g_mi355x_threads_seen.load());
+            for (int i = 0; i < seen; ++i) n += anakin::saber::g_mi355x_thread_d2h[i].load() >= 200 ? 1 : 0;      // (a thread's first ~100 requests are slow: its stream, its buffers)
+            return n;
+        };
+        const auto w0 = std::chrono::steady_clock::now();
+        int warm = 0;
+        std::deque<std::future<std::vector<Tensor4d<X86> > > > fly;
+        while (serving() < std::min(threads, 15) && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < 240.0) {
+            if ((int)fly.size() >= 2 * threads) { fly.front().get(); fly.pop_front(); }
+            fly.emplace_back(worker.sync_prediction(ins));
+            ++warm;
+        }
+        while (!fly.empty()) { fly.front().get(); fly.pop_front(); }
+        for (int w = 0; w < 2 * threads; ++w) worker.sync_prediction(ins).get();
+        printf("warm-up: %d requests, %.2f s until %d of %d pool threads served\n", warm,
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(), serving(), threads);
+    }
     typedef std::chrono::steady_clock clk;
     int bad = 0;
     std::vector<double> lat_ms;
@@ -278,6 +312,7 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
         printf("per request (us, mean over %.0f): host->device %.1f, plan enqueue %.1f, plan wait for outputs %.1f, drain env streams %.1f, device->host %.1f\n", n,
                anakin::saber::g_mi355x_h2d_ns.load() / n / 1e3, MI355XNetPlanStats::enqueue_ns().load() / n / 1e3, MI355XNetPlanStats::wait_ns().load() / n / 1e3,
                anakin::saber::g_mi355x_drain_ns.load() / n / 1e3, anakin::saber::g_mi355x_d2h_ns.load() / n / 1e3);
+        print_between();
     }
     double med = 0, mx = 0;
     if (!lat_ms.empty()) {
@@ -324,7 +359,7 @@ static int run_threads(const std::string& model_path, const std::vector<float>& 
             auto out = net.get_out(g.get_outs()[0]);
             Tensor4d<X86> hin(in->valid_shape(), AK_FLOAT), hout(out->valid_shape(), AK_FLOAT);
             memcpy(hin.mutable_data(), input.data(), input.size() * sizeof(float));
-            for (int w = 0; w < 3; ++w) { in->copy_from(hin); net.prediction(); hout.copy_from(*out); }
+            for (int w = 0; w < 200; ++w) { in->copy_from(hin); net.prediction(); hout.copy_from(*out); }      // (a thread's first ~100 requests are slow: its stream, its buffers)
             {
                 std::lock_guard<std::mutex> l(first_mut);
                 if (first.empty()) first.assign((const float*)hout.data(), (const float*)hout.data() + hout.valid_size());
@@ -347,6 +382,7 @@ static int run_threads(const std::string& model_path, const std::vector<float>& 
     printf("per request (us, mean over %.0f): host->device %.1f, plan enqueue %.1f, plan wait for outputs %.1f, drain env streams %.1f, device->host %.1f\n", n,
            anakin::saber::g_mi355x_h2d_ns.load() / n / 1e3, MI355XNetPlanStats::enqueue_ns().load() / n / 1e3, MI355XNetPlanStats::wait_ns().load() / n / 1e3,
            anakin::saber::g_mi355x_drain_ns.load() / n / 1e3, anakin::saber::g_mi355x_d2h_ns.load() / n / 1e3);
+    print_between();
     FILE* f = fopen((outdir + "/worker.txt").c_str(), "w");
     fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f median_ms 0 max_ms 0 coop_fallbacks %d async 0 pinned 0\n",
             threads, requests, bad.load(), sec, requests / sec, requests * 8.0 / sec, saber_hip_coop_fallbacks_total());
