@@ -155,7 +155,8 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
     for (auto& o : graph->get_outs()) dump(net.get_out(o), outdir + "/out_" + o + ".bin");
     auto time_predictions = [&](int n) {
         Context<MI355X> ctx(0, 0, 0);
-        for (int i = 0; i < 10; ++i) net.prediction();
+        static const int warm = getenv("SABER_TEST_WARMUP") ? atoi(getenv("SABER_TEST_WARMUP")) : 10;
+        for (int i = 0; i < warm; ++i) net.prediction();
         TargetWrapper<MI355X>::device_sync();
         SaberTimer<MI355X> timer;
         timer.start(ctx);
