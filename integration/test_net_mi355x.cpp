@@ -199,6 +199,17 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
     return 0;
 }
 
+// An answer against the first one: INT8 nets answer bit-identically whichever pool thread serves (integer accumulation: the kernel
+// selection cannot change a bit); FP32 nets are autotuned per pool thread and may select kernels with different accumulation orders -
+// answers of different Nets then differ inside the FP32 contract (1e-4 of the largest output), which is what is checked for them.
+static bool same_answer(const float* a, const float* b, size_t n, bool exact) {
+    if (memcmp(a, b, n * sizeof(float)) == 0) return true;
+    if (exact) return false;
+    float mx = 0.f, d = 0.f;
+    for (size_t i = 0; i < n; ++i) { mx = std::max(mx, std::fabs(b[i])); d = std::max(d, std::fabs(a[i] - b[i])); }
+    return d <= 1e-4f * mx;
+}
+
 // between a thread's requests (end of its device -> host copy .. start of its next host -> device copy) and the requests per calling thread
 static void print_between() {
     const long long bn = std::max<long long>(1, anakin::saber::g_mi355x_between_n.load());
@@ -278,7 +289,7 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
             lat_ms.push_back(std::chrono::duration<double, std::milli>(clk::now() - fly.front().second).count());
             fly.pop_front();
             if (out.size() != 1 || out[0].valid_size() != first[0].valid_size() ||
-                memcmp(out[0].data(), first[0].data(), first[0].valid_size() * sizeof(float)) != 0) ++bad;
+                !same_answer((const float*)out[0].data(), (const float*)first[0].data(), first[0].valid_size(), P == Precision::INT8)) ++bad;
         };
         for (int r = 0; r < requests; ++r) {
             if ((int)fly.size() >= 2 * threads) reap();
@@ -297,7 +308,7 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
             Tensor4d<X86> h(outs[0]->valid_shape(), AK_FLOAT);
             h.copy_from(*outs[0]);
             if (outs.size() != 1 || h.valid_size() != first[0].valid_size() ||
-                memcmp(h.data(), first[0].data(), first[0].valid_size() * sizeof(float)) != 0) ++bad;
+                !same_answer((const float*)h.data(), (const float*)first[0].data(), first[0].valid_size(), P == Precision::INT8)) ++bad;
         };
         for (int r = 0; r < requests; ++r) {
             if (outstanding >= threads) reap();          // (the answer is a tensor of the Net that served it: do not let a thread lap it)

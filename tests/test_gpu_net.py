@@ -205,8 +205,9 @@ def _run_mode(tmp_path, name, batch, x, mode_args, env_extra=None, precision="fp
 def test_worker_mi355x_fp32_serves_requests_from_a_thread_pool(tmp_path):
     """Worker<MI355X, FP32> (framework/core/net/worker.h:38-60; round-3 verdict, missing 5): three pool threads, each loads the
     model through Graph::load (the text model parser standing in for the protobuf one), optimises it, owns a Net<MI355X> whose
-    prediction() runs its captured plan on a stream of its own; 48 requests of one batch-8 input - every answer bit-identical, and
-    within 1e-4 of the CPU oracle."""
+    prediction() runs its captured plan on a stream of its own; 48 requests of one batch-8 input, timed once EVERY pool thread serves -
+    every answer within the FP32 contract of the first (each pool thread autotunes its own Net: kernels with different accumulation
+    orders may be selected; the INT8 test below demands bit-identical answers), and within 1e-4 of the CPU oracle."""
     batch = 8
     x = W.make_input(batch)
     model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["worker", "3", "48"])      # (the Worker's constructor asks for a stream per Net)
