@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256, MINB) void conv_wlds_kernel(const ConvKArgs a)
     constexpr int R = DX + 1;                        // ring slots (LDS) and activation register buffers
     constexpr int L = 3 + 2 * P;                     // vector-memory instructions a wave issues per stage
     __shared__ v4i lds[R][TM * 3][64];               // 12 KB per stage
+    SABER_TL_DECL;
+    SABER_TL(0);
     const int M = a.M, K = a.K, C = a.C, W = a.W, H = a.H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,8 +125,7 @@ __global__ __launch_bounds__(256, MINB) void conv_wlds_kernel(const ConvKArgs a)
                      :
                      : "memory");
     };
-    auto combine = [&](const v4i (&wv)[TM][3], const v4i (&xv)[P][2]) {
-        v4i bp[P][3];
+    auto split_planes = [&](const v4i (&xv)[P][2], v4i (&bp)[P][3]) {
 #pragma unroll
         for (int g = 0; g < P; ++g) {
             const v4f f0 = __builtin_bit_cast(v4f, xv[g][0]), f1 = __builtin_bit_cast(v4f, xv[g][1]);
@@ -137,6 +138,8 @@ __global__ __launch_bounds__(256, MINB) void conv_wlds_kernel(const ConvKArgs a)
             bp[g][1] = v4i{(int)m[0], (int)m[1], (int)m[2], (int)m[3]};
             bp[g][2] = v4i{(int)l[0], (int)l[1], (int)l[2], (int)l[3]};
         }
+    };
+    auto mma = [&](const v4i (&wv)[TM][3], const v4i (&bp)[P][3]) {
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (weights, activations): small terms first
 #pragma unroll
         for (int tt = 0; tt < 6; ++tt)
@@ -147,6 +150,11 @@ __global__ __launch_bounds__(256, MINB) void conv_wlds_kernel(const ConvKArgs a)
                     acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wv[i][PA[tt]]),
                                                                         __builtin_bit_cast(v8bf, bp[g][PB[tt]]), acc[i][g], 0, 0, 0);
     };
+    auto combine = [&](const v4i (&wv)[TM][3], const v4i (&xv)[P][2]) {
+        v4i bp[P][3];
+        split_planes(xv, bp);
+        mma(wv, bp);
+    };
 
     v4i xv[R][P][2];
     v4i wv[TM][3];
@@ -155,25 +163,49 @@ __global__ __launch_bounds__(256, MINB) void conv_wlds_kernel(const ConvKArgs a)
     // everybody's DMA of stage i has landed), issue stage i + DX, combine stage i. When nothing is left to issue the loop falls into a
     // drain that only combines (wait counts shrink with the loads behind).
     if constexpr (NFIX != 0) {
-        // exactly NFIX stages (launcher): straight-line code. In a loop the compiler's wait-count pass merges the back edge conservatively and,
-        // with a DMA pending, turns every wait it needs itself into s_waitcnt vmcnt(0): two of three stages waited for the loads they had
-        // just issued. Here every stage is: counted wait, barrier, LDS reads, issue, combine - and nothing else.
+        // exactly NFIX stages (launcher): straight-line code, SOFTWARE-PIPELINED inside the wave. (Straight-line: in a loop the compiler's
+        // wait-count pass merges the back edge conservatively and, with a DMA pending, turns every wait it needs itself into s_waitcnt
+        // vmcnt(0).) The first version did per stage: wait, barrier, LDS reads, issue, wait for the LDS reads, split the planes (~90 VALU
+        // instructions), 48 MFMAs - one after the other at ONE wave per SIMD: 0.57 us per stage for 0.32 us of MFMAs. Now stage i's operands are
+        // in registers when its MFMAs start, and UNDER them the wave reads stage i + 1's fragments from LDS and splits stage i + 1's planes.
+        v4i wv2[2][TM][3], bp2[2][P][3];
 #pragma unroll
         for (int j = 0; j < DX; ++j) issue(j, j, xv[j]);
         __builtin_amdgcn_sched_barrier(0);
+        wait_vm_older_than<(DX - 1) * L>();                      // stage 0 has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();
+        read_w(0, wv2[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DX < NFIX) issue(DX, DX % R, xv[DX % R]);
+        __builtin_amdgcn_sched_barrier(0);
+        read_w_wait(wv2[0]);
+        split_planes(xv[0], bp2[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        SABER_TL(1);
 #pragma unroll
         for (int i = 0; i < NFIX; ++i) {
-            constexpr int after = 0;
-            if (NFIX - 1 - i >= DX - 1) wait_vm_older_than<(DX - 1) * L>();
-            else if (NFIX - 1 - i == 1) wait_vm_older_than<L>();
-            else wait_vm_older_than<after>();
-            __builtin_amdgcn_s_barrier();
-            read_w(i % R, wv);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + DX < NFIX) issue(i + DX, (i + DX) % R, xv[(i + DX) % R]);
-            __builtin_amdgcn_sched_barrier(0);
-            read_w_wait(wv);
-            combine(wv, xv[i % R]);
+            if (i == 6) SABER_TL(2);
+            if (i == 12) SABER_TL(3);
+            if (i + 1 < NFIX) {
+                // stage i + 1: landed for this wave (the stages requested after it may be in flight), then for all (barrier: also, everybody has
+                // stage i's fragments in registers - its ring slot and activation buffer are free for stage i + 1 + DX)
+                constexpr int behind = 0;
+                if (NFIX - 2 - i >= DX - 1) wait_vm_older_than<(DX - 1) * L>();
+                else if (NFIX - 2 - i == 2) wait_vm_older_than<2 * L>();
+                else if (NFIX - 2 - i == 1) wait_vm_older_than<L>();
+                else wait_vm_older_than<behind>();
+                __builtin_amdgcn_s_barrier();
+                read_w((i + 1) % R, wv2[(i + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 + DX < NFIX) issue(i + 1 + DX, (i + 1 + DX) % R, xv[(i + 1 + DX) % R]);
+                __builtin_amdgcn_sched_barrier(0);
+                split_planes(xv[(i + 1) % R], bp2[(i + 1) & 1]);        // (one scheduling region with the MFMAs below: the VALU work runs under them)
+                mma(wv2[i & 1], bp2[i & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_w_wait(wv2[(i + 1) & 1]);
+            } else {
+                mma(wv2[i & 1], bp2[i & 1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
@@ -222,6 +254,7 @@ drain:
     }
     }
 
+    SABER_TL(4);
     if (a.ksplit_sh > 0) {
         // ---- split-K: partial accumulators -> this XCD's L2; the last arrival sums them in split order (conv_igemm_impl.h) ----
         const int S = 1 << a.ksplit_sh;
@@ -239,7 +272,11 @@ drain:
         if (tid == 0) s_old = __hip_atomic_fetch_add(a.part_ctr + tile_L, 1u << (4u * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned arrived = (((s_old & 0x0f0f0f0fu) + ((s_old >> 4) & 0x0f0f0f0fu)) * 0x01010101u) >> 24;
-        if (arrived != (unsigned)(S - 1)) return;
+        if (arrived != (unsigned)(S - 1)) {
+            SABER_TL_FLUSH();
+            return;
+        }
+        SABER_TL(5);
         if (tid == 0) a.part_ctr[tile_L] = 0u;       // re-armed for the next launch
         const L2Reader part_l2(a.part);
         const unsigned pr0 = (unsigned)(((size_t)(tile_L * S) * 4 + wave) * (TM * P * 64) + lane) * 16u;      // byte offset
@@ -264,6 +301,7 @@ drain:
         }
     }
 
+    SABER_TL(6);
     // ---- epilogue: lane (pixel frow of group g, quarter fq) owns channels kbase + 16 i + 4 fq .. + 3 ----
     const int ohw = H * W;
 #pragma unroll
@@ -281,11 +319,13 @@ drain:
             epilogue_f32<4>(a, v, cp, p, kb, nimg, sp);
         }
     }
+    SABER_TL(7);
+    SABER_TL_FLUSH();
 }
 
 // Variant v = 1 .. 3 -> (pixel groups per wave, stages in flight, workgroups per CU)
 bool conv_wlds_variant(int v, int* p, int* dx, int* minb) {
-    static const int Tb[3][3] = {{2, 2, 2}, {2, 3, 2}, {4, 2, 1}};
+    static const int Tb[3][3] = {{2, 3, 2}, {2, 4, 1}, {4, 2, 1}};
     if (v < 1 || v > 3) return false;
     *p = Tb[v - 1][0]; *dx = Tb[v - 1][1]; *minb = Tb[v - 1][2];
     return true;
@@ -321,14 +361,14 @@ hipError_t launch_conv_wlds(int variant, const ConvKArgs& a, hipStream_t s) {
     ConvKArgs k = a;
     if (ks == 3) {
         switch (variant) {
-        case 1: return launch_wlds<3, 2, 2, 2>(k, s);
-        case 2: return launch_wlds<3, 2, 3, 2>(k, s);
+        case 1: return launch_wlds<3, 2, 3, 2>(k, s);
+        case 2: return launch_wlds<3, 2, 4, 1>(k, s);
         default: return launch_wlds<3, 4, 2, 1>(k, s);
         }
     }
     switch (variant) {
-    case 1: return launch_wlds<1, 2, 2, 2>(k, s);
-    case 2: return launch_wlds<1, 2, 3, 2>(k, s);
+    case 1: return launch_wlds<1, 2, 3, 2>(k, s);
+    case 2: return launch_wlds<1, 2, 4, 1>(k, s);
     default: return launch_wlds<1, 4, 2, 1>(k, s);
     }
 }
