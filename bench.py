@@ -176,6 +176,50 @@ def respawn_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
+def cpu_baseline_fp32(args, model):
+    """BASELINE.json configs[0] ("ResNet50 FP32 batch=1 via Net<X86,Precision::FP32> on host CPU") and its VGG16 twin: the FP32 op
+    list, batch 1, through the REFERENCE'S OWN x86 objects compiled into oracle/_ref (oracle/net_oracle.RefNetF32), each convolution
+    on the implementation saber/funcs/impl/x86/saber_conv.cpp:49-136 selects for it when the xbyak JIT kernels are absent
+    (SaberConvWinograd / SaberConv1X1 / SaberIm2colConv), 8 threads, warm-up 10 (README.md:85-86); the same list with im2col forced
+    wherever the rule says Winograd is timed beside it. CHECKER / BASELINE code: never part of a timed GPU region."""
+    try:
+        from oracle import net_oracle as NO
+        from oracle import oracle as ORC
+        from anakin_amd import workloads as W
+        if not ORC.ref_available():
+            return {"error": "oracle/_ref not present", "value": None, "unit": "images/s", "cores": 0, "kind": "none",
+                    "sample": "the FP32 x86 baseline needs the compiled reference objects (oracle/Makefile ref)"}
+        ncpu = os.cpu_count() or 1
+        cores = min(8, ncpu)
+        xs = W.make_input(1)
+        res = {}
+        for tag, impl in (("dispatcher_rule", 0), ("im2col_forced", 1)):
+            rn = NO.RefNetF32(model, 1, impl=impl)
+            NO.ref_set_threads(cores)
+            rn.run(xs)
+            one = rn.time_ms(1, 2)
+            budget_ms = args.cpu_seconds * 1000.0 * (0.6 if impl == 0 else 0.3)
+            iters = max(3, min(200, int(budget_ms / max(one, 1e-3)) - 10))
+            ms = rn.time_ms(min(10, max(2, iters // 3)), iters)
+            res[tag] = dict(ms_per_image=round(ms, 3), images_per_s=round(1000.0 / ms, 3), timed_forwards=iters, conv_impls=rn.impl_counts())
+            del rn
+        d = res["dispatcher_rule"]
+        published = {"resnet50": "README.md:92 quotes 20.62 ms/image for ResNet50 FP32 batch 1 on 8 threads of a Xeon E5-2650 v4 through the "
+                                 "JIT AVX2 kernels", "vgg16": "README.md:96 quotes 55.61 ms/image for VGG16 FP32 batch 1 on 8 threads of a Xeon E5-2650 v4"}
+        return dict(value=d["images_per_s"], unit="images/s", cores=cores, kind="reference", ms_per_image=d["ms_per_image"],
+                    sample="%s FP32 batch 1, 224x224 (BASELINE.json configs[0] for resnet50), %d timed forwards after warm-up, through the "
+                           "reference's own x86 Saber objects compiled unmodified into oracle/_ref: per convolution the implementation "
+                           "SaberConv2D<X86,AK_FLOAT>::init (saber_conv.cpp:49-136) selects with the xbyak JIT kernels absent - %s; ConvEltwise = "
+                           "SaberConv1X1 with beta = 1; fc = Gemm<X86,VENDER_IMPL,float> + bias; pooling restated; MKL/OpenMP threads = %d of %d host "
+                           "cores. %s - not buildable here (xbyak)" % (
+                               args.model, d["timed_forwards"], ", ".join("%d x %s" % (v, k) for k, v in sorted(d["conv_impls"].items())),
+                               cores, ncpu, published.get(args.model, "")),
+                    im2col_forced=res["im2col_forced"], dispatcher_rule=d)
+    except Exception as e:   # noqa: BLE001 - a broken checker must not cost the measured line; it is reported instead
+        return {"error": "%s: %s" % (type(e).__name__, e), "value": None, "unit": "images/s", "cores": 0, "kind": "none",
+                "sample": "cpu baseline failed to run on this host"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -689,6 +733,8 @@ def main():
             except Exception as e:   # noqa: BLE001 - a broken checker must not cost the measured line; it is reported instead
                 cpu = {"error": "%s: %s" % (type(e).__name__, e), "value": None, "unit": "images/s", "cores": 0, "kind": "none",
                        "sample": "cpu baseline failed to run on this host"}
+        elif not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline_fp32(args, model)
 
         out = {
             # BASELINE.json's metric: value = images/s at batch 8 per GPU; the p50 latencies at batch 8 and batch 1 are

@@ -207,3 +207,113 @@ class RefNet:
 
 def ref_set_threads(n):
     O.ref().ref_set_threads(int(n))
+
+
+class RefNetF32:
+    """BASELINE.json configs[0]: the FP32 op list (ResNet50 / VGG16, NCHW f32) run by the REFERENCE'S OWN compiled x86 objects
+    (oracle/_ref; ref_net_conv_f32 / ref_net_pool_f32 / ref_net_fc_f32 in oracle/ref_driver.cpp). Every convolution runs on the
+    implementation SaberConv2D<X86,AK_FLOAT>::init (saber/funcs/impl/x86/saber_conv.cpp:49-136) selects for it when the xbyak JIT
+    kernels are absent - SaberConvWinograd (3x3 / stride 1, maps >= 12), SaberConv1X1 (1x1 / stride 1), SaberIm2colConv (the rest:
+    7x7 / stride 2, strided 1x1, 3x3 at 7x7) - or on `impl` when forced (1 = im2col everywhere it applies). `branch2c` + eltwise
+    run as the ConvEltwise operator does (saber_conv_eltwise.cpp:68-151: SaberConv1X1 with beta = 1 onto the shortcut's buffer).
+    Pooling is restated (its x86 source needs xbyak); the fc is the reference's float Gemm object + bias (ref_fc_f32 says why).
+    Used by bench.py's cpu_baseline for the FP32 configurations and by tests/test_oracle_vs_ref.py. TEST / BASELINE INFRASTRUCTURE ONLY."""
+
+    def __init__(self, model, batch, hw=224, impl=0):
+        import ctypes as C
+        self.R = R = O.ref()
+        R.ref_net_new.restype = C.c_void_p
+        R.ref_net_time_ms.restype = C.c_double
+        R.ref_net_tensor.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_float]
+        R.ref_net_conv_f32.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        R.ref_net_pool_f32.argtypes = [C.c_void_p] + [C.c_int] * 6
+        R.ref_net_fc_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        R.ref_net_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        R.ref_net_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        R.ref_net_time_ms.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        R.ref_net_free.argtypes = [C.c_void_p]
+        self.h = C.c_void_p(R.ref_net_new())
+        B = self.batch = batch
+        self.ids, self.shape, self.keep, self.impl_of = {}, {}, [], {}
+        alias = {}
+
+        def T(n):
+            return alias.get(n, n)
+
+        def tensor(name, c, s):
+            self.ids[name] = R.ref_net_tensor(self.h, B, c, s, s, F32, 1.0)
+            self.shape[name] = (c, s)
+        tensor("data", 3, hw)
+        spec = model["spec"]
+        by = {l["name"]: l for l in spec}
+        for l in spec:
+            kd, nm = l["kind"], l["name"]
+            if kd == "conv":
+                cin, hin = self.shape[T(l["src"])]
+                ho = (hin + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+                w, b = model["params"][nm]
+                w = np.ascontiguousarray(w, np.float32)
+                b = np.ascontiguousarray(b, np.float32)
+                self.keep += [w, b]
+                if "eltwise" in l:           # ConvEltwise: accumulate onto the other eltwise input, relu of the eltwise
+                    el = by[l["eltwise"]]
+                    dst, res, relu = T(el["b"]), 1, int(el["relu"])
+                    alias[el["name"]] = dst
+                else:
+                    tensor(nm, l["cout"], ho)
+                    dst, res, relu = nm, 0, int(l["relu"])
+                force = impl if (impl and not (impl == 1 and res)) else 0       # (the fused residual needs SaberConv1X1's beta = 1)
+                rc = R.ref_net_conv_f32(self.h, self.ids[T(l["src"])], self.ids[dst], l["cout"], cin, l["k"], l["pad"], l["stride"],
+                                        relu, w.ctypes.data, b.ctypes.data, res, force)
+                assert rc > 0, (nm, rc)
+                self.impl_of[nm] = rc
+            elif kd == "pool":
+                c, hin = self.shape[T(l["src"])]
+                ho = O.pool_out_dim(hin, l["pad"], l["win"], l["stride"], l.get("floor", False))
+                tensor(nm, c, ho)
+                R.ref_net_pool_f32(self.h, self.ids[T(l["src"])], self.ids[nm], l["win"], l["stride"], l["pad"], l["type"])
+            elif kd == "gpool":
+                c, hin = self.shape[T(l["src"])]
+                tensor(nm, c, 1)
+                R.ref_net_pool_f32(self.h, self.ids[T(l["src"])], self.ids[nm], hin, hin, 0, 1)
+            elif kd == "fc":
+                w, b = model["params"][nm]
+                w = np.ascontiguousarray(w, np.float32)
+                b = np.ascontiguousarray(b, np.float32)
+                self.keep += [w, b]
+                tensor(nm, l["cout"], 1)
+                rc = R.ref_net_fc_f32(self.h, self.ids[T(l["src"])], self.ids[nm], l["cout"], w.ctypes.data, b.ctypes.data,
+                                      int(bool(l.get("relu"))))
+                assert rc == 0, (nm, rc)
+                self.out_name, self.n_out = nm, l["cout"]
+            # eltwise: fused into branch2c above; softmax is not part of the timed reference list
+        self.alias = alias
+
+    def impl_counts(self):
+        c = {}
+        for v in self.impl_of.values():
+            c[O.REF_F32_IMPL_NAME[v]] = c.get(O.REF_F32_IMPL_NAME[v], 0) + 1
+        return c
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty((self.batch, self.n_out), np.float32)
+        rc = self.R.ref_net_run(self.h, self.ids["data"], x.ctypes.data, self.ids[self.out_name], out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
+    def read(self, name):
+        name = self.alias.get(name, name)
+        c, s = self.shape[name]
+        a = np.empty((self.batch, c, s, s), np.float32)
+        self.R.ref_net_read(self.h, self.ids[name], a.ctypes.data)
+        return a
+
+    def time_ms(self, warmup=10, iters=200):
+        return float(self.R.ref_net_time_ms(self.h, warmup, iters))
+
+    def __del__(self):
+        try:
+            self.R.ref_net_free(self.h)
+        except Exception:
+            pass

@@ -512,3 +512,42 @@ def ref_pool_basic_check_int8(x, oh, ow, win, stride, pad, ptype):
     ref().ref_pool_basic_check_int8(N, H, W, Cc, oh, ow, win[0], win[1], stride[0], stride[1], pad[0],
                                     pad[1], ptype, code_of(x), _ptr(x), _ptr(out))
     return out
+
+
+# ---- round 6: the reference's FP32 PRODUCTION convolutions / fc (oracle/ref_driver.cpp: ref_conv_f32, ref_vender_fc_f32) ----
+REF_F32_IM2COL, REF_F32_CONV1X1, REF_F32_WINOGRAD = 1, 2, 3
+REF_F32_IMPL_NAME = {1: "SaberIm2colConv", 2: "SaberConv1X1", 3: "SaberConvWinograd"}
+
+
+def ref_f32_conv_rule(cin, h, w, cout, k, pad, stride, dil=1, group=1):
+    """the implementation SaberConv2D<X86,AK_FLOAT>::init (saber_conv.cpp:49-136) selects, JIT kernels absent"""
+    return int(ref().ref_f32_conv_rule(cin, h, w, cout, k, k, pad, pad, stride, stride, dil, dil, group))
+
+
+def ref_conv_f32(x, w, bias, relu, pad=(0, 0), stride=(1, 1), dil=(1, 1), group=1, impl=0):
+    """NCHW f32 convolution through the reference's own x86 objects (impl 0: the dispatcher's rule). Returns (out, impl used)."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    N, Cc, H, W = x.shape
+    K, _, kh, kw = w.shape
+    oh, ow = conv_out_hw(H, W, kh, kw, pad, stride, dil)
+    out = np.zeros((N, K, oh, ow), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    used = C.c_int(0)
+    rc = ref().ref_conv_f32(int(impl), N, Cc, H, W, K, kh, kw, pad[0], pad[1], stride[0], stride[1], dil[0], dil[1], group,
+                            _ptr(x), _ptr(w), _ptr(b), int(relu), _ptr(out), C.byref(used))
+    assert rc == 0, rc
+    return out, used.value
+
+
+def ref_fc_f32(x, w_nk, bias):
+    """x [m,k] . w[n,k]^T + bias through the reference's Gemm<X86,VENDER_IMPL,float> (ref_driver.cpp: ref_fc_f32 says why not VenderFc)"""
+    x = np.ascontiguousarray(x, np.float32)
+    w_nk = np.ascontiguousarray(w_nk, np.float32)
+    m, k = x.shape
+    n = w_nk.shape[0]
+    out = np.zeros((m, n), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    rc = ref().ref_fc_f32(m, n, k, _ptr(x), _ptr(w_nk), _ptr(b), _ptr(out))
+    assert rc == 0, rc
+    return out

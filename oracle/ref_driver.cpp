@@ -20,6 +20,12 @@
 //   WeightsFusion<float,X86>::update_weights   framework/utils/parameter_fusion.cpp:88-131 (BN + Scale folding)
 //   conv_basic_check / conv_basic_check_int8 / pool_basic_check_int8
 //                                        test/saber/conv_func_helper.h:29-264
+//   round 6 - the FP32 PRODUCTION convolutions SaberConv2D<X86,AK_FLOAT>::init chooses between (saber_conv.cpp:21-157;
+//   that translation unit itself includes the xbyak JIT headers and cannot be built here, so its selection rule is
+//   restated in ref_f32_conv_rule below, the implementations are the reference's own objects):
+//   SaberIm2colConv<AK_FLOAT>            saber/funcs/impl/x86/saber_im2col_conv.cpp:93-219 (+ Gemm<X86,VENDER_IMPL,float>, vender_gemm.cpp:8-38)
+//   SaberConvWinograd<AK_FLOAT>          saber/funcs/impl/x86/winograd.cpp:8-47 -> SaberConvWinogradAvx2, winograd_avx2.cpp
+//   Gemm<X86,VENDER_IMPL,float>          saber/funcs/impl/x86/vender_gemm.cpp:8-38 (the FP32 fc product; VenderFc<X86,AK_FLOAT> itself: see ref_fc_f32)
 #include "anakin_config.h"
 #include "saber/core/tensor.h"
 #include "saber/core/context.h"
@@ -27,6 +33,9 @@
 #include "saber/funcs/saber_util.h"
 #include "saber/funcs/impl/x86/gemm_x8s8s32x_conv.h"
 #include "saber/funcs/impl/x86/saber_conv_1x1.h"
+#include "saber/funcs/impl/x86/saber_im2col_conv.h"
+#include "saber/funcs/impl/x86/vender_gemm.h"
+#include "saber/funcs/impl/x86/winograd.h"
 #include "saber/funcs/impl/x86/saber_eltwise.h"
 #include "saber/funcs/impl/x86/x86_utils.h"
 #include "saber/funcs/impl/x86/mkl_gemm.h"
@@ -36,6 +45,7 @@
 #include "framework/utils/parameter_fusion.h"
 
 #include <cstring>
+#include <memory>
 #include <vector>
 
 using namespace anakin::saber;
@@ -228,6 +238,82 @@ int ref_conv1x1_f32(int N, int C, int H, int W, int K, const float* x, const flo
     return 0;
 }
 
+// Which implementation SaberConv2D<X86,AK_FLOAT>::init (saber_conv.cpp:49-136) ends up with for an NCHW -> NCHW
+// convolution when the xbyak JIT kernels are not available (they are not buildable here):
+//   3 = SaberConvWinograd   3x3 / stride 1 / dilation 1 / group 1, ic >= 16, oc >= 16, ih >= 12, iw >= 12      (:92-96)
+//   2 = SaberConv1X1        1x1 / stride 1 / pad 0 / group 1                                                  (:77-78, :98-100)
+//   1 = SaberIm2colConv     everything else: on a full build the JitAvx2Conv / JitAvx512Conv kernels (:101-118), and
+//                           im2col whenever their init refuses (:126-134) - the one generic FP32 path that exists here
+int ref_f32_conv_rule(int C, int H, int W, int K, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                      int dil_h, int dil_w, int group) {
+    const bool wino = kh == 3 && kw == 3 && stride_h == 1 && stride_w == 1 && dil_h == 1 && dil_w == 1 && group == 1;
+    if (wino && K >= 16 && C >= 16 && H >= 12 && W >= 12) return 3;
+    if (kh == 1 && kw == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1 && group == 1) return 2;
+    return 1;
+}
+
+namespace {
+typedef ImplBase<X86, AK_FLOAT, ConvEltwiseParam<X86> > F32ConvImpl;
+F32ConvImpl* new_f32_conv(int impl) {
+    switch (impl) {
+    case 1: return new SaberIm2colConv<AK_FLOAT>();
+    case 2: return new SaberConv1X1<AK_FLOAT>();
+    case 3: return new SaberConvWinograd<AK_FLOAT>();
+    default: return nullptr;
+    }
+}
+}  // namespace
+
+// One FP32 NCHW convolution (+bias)(+relu) through the reference's PRODUCTION objects. impl: 0 = the dispatcher's rule
+// above, 1 im2col, 2 conv1x1, 3 winograd. Returns 0, or 1 / 2 when init / dispatch refuse. *impl_used (may be null)
+// reports which one ran.
+int ref_conv_f32(int impl, int N, int C, int H, int W, int K, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                 int stride_w, int dil_h, int dil_w, int group, const float* x, const float* w, const float* bias,
+                 int with_relu, float* out, int* impl_used) {
+    int OH = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+    int OW = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+    if (impl == 0) impl = ref_f32_conv_rule(C, H, W, K, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, group);
+    if (impl_used) *impl_used = impl;
+    Tensor<X86> tin(Shape({N, C, H, W}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tout(Shape({N, K, OH, OW}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tw(Shape({K, C / group, kh, kw}, Layout_NCHW), AK_FLOAT);
+    Tensor<X86> tb;
+    memcpy(tin.mutable_data(), x, sizeof(float) * (size_t)N * C * H * W);
+    memcpy(tw.mutable_data(), w, sizeof(float) * (size_t)K * (C / group) * kh * kw);
+    memset(tout.mutable_data(), 0, sizeof(float) * (size_t)N * K * OH * OW);
+    if (bias) {
+        tb.re_alloc(Shape({1, K, 1, 1}, Layout_NCHW), AK_FLOAT);
+        memcpy(tb.mutable_data(), bias, sizeof(float) * K);
+    }
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    // (the im2col path dereferences conv_param->bias() unconditionally, saber_im2col_conv.cpp:153: an EMPTY tensor stands
+    // for "no bias", as the framework's ConvParam always carries a bias tensor)
+    ConvParam<X86> cp(group, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, &tw, &tb, act);
+    EltwiseParam<X86> ep(Eltwise_sum);
+    ep.has_eltwise = false;
+    ConvEltwiseParam<X86> cep(cp, ep);
+    std::vector<Tensor<X86>*> ins{&tin}, outs{&tout};
+    std::unique_ptr<F32ConvImpl> op(new_f32_conv(impl));
+    if (!op || op->init(ins, outs, cep, ctx()) != SaberSuccess) return 1;
+    if (op->dispatch(ins, outs, cep) != SaberSuccess) return 2;
+    memcpy(out, tout.data(), sizeof(float) * (size_t)N * K * OH * OW);
+    return 0;
+}
+
+// FP32 fc: out[m,n] = x[m,k] . W[n,k]^T + bias. VenderFc<X86,AK_FLOAT> (vender_fc.cpp:31-212) runs this product through MKL's
+// PACKED sgemm API (cblas_sgemm_pack / cblas_sgemm_compute), and cblas_sgemm_pack of the container's oneMKL 2021.4 segfaults on this
+// host in a 12-line C program (any shape, any threading layer / instruction switch) - so the operator object itself cannot run here.
+// The same product through the reference's Gemm<X86,VENDER_IMPL,float> object (vender_gemm.cpp:8-38: plain cblas_sgemm) and the bias
+// add VenderFc::dispatch ends with (vender_fc.cpp:203-209: y[mb,:] += bias) is what stands in for it.
+int ref_fc_f32(int m, int n, int k, const float* x, const float* w_nk, const float* bias, float* out) {
+    Gemm<X86, VENDER_IMPL, float> g;
+    if (g.init(false, true, m, n, k, ctx()) != SaberSuccess) return 1;
+    if (g.dispatch(1.f, 0.f, x, w_nk, out) != SaberSuccess) return 2;
+    if (bias)
+        for (int mb = 0; mb < m; ++mb) cblas_saxpy(n, 1.0f, bias, 1, out + (size_t)mb * n, 1);
+    return 0;
+}
+
 // The reference's own naive test oracles (test/saber/conv_func_helper.h).
 int ref_conv_basic_check_f32(int N, int C, int H, int W, int K, int kh, int kw, int pad_h, int pad_w,
                              int stride_h, int stride_w, int dil_h, int dil_w, int group,
@@ -415,6 +501,12 @@ struct RefOp {
     std::unique_ptr<PackedMKLInt8Gemm> fc;
     std::unique_ptr<Tensor<X86>> deq, pooled, fb, fout;
     int m = 0, n = 0, k = 0;
+    // FP32 list (kinds 10 .. 13)
+    std::unique_ptr<F32ConvImpl> fconv;
+    std::unique_ptr<SaberEltwise<X86, AK_FLOAT>> felt;     // conv -> tmp, then sum (SaberConvEltwise's non-1x1 branch)
+    std::unique_ptr<Tensor<X86>> ftmp;
+    std::unique_ptr<Gemm<X86, VENDER_IMPL, float>> fgemm;
+    int fimpl = 0, ptype = 0, relu = 0;
 };
 struct RefNet {
     std::vector<std::unique_ptr<Tensor<X86>>> t;
@@ -555,6 +647,82 @@ int ref_net_avgpool_fc_s8(void* h, int in_id, int pooled_id, int out_id, int n, 
     return 0;
 }
 
+// ---- the FP32 op list (round 6): BASELINE.json's configs[0], "ResNet50 FP32 batch=1 via Net<X86,FP32> on host CPU" -------------
+// conv: impl 0 = what SaberConv2D<X86,AK_FLOAT>::init selects (ref_f32_conv_rule), or forced 1 / 2 / 3. residual != 0: the
+// ConvEltwise operator (saber_conv_eltwise.cpp:68-151) - out_id already holds the other eltwise input and is summed in place
+// (+ relu of the eltwise): 1x1 / stride 1 -> SaberConv1X1 with beta = 1 (its _do_in_impl branch), otherwise conv -> inner
+// tensor -> SaberEltwise<X86,AK_FLOAT>. Returns the implementation used (1 / 2 / 3) or a negative error.
+int ref_net_conv_f32(void* h, int in_id, int out_id, int K, int C, int k, int pad, int stride, int with_relu, const float* w,
+                     const float* bias, int residual, int impl) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 10; op->in = in_id; op->out = out_id;
+    Tensor<X86>* tin = net->t[in_id].get();
+    Tensor<X86>* tout = net->t[out_id].get();
+    Shape si = tin->valid_shape();
+    if (impl == 0) impl = ref_f32_conv_rule(C, si[2], si[3], K, k, k, pad, pad, stride, stride, 1, 1, 1);
+    op->fimpl = impl;
+    op->w.reset(new Tensor<X86>(Shape({K, C, k, k}, Layout_NCHW), AK_FLOAT));
+    memcpy(op->w->mutable_data(), w, sizeof(float) * (size_t)K * C * k * k);
+    op->b.reset(new Tensor<X86>());
+    if (bias) {
+        op->b->re_alloc(Shape({1, K, 1, 1}, Layout_NCHW), AK_FLOAT);
+        memcpy(op->b->mutable_data(), bias, sizeof(float) * K);
+    }
+    ActivationParam<X86> act = with_relu ? ActivationParam<X86>(Active_relu) : ActivationParam<X86>();
+    const bool in_impl = residual && impl == 2;
+    ConvParam<X86> cp(1, pad, pad, stride, stride, 1, 1, op->w.get(), op->b.get(), residual ? ActivationParam<X86>() : act);
+    EltwiseParam<X86> ep(Eltwise_sum, {1.f, 1.f}, residual ? act : ActivationParam<X86>());
+    ep.has_eltwise = in_impl;
+    op->cep.reset(new ConvEltwiseParam<X86>(cp, ep));
+    op->fconv.reset(new_f32_conv(impl));
+    if (!op->fconv) return -2;
+    std::vector<Tensor<X86>*> ins{tin}, outs{tout};
+    if (residual && !in_impl) {
+        op->ftmp.reset(new Tensor<X86>(tout->valid_shape(), AK_FLOAT));
+        outs[0] = op->ftmp.get();
+        op->ep.reset(new EltwiseParam<X86>(Eltwise_sum, {1.f, 1.f}, act));
+        op->felt.reset(new SaberEltwise<X86, AK_FLOAT>());
+        std::vector<Tensor<X86>*> eins{op->ftmp.get(), tout}, eouts{tout};
+        if (op->felt->init(eins, eouts, *op->ep, ctx()) != SaberSuccess) return -3;
+    }
+    if (op->fconv->init(ins, outs, *op->cep, ctx()) != SaberSuccess) return -1;
+    net->ops.push_back(std::move(op));
+    return impl;
+}
+
+// FP32 pooling, NCHW. type 0 max, 1 average (global: win = the whole map). The reference's x86 FP32 pooling includes the xbyak
+// JIT headers (saber_pooling.cpp:1-20) and cannot be built here: restated (window clipped to the map, pooling.h:109-115 ceil
+// shape rule decided by the caller; average over (h, w) in that order, divided by the window size).
+int ref_net_pool_f32(void* h, int in_id, int out_id, int win, int stride, int pad, int type) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 11; op->in = in_id; op->out = out_id; op->win = win; op->stride = stride; op->pad = pad; op->ptype = type;
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
+// FP32 fc on the flattened input tensor: Gemm<X86,VENDER_IMPL,float> + bias (see ref_fc_f32 for why not the VenderFc object)
+// (+ relu restated in place: the reference runs it as its own Activation operator)
+int ref_net_fc_f32(void* h, int in_id, int out_id, int n, const float* w_nk, const float* bias, int with_relu) {
+    RefNet* net = (RefNet*)h;
+    std::unique_ptr<RefOp> op(new RefOp());
+    op->kind = 12; op->in = in_id; op->out = out_id; op->relu = with_relu;
+    Tensor<X86>* tin = net->t[in_id].get();
+    const int k = (int)(tin->valid_size() / tin->num());
+    op->m = tin->num(); op->n = n; op->k = k;
+    op->w.reset(new Tensor<X86>(Shape({1, 1, n, k}, Layout_NCHW), AK_FLOAT));
+    memcpy(op->w->mutable_data(), w_nk, sizeof(float) * (size_t)n * k);
+    if (bias) {
+        op->b.reset(new Tensor<X86>(Shape({1, n, 1, 1}, Layout_NCHW), AK_FLOAT));
+        memcpy(op->b->mutable_data(), bias, sizeof(float) * n);
+    }
+    op->fgemm.reset(new Gemm<X86, VENDER_IMPL, float>());
+    if (op->fgemm->init(false, true, op->m, n, k, ctx()) != SaberSuccess) return -1;
+    net->ops.push_back(std::move(op));
+    return 0;
+}
+
 static int ref_net_forward(RefNet* net) {
     for (auto& up : net->ops) {
         RefOp* op = up.get();
@@ -568,6 +736,44 @@ static int ref_net_forward(RefNet* net) {
             SaberStatus st = op->u8s8 ? op->conv->sub_dispatch<uint8_t, int8_t>(ins, outs, *op->cep)
                                       : op->conv->dispatch(ins, outs, *op->cep);
             if (st != SaberSuccess) return 1;
+        } else if (op->kind == 10) {
+            std::vector<Tensor<X86>*> ins{net->t[op->in].get()}, outs{op->ftmp ? op->ftmp.get() : net->t[op->out].get()};
+            if (op->fconv->dispatch(ins, outs, *op->cep) != SaberSuccess) return 10;
+            if (op->felt) {
+                std::vector<Tensor<X86>*> eins{op->ftmp.get(), net->t[op->out].get()}, eouts{net->t[op->out].get()};
+                if (op->felt->dispatch(eins, eouts, *op->ep) != SaberSuccess) return 10;
+            }
+        } else if (op->kind == 11) {
+            Tensor<X86>* ti = net->t[op->in].get();
+            Tensor<X86>* to = net->t[op->out].get();
+            Shape si = ti->valid_shape(), so = to->valid_shape();
+            const int NC = si[0] * si[1], H = si[2], W = si[3], OH = so[2], OW = so[3];
+            const float* src = (const float*)ti->data();
+            float* dst = (float*)to->mutable_data();
+#pragma omp parallel for
+            for (int nc = 0; nc < NC; ++nc)
+                for (int oy = 0; oy < OH; ++oy)
+                    for (int ox = 0; ox < OW; ++ox) {
+                        const int hs = std::max(oy * op->stride - op->pad, 0), ws = std::max(ox * op->stride - op->pad, 0);
+                        const int he = std::min(oy * op->stride - op->pad + op->win, H);
+                        const int we = std::min(ox * op->stride - op->pad + op->win, W);
+                        float acc = op->ptype == 0 ? -3.4e38f : 0.f;
+                        for (int iy = hs; iy < he; ++iy)
+                            for (int ix = ws; ix < we; ++ix) {
+                                const float v = src[((size_t)nc * H + iy) * W + ix];
+                                acc = op->ptype == 0 ? (v > acc ? v : acc) : acc + v;
+                            }
+                        dst[((size_t)nc * OH + oy) * OW + ox] = op->ptype == 0 ? acc : acc / (float)((he - hs) * (we - ws));
+                    }
+        } else if (op->kind == 12) {
+            float* y = (float*)net->t[op->out]->mutable_data();
+            if (op->fgemm->dispatch(1.f, 0.f, (const float*)net->t[op->in]->data(), (const float*)op->w->data(), y) != SaberSuccess) return 12;
+            if (op->b)
+                for (int mb = 0; mb < op->m; ++mb) cblas_saxpy(op->n, 1.0f, (const float*)op->b->data(), 1, y + (size_t)mb * op->n, 1);
+            if (op->relu) {
+                float* d = (float*)net->t[op->out]->mutable_data();
+                for (int i = 0; i < op->m * op->n; ++i) d[i] = d[i] > 0.f ? d[i] : 0.f;
+            }
         } else if (op->kind == 1) {
             std::vector<Tensor<X86>*> ins{net->t[op->in].get(), net->t[op->in2].get()}, outs{net->t[op->out].get()};
             if (op->elt->dispatch(ins, outs, *op->ep) != SaberSuccess) return 2;
