@@ -6,6 +6,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
+#include <vector>
 
 #ifdef USE_MI355X_PLACE
 namespace anakin {
@@ -36,14 +38,45 @@ void MI355X_API::record_event(event_t event, stream_t stream) { MI355X_CHECK(hip
 void MI355X_API::query_event(event_t event) { (void)hipEventQuery(event); }
 void MI355X_API::sync_event(event_t event) { MI355X_CHECK(hipEventSynchronize(event)); }
 
-void MI355X_API::create_stream(stream_t* stream) { MI355X_CHECK(hipStreamCreate(stream)); }
+// ---- every stream the target hands out is known to it (round 6, advisor): a SYNCHRONOUS device-to-host copy must be ordered after
+// whatever can have produced the tensor, and the target's streams are non-blocking - so sync_memcpy(__DtoH) drains the legacy null
+// stream, the Env streams AND every stream made through create_stream* on the calling thread's device (an idle stream returns at
+// once). A stream whose OWNER synchronises its results itself before handing them out - a plan's own stream: prediction() returns
+// with its outputs complete, mi355x_net_planner.h run() - is taken out of that set with owner_syncs_stream(): draining it would make
+// every Worker thread's copy wait for the other threads' forward passes again (the round-4 shape, 18k instead of 41k images/s).
+namespace {
+struct KnownStream { int dev; hipStream_t s; };
+std::mutex g_streams_mu;
+std::vector<KnownStream> g_streams;
+void remember_stream(hipStream_t s) {
+    int dev = 0;
+    MI355X_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    g_streams.push_back({dev, s});
+}
+void forget_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    for (size_t i = 0; i < g_streams.size(); ++i)
+        if (g_streams[i].s == s) { g_streams.erase(g_streams.begin() + i); break; }
+}
+}  // namespace
+void MI355X_API::create_stream(stream_t* stream) { MI355X_CHECK(hipStreamCreate(stream)); remember_stream(*stream); }
 void MI355X_API::create_stream_with_flag(stream_t* stream, unsigned int flag) {
     MI355X_CHECK(hipStreamCreateWithFlags(stream, flag ? hipStreamNonBlocking : hipStreamDefault));
+    remember_stream(*stream);
 }
 void MI355X_API::create_stream_with_priority(stream_t* stream, unsigned int flag, int priority) {
     MI355X_CHECK(hipStreamCreateWithPriority(stream, flag ? hipStreamNonBlocking : hipStreamDefault, priority));
+    remember_stream(*stream);
 }
-void MI355X_API::destroy_stream(stream_t stream) { MI355X_CHECK(hipStreamDestroy(stream)); }
+void MI355X_API::destroy_stream(stream_t stream) { forget_stream(stream); MI355X_CHECK(hipStreamDestroy(stream)); }
+void MI355X_API::owner_syncs_stream(stream_t stream) { forget_stream(stream); }
+int MI355X_API::known_streams(int dev) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    int n = 0;
+    for (auto& k : g_streams) n += k.dev == dev;
+    return n;
+}
 void MI355X_API::sync_stream(event_t event, stream_t stream) { MI355X_CHECK(hipStreamWaitEvent(stream, event, 0)); }
 void MI355X_API::sync_stream(stream_t stream) { MI355X_CHECK(hipStreamSynchronize(stream)); }
 
@@ -66,10 +99,11 @@ static inline void mi355x_copy(void* dst, size_t dst_offset, const void* src, si
 //                   to the runtime as they are: it pins the pages in place for the transfer and reaches the pinned rate (4.8 MB in
 //                   0.105 ms = 46 GB/s against 47.6 pinned, profiles/r05/pcie_probe.txt) - a staging ring with a CPU copy, tried first
 //                   this round, cost 0.3 - 0.5 ms per request and took Worker<MI355X, INT8> from 18.0k to 14.1k images/s;
-//   device -> host  ordered after the work that produced the tensor, NOT after the whole device: the current device's Env streams
-//                   (the contexts' data + compute streams every Net of the process shares; idle ones return at once) are drained -
-//                   a plan on a stream of its own has synchronised its outputs before prediction() returned
-//                   (mi355x_net_planner.h: run) - then the copy runs on the lane.
+//   device -> host  ordered after the work that produced the tensor, NOT after the whole device: the legacy null stream, the current
+//                   device's Env streams (the contexts' data + compute streams every Net of the process shares) and every other stream
+//                   made through this target's create_stream* are drained (idle ones return at once) - except a plan's own stream,
+//                   whose owner has synchronised its outputs before prediction() returned (mi355x_net_planner.h: run;
+//                   owner_syncs_stream) - then the copy runs on the lane.
 // The lane is leaked at thread exit on purpose (the HIP runtime may be gone when thread_local destructors run).
 // MI355XCopyStats: nanoseconds this process spent in the two directions (all threads), for the Worker driver's breakdown.
 std::atomic<long long> g_mi355x_h2d_ns{0}, g_mi355x_d2h_ns{0}, g_mi355x_drain_ns{0}, g_mi355x_copies{0};
@@ -100,12 +134,17 @@ CopyLane* copy_lane() {
 inline long long now_ns() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-void drain_env_streams() {
+void drain_producer_streams() {
+    // (Env's own streams come from Device<MI355X>::create_stream -> create_stream_with_flag: they are in the known set)
     const int dev = MI355X_API::get_device_id();
-    auto& devs = Env<MI355X>::cur_env();
-    if (dev < 0 || (size_t)dev >= devs.size()) return;
-    for (auto s : devs[dev]._compute_stream) MI355X_CHECK(hipStreamSynchronize(s));
-    for (auto s : devs[dev]._data_stream) MI355X_CHECK(hipStreamSynchronize(s));
+    MI355X_CHECK(hipStreamSynchronize(nullptr));      // the legacy null stream: sync_memcpy(__DtoD), mem_set, a caller's own hipMemcpy
+    std::vector<hipStream_t> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        for (auto& k : g_streams)
+            if (k.dev == dev) mine.push_back(k.s);
+    }
+    for (auto s : mine) MI355X_CHECK(hipStreamSynchronize(s));
 }
 void lane_copy(void* dst, const void* src, size_t count, hipMemcpyKind kind) {
     CopyLane* l = copy_lane();
@@ -142,7 +181,7 @@ void MI355X_API::sync_memcpy(void* dst, size_t dst_offset, int, const void* src,
     // the tensor, not against the whole device (see the copy-lane comment above).
     if (!count) return;
     const long long t0 = now_ns();
-    drain_env_streams();
+    drain_producer_streams();
     const long long t1 = now_ns();
     lane_copy((char*)dst + dst_offset, (const char*)src + src_offset, count, hipMemcpyDeviceToHost);
     g_mi355x_drain_ns += t1 - t0;

@@ -45,6 +45,11 @@ struct TargetWrapper<MI355X, __device_target> {
     static void destroy_stream(stream_t stream);
     static void sync_stream(event_t event, stream_t stream);   // stream waits for event
     static void sync_stream(stream_t stream);
+    // additions to the reference's member list: a synchronous device-to-host copy drains every stream made through create_stream*
+    // on the calling thread's device - except one whose owner declares here that it synchronises its own results before it hands them
+    // out (a plan's stream); known_streams: how many streams of `dev` that drain covers (tests)
+    static void owner_syncs_stream(stream_t stream);
+    static int known_streams(int dev);
 
     static void sync_memcpy(void* dst, size_t dst_offset, int dst_id, const void* src, size_t src_offset, int src_id,
                             size_t count, __DtoD);

@@ -75,6 +75,7 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
                 API::stream_t s;
                 API::event_t e;
                 API::create_stream_with_flag(&s, 1);
+                API::owner_syncs_stream(s);      // run() synchronises the plan's outputs itself: not part of a device-to-host copy's drain
                 API::create_event(&e, false);
                 plan.own_stream = (void*)s;
                 plan.own_event = (void*)e;

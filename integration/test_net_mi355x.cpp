@@ -359,6 +359,7 @@ static int run_threads(const std::string& model_path, const std::vector<float>& 
     std::atomic<int> ready{0};
     std::atomic<bool> go{false};
     typedef std::chrono::steady_clock clk;
+    std::vector<double> lat_ms;      // every request's latency, all threads (under first_mut)
     for (int t = 0; t < threads; ++t)
         pool.emplace_back([&, t]() {
             Graph<MI355X, P> g;
@@ -378,12 +379,17 @@ static int run_threads(const std::string& model_path, const std::vector<float>& 
             }
             ++ready;
             while (!go.load()) std::this_thread::yield();
+            std::vector<double> mine;
             while (next.fetch_add(1) < requests) {
+                const auto r0 = clk::now();
                 in->copy_from(hin);
                 net.prediction();
                 hout.copy_from(*out);
+                mine.push_back(std::chrono::duration<double, std::milli>(clk::now() - r0).count());      // request latency: copy in -> answer on the host
                 if (memcmp(hout.data(), first.data(), first.size() * sizeof(float)) != 0) ++bad;
             }
+            std::lock_guard<std::mutex> l(first_mut);
+            lat_ms.insert(lat_ms.end(), mine.begin(), mine.end());
         });
     while (ready.load() < threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     const auto t0 = clk::now();
@@ -396,8 +402,10 @@ static int run_threads(const std::string& model_path, const std::vector<float>& 
            anakin::saber::g_mi355x_drain_ns.load() / n / 1e3, anakin::saber::g_mi355x_d2h_ns.load() / n / 1e3);
     print_between();
     FILE* f = fopen((outdir + "/worker.txt").c_str(), "w");
-    fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f median_ms 0 max_ms 0 coop_fallbacks %d async 0 pinned 0\n",
-            threads, requests, bad.load(), sec, requests / sec, requests * 8.0 / sec, saber_hip_coop_fallbacks_total());
+    std::sort(lat_ms.begin(), lat_ms.end());
+    const double med = lat_ms.empty() ? 0.0 : lat_ms[lat_ms.size() / 2], mx = lat_ms.empty() ? 0.0 : lat_ms.back();
+    fprintf(f, "threads %d requests %d mismatches %d seconds %.6f requests_per_s %.3f images_per_s %.3f median_ms %.4f max_ms %.4f coop_fallbacks %d async 0 pinned 0\n",
+            threads, requests, bad.load(), sec, requests / sec, requests * 8.0 / sec, med, mx, saber_hip_coop_fallbacks_total());
     fclose(f);
     printf("threads ok: %d plain threads, %d requests, %d mismatches, %.1f requests/s\n", threads, requests, bad.load(), requests / sec);
     return bad.load() ? 3 : 0;
