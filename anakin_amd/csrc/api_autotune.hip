@@ -100,6 +100,7 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
             set_choice(op, chv);
             time_current();
         }
+    (void)pw_prepare(op);      // the pointwise kernels' fragment-ordered planes, packed on demand (api_conv.hip); not eligible: no-op
     if (pw_ok(op)) {      // FP32 1x1, C = 64 / 128: persistent waves with their weights in registers (conv1x1_pw.hip)
         ConvChoice cp = {op->tile, 1, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 1};
         set_choice(op, cp);
@@ -174,8 +175,8 @@ int saber_hip_conv2d_autotune(saber_hip_conv_t* op, const void* x, void* y, cons
     }
     // ... and so are the weight repacks only ONE kernel family reads: the fragment-ordered bf16 planes of the FP32 halo /
     // pointwise kernels (2 x 1.5 x the f32 weights: > 200 MB over VGG16) and the image-resident kernel's stage. (d_w and the
-    // bf16 planes d_w3 stay: the net-level consolidation pass still switches implicit-GEMM tiles. A later set_tile to a
-    // released family reports INVALID_VALUE; img_conv_prepare re-packs on demand.)
+    // bf16 planes d_w3 stay: the net-level consolidation pass still switches implicit-GEMM tiles. A later set_tile to the released
+    // halo family reports INVALID_VALUE; img_conv_prepare and pw_prepare re-pack on demand.)
     if (!op->b3h) {
         op->d_w3h1.release();
         op->d_w3h2.release();

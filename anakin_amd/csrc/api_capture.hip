@@ -90,7 +90,11 @@ struct Capture {
         // A target nobody has written earlier in the pass becomes an INPUT bound to the caller's memory that every run of the list
         // accumulates into: legitimate for a caller who refills it per run (a single captured ConvEltwise), fatal for anything that runs
         // the list repeatedly on its own - saber_hip_net_autotune refuses such a net (saber_hip_net::inplace_external).
-        if (p && live.find((uintptr_t)p) == live.end()) net->inplace_external = true;
+        // (round-5 advisor: a caller-owned input that an earlier op of the pass only READ is in `live` too, with tensor_ext set)
+        if (p) {
+            auto it = live.find((uintptr_t)p);
+            if (it == live.end() || net->tensor_ext[it->second.id]) net->inplace_external = true;
+        }
         return read(p, bytes);
     }
     void note(const void* p, int id) {

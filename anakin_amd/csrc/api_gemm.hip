@@ -207,20 +207,27 @@ GemmPlan* find_plan(int dev, hipStream_t s, int ta, int tb, int m, int n, int k,
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     GemmPlan* pinned_match = nullptr;
+    GemmPlan* eager_match = nullptr;
     for (GemmPlan* p : *g_plans)
         if (p->dev == dev && p->stream == s && p->ta == ta && p->tb == tb && p->m == m && p->n == n && p->k == k && p->sum == sum) {
-            if (p->pinned) {
-                pinned_match = p;
-                continue;
-            }
-            if (capturing) p->pinned = true;
-            p->stamp = ++g_stamp;
-            return p;
+            if (p->pinned) pinned_match = pinned_match ? pinned_match : p;
+            else eager_match = eager_match ? eager_match : p;
         }
     if (capturing) {
-        if (pinned_match) return pinned_match;      // a second capture of the same key on this stream: the same graph-owned plan
+        // (round-5 advisor) a capture of a key that already HAS a graph-owned plan shares it - pinning the next unpinned match on every
+        // capture grew the pinned set by one plan per capture / eager cycle, and pinned plans are never evicted
+        if (pinned_match) return pinned_match;
+        if (eager_match) {
+            eager_match->pinned = true;
+            eager_match->stamp = ++g_stamp;
+            return eager_match;
+        }
         *stateless = true;
         return nullptr;
+    }
+    if (eager_match) {
+        eager_match->stamp = ++g_stamp;
+        return eager_match;
     }
     size_t unpinned = 0;
     for (GemmPlan* p : *g_plans) unpinned += p->pinned ? 0 : 1;

@@ -217,7 +217,7 @@ inline void set_choice(saber_hip_conv* op, const ConvChoice& c) {
     op->tile = c.tile; op->ks = c.ks; op->dma = c.dma; op->stem = c.stem; op->halo = c.halo;
     op->img_ib = c.img_ib; op->img_rb = c.img_rb; op->img_nw = c.img_nw; op->fc_small = c.fc_small; op->b3 = c.b3; op->ksplit = c.ksplit; op->img1 = c.img1 || op->gpool; op->b3h = c.b3h; op->pw = c.pw;
 }
-inline bool pw_ok(const saber_hip_conv* op) {      // the persistent pointwise kernel exists for this op (planes packed by set_weights)
+inline bool pw_ok(const saber_hip_conv* op) {      // the persistent pointwise kernel exists for this op (planes packed by pw_prepare)
     return op->algo == ALGO_IGEMM_F32 && op->d_wpw.p != nullptr && !op->pair_k2 && !op->pool2 && conv1x1_pw_ok(op->c_eff, op->d.k);
 }
 inline bool pwk_ok(const saber_hip_conv* op, int variant) {      // ... the reduction-split pointwise kernel, variant 1 .. 4
@@ -412,6 +412,7 @@ struct saber_hip_net {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool finalized = false;
+    bool compacted = false;      // saber_hip_net_compact_arena ran: edges of disjoint lifetimes share memory (intermediate edges are not readable after a pass)
     // saber_hip_net_optimize flag 2048: other streams / processes run kernels on this device while the net does. Kernel variants whose
     // SPEED or completion depends on where the hardware places workgroups relative to each other - the persistent stage launch (needs
     // every workgroup of an image resident on its XCD at once), the cooperating-workgroup chains (tile codes 7 / 15), FP32 split-K
@@ -460,6 +461,8 @@ int split_prepare(saber_hip_conv* op);      // api_conv.hip
 // image-resident kernel variant of an INT8 conv on <= 64-pixel images (api_stage.hip)
 bool img_conv_ok(const saber_hip_conv* op);
 int img_conv_prepare(saber_hip_conv* op);
+int pw_prepare(saber_hip_conv* op);      // api_conv.hip: the FP32 pointwise kernels' fragment-ordered weight planes, on demand
+bool pw_eligible(const saber_hip_conv* op);
 int img_conv_run(saber_hip_conv* op, const void* x, void* y, const void* res, void* y_pool, hipStream_t stream);
 void img_conv_release(saber_hip_conv* op);
 int net_launch(saber_hip_net* net, const NetOp& o, hipStream_t s);      // api_net.hip

@@ -265,6 +265,118 @@ int saber_hip_net_finalize(saber_hip_net_t* net) {
     net->finalized = true;
     return SABER_HIP_OK;
 }
+// ---- lifetime aliasing of the arena (round 6; the role framework/graph/llvm/optimizer/memory_scheduler.cpp plays for Net<>) ------------
+// finalize gives EVERY edge its own slot (~166 MB of activations for a batch-8 ResNet50 INT8 net): that is what lets a test read any
+// edge after a pass and lets the autotuner re-run any op on the operands a whole pass left behind. A net that only serves needs the
+// edges alive from their producer to their last reader: compact_arena re-lays the arena out with tensors of disjoint lifetimes sharing
+// memory, allocates the smaller arena and frees the old one. Three nets in flight then fit the 256 MB Infinity Cache together
+// (multi_stream, Worker<MI355X>: the reference's own MemoryScheduler already does this for Net<MI355X>'s tensors; the plan behind
+// prediction() was the part that did not).
+//   * time = the op index; ops that MAY run as one launch in some selection (a chain head + its follower, a 3x3-led chain = 3 ops, a
+//     stage = 3 x stage_n ops, the stem + its sibling pair, fc + softmax) count as ONE step: every tensor any of them touches is live
+//     through the whole group - a persistent launch's workgroups are not in step with each other, and the selection may change later;
+//   * never aliased: caller-owned tensors, tensors no op writes (the pass's inputs), tensors no op reads (its outputs), `keep` ids;
+//   * a net with a side lane keeps the full arena (ops of the two lanes overlap in time);
+//   * placement: largest first, lowest offset that overlaps no already placed tensor whose lifetime intersects (256-byte slots).
+// Returns SABER_HIP_OK; saber_hip_net_arena_bytes reports the new size; a captured hipGraph is dropped (it holds the old addresses);
+// tensor pointers handed out earlier are invalid. Edges between kept tensors hold garbage after a pass: call it AFTER the autotuner
+// and after the last test that reads intermediate edges.
+int saber_hip_net_compact_arena(saber_hip_net_t* net, const int* keep, int n_keep) {
+    if (!net || !net->finalized) return fail(SABER_HIP_INVALID_VALUE, "compact_arena: net not finalized");
+    const int nt = (int)net->tensor_bytes.size(), nops = (int)net->ops.size();
+    for (const NetOp& o : net->ops)
+        if (o.lane) return SABER_HIP_OK;      // two lanes: lifetimes by op index do not order the lanes against each other
+    std::vector<int> first(nt, nops), last(nt, -1), writes(nt, 0), reads(nt, 0);
+    std::vector<char> pinned(nt, 0);
+    for (int i = 0; i < n_keep; ++i)
+        if (keep && keep[i] >= 0 && keep[i] < nt) pinned[keep[i]] = 1;
+    // group extents: g_lo[i] .. g_hi[i] = the widest run of ops op i can be launched together with
+    std::vector<int> g_lo(nops), g_hi(nops);
+    for (int i = 0; i < nops; ++i) g_lo[i] = g_hi[i] = i;
+    auto span = [&](int i, int n) {
+        const int hi = std::min(nops - 1, i + n - 1);
+        int lo = i;
+        for (int j = i; j <= hi; ++j) lo = std::min(lo, g_lo[j]);
+        int h2 = hi;
+        for (int j = i; j <= hi; ++j) h2 = std::max(h2, g_hi[j]);
+        for (int j = lo; j <= h2; ++j) { g_lo[j] = std::min(g_lo[j], lo); g_hi[j] = std::max(g_hi[j], h2); }
+    };
+    for (int i = 0; i < nops; ++i) {
+        const NetOp& o = net->ops[i];
+        if (o.stage) span(i, 3 * o.stage_n);
+        if (o.chain3) span(i, 3);
+        if (o.chain) span(i, 2);
+        if (o.stem_pair) span(i, 2);
+        if ((o.kind == OP_FC || o.kind == OP_FC_Q) && o.out2 >= 0) span(i, 2);
+        if (i + 1 < nops && net->ops[i + 1].skip) span(i, 2);      // (whatever else made the follower silent)
+    }
+    for (int i = 0; i < nops; ++i) {
+        const NetOp& o = net->ops[i];
+        const int rd[] = {o.in, o.in2, o.chain3_res};
+        const int wr[] = {o.out, o.out2, o.chain_out, o.chain3_y1, o.chain3_y2, o.chain3_y3, o.stem_y1, o.stem_y2};
+        auto touch = [&](int t) {
+            if (t < 0 || t >= nt) return;
+            first[t] = std::min(first[t], g_lo[i]);
+            last[t] = std::max(last[t], g_hi[i]);
+        };
+        for (int t : rd) { touch(t); if (t >= 0 && t < nt) ++reads[t]; }
+        for (int t : wr) { touch(t); if (t >= 0 && t < nt) ++writes[t]; }
+    }
+    for (int t = 0; t < nt; ++t)
+        if (net->tensor_ext[t] || !writes[t] || !reads[t] || last[t] < 0) pinned[t] = 1;      // external / input / output / untouched
+    for (int t = 0; t < nt; ++t)
+        if (pinned[t]) { first[t] = -1; last[t] = nops; }
+    std::vector<int> order;
+    for (int t = 0; t < nt; ++t)
+        if (!net->tensor_ext[t]) order.push_back(t);
+    auto slot = [&](int t) { return (net->tensor_bytes[t] + 255) / 256 * 256; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return slot(a) > slot(b); });
+    std::vector<size_t> off(nt, 0);
+    std::vector<int> placed;
+    size_t top = 0;
+    for (int t : order) {
+        const size_t sz = slot(t);
+        if (!sz) { off[t] = 0; continue; }
+        std::vector<std::pair<size_t, size_t>> busy;      // [begin, end) of placed tensors alive at the same time
+        for (int u : placed)
+            if (first[u] <= last[t] && first[t] <= last[u]) busy.push_back({off[u], off[u] + slot(u)});
+        std::sort(busy.begin(), busy.end());
+        size_t at = 0;
+        for (const auto& b : busy) {
+            if (at + sz <= b.first) break;
+            at = std::max(at, b.second);
+        }
+        off[t] = at;
+        top = std::max(top, at + sz);
+        placed.push_back(t);
+    }
+    const size_t ws_off = top, total = std::max<size_t>(256, top + (net->ws_bytes + 255) / 256 * 256);
+    if (total >= net->arena_bytes) return SABER_HIP_OK;      // nothing to gain
+    char* fresh = nullptr;
+    HIP_TRY(hipMalloc((void**)&fresh, total));
+    HIP_TRY(hipMemset(fresh, 0, total));
+    HIP_TRY(hipDeviceSynchronize());      // whatever still runs on the old arena
+    // the pass's inputs keep their contents (a caller may have filled them already)
+    for (int t = 0; t < nt; ++t)
+        if (!net->tensor_ext[t] && !writes[t] && net->tensor_bytes[t])
+            HIP_TRY(hipMemcpy(fresh + off[t], net->arena + net->tensor_off[t], net->tensor_bytes[t], hipMemcpyDeviceToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(net->arena);
+    net->arena = fresh;
+    net->arena_bytes = total;
+    net->ws_off = ws_off;
+    for (int t = 0; t < nt; ++t)
+        if (!net->tensor_ext[t]) net->tensor_off[t] = off[t];
+    net->compacted = true;
+    if (net->exec) {
+        (void)hipGraphExecDestroy(net->exec);
+        (void)hipGraphDestroy(net->graph);
+        net->exec = nullptr;
+        net->graph = nullptr;
+    }
+    return SABER_HIP_OK;
+}
+int saber_hip_net_arena_compacted(const saber_hip_net_t* net) { return net && net->compacted ? 1 : 0; }
 void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id) {
     if (!net->finalized || id < 0 || id >= (int)net->tensor_off.size()) return nullptr;
     return net->ptr(id);

@@ -28,7 +28,14 @@ struct FcSoftmaxTail {
     float* prob;        // [M][K]
     unsigned* ctr;      // one word, zero between launches
 };
-template <int KSW, bool SM>
+// FENCED (round 6, round-5 advisor): the same hand-off in the textbook form - plain visibility through an agent-scope RELEASE fence before
+// the arrival and an agent-scope ACQUIRE fence in the last workgroup (L2 write-back + L1 invalidate: the 1.7 - 6.5 us rows of the guide's
+// table) - selected by SABER_HIP_FC_SOFTMAX_FENCED=1 as the A/B and fall-back for a runtime / part where the write-through form's timing
+// assumptions (sc1 stores acknowledged at the device's coherence point before `s_waitcnt vmcnt(0)` returns) should not hold. The default
+// form is the guide's "sc1 payload -> asm vmcnt(0) -> device-scope counter, sc0 sc1 loads on the reader" (MI355X_MICROARCH.md, valid forms).
+// ONE launch of an fc object may be in flight at a time (the counter word belongs to the object): the reference's contract - an impl
+// instance is never called concurrently (threading) - and a Net's / plan's launches are stream-ordered.
+template <int KSW, bool SM, bool FENCED = false>
 __device__ __forceinline__ void fc_i8_small_body(const ConvKArgs& a, const FcSoftmaxTail& t) {
     __shared__ v4i red[3][64];
     __shared__ unsigned last_flag;
@@ -97,7 +104,16 @@ __device__ __forceinline__ void fc_i8_small_body(const ConvKArgs& a, const FcSof
         SABER_TL_FLUSH();
         return;
     } else {
-        if (wave == 0) {
+        if constexpr (FENCED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                          // every wave's logits are issued and acknowledged
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the fence's own wait: guide, compiler hazard)
+                last_flag = __hip_atomic_fetch_add(t.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+                if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        } else if (wave == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's logits are at the device's coherence point
             if (lane == 0) last_flag = __hip_atomic_fetch_add(t.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
         }
@@ -155,9 +171,9 @@ template <int KSW>
 __global__ __launch_bounds__(256) void fc_i8_small_kernel(const ConvKArgs a) {
     fc_i8_small_body<KSW, false>(a, FcSoftmaxTail{nullptr, nullptr});
 }
-template <int KSW>
+template <int KSW, bool FENCED>
 __global__ __launch_bounds__(256) void fc_i8_small_softmax_kernel(const ConvKArgs a, const FcSoftmaxTail t) {
-    fc_i8_small_body<KSW, true>(a, t);
+    fc_i8_small_body<KSW, true, FENCED>(a, t);
 }
 
 // FP32 fc (VenderFc<X86,AK_FLOAT>, vender_fc.cpp:154-212: out = in W^T + bias) at <= 16 batch rows, and Gemm<float> with a few rows
@@ -454,7 +470,9 @@ hipError_t launch_fc_i8_small_softmax(const ConvKArgs& a, float* prob, unsigned*
     const int ksw = (a.C + 255) / 256;
     dim3 grid((a.K + 15) / 16), block(256);
     const FcSoftmaxTail t{prob, ctr};
-#define SABER_FC_CASE(n) case n: hipLaunchKernelGGL((fc_i8_small_softmax_kernel<n>), grid, block, 0, s, a, t); break;
+    static const bool fenced = [] { const char* e = std::getenv("SABER_HIP_FC_SOFTMAX_FENCED"); return e && e[0] == '1'; }();
+#define SABER_FC_CASE(n) case n: if (fenced) hipLaunchKernelGGL((fc_i8_small_softmax_kernel<n, true>), grid, block, 0, s, a, t); \
+                                 else hipLaunchKernelGGL((fc_i8_small_softmax_kernel<n, false>), grid, block, 0, s, a, t); break;
     switch (ksw) {      // (ResNet's 2048- and VGG's 4096-long reductions and their neighbours; other lengths run the two launches)
         SABER_FC_CASE(2) SABER_FC_CASE(4) SABER_FC_CASE(8) SABER_FC_CASE(16)
     default: return hipErrorInvalidValue;

@@ -50,6 +50,7 @@ SYMBOLS = [
     "saber_hip_net_autotune", "saber_hip_net_destroy",
     "saber_hip_net_add_relu_f32", "saber_hip_net_add_activation_f32", "saber_hip_net_bind_tensor", "saber_hip_net_num_tensors", "saber_hip_net_tensor_bytes",
     "saber_hip_capture_begin", "saber_hip_capture_end", "saber_hip_capture_active", "saber_hip_net_tensor_of_ptr",
+    "saber_hip_net_compact_arena", "saber_hip_net_arena_compacted",
 ]
 
 
@@ -211,6 +212,8 @@ def load():
     lib.saber_hip_net_tensor_ptr.restype = P
     lib.saber_hip_net_arena_bytes.argtypes = [P]
     lib.saber_hip_net_arena_bytes.restype = Z
+    lib.saber_hip_net_compact_arena.argtypes = [P, P, I]
+    lib.saber_hip_net_arena_compacted.argtypes = [P]
     lib.saber_hip_net_num_ops.argtypes = [P]
     lib.saber_hip_net_run.argtypes = [P, P]
     lib.saber_hip_net_run_op.argtypes = [P, I, P]

@@ -839,6 +839,17 @@ class Net:
     def arena_bytes(self):
         return L.load().saber_hip_net_arena_bytes(self.h)
 
+    def compact(self, keep=()):
+        """saber_hip_net_compact_arena: edges of disjoint lifetimes share memory from now on (the reference's MemoryScheduler role);
+        inputs, outputs and the named `keep` tensors stay readable, every other edge holds garbage after a pass. Views from
+        tensor() taken earlier are invalid: fetch them again. Call after autotune / set_choices / the last per-edge check."""
+        ids = (C.c_int * max(1, len(keep)))(*[self.tensors[k][0] for k in keep])
+        L.check(L.load().saber_hip_net_compact_arena(self.h, ids, len(keep)))
+        return self.arena_bytes()
+
+    def compacted(self):
+        return bool(L.load().saber_hip_net_arena_compacted(self.h))
+
     # ---- caller-owned tensors / captured lists (saber_hip_capture_begin / _end) ----
     def tensor_of_ptr(self, t):
         """captured lists: id of the newest tensor the pass saw at torch tensor `t`'s address (-1: none)"""

@@ -70,6 +70,11 @@ def parse():
                     help="INT8 ResNet: 0 no conv1x1 chains, 1 chains, 2 (default) chains that may start with the block's 3x3 conv")
     ap.add_argument("--gather-every", type=int, default=16,
                     help="N > 1: all-gather the per-step logits once per this many steps (each step's logits are kept in a ring)")
+    ap.add_argument("--compact-arena", type=int, default=0,
+                    help="1: after kernel selection the net's arena is re-laid out with lifetime aliasing (saber_hip_net_compact_arena: what the "
+                         "reference's MemoryScheduler does for a Net's edges; ResNet50 INT8 batch 8: 72.3 -> 24.5 MB); 0 (default): every edge keeps "
+                         "its own slot - measured 3 % FASTER single-stream (0.2152 vs 0.2216 ms, profiles/r06/compact_ab.txt); the multi-stream "
+                         "leg reports both forms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -270,6 +275,11 @@ def main():
     net.run()
     torch.cuda.synchronize()
     selection = tune(net, args, B, L, rank, refill=lambda: net.tensor("data").copy_(torch.from_numpy(x).cuda()))
+    arena_full = net.arena_bytes()
+    if args.compact_arena:
+        net.compact()
+        net.run()
+        torch.cuda.synchronize()
     use_graph = not args.no_graph
     launch_probe = None
     if use_graph:
@@ -475,6 +485,10 @@ def main():
             net1.tensor("data").copy_(torch.from_numpy(W.make_input(1)).cuda())
             net1.run()
             sel1 = tune(net1, args, 1, L, rank)
+            if args.compact_arena:
+                net1.compact()
+                net1.tensor("data").copy_(torch.from_numpy(W.make_input(1)).cuda())
+                net1.run()
             g1 = not args.no_graph
             if g1:
                 net1.capture()
@@ -519,25 +533,42 @@ def main():
                     extra.append(ne)
                     streams.append(st)
                 torch.cuda.synchronize()
-                for k in (2, 3):
-                    group = list(zip(extra[:k], streams[:k]))
-
-                    def round_():
-                        for n_, s_ in group:
+                arena_full = extra[0].arena_bytes()
+                # every edge in its own slot first, then the same nets with lifetime-aliased arenas (saber_hip_net_compact_arena - the
+                # reference's MemoryScheduler role: three nets' working sets then fit the 256 MB Infinity Cache together)
+                for form in ("every_edge", "compact"):
+                    if form == "compact":
+                        if os.environ.get("BENCH_NO_COMPACT"):
+                            break
+                        for n_, s_ in zip(extra, streams):
                             with torch.cuda.stream(s_):
-                                n_.replay()
-                    for _ in range(20):
-                        round_()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(200):
-                        round_()
-                    torch.cuda.synchronize()
-                    dt = (time.perf_counter() - t0) / 200
-                    multi["streams_%d" % k] = {"images_per_s": round(k * B / dt, 1), "ms_per_round": round(dt * 1e3, 4),
-                                               "batches_in_flight": k, "batch": B}
+                                n_.compact()
+                                n_.run()
+                                n_.capture()
+                        torch.cuda.synchronize()
+                    for k in (2, 3):
+                        group = list(zip(extra[:k], streams[:k]))
+
+                        def round_():
+                            for n_, s_ in group:
+                                with torch.cuda.stream(s_):
+                                    n_.replay()
+                        for _ in range(20):
+                            round_()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(200):
+                            round_()
+                        torch.cuda.synchronize()
+                        dt = (time.perf_counter() - t0) / 200
+                        key = "streams_%d" % k if form == "every_edge" else "streams_%d_compact_arena" % k
+                        multi[key] = {"images_per_s": round(k * B / dt, 1), "ms_per_round": round(dt * 1e3, 4),
+                                      "batches_in_flight": k, "batch": B}
+                arena_now = extra[0].arena_bytes()
                 multi["coop_fallbacks"] = sum(n_.coop_fallbacks() for n_ in extra)
                 multi["launches_per_net"] = extra[0].num_launches()
+                multi["arena_mb_per_net"] = round(arena_now / 2**20, 1)
+                multi["arena_mb_per_net_every_edge"] = round(arena_full / 2**20, 1)
                 multi["note"] = "independent batch-%d forward passes in flight on separate streams; each batch's latency is ms_per_round" % B
             except Exception as e:   # noqa: BLE001 - an optional extra must never cost the headline line
                 multi = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -761,6 +792,7 @@ def main():
                                     if (args.precision == "int8" and args.graph == "framework") else "post-fusion op list (Caffe topology)"),
                        "graph": args.graph if args.precision == "int8" else "caffe",
                        "global_batch": B * n_gpus, "ops": net.num_ops(), "launches": net.num_launches(), "hip_graph": use_graph,
+                       "arena_mb": round(net.arena_bytes() / 2**20, 1), "arena_mb_every_edge": round(arena_full / 2**20, 1),
                        "launch_probe": launch_probe,
                        "fused_eltwise": not args.no_fuse, "parallelism": "batch-shard x%d" % n_gpus,
                        "dist_backend": dist.get_backend() if world > 1 else None,

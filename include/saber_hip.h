@@ -296,7 +296,10 @@ int saber_hip_fc_run_q(saber_hip_fc_t* op, const int8_t* xq, float* y, saber_hip
  * (m <= 16, n <= 1024, 8-bit operand, reduction 512 / 1024 / 2048 / 4096): the workgroup that arrives last on a device-wide counter
  * normalises the rows. y (the logits) is written as by saber_hip_fc_run; prob = softmax(y) per row, the arithmetic of
  * saber_hip_softmax_f32 with the row sum taken lane-major (within the 1e-4 the softmax output is held to). Every other case runs
- * saber_hip_fc_run + saber_hip_softmax_f32: the result is the same either way. saber_hip_net_optimize flag 4096 forms it. */
+ * saber_hip_fc_run + saber_hip_softmax_f32: the result is the same either way. saber_hip_net_optimize flag 4096 forms it.
+ * The arrival counter belongs to `op`: at most ONE launch of an fc object may be in flight at a time (launches of one stream are
+ * ordered; the same object on two streams / in two concurrently replayed graphs is the caller's error - the reference never calls an
+ * impl instance concurrently). SABER_HIP_FC_SOFTMAX_FENCED=1 selects the release / acquire-fence form of the hand-off (A/B, slower). */
 int saber_hip_fc_run_softmax(saber_hip_fc_t* op, const void* x, float* y, float* prob, void* workspace, saber_hip_stream_t stream);
 /* Kernel selection of the INT8 fc, same encoding as saber_hip_conv2d_set_tile: variant 10 (<< 16) = the small-batch
  * weight-streaming kernel (m <= 16, k <= 4096; the STATIC choice when eligible), 1..4 = implicit-GEMM variants. */
@@ -492,6 +495,15 @@ int saber_hip_net_set_lane(saber_hip_net_t* net, int op_index, int lane);
 int saber_hip_net_finalize(saber_hip_net_t* net);
 void* saber_hip_net_tensor_ptr(saber_hip_net_t* net, int id);
 size_t saber_hip_net_arena_bytes(const saber_hip_net_t* net);
+/* Lifetime aliasing of the arena - what the reference's memory planner does for the edges of a Net
+ * (framework/graph/llvm/optimizer/memory_scheduler.cpp; Graph::Optimize, graph.cpp:351-477): after finalize (and after autotune - the
+ * autotuner re-runs single ops on the operands a whole pass left behind) re-lay the arena out so that tensors whose lifetimes do not
+ * overlap share memory; ops that may run as one launch in some kernel selection count as one time step. Never aliased: caller-owned
+ * tensors, the pass's inputs (no op writes them), its outputs (no op reads them) and the `keep` ids (may be NULL / 0). Afterwards only
+ * those tensors hold defined data after a pass, pointers from saber_hip_net_tensor_ptr must be fetched again, a captured hipGraph is
+ * dropped. A net with a side lane is left as it is. saber_hip_net_arena_bytes reports the new footprint. */
+int saber_hip_net_compact_arena(saber_hip_net_t* net, const int* keep, int n_keep);
+int saber_hip_net_arena_compacted(const saber_hip_net_t* net);
 int saber_hip_net_num_ops(const saber_hip_net_t* net);
 /* Enqueue every op in order on `stream` (eager launches). */
 int saber_hip_net_run(saber_hip_net_t* net, saber_hip_stream_t stream);

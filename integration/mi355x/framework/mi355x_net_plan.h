@@ -72,6 +72,7 @@ struct MI355XNetPlan {
     bool use_graph = false;
     int builds = 0;
     int captured_ops = 0, launches = 0;
+    size_t arena_bytes = 0, arena_bytes_full = 0;      // the plan's device footprint: after / before saber_hip_net_compact_arena
     float eager_ms = 0.f, graph_ms = 0.f;
     std::string why;             // why there is no plan (capture refused, switched off ...)
     std::vector<void*> in_t, out_t;      // the Net's input / output Tensor objects (edge tensors: stable for the Net's lifetime)

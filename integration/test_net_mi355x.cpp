@@ -135,7 +135,8 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
         fprintf(fp, "plan %d captured_ops %d launches %d graph %d eager_ms %.6f graph_ms %.6f why %s\n", plan.net ? 1 : 0, plan.captured_ops,
                 plan.launches, plan.use_graph ? 1 : 0, plan.eager_ms, plan.graph_ms, plan.why.empty() ? "-" : plan.why.c_str());
         if (plan.net) {
-            fprintf(fp, "tensors %d arena_bytes %zu\n", saber_hip_net_num_tensors(plan.net), saber_hip_net_arena_bytes(plan.net));
+            fprintf(fp, "tensors %d arena_bytes %zu arena_bytes_every_edge %zu\n", saber_hip_net_num_tensors(plan.net), saber_hip_net_arena_bytes(plan.net),
+                    plan.arena_bytes_full);
             for (int i = 0; i < saber_hip_net_num_ops(plan.net); ++i) fprintf(fp, "op %d %s\n", i, saber_hip_net_op_name(plan.net, i));
         }
         fclose(fp);

@@ -13,5 +13,57 @@ baseline)   # this round's box: the headline line, the FP32 lines WITH the x86 F
   python bench.py --precision fp32 --batch 8 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b8.json 2> $O/fp32_b8_per_op.txt
   python bench.py --model vgg16 --precision fp32 --batch 8 --steps 100 --no-b1 --cpu-seconds 20 > $O/vgg16_b8.json 2> $O/vgg16.err
   nproc > $O/host.txt; lscpu | head -20 >> $O/host.txt ;;
+compact_ab) # the arena with lifetime aliasing against every edge materialised: the headline pass, batch 1, multi-stream; retunes once (new sources)
+  python bench.py --steps 400 --no-cpu-baseline --retune --write-tune-cache > $O/compact1.json 2> $O/compact1.err
+  python bench.py --steps 400 --no-cpu-baseline --no-b1 --compact-arena 0 > $O/compact0.json 2> $O/compact0.err
+  BENCH_NO_COMPACT=1 python bench.py --steps 100 --no-cpu-baseline --compact-arena 0 > $O/compact0_multi.json 2> $O/compact0_multi.err
+  python bench.py --steps 400 --no-cpu-baseline --no-b1 > $O/compact1_again.json 2> $O/compact1_again.err
+  cp profiles/tune.json $O/tune.json
+  python - <<'PY'
+import json
+for f in ("compact1","compact0","compact0_multi","compact1_again"):
+    try:
+        d=json.load(open("gpurun_out/r06_compact_ab/%s.json"%f))
+        print(f, d["value"], d["ms_per_step"], d["latency_ms"], d["config"].get("arena_mb"), d["config"].get("arena_mb_every_edge"), d["config"]["kernel_selection"])
+        if d.get("batch1"): print("   b1", d["batch1"])
+        if d.get("multi_stream"): print("   multi", d["multi_stream"])
+        r=d.get("reference_op_list") or {}
+        for k in ("net_prediction","worker","worker_6_threads","net_threads_1","net_threads_3"):
+            if k in r: print("   ",k,{a:b for a,b in r[k].items() if a!="what"})
+    except Exception as e: print(f,"ERR",e)
+PY
+  ;;
+worker_ab)  # Worker<MI355X, INT8> / Net::prediction with the plan's arena compacted (default for shared-device plans) and not
+  python - <<'PY'
+import os, subprocess, tempfile, json, sys
+sys.path.insert(0, os.getcwd())
+from anakin_amd import workloads as W
+from integration import net_model as NM
+exe = os.path.join("integration", "_build", "test_net_mi355x.bin")
+model = W.framework_model(W.build_model("resnet50"), "int8")
+scales = W.calibrate(model, W.make_input(2))
+out = []
+with tempfile.TemporaryDirectory() as td:
+    base = W.build_model("resnet50")
+    mt, wb = NM.write_model(base, dict(scales), 8, td, "int8", calibrator_config=True)
+    W.make_input(8).tofile(os.path.join(td, "input.bin"))
+    for rep in range(2):
+        for compact in ("0", "1"):
+            env = dict(os.environ, SABER_MI355X_NET_PLAN_COMPACT=compact)
+            for threads in (3, 6):
+                r = subprocess.run([os.path.abspath(exe), mt, wb, os.path.join(td, "input.bin"), td, "worker", str(threads), "900"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", cwd=td, env=env, timeout=600)
+                wt = open(os.path.join(td, "worker.txt")).read().split()
+                f = {wt[i]: wt[i + 1] for i in range(0, len(wt) - 1, 2)}
+                out.append("rep %d compact %s worker threads %d: %s images/s median %s ms max %s ms mismatches %s" % (rep, compact, threads, f["images_per_s"], f["median_ms"], f["max_ms"], f["mismatches"]))
+            r = subprocess.run([os.path.abspath(exe), mt, wb, os.path.join(td, "input.bin"), td, "300"], capture_output=True, text=True, cwd=td, env=env, timeout=600)
+            tt = open(os.path.join(td, "timing.txt")).read().split()
+            pl = open(os.path.join(td, "plan.txt")).read().split("\n")
+            out.append("rep %d compact %s Net::prediction %s ms (op loop %s) | %s" % (rep, compact, tt[tt.index("ms_per_prediction") + 1], tt[tt.index("ms_per_prediction_op_loop") + 1], pl[1]))
+open("gpurun_out/r06_worker_ab/worker_compact_ab.txt", "w").write("\n".join(out) + "\n")
+print("\n".join(out))
+PY
+  ;;
+pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
+  python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;
 esac

@@ -1539,6 +1539,56 @@ def test_fc_i8_softmax_in_one_launch(M, K, N):
             assert np.allclose(got_p.sum(1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("fenced", [False, True], ids=["write_through", "fenced"])
+def test_fc_i8_softmax_hand_off_under_concurrent_load(fenced):
+    """(round-5 advisor) the fc + softmax launch hands its logits to the last-arriving workgroup through memory across XCDs with
+    write-through stores and a relaxed device-scope counter (fc_small.hip). Stress: 400 launches on CHANGING inputs while two other
+    streams keep every CU busy with memory traffic and the logits / probabilities buffers are poisoned between launches - a stale or
+    late line shows as a row normalised from poisoned or old logits (checked: every row sums to 1 and equals softmax of the logits the
+    SAME launch wrote). The release / acquire-fence form (SABER_HIP_FC_SOFTMAX_FENCED=1) runs the same test in a fresh process."""
+    if fenced:
+        import os
+        import subprocess
+        import sys
+        env = dict(os.environ, SABER_HIP_FC_SOFTMAX_FENCED="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "hand_off_under_concurrent_load and write_through"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    M, K, N = 8, 2048, 1000
+    rng = np.random.default_rng(4242)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    fc = S.SaberFc(True).init(M, N, K, wq, b, L.S8, 0.031, 1.0, w_scale=ws)
+    xs = [dev(rng.integers(-128, 128, (M, K)).astype(np.int8)) for _ in range(8)]
+    ys = [torch.empty((M, N), dtype=torch.float32, device="cuda") for _ in range(8)]
+    ps = [torch.empty((M, N), dtype=torch.float32, device="cuda") for _ in range(8)]
+    big_a = torch.randn(64 << 20, device="cuda")          # 256 MB: past the Infinity Cache
+    big_b = torch.empty_like(big_a)
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    main = torch.cuda.current_stream()
+    bad = 0
+    for rnd in range(50):
+        for st in side:                                    # keep the memory system and the CUs busy beside the fc launches
+            with torch.cuda.stream(st):
+                big_b.copy_(big_a)
+                big_b.mul_(1.0001)
+        for i in range(8):
+            ys[i].fill_(1e30)
+            ps[i].fill_(-1.0)
+            fc.dispatch_softmax(xs[(i + rnd) % 8], ys[i], ps[i])
+        main.synchronize()
+        for i in range(8):
+            p = ps[i]
+            want = torch.softmax(ys[i], 1)
+            if not (torch.allclose(p.sum(1), torch.ones(M, device="cuda"), atol=1e-5) and (p - want).abs().max() <= 1e-4 * want.max()):
+                bad += 1
+    torch.cuda.synchronize()
+    assert bad == 0, bad
+
+
 def test_softmax_vs_oracle():
     rng = np.random.default_rng(61)
     x = (rng.standard_normal((8, 1000)) * 4).astype(np.float32)

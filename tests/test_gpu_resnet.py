@@ -474,3 +474,89 @@ def test_resnet50_int8_framework_list_batch16_invariance(setup_fw):
         net1.tensor("data").copy_(torch.from_numpy(x16[i:i + 1]).cuda())
         net1.run()
         assert np.array_equal(_h(net1.tensor("fc1000"))[0], l16[i]), i
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the executor's arena with lifetime aliasing (saber_hip_net_compact_arena; the reference's MemoryScheduler role,
+# framework/graph/llvm/optimizer/memory_scheduler.cpp). Materialise-everything stays the mode of every parity test above.
+def _all_modes(net, fn):
+    """runs fn() under the static selection, then with every stage / chain decision flipped off and on again (restored selections
+    change WHICH op launches which tensors: the compacted layout must be valid for all of them)"""
+    base = net.choices()
+    fn("static")
+    # (saber_hip_net_get_choice: bits 28 / 29 = a chain / 3x3-led chain decision is recorded, bits 24..27 its pixel fragments with
+    # 0 = "run as separate launches", bit 30 = this op launches its whole stage)
+    off = [(c & ~(0xf << 24)) & ~(1 << 30) for c in base]
+    try:
+        net.set_choices(off)
+        fn("chains_off")
+    finally:
+        net.set_choices(base)
+    fn("restored")
+
+
+@pytest.mark.parametrize("batch", [2, 8])
+def test_compacted_arena_int8_same_bits_smaller_footprint(setup_fw, batch):
+    """ResNet50 INT8, the driver's configuration (C++-fused framework list, stage + stem pair): outputs before compaction ==
+    outputs after, bit for bit - eager, hipGraph, and with the chain / stage decisions switched off and on AFTER the compaction -
+    and the footprint drops several-fold. Inputs and outputs stay readable; `keep` pins an intermediate edge."""
+    model, _, scales, _ = setup_fw
+    x = W.make_input(batch)
+    net = W.build_int8_net(model, dict(scales), batch, cxx_optimize=True)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    want = {n: _h(net.tensor(n)).copy() for n in ("fc1000", "prob", "res3a")}
+    before = net.arena_bytes()
+    after = net.compact(keep=("res3a",))
+    assert net.compacted() and after * 2 < before, (before, after)
+    assert np.array_equal(_h(net.tensor("data")), x)                 # the pass's input survived the move
+
+    def check(tag):
+        for mode in ("eager", "graph"):
+            net.tensor("fc1000").fill_(0)
+            net.tensor("prob").fill_(0)
+            if mode == "graph":
+                net.capture()
+                net.replay()
+            else:
+                net.run()
+            for n in want:
+                assert np.array_equal(_h(net.tensor(n)), want[n]), (tag, mode, n)
+    _all_modes(net, check)
+    # several passes back to back (a slot reused by a later edge must not leak into the next pass)
+    for _ in range(3):
+        net.run()
+    assert np.array_equal(_h(net.tensor("fc1000")), want["fc1000"])
+
+
+def test_compacted_arena_fp32_and_two_nets_side_by_side():
+    """FP32 ResNet50 (in-place residual sums: the ConvEltwise output aliases the shortcut's buffer already) through the compacted
+    arena within bit identity of the materialised run; two compacted nets on two streams do not disturb each other."""
+    model = W.build_model("resnet50")
+    x = W.make_input(2)
+    nets = []
+    for i in range(2):
+        net = W.build_fp32_net(model, 2, shared_device=True)
+        net.tensor("data").copy_(torch.from_numpy(x if i == 0 else x[::-1].copy()).cuda())
+        net.run()
+        torch.cuda.synchronize()
+        want = _h(net.tensor("fc1000")).copy()
+        before = net.arena_bytes()
+        after = net.compact()
+        assert after * 2 < before, (before, after)
+        nets.append((net, want))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(5):
+        for (net, _), st in zip(nets, streams):
+            with torch.cuda.stream(st):
+                net.run()
+    torch.cuda.synchronize()
+    for net, want in nets:
+        assert np.array_equal(_h(net.tensor("fc1000")), want)
+
+
+def test_compact_arena_leaves_a_two_lane_net_alone(setup_fw):
+    model, _, scales, _ = setup_fw
+    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=True, lanes=True)
+    before = net.arena_bytes()
+    assert net.compact() == before and not net.compacted()
