@@ -6,7 +6,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #ifdef USE_MI355X_PLACE
@@ -30,13 +32,70 @@ void MI355X_API::mem_free(void* ptr) {
 }
 void MI355X_API::mem_set(void* ptr, int value, size_t n) { MI355X_CHECK(hipMemset(ptr, value, n)); }
 
+// ---- events: Tensor::record_event is LAZY (round 6, round-5 verdict item 5) ----------------------------------------------------------
+// Net::prediction records one event per output edge of every executor (net.cpp:456-458 -> Tensor::record_event -> Events::record ->
+// record_event below): ~100 hipEventRecord calls per ResNet50 pass at 1 - 2 us of host time each, and nothing ever waits for all but
+// the few whose tensor an executor syncs (need_sync inputs, the Output executors, net.cpp:427-432) - producer and consumer share the
+// context's compute stream, so the stream already orders them. A non-timing event therefore only NOTES the stream it was recorded on;
+// the hipEventRecord happens when somebody needs the event:
+//   sync_event(e)           record on the noted stream NOW, then hipEventSynchronize: waits for everything enqueued on that stream up
+//                           to this moment - a superset of what was enqueued at the original record point (never less; the framework
+//                           syncs right after the loop that recorded);
+//   sync_stream(e, s)       s == the noted stream: nothing to do (stream order); another stream: record now, then hipStreamWaitEvent;
+//   query_event / destroy_stream(noted stream): record now.
+// Timing events (create_event(.., true): the planner's A/B timing, anything elapsed-time reads) record immediately as before.
+// SABER_MI355X_EAGER_EVENTS=1 restores the immediate form (A/B). The note table is keyed by the event and guarded by one mutex: a
+// tensor (and its event) is used by one thread at a time - the lock is uncontended, ~50 ns against ~1.5 us per hipEventRecord.
+namespace {
+struct EventNote { bool timing = false; bool pending = false; hipStream_t stream = nullptr; };
+// (function-local, leaked: tensors with events exist as globals of other translation units, before and after this one's statics)
+struct EventTable { std::mutex mu; std::unordered_map<hipEvent_t, EventNote> map; };
+EventTable& event_table() { static EventTable* t = new EventTable(); return *t; }
+#define g_events_mu event_table().mu
+#define g_events event_table().map
+const bool g_eager_events = [] { const char* e = std::getenv("SABER_MI355X_EAGER_EVENTS"); return e && e[0] == '1'; }();
+std::atomic<long long> g_lazy_noted{0}, g_lazy_flushed{0};
+// records the event for real if a record is pending; returns with the note cleared
+void flush_event(hipEvent_t event) {
+    hipStream_t s = nullptr;
+    bool pending = false;
+    {
+        std::lock_guard<std::mutex> lk(g_events_mu);
+        auto it = g_events.find(event);
+        if (it != g_events.end() && it->second.pending) { pending = true; s = it->second.stream; it->second.pending = false; }
+    }
+    if (pending) { MI355X_CHECK(hipEventRecord(event, s)); ++g_lazy_flushed; }
+}
+}  // namespace
+void MI355X_API::lazy_event_stats(long long* noted, long long* flushed) { *noted = g_lazy_noted.load(); *flushed = g_lazy_flushed.load(); }
+
 void MI355X_API::create_event(event_t* event, bool flag) {
     MI355X_CHECK(hipEventCreateWithFlags(event, flag ? hipEventDefault : hipEventDisableTiming));
+    std::lock_guard<std::mutex> lk(g_events_mu);
+    g_events[*event].timing = flag;
 }
-void MI355X_API::destroy_event(event_t event) { MI355X_CHECK(hipEventDestroy(event)); }
-void MI355X_API::record_event(event_t event, stream_t stream) { MI355X_CHECK(hipEventRecord(event, stream)); }
-void MI355X_API::query_event(event_t event) { (void)hipEventQuery(event); }
-void MI355X_API::sync_event(event_t event) { MI355X_CHECK(hipEventSynchronize(event)); }
+void MI355X_API::destroy_event(event_t event) {
+    {
+        std::lock_guard<std::mutex> lk(g_events_mu);
+        g_events.erase(event);
+    }
+    MI355X_CHECK(hipEventDestroy(event));
+}
+void MI355X_API::record_event(event_t event, stream_t stream) {
+    if (!g_eager_events) {
+        std::lock_guard<std::mutex> lk(g_events_mu);
+        auto it = g_events.find(event);
+        if (it != g_events.end() && !it->second.timing) {
+            it->second.pending = true;
+            it->second.stream = stream;
+            ++g_lazy_noted;
+            return;
+        }
+    }
+    MI355X_CHECK(hipEventRecord(event, stream));
+}
+void MI355X_API::query_event(event_t event) { flush_event(event); (void)hipEventQuery(event); }
+void MI355X_API::sync_event(event_t event) { flush_event(event); MI355X_CHECK(hipEventSynchronize(event)); }
 
 // ---- every stream the target hands out is known to it (round 6, advisor): a SYNCHRONOUS device-to-host copy must be ordered after
 // whatever can have produced the tensor, and the target's streams are non-blocking - so sync_memcpy(__DtoH) drains the legacy null
@@ -46,8 +105,10 @@ void MI355X_API::sync_event(event_t event) { MI355X_CHECK(hipEventSynchronize(ev
 // every Worker thread's copy wait for the other threads' forward passes again (the round-4 shape, 18k instead of 41k images/s).
 namespace {
 struct KnownStream { int dev; hipStream_t s; };
-std::mutex g_streams_mu;
-std::vector<KnownStream> g_streams;
+struct StreamTable { std::mutex mu; std::vector<KnownStream> v; };
+StreamTable& stream_table() { static StreamTable* t = new StreamTable(); return *t; }
+#define g_streams_mu stream_table().mu
+#define g_streams stream_table().v
 void remember_stream(hipStream_t s) {
     int dev = 0;
     MI355X_CHECK(hipGetDevice(&dev));
@@ -69,7 +130,17 @@ void MI355X_API::create_stream_with_priority(stream_t* stream, unsigned int flag
     MI355X_CHECK(hipStreamCreateWithPriority(stream, flag ? hipStreamNonBlocking : hipStreamDefault, priority));
     remember_stream(*stream);
 }
-void MI355X_API::destroy_stream(stream_t stream) { forget_stream(stream); MI355X_CHECK(hipStreamDestroy(stream)); }
+void MI355X_API::destroy_stream(stream_t stream) {
+    std::vector<hipEvent_t> on_it;      // events whose record is still only noted for this stream: record them while it exists
+    {
+        std::lock_guard<std::mutex> lk(g_events_mu);
+        for (auto& kv : g_events)
+            if (kv.second.pending && kv.second.stream == stream) on_it.push_back(kv.first);
+    }
+    for (hipEvent_t e : on_it) flush_event(e);
+    forget_stream(stream);
+    MI355X_CHECK(hipStreamDestroy(stream));
+}
 void MI355X_API::owner_syncs_stream(stream_t stream) { forget_stream(stream); }
 int MI355X_API::known_streams(int dev) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
@@ -77,7 +148,15 @@ int MI355X_API::known_streams(int dev) {
     for (auto& k : g_streams) n += k.dev == dev;
     return n;
 }
-void MI355X_API::sync_stream(event_t event, stream_t stream) { MI355X_CHECK(hipStreamWaitEvent(stream, event, 0)); }
+void MI355X_API::sync_stream(event_t event, stream_t stream) {
+    {
+        std::lock_guard<std::mutex> lk(g_events_mu);
+        auto it = g_events.find(event);
+        if (it != g_events.end() && it->second.pending && it->second.stream == stream) return;      // same stream: already ordered
+    }
+    flush_event(event);
+    MI355X_CHECK(hipStreamWaitEvent(stream, event, 0));
+}
 void MI355X_API::sync_stream(stream_t stream) { MI355X_CHECK(hipStreamSynchronize(stream)); }
 
 static inline void mi355x_copy(void* dst, size_t dst_offset, const void* src, size_t src_offset, size_t count,

@@ -50,6 +50,8 @@ struct TargetWrapper<MI355X, __device_target> {
     // out (a plan's stream); known_streams: how many streams of `dev` that drain covers (tests)
     static void owner_syncs_stream(stream_t stream);
     static int known_streams(int dev);
+    // record_event on a non-timing event is lazy (mi355x_impl.cpp): how many records were only noted / how many became a hipEventRecord
+    static void lazy_event_stats(long long* noted, long long* flushed);
 
     static void sync_memcpy(void* dst, size_t dst_offset, int dst_id, const void* src, size_t src_offset, int src_id,
                             size_t count, __DtoD);

@@ -63,6 +63,35 @@ open("gpurun_out/r06_worker_ab/worker_compact_ab.txt", "w").write("\n".join(out)
 print("\n".join(out))
 PY
   ;;
+oploop)     # where the unplanned operator loop's host time goes; lazy against eager event records; HIP API split under rocprofv3
+  python - <<'PY'
+import os, subprocess, tempfile, sys, shutil
+sys.path.insert(0, os.getcwd())
+from anakin_amd import workloads as W
+from integration import net_model as NM
+O = "gpurun_out/r06_oploop"
+exe = os.path.abspath(os.path.join("integration", "_build", "test_net_mi355x.bin"))
+model = W.framework_model(W.build_model("resnet50"), "int8")
+scales = W.calibrate(model, W.make_input(2))
+td = tempfile.mkdtemp()
+mt, wb = NM.write_model(W.build_model("resnet50"), dict(scales), 8, td, "int8", calibrator_config=True)
+W.make_input(8).tofile(os.path.join(td, "input.bin"))
+lines = []
+for rep in range(2):
+    for eager in ("1", "0"):
+        env = dict(os.environ, SABER_MI355X_EAGER_EVENTS=eager)
+        r = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, "300"], capture_output=True, text=True, cwd=td, env=env, timeout=900)
+        tt = open(os.path.join(td, "timing.txt")).read().split()
+        lines.append("rep %d eager_events %s: prediction (plan) %s ms, operator loop %s ms" % (rep, eager, tt[tt.index("ms_per_prediction") + 1], tt[tt.index("ms_per_prediction_op_loop") + 1]))
+        shutil.copy(os.path.join(td, "op_loop.txt"), os.path.join(O, "op_loop_eager%s_rep%d.txt" % (eager, rep)))
+open(os.path.join(O, "summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+open(os.path.join(O, "cmd.txt"), "w").write(" ".join([exe, mt, wb, os.path.join(td, "input.bin"), td, "100"]) + "\n" + td + "\n")
+PY
+  CMD=$(head -1 $O/cmd.txt); TD=$(tail -1 $O/cmd.txt)
+  (cd $TD && SABER_MI355X_NET_PLAN=0 rocprofv3 --hip-runtime-trace --stats -d $TD/hiptrace -o h -- $CMD > $TD/hiptrace.log 2>&1)
+  find $TD/hiptrace -name '*stats*' | head; for f in $(find $TD/hiptrace -name '*hip_api_stats*.csv' -o -name '*_stats.csv' | head -3); do cp $f $O/; done
+  ls $O ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;
