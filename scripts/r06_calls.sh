@@ -92,6 +92,8 @@ PY
   (cd $TD && SABER_MI355X_NET_PLAN=0 rocprofv3 --hip-runtime-trace --stats -d $TD/hiptrace -o h -- $CMD > $TD/hiptrace.log 2>&1)
   find $TD/hiptrace -name '*stats*' | head; for f in $(find $TD/hiptrace -name '*hip_api_stats*.csv' -o -name '*_stats.csv' | head -3); do cp $f $O/; done
   ls $O ;;
+stage_b1)   # the XCD-resident res5 stage launch against the ops one by one at batch 1 / 2 / 8 (round-5 verdict item 3: re-measure at batch 1)
+  for n in 1 2 8; do python scripts/probe/stage_time.py $n; done > $O/stage_time.txt 2>&1; cat $O/stage_time.txt ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;
