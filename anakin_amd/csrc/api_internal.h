@@ -418,6 +418,10 @@ struct saber_hip_net {
     // every workgroup of an image resident on its XCD at once), the cooperating-workgroup chains (tile codes 7 / 15), FP32 split-K
     // through one XCD's L2 - are then never selected: not statically, not by the autotuner, not from a restored selection.
     bool shared_device = false;
+    // saber_hip_net_optimize flag 8192: FP32 ops keep their STATIC kernel selection - saber_hip_net_autotune and restored selections leave
+    // them alone - so that two nets of one model answer bit-identically (the FP32 kernels differ in accumulation order; which one a
+    // timing-based tuner picks depends on the box and the moment)
+    bool reproducible_fp32 = false;
     bool inplace_external = false;   // captured nets: an in-place sum accumulates into a caller-owned input (api_capture.hip: readwrite)
     int coop_fallbacks = 0;   // cooperative launches that reported a failed pass (saber_hip_net_status), since the net was created
     // two-lane execution: independent branches (ResNet branch1 vs branch2a/2b) run on a side stream

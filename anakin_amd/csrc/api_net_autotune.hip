@@ -28,6 +28,7 @@ int saber_hip_net_stage_blocks(const saber_hip_net_t* net, int index) {
 int saber_hip_net_set_choice(saber_hip_net_t* net, int index, int choice) {
     saber_hip_conv* c = net_op_conv(net, index);
     if (!c || !choice || c->pool_fused || c->algo > ALGO_IGEMM_F32) return SABER_HIP_OK;
+    if (net->reproducible_fp32 && !c->is_i8) return SABER_HIP_OK;      // flag 8192: a restored selection does not move FP32 ops either
     if (net->ops[index].kind == OP_CONV_PAIR && index > 0 && net->ops[index - 1].stem_pair) return SABER_HIP_OK;      // no kernel of its own (flag 512)
     int chain_bits = (choice >> 24) & 63;
     const bool stage_on = ((choice >> 30) & 1) && !net->shared_device;
@@ -167,6 +168,8 @@ int saber_hip_net_autotune(saber_hip_net_t* net, saber_hip_stream_t stream, int 
         // a pair that runs inside the stem launch (flag 512) has no kernel of its own (one absorbed by a chain launch - flag 1024 -
         // keeps its own for the mode in which the chain is off: it is tuned like any other)
         if (o.kind == OP_CONV_PAIR && o.skip && &o != net->ops.data() && (&o)[-1].stem_pair) continue;
+        if (net->reproducible_fp32 && o.conv && !o.conv->is_i8) continue;      // flag 8192: FP32 convs / pairs keep the static selection
+        if (net->reproducible_fp32 && o.fc && o.fc->conv && !o.fc->conv->is_i8) continue;
         if (o.kind == OP_CONV_PAIR) {
             int rc = saber_hip_conv2d_autotune_pair(o.conv, T(o.in), T(o.out), T(o.out2), stream, iters);
             if (rc) return rc;

@@ -105,6 +105,7 @@ int saber_hip_net_optimize(saber_hip_net_t* net, int flags) {
         flags &= ~256;       // no persistent stage launch
     }
     if (net->shared_device) flags &= ~256;
+    if (flags & SABER_HIP_NET_REPRODUCIBLE_FP32) net->reproducible_fp32 = true;      // sticks to the net (api_net_autotune.hip)
     std::vector<NetOp>& ops = net->ops;
     const int nt = (int)net->tensor_bytes.size();
     std::vector<char> dead(ops.size(), 0);

@@ -11,8 +11,8 @@ Edge dtype / layout rules for the INT8 graph follow the x86 calibrator
 (framework/core/net/calibrator_parse.cpp:82-128,194-244): 8-bit edges are NHWC; conv+relu outputs are
 u8, conv without relu and eltwise outputs are s8; the first conv takes the f32 NCHW image and
 quantises on entry (saber_conv.cpp:223-242,308); conv+eltwise fusion is OFF for INT8 (graph.cpp:423-436)
-so `fuse_eltwise=False` reproduces the reference op list one to one, while `fuse_eltwise=True` uses the
-bit-identical fused epilogue (include/saber_hip.h RES_ELTWISE).
+so `build_int8_net(fuse=False)` reproduces the reference op list one to one, while the default hands that list to the
+C++ executor-level fuser (saber_hip_net_optimize), whose fused epilogue (include/saber_hip.h RES_ELTWISE) is bit-identical.
 """
 import numpy as np
 
@@ -258,68 +258,39 @@ def _out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False, pair_siblings=None, fuse_tail=None, fuse_pool=None,
-                   cxx_optimize=False, chain=None, absorb_pool=True, stage=True, stem_pair=True, head_pair=False, shared_device=False,
-                   fc_softmax=True):
-    """ResNet INT8 op list on the device (see module docstring for the dtype rules).
+def build_int8_net(model, scales, batch, hw=224, fuse=True, chain=2, stage=True, stem_pair=True, head_pair=False, shared_device=False,
+                   fc_softmax=True, absorb_pool=True, **legacy):
+    """ResNet INT8 op list on the device (see the module docstring for the dtype rules): ONE op per reference operator, exactly the list
+    `model["spec"]` holds (workloads.framework_spec: what the reference's own optimiser emits) - and, with `fuse`, handed to the C++ host
+    side (saber_hip_net_optimize, the product's only executor-level fuser) which finds conv + eltwise, sibling pairs, conv + pooling,
+    the pool -> fc quantisation, the conv1x1 chains and their 3x3 heads itself. Bytes of every surviving edge unchanged.
 
-    pair_siblings (default: same as fuse_eltwise): the stage-entry `branch1` projection and `branch2a`
-    read the same tensor with the same 1x1 geometry; they run as ONE launch (SaberConvPair), outputs
-    bit-identical to the two separate ops.
-    fuse_tail (default: same as fuse_eltwise): the global average pool also writes the s8 quantisation that the
-    INT8 fc would otherwise compute on entry (same bytes, one launch fewer).
-    fuse_pool (default: same as fuse_eltwise): a conv whose only consumer is a max pooling becomes one
-    SaberConv2DPooling op where the library has a fused kernel (the stem: conv1 + pool1); the conv's own output
-    edge then does not exist.
-    chain (default: 2 whenever the eltwise is fused): 1 = `branch2c + sum + relu` and the next block's 1x1 `branch2a` run
-    as one conv1x1-chain launch (saber_hip_net_optimize flag 16; both ops stay in the list, the autotuner keeps the faster
-    form); 2 = the block's 3x3 `branch2b` may lead that launch as well (flag 32; its output edge then stays in LDS:
-    Net.unwritten(name)). Bytes of every written edge unchanged.
-    stage (with chain = 2): runs of 3x3-led C = 256 chains whose blocks feed each other (the res4 stage) may run as ONE persistent
-    launch (flag 256; saber_hip_conv2d_stage_create) - for a net that has the GPU to itself; pass False for nets that run
-    concurrently with others on their own streams.
-    stem_pair: the fused conv1 + pool1 launch also runs the sibling pair that reads pool1 (res2a_branch1 / res2a_branch2a; flag 512;
-    saber_hip_conv2d_stem_pair_create); pool1's edge is then not written.
-    head_pair (with chain = 2): the strided head of a stage (conv3x3 / stride 2 + conv1x1 + eltwise, C = 64: res2c) also runs the next
-    stage's sibling pair (res3a_branch1 / res3a_branch2a) that reads its output (flag 1024; saber_hip_conv2d_chain_create3_pair).
-    Off by default: measured no faster than the two launches.
-    fc_softmax: the fc and the Softmax that reads it run as one launch (flag 4096; saber_hip_fc_run_softmax).
-    shared_device: the net runs beside other nets / streams / processes on its GPU (saber_hip_net_optimize flag
-    SABER_HIP_NET_SHARED_DEVICE = 2048): no stage launch, no cooperating-workgroup chains, no split-K through one XCD's L2 - excluded
-    from the static selection, the autotuner and restored selections."""
+    fuse=False: the reference op list one launch per operator (what bench.py times as `reference_op_list`).
+    chain: 0 no conv1x1 chains, 1 = `branch2c + sum + relu` and the next block's 1x1 `branch2a` as one launch (flag 16), 2 (default) = the
+    block's 3x3 `branch2b` may lead that launch as well (flag 32; its output edge then stays in LDS: Net.unwritten(name)).
+    stage (with chain = 2): runs of 3x3-led C = 256 chains whose blocks feed each other (the res4 stage) may run as ONE persistent launch
+    (flag 256) - for a net that has the GPU to itself.
+    stem_pair: the fused conv1 + pool1 launch also runs the sibling pair that reads pool1 (flag 512); pool1's edge is then not written.
+    head_pair (with chain = 2): res2c's strided-head chain launch also runs the res3a sibling pair (flag 1024; measured no faster, off).
+    fc_softmax: the fc and the Softmax that reads it run as one launch (flag 4096).
+    shared_device: the net runs beside other nets / streams / processes on its GPU (flag SABER_HIP_NET_SHARED_DEVICE = 2048): no stage
+    launch, no cooperating-workgroup chains, no split-K through one XCD's L2 - excluded from the static selection, the autotuner and
+    restored selections.
+    (The Python fuser of rounds 1 - 5 lives in tests/py_fuser.py: test infrastructure.)"""
     from . import lib as L
     from . import saber as S
-    if chain is None:
-        chain = 2 if (fuse_eltwise or cxx_optimize) and not lanes else 0
-    if cxx_optimize:
-        # the reference op list one to one; the fusions below are then found by the C++ host side
-        # (saber_hip_net_optimize), not by this builder
-        fuse_eltwise, pair_siblings, fuse_tail, fuse_pool, lanes = False, False, False, False, False
+    legacy.pop("cxx_optimize", None)      # (rounds 3 - 5 spelling of what is now the only mode)
+    chain = 2 if chain is None else chain
+    if legacy:
+        raise TypeError("build_int8_net: %s belong to the Python fuser, which is test infrastructure now (tests/py_fuser.py)" % sorted(legacy))
     net = S.Net()
     B = batch
     net.add_tensor("data", (B, 3, hw, hw), F32)
     shape = {"data": (hw, 3)}        # name -> (spatial, channels)
     dtype = {"data": F32}
-    pending = {}                     # branch2c convs waiting for their eltwise when fusing
-    if pair_siblings is None:
-        pair_siblings = fuse_eltwise and not lanes
-    if fuse_tail is None:
-        fuse_tail = fuse_eltwise
-    if fuse_pool is None:
-        fuse_pool = fuse_eltwise
-    consumers = {}
-    for e in model["spec"]:
-        for key in ("src", "a", "b"):
-            if key in e:
-                consumers[e[key]] = consumers.get(e[key], 0) + 1
-    spec = model["spec"]
-    done = set()                     # ops already emitted as part of a fused predecessor
-    quantised = {}                   # f32 edge -> its s8 twin written by the producer (fused quantise-on-entry)
-    sib = {}                         # name of the first sibling -> (conv object, tensor name), waiting for the second
-    for li, l in enumerate(spec):
+    scales = dict(scales)
+    for l in model["spec"]:
         kd, nm = l["kind"], l["name"]
-        if nm in done:
-            continue
         if kd == "conv":
             hin, cin = shape[l["src"]]
             ho = _out_hw(hin, l["k"], l["stride"], l["pad"])
@@ -327,43 +298,10 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             odt = l.get("odt", U8 if l["relu"] else S8)   # framework_spec: conv1's output dtype follows its consumer
             p = S.ConvParam(w, b, 1, (l["pad"],) * 2, (l["stride"],) * 2, (1, 1), l["relu"])
             shape[nm], dtype[nm] = (ho, l["cout"]), odt
-            if fuse_eltwise and "eltwise" in l:
-                pending[l["eltwise"]] = (l, p, hin, cin, ho)
-                continue
-            nxt = spec[li + 1] if li + 1 < len(spec) else None
-            if fuse_pool and nxt is not None and nxt["kind"] == "pool" and nxt["src"] == nm and consumers.get(nm) == 1 \
-                    and nxt["type"] == 0:
-                cp = S.SaberConv2DPooling().init((B, cin, hin, hin), p, nxt["type"], (nxt["win"],) * 2,
-                                                 (nxt["stride"],) * 2, (nxt["pad"],) * 2, dtype[l["src"]], odt,
-                                                 scales[l["src"]], scales[nm],
-                                                 in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
-                if cp.fused:
-                    pn = nxt["name"]
-                    po = cp.out_hw[0]
-                    shape[pn], dtype[pn] = (po, l["cout"]), odt
-                    scales[pn] = scales[nm]
-                    net.add_tensor(pn, (B, po, po, l["cout"]), odt)
-                    net.add_conv(cp.conv, l["src"], pn)
-                    net.keep.append(cp)
-                    done.add(pn)
-                    continue
             conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[l["src"]], odt, scales[l["src"]], scales[nm],
                                             in_layout=L.NCHW if dtype[l["src"]] == F32 else L.NHWC)
             net.add_tensor(nm, (B, ho, ho, l["cout"]), odt)
-            nxt = spec[li + 1] if li + 1 < len(spec) else None
-            geo = ("src", "k", "stride", "pad")
-            if pair_siblings and nxt is not None and nxt["kind"] == "conv" and "eltwise" not in nxt and \
-                    all(nxt[g] == l[g] for g in geo) and l["cout"] % 128 == 0 and nxt["cout"] % 16 == 0 and \
-                    dtype[l["src"]] != F32:
-                sib[nxt["name"]] = (conv, nm)      # launched together with the next conv
-                continue
-            if nm in sib:
-                first, first_nm = sib.pop(nm)
-                net.add_conv_pair(S.SaberConvPair(first, conv), l["src"], first_nm, nm)
-                continue
-            idx = net.add_conv(conv, l["src"], nm)
-            if lanes and nm.endswith("_branch1"):
-                net.set_lane(idx, 1)   # the shortcut projection is independent of branch2a/2b: side lane
+            net.add_conv(conv, l["src"], nm)
         elif kd == "pool":
             hin, c = shape[l["src"]]
             ho = S.pool_out_dim(hin, l["pad"], l["win"], l["stride"], l.get("floor", False))
@@ -377,16 +315,7 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             shape[nm], dtype[nm] = (ho, c), S8
             net.add_tensor(nm, (B, ho, ho, c), S8)
             coeff = 1.0 / scales[nm]
-            if nm in pending:
-                cl, p, hin, cin, _ = pending.pop(nm)
-                p.res_mode, p.res_relu = L.RES_ELTWISE, l["relu"]
-                p.coeff, p.scale_res = (coeff, coeff), scales[l["b"]]
-                conv = S.SaberConv2D(True).init((B, cin, hin, hin), p, dtype[cl["src"]], S8, scales[cl["src"]],
-                                                scales[cl["name"]])
-                net.add_conv(conv, cl["src"], nm, res=l["b"])
-            else:
-                net.add_eltwise_i8(B * ho * ho * c, scales[l["a"]], scales[l["b"]], coeff, coeff, l["relu"], l["a"],
-                                   l["b"], nm)
+            net.add_eltwise_i8(B * ho * ho * c, scales[l["a"]], scales[l["b"]], coeff, coeff, l["relu"], l["a"], l["b"], nm)
         elif kd == "gpool" and l.get("int8"):
             # INT8 global average pooling (framework_spec): s8 NHWC -> s8 [B,1,1,c], scale inherited
             hin, c = shape[l["src"]]
@@ -398,51 +327,43 @@ def build_int8_net(model, scales, batch, fuse_eltwise=True, hw=224, lanes=False,
             # FP32 pooling op fed an s8 NHWC edge: dequantise on entry (saber_pooling.cpp:399-402), then avg
             hin, c = shape[l["src"]]
             net.add_tensor(nm, (B, c, 1, 1), F32)
-            nxt = spec[li + 1] if li + 1 < len(spec) else None
-            if fuse_tail and nxt is not None and nxt["kind"] == "fc" and nxt["src"] == nm:
-                # the fc quantises its f32 input on entry: fused into the pooling's store (same bytes)
-                net.add_tensor(nm + "_q", (B, c), S8)
-                net.add_pool_f32_from_i8_q(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
-                                           scales[l["src"]], l["src"], nm, scales[nm], nm + "_q")
-                quantised[nm] = nm + "_q"
-            else:
-                net.add_pool_f32_from_i8(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
-                                         scales[l["src"]], l["src"], nm)
+            net.add_pool_f32_from_i8(B, hin, hin, c, 1, 1, (hin, hin), (hin, hin), (0, 0), 1, dtype[l["src"]],
+                                     scales[l["src"]], l["src"], nm)
             shape[nm], dtype[nm] = (1, c), F32
         elif kd == "fc":
             w, b = model["params"][nm]
             fc = S.SaberFc(True).init(B, l["cout"], l["cin"], w, b, dtype.get(l["src"], F32), scales[l["src"]])
             net.add_tensor(nm, (B, l["cout"]), F32)
-            if l["src"] in quantised:
-                net.add_fc_q(fc, quantised[l["src"]], nm)
-            else:
-                net.add_fc(fc, l["src"], nm)
+            net.add_fc(fc, l["src"], nm)
         elif kd == "softmax":
             net.add_tensor(nm, (B, 1000), F32)
             net.add_softmax(B, 1000, l["src"], nm)
+    net.unfused_ops = net.num_ops()
     if shared_device:
         net.optimize(2048)           # (sticks to the net: every later optimize / autotune / set_choices call honours it)
         stage = False
-    if cxx_optimize:
-        net.unfused_ops = net.num_ops()
-        net.removed = net.optimize(15)
-    # a stride-up shortcut pooling (framework_spec) read only by a fused eltwise epilogue is folded into that read
-    net.absorbed = net.optimize(64) if (fuse_eltwise or cxx_optimize) and absorb_pool else 0
-    # the last block's conv (+ fused eltwise) also writes the global average pooling of its output (flag 128): pool5's launch goes
-    net.gpooled = net.optimize(128) if (fuse_eltwise or cxx_optimize) and absorb_pool else 0
-    net.stem_paired = net.optimize(512) if stem_pair and not lanes and (fuse_eltwise or cxx_optimize) else 0
-    net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0) | (256 if int(chain) >= 2 and stage else 0) |
-                               (1024 if int(chain) >= 2 and head_pair else 0)) if chain else 0
-    # the fc and the Softmax over its output as one launch (flag 4096: the last-arriving workgroup of the fc kernel normalises the rows)
-    net.fc_softmaxed = net.optimize(4096) if fc_softmax and (fuse_eltwise or cxx_optimize) else 0
+    net.removed = net.absorbed = net.gpooled = net.stem_paired = net.chained = net.fc_softmaxed = 0
+    if fuse:
+        net.removed = net.optimize(15)      # conv + eltwise, sibling pairs, conv + pooling, pool -> fc quantisation
+        # a stride-up shortcut pooling (framework_spec) read only by a fused eltwise epilogue is folded into that read
+        net.absorbed = net.optimize(64) if absorb_pool else 0
+        # the last block's conv (+ fused eltwise) also writes the global average pooling of its output (flag 128): pool5's launch goes
+        net.gpooled = net.optimize(128) if absorb_pool else 0
+        net.stem_paired = net.optimize(512) if stem_pair else 0
+        net.chained = net.optimize(16 | (32 if int(chain) >= 2 else 0) | (256 if int(chain) >= 2 and stage else 0) |
+                                   (1024 if int(chain) >= 2 and head_pair else 0)) if chain else 0
+        # the fc and the Softmax over its output as one launch (flag 4096: the last-arriving workgroup of the fc kernel normalises the rows)
+        net.fc_softmaxed = net.optimize(4096) if fc_softmax else 0
     net.finalize()
     return net
 
 
-def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False):
+def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False, reproducible=False):
     """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
     does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132).
-    shared_device: see build_int8_net (here: no split-K through one XCD's L2)."""
+    shared_device: see build_int8_net (here: no split-K through one XCD's L2).
+    reproducible: saber_hip_net_optimize flag SABER_HIP_NET_REPRODUCIBLE_FP32 - FP32 ops keep their static kernel selection whatever
+    autotune / set_choices say, so that two nets of one model answer bit-identically."""
     from . import lib as L
     from . import saber as S
     net = S.Net()
@@ -560,6 +481,8 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, sha
     net.produced = produced
     if shared_device:
         net.optimize(2048)
+    if reproducible:
+        net.optimize(8192)
     net.finalize()
     return net
 

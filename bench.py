@@ -52,10 +52,6 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--force-graph", action="store_true", help="hipGraph replay without timing it against eager launches (A/B aid)")
     ap.add_argument("--no-fuse", action="store_true", help="keep the 16 eltwise ops separate (reference op list)")
-    ap.add_argument("--py-fuse", action="store_true",
-                    help="INT8: let workloads.py (Python) apply the executor-level fusions while it builds the list; default: the list is "
-                         "handed over UNFUSED, one op per reference operator, and the C++ host side fuses it (saber_hip_net_optimize) - "
-                         "the same ops and bytes (tests/test_gpu_resnet.py::test_cxx_net_optimize_equals_python_fused_list)")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--tune-cache", default=os.path.join(ROOT, "profiles", "tune.json"),
                     help="JSON file with the autotuned kernel selection per (config, source hash): applied instead of autotuning when it "
@@ -64,8 +60,6 @@ def parse():
                          "mismatch the net is autotuned as before and - with --write-tune-cache - the entry is (re)written")
     ap.add_argument("--write-tune-cache", action="store_true", help="store the autotuned selection in --tune-cache")
     ap.add_argument("--retune", action="store_true", help="ignore --tune-cache entries: autotune on this box")
-    ap.add_argument("--lanes", action="store_true",
-                    help="run the shortcut projections on a side stream (measured SLOWER under hipGraph: 0.464 vs 0.371 ms)")
     ap.add_argument("--chain", type=int, default=None,
                     help="INT8 ResNet: 0 no conv1x1 chains, 1 chains, 2 (default) chains that may start with the block's 3x3 conv")
     ap.add_argument("--gather-every", type=int, default=16,
@@ -97,8 +91,9 @@ def build_net(W, model, scales, batch, args, stage=True, shared_device=False):
     """shared_device: the net will run BESIDE other nets on this GPU (the multi-stream leg, ranks sharing a device): declared to the
     executor (saber_hip_net_optimize flag SABER_HIP_NET_SHARED_DEVICE), which then never selects a placement-dependent kernel variant"""
     if args.precision == "int8":
-        cxx = not (args.py_fuse or args.no_fuse or args.lanes)      # the C++ host side finds the fusions (the north star's "host side stays C++")
-        return W.build_int8_net(model, dict(scales), batch, fuse_eltwise=not args.no_fuse, lanes=args.lanes, chain=args.chain, cxx_optimize=cxx,
+        # the list is handed over one op per reference operator; the C++ host side finds the fusions (saber_hip_net_optimize: the only
+        # executor-level fuser of the product - the north star's "host side stays C++"); --no-fuse: the reference list as it is
+        return W.build_int8_net(model, dict(scales), batch, fuse=not args.no_fuse, chain=args.chain,
                                 stage=stage and not args.no_stage and not shared_device, stem_pair=not args.no_stem_pair, head_pair=args.head_pair,
                                 shared_device=shared_device, fc_softmax=not args.no_fc_softmax)
     return W.build_fp32_net(model, batch, shared_device=shared_device)
@@ -107,7 +102,7 @@ def build_net(W, model, scales, batch, args, stage=True, shared_device=False):
 def tune_key(args, batch, L):
     """a cached selection is only valid for the sources and executor options it was tuned on"""
     return "%s_%s_%s_b%d_fuse%d_lanes%d_chain%s_py%d_stage%d_sp%d_hp%d_fs%d_%s" % (args.model, args.precision, args.graph, batch, int(not args.no_fuse),
-                                                                       int(args.lanes), args.chain, int(args.py_fuse), int(not args.no_stage),
+                                                                       0, args.chain, 0, int(not args.no_stage),
                                                                        int(not args.no_stem_pair), int(args.head_pair),
                                                                        int(not getattr(args, "no_fc_softmax", False)), L.source_sha())
 
@@ -582,8 +577,7 @@ def main():
         ref_list = None
         if not args.no_b1 and world == 1 and args.precision == "int8" and args.graph == "framework":
             try:
-                rn = W.build_int8_net(model, dict(scales), B, fuse_eltwise=False, chain=0, pair_siblings=False, fuse_tail=False,
-                                      fuse_pool=False)
+                rn = W.build_int8_net(model, dict(scales), B, fuse=False)
                 rn.tensor("data").copy_(torch.from_numpy(x).cuda())
                 rn.run()
                 if not args.no_autotune:
@@ -799,7 +793,7 @@ def main():
                        # ranks of an RCCL communicator that really exists (0 under the gloo dry run of the multi-rank control flow)
                        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
                        "kernel_selection": selection, "coop_fallback": coop_fallback,
-                       "coop_fallbacks": net.coop_fallbacks() if hasattr(net, "coop_fallbacks") else 0, "shared_device": shared, "fused_by": "saber_hip_net_optimize (C++)" if (args.precision == "int8" and not (args.py_fuse or args.no_fuse or args.lanes)) else "workloads.py",
+                       "coop_fallbacks": net.coop_fallbacks() if hasattr(net, "coop_fallbacks") else 0, "shared_device": shared, "fused_by": "saber_hip_net_optimize (C++)" if (args.precision == "int8" and not args.no_fuse) else ("none (reference list)" if args.precision == "int8" else "workloads.build_fp32_net (conv + eltwise in place, sibling pairs, conv + pooling: the reference's own FP32 graph fusions)"),
                        "gather": None if (world == 1 or gather is None) else {"every_steps": args.gather_every, "backend": dist.get_backend(),
                                                           "host_us_per_step": round(gather_host_us, 1),
                                                           "per_request": per_request,

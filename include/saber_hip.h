@@ -462,8 +462,15 @@ int saber_hip_net_add_fc_q(saber_hip_net_t* net, saber_hip_fc_t* op, int in_q_id
  * FP32 split-K through one XCD's L2 are neither chosen statically, nor offered to saber_hip_net_autotune, nor accepted from a
  * restored selection (saber_hip_net_set_choice maps them to their plain forms) - instead of being found out by a timed-out
  * hand-off (~20 ms) at run time.
+ * 8192 (SABER_HIP_NET_REPRODUCIBLE_FP32; NOT in 255; may be passed on its own, sticks to the net): FP32 ops keep their STATIC kernel
+ * selection - saber_hip_net_autotune skips them and saber_hip_net_set_choice leaves them alone. The FP32 kernel families differ in
+ * accumulation order (all within the 1e-4 contract), and a timing-based choice depends on the box and the moment: with this flag two
+ * nets built from one model answer bit-identically (the reference's x86 FP32 path is deterministic for a fixed thread count; this is
+ * the switch that gives a maintainer the same property, at the static selection's speed). INT8 ops are exact under every selection
+ * and stay tunable.
  * Bytes of every surviving edge are unchanged. Returns the number of launches removed (>= 0) or a status < 0. */
 #define SABER_HIP_NET_SHARED_DEVICE 2048
+#define SABER_HIP_NET_REPRODUCIBLE_FP32 8192
 int saber_hip_net_optimize(saber_hip_net_t* net, int flags);
 /* How many cooperative launches of this net have reported a failed pass since it was created (each made saber_hip_net_status /
  * the site's next launch return SABER_HIP_RUNTIME_ERROR once and its site fall back to single-workgroup launches): 0 on a net that

@@ -49,6 +49,10 @@ namespace anakin {
 struct MI355XNetPlanDefaults {
     static int& shared_device() { static int v = 0; return v; }   // other Nets / streams run on the device concurrently
     static int& own_stream() { static int v = 0; return v; }      // every plan gets a non-blocking stream of its own
+    // FP32 plans keep the executor's STATIC kernel selection (saber_hip_net_optimize flag SABER_HIP_NET_REPRODUCIBLE_FP32): every Net of
+    // the process - e.g. the Nets of a Worker's pool threads - then answers a request with the same bits. Off by default (the tuned
+    // selection is faster); set before the Nets are initialised. The reference's FP32 answers do not depend on which Worker thread serves.
+    static int& reproducible_fp32() { static int v = 0; return v; }
     // Worker<MI355X, P, R>(model, n): n pool threads = n Nets in flight on one GPU (framework/core/net/worker.cpp:59)
     static void worker_threads(int n) {
         if (n > 1) { shared_device() = 1; own_stream() = 1; }

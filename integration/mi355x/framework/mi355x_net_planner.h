@@ -95,7 +95,8 @@ struct MI355XPlanner<saber::MI355X, Ptype, RunType> {
         // 4096: the fc and the Softmax over its output as one launch
         const bool fc_softmax = env_on("SABER_MI355X_NET_FC_SOFTMAX", true);
         if (ok) ok = saber_hip_net_optimize(n, 255 | (stage ? 256 : 0) | (stem_pair ? 512 : 0) | (head_pair ? 1024 : 0) | (fc_softmax ? 4096 : 0) |
-                                               (plan.shared_device ? SABER_HIP_NET_SHARED_DEVICE : 0)) >= 0;
+                                               (plan.shared_device ? SABER_HIP_NET_SHARED_DEVICE : 0) |
+                                               (MI355XNetPlanDefaults::reproducible_fp32() ? SABER_HIP_NET_REPRODUCIBLE_FP32 : 0)) >= 0;
         if (ok) ok = saber_hip_net_finalize(n) == SABER_HIP_OK;
         if (ok && plan.builds == 0 && env_on("SABER_MI355X_NET_PLAN_TUNE", true))
             ok = saber_hip_net_autotune(n, plan.stream, 9) == SABER_HIP_OK;

@@ -278,6 +278,11 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
                       const std::string& mode) {
     typedef Worker<MI355X, P, OpRunType::ASYNC> worker_t;
     const bool use_async = mode.find("async") != std::string::npos, pinned = mode.find("pinned") != std::string::npos;
+    // `worker_repro`: FP32 plans keep the static kernel selection (MI355XNetPlanDefaults::reproducible_fp32 -> saber_hip_net_optimize flag
+    // SABER_HIP_NET_REPRODUCIBLE_FP32): every pool thread's Net must then answer with the SAME BITS, as INT8 nets always do
+    const bool repro = mode.find("repro") != std::string::npos;
+    if (repro) MI355XNetPlanDefaults::reproducible_fp32() = 1;
+    const bool exact = P == Precision::INT8 || repro;
     std::string in_name, out_name;
     std::vector<int> shape;
     {
@@ -340,7 +345,7 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
             lat_ms.push_back(std::chrono::duration<double, std::milli>(clk::now() - fly.front().second).count());
             fly.pop_front();
             if (out.size() != 1 || out[0].valid_size() != first[0].valid_size() ||
-                !same_answer((const float*)out[0].data(), (const float*)first[0].data(), first[0].valid_size(), P == Precision::INT8)) ++bad;
+                !same_answer((const float*)out[0].data(), (const float*)first[0].data(), first[0].valid_size(), exact)) ++bad;
         };
         for (int r = 0; r < requests; ++r) {
             if ((int)fly.size() >= 2 * threads) reap();
@@ -359,7 +364,7 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
             Tensor4d<X86> h(outs[0]->valid_shape(), AK_FLOAT);
             h.copy_from(*outs[0]);
             if (outs.size() != 1 || h.valid_size() != first[0].valid_size() ||
-                !same_answer((const float*)h.data(), (const float*)first[0].data(), first[0].valid_size(), P == Precision::INT8)) ++bad;
+                !same_answer((const float*)h.data(), (const float*)first[0].data(), first[0].valid_size(), exact)) ++bad;
         };
         for (int r = 0; r < requests; ++r) {
             if (outstanding >= threads) reap();          // (the answer is a tensor of the Net that served it: do not let a thread lap it)

@@ -4,7 +4,8 @@ import os, sys, statistics, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from anakin_amd import lib as L, workloads as W
+from anakin_amd import lib as L, workloads as W  # noqa: F401
+from tests import py_fuser as PF      # the step-by-step fusion presets below are the PYTHON fuser (test infrastructure)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 VARIANTS = {
@@ -21,7 +22,7 @@ scales = W.calibrate(model, W.make_input(2))
 x = torch.from_numpy(W.make_input(B)).cuda()
 nets = {}
 for name, kw in VARIANTS.items():
-    net = W.build_int8_net(model, dict(scales), B, **kw)
+    net = PF.build_int8_net(model, dict(scales), B, **kw)
     net.tensor("data").copy_(x); net.run(); net.autotune(iters=10); net.tensor("data").copy_(x); net.capture()
     for _ in range(20): net.replay()
     nets[name] = net

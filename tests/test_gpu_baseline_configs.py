@@ -20,6 +20,7 @@ torch = pytest.importorskip("torch")
 
 from anakin_amd import lib as L  # noqa: E402
 from anakin_amd import workloads as W  # noqa: E402
+from tests import py_fuser as PF  # noqa: E402  (the Python fuser: test infrastructure)
 from oracle import net_oracle as NO  # noqa: E402
 
 FP32_RTOL = 1e-4
@@ -66,10 +67,9 @@ def _int8_every_edge(name, batch, min_edges, driver_config=False):
     if driver_config:
         # exactly bench.build_net's call: the list handed over UNFUSED, fused by the C++ host side (saber_hip_net_optimize), the res4
         # stage launch and the stem pair on
-        net = W.build_int8_net(model, dict(scales), batch, fuse_eltwise=True, lanes=False, chain=None, cxx_optimize=True, stage=True,
-                               stem_pair=True, head_pair=False)
+        net = W.build_int8_net(model, dict(scales), batch, chain=None, stage=True, stem_pair=True, head_pair=False)
     else:
-        net = W.build_int8_net(model, dict(scales), batch)
+        net = PF.build_int8_net(model, dict(scales), batch)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     if driver_config:
@@ -215,7 +215,7 @@ def test_shared_device_nets_never_select_placement_dependent_variants():
     x = W.make_input(batch, hw=224)
     scales = W.calibrate(model, W.make_input(2))
     ref = NO.run_int8(model, dict(scales), x)
-    owner = W.build_int8_net(model, dict(scales), batch, cxx_optimize=True)
+    owner = W.build_int8_net(model, dict(scales), batch)
     owner.tensor("data").copy_(torch.from_numpy(x).cuda())
     owner.run()
     _apply_committed_selection(owner, "resnet50", batch)
@@ -240,7 +240,7 @@ def test_shared_device_nets_never_select_placement_dependent_variants():
             assert np.array_equal(got, ref[nm].reshape(got.shape)), (what, nm)
         assert net.coop_fallbacks() == 0
 
-    shared = W.build_int8_net(model, dict(scales), batch, cxx_optimize=True, shared_device=True)
+    shared = W.build_int8_net(model, dict(scales), batch, shared_device=True)
     assert shared.num_ops() == owner.num_ops()
     placement_free(shared, "static selection")
     exact(shared, "static selection")

@@ -9,6 +9,7 @@ torch = pytest.importorskip("torch")
 
 from anakin_amd import lib as L  # noqa: E402
 from anakin_amd import workloads as W  # noqa: E402
+from tests import py_fuser as PF  # noqa: E402  (the Python fuser: test infrastructure)
 from oracle import net_oracle as NO  # noqa: E402
 
 
@@ -34,7 +35,7 @@ def test_resnet50_int8_every_edge_bit_exact(setup, fuse):
     that plus the 3x3 convs leading their chain launch (their own output edges stay in LDS and are skipped here; every
     written edge and the logits must still match). "lanes": fused epilogues with two-lane execution instead of the pairs."""
     model, x, scales, ref = setup
-    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=bool(fuse), lanes=fuse == "lanes",
+    net = PF.build_int8_net(model, dict(scales), 2, fuse_eltwise=bool(fuse), lanes=fuse == "lanes",
                            chain=None if fuse in (False, "lanes", "chain3") else 1)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
@@ -145,7 +146,7 @@ def test_resnet101_int8_full_size_every_edge_bit_exact():
     x = W.make_input(1, hw=224)
     scales = W.calibrate(model, x)
     ref = NO.run_int8(model, scales, x)
-    net = W.build_int8_net(model, dict(scales), 1)
+    net = PF.build_int8_net(model, dict(scales), 1)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     checked = 0
@@ -181,7 +182,7 @@ def test_resnet101_int8_logits_bit_exact():
     x = W.make_input(1, hw=96)
     scales = W.calibrate(model, x)
     ref = NO.run_int8(model, scales, x)
-    net = W.build_int8_net(model, dict(scales), 1, fuse_eltwise=True, hw=96)
+    net = PF.build_int8_net(model, dict(scales), 1, fuse_eltwise=True, hw=96)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     assert np.array_equal(_h(net.tensor("fc1000")), ref["fc1000"])
@@ -214,7 +215,7 @@ def test_resnet50_int8_batch_invariance_full_size(setup):
     for bit, and both must equal the oracle's logits for the images it was run on."""
     model, x2, scales, ref = setup
     x8 = np.concatenate([x2, W.make_input(6, seed=99)], 0)
-    net8 = W.build_int8_net(model, dict(scales), 8)
+    net8 = PF.build_int8_net(model, dict(scales), 8)
     net8.tensor("data").copy_(torch.from_numpy(x8).cuda())
     net8.run()
     net8.autotune(iters=3)
@@ -223,7 +224,7 @@ def test_resnet50_int8_batch_invariance_full_size(setup):
     net8.replay()
     l8 = _h(net8.tensor("fc1000")).copy()
     assert np.array_equal(l8[:2], ref["fc1000"])          # the two images the oracle ran
-    net1 = W.build_int8_net(model, dict(scales), 1)
+    net1 = PF.build_int8_net(model, dict(scales), 1)
     for i in (0, 5, 7):
         net1.tensor("data").copy_(torch.from_numpy(x8[i:i + 1]).cuda())
         net1.run()
@@ -235,8 +236,8 @@ def test_cxx_net_optimize_equals_python_fused_list(setup):
     Python list builder applies (16 conv+eltwise, 4 sibling pairs, conv1+pool1, pool5 -> fc quantisation): 73 ops -> 52
     launches, and every surviving edge + the logits are bit-identical to the Python-fused list's and to the oracle's."""
     model, x, scales, ref = setup
-    a = W.build_int8_net(model, dict(scales), 2)                       # fused by workloads.py
-    b = W.build_int8_net(model, dict(scales), 2, cxx_optimize=True)    # unfused list + saber_hip_net_optimize
+    a = PF.build_int8_net(model, dict(scales), 2)                      # fused by the Python fuser (tests/py_fuser.py)
+    b = W.build_int8_net(model, dict(scales), 2)                       # the product: unfused list + saber_hip_net_optimize
     assert b.unfused_ops == 73 and b.removed == 22 and b.num_ops() == a.num_ops() == 52, (b.unfused_ops, b.removed, b.num_ops())
     # ... and both lists then get the conv1x1 chains (branch2c + sum -> next branch2a): 12 candidates, the 10 with C <= 256 on
     # and where the chain head is the only reader of the block's 3x3 conv that conv leads the launch (5 with C <= 128 on)
@@ -273,8 +274,8 @@ def test_strided_head_chain_with_the_next_pair_in_the_net():
     x = W.make_input(2, hw=224)
     scales = W.calibrate(model, x)
     ref = NO.run_int8(model, dict(scales), x)
-    a = W.build_int8_net(model, dict(scales), 2)
-    b = W.build_int8_net(model, dict(scales), 2, head_pair=True)
+    a = PF.build_int8_net(model, dict(scales), 2)
+    b = PF.build_int8_net(model, dict(scales), 2, head_pair=True)
     assert b.chained == a.chained + 1 and b.num_launches() == a.num_launches() - 1, (a.chained, b.chained, a.num_launches(), b.num_launches())
     assert sum("conv3x3+conv1x1+pair1x1_c64" in b.op_name(i) for i in range(b.num_ops())) == 1
     for net in (a, b):
@@ -295,7 +296,7 @@ def test_strided_head_chain_with_the_next_pair_in_the_net():
     b.tensor("data").copy_(torch.from_numpy(x).cuda())
     b.run()
     same()
-    c = W.build_int8_net(model, dict(scales), 2, head_pair=True)
+    c = PF.build_int8_net(model, dict(scales), 2, head_pair=True)
     c.set_choices(b.choices())
     assert [b.op_name(i) for i in range(b.num_ops())] == [c.op_name(i) for i in range(c.num_ops())]
     c.tensor("data").copy_(torch.from_numpy(x).cuda())
@@ -308,13 +309,13 @@ def test_autotuned_selection_round_trips_through_choices(setup):
     AND the chain decisions (separate launches / conv1x1 chain / chain led by the 3x3 conv, with their tile sizes) - into a
     freshly built net: same op names, same launch count, bit-identical logits."""
     model, x, scales, ref = setup
-    a = W.build_int8_net(model, dict(scales), 2)
+    a = PF.build_int8_net(model, dict(scales), 2)
     a.tensor("data").copy_(torch.from_numpy(x).cuda())
     a.run()
     a.autotune(iters=3)
     a.run()
     torch.cuda.synchronize()
-    b = W.build_int8_net(model, dict(scales), 2)
+    b = PF.build_int8_net(model, dict(scales), 2)
     b.set_choices(a.choices())
     assert [a.op_name(i) for i in range(a.num_ops())] == [b.op_name(i) for i in range(b.num_ops())]
     assert a.num_launches() == b.num_launches()
@@ -332,7 +333,7 @@ def test_measurement_entry_points_agree_with_each_other(setup):
     and the bracketed time of the longest launch is of the order of its share (the markers stretch a pass, so the two differ -
     by tens of per cent, not by factors)."""
     model, x, scales, ref = setup
-    net = W.build_int8_net(model, dict(scales), 2)
+    net = PF.build_int8_net(model, dict(scales), 2)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     shares = net.time_pass(iters=5)
@@ -369,8 +370,11 @@ def setup_fw():
 @pytest.mark.parametrize("fuse", [False, "lanes", True, "chain3", "cxx"])
 def test_resnet50_int8_framework_list_every_edge_bit_exact(setup_fw, fuse):
     model, x, scales, ref = setup_fw
-    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=bool(fuse) and fuse != "cxx", lanes=fuse == "lanes",
-                           chain=None if fuse in (False, "lanes", "chain3", "cxx") else 1, cxx_optimize=fuse == "cxx")
+    if fuse == "cxx":      # the PRODUCT builder: the list one op per reference operator + saber_hip_net_optimize (the only product fuser)
+        net = W.build_int8_net(model, dict(scales), 2)
+    else:
+        net = PF.build_int8_net(model, dict(scales), 2, fuse_eltwise=bool(fuse), lanes=fuse == "lanes",
+                                chain=None if fuse in (False, "lanes", "chain3") else 1)
     if not fuse:
         assert net.num_ops() == 76           # one op per reference operator
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
@@ -379,7 +383,7 @@ def test_resnet50_int8_framework_list_every_edge_bit_exact(setup_fw, fuse):
     # "cxx": the list is handed over unfused and saber_hip_net_optimize removes ops; the edges of removed ops (conv1 inside
     # SaberConv2DPooling, the separate eltwise inputs) stay declared but are never written: compare what the Python-fused
     # list materialises
-    live = set(W.build_int8_net(model, dict(scales), 2).tensors) if fuse == "cxx" else None
+    live = set(PF.build_int8_net(model, dict(scales), 2).tensors) if fuse == "cxx" else None
     for name in net.tensors:
         if net.unwritten(name) or (live is not None and name not in live):
             checked += 1
@@ -407,7 +411,7 @@ def test_resnet50_int8_framework_list_every_edge_bit_exact(setup_fw, fuse):
 def test_resnet50_int8_framework_list_batch8_invariance(setup_fw):
     model, x2, scales, ref = setup_fw
     x8 = np.concatenate([x2, W.make_input(6, seed=99)], 0)
-    net8 = W.build_int8_net(model, dict(scales), 8)
+    net8 = PF.build_int8_net(model, dict(scales), 8)
     net8.tensor("data").copy_(torch.from_numpy(x8).cuda())
     net8.run()
     net8.autotune(iters=3)
@@ -416,7 +420,7 @@ def test_resnet50_int8_framework_list_batch8_invariance(setup_fw):
     net8.replay()
     l8 = _h(net8.tensor("fc1000")).copy()
     assert np.array_equal(l8[:2], ref["fc1000"].reshape(2, -1))
-    net1 = W.build_int8_net(model, dict(scales), 1)
+    net1 = PF.build_int8_net(model, dict(scales), 1)
     for i in (0, 5, 7):
         net1.tensor("data").copy_(torch.from_numpy(x8[i:i + 1]).cuda())
         net1.run()
@@ -431,7 +435,7 @@ def test_resnet101_int8_framework_list_every_edge_bit_exact():
     x = W.make_input(1, hw=224)
     scales = W.calibrate(model, x)
     ref = NO.run_int8(model, dict(scales), x)
-    net = W.build_int8_net(model, dict(scales), 1)
+    net = PF.build_int8_net(model, dict(scales), 1)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     checked = 0
@@ -457,7 +461,7 @@ def test_resnet50_int8_framework_list_batch16_invariance(setup_fw):
     batch == the same image run alone, after autotuning, eager and as a hipGraph."""
     model, x2, scales, ref = setup_fw
     x16 = np.concatenate([x2, W.make_input(14, seed=123)], 0)
-    net = W.build_int8_net(model, dict(scales), 16)
+    net = PF.build_int8_net(model, dict(scales), 16)
     net.tensor("data").copy_(torch.from_numpy(x16).cuda())
     net.run()
     net.autotune(iters=2)
@@ -469,7 +473,7 @@ def test_resnet50_int8_framework_list_batch16_invariance(setup_fw):
     net.tensor("fc1000").zero_()
     net.replay()
     assert np.array_equal(_h(net.tensor("fc1000")), l16)
-    net1 = W.build_int8_net(model, dict(scales), 1)
+    net1 = PF.build_int8_net(model, dict(scales), 1)
     for i in (3, 9, 15):
         net1.tensor("data").copy_(torch.from_numpy(x16[i:i + 1]).cuda())
         net1.run()
@@ -502,7 +506,7 @@ def test_compacted_arena_int8_same_bits_smaller_footprint(setup_fw, batch):
     and the footprint drops several-fold. Inputs and outputs stay readable; `keep` pins an intermediate edge."""
     model, _, scales, _ = setup_fw
     x = W.make_input(batch)
-    net = W.build_int8_net(model, dict(scales), batch, cxx_optimize=True)
+    net = W.build_int8_net(model, dict(scales), batch)
     net.tensor("data").copy_(torch.from_numpy(x).cuda())
     net.run()
     want = {n: _h(net.tensor(n)).copy() for n in ("fc1000", "prob", "res3a")}
@@ -557,6 +561,32 @@ def test_compacted_arena_fp32_and_two_nets_side_by_side():
 
 def test_compact_arena_leaves_a_two_lane_net_alone(setup_fw):
     model, _, scales, _ = setup_fw
-    net = W.build_int8_net(model, dict(scales), 2, fuse_eltwise=True, lanes=True)
+    net = PF.build_int8_net(model, dict(scales), 2, fuse_eltwise=True, lanes=True)
     before = net.arena_bytes()
     assert net.compact() == before and not net.compacted()
+
+
+def test_reproducible_fp32_flag_two_autotuned_nets_same_bits():
+    """saber_hip_net_optimize flag 8192 (SABER_HIP_NET_REPRODUCIBLE_FP32): the autotuner and a restored selection leave FP32 ops on
+    their static kernels - two nets of one model, each "autotuned" on its own, answer bit-identically on every edge they share; without
+    the flag the autotuner does move FP32 ops (that is its job) and only the 1e-4 contract holds."""
+    model = W.build_model("resnet50")
+    x = W.make_input(2)
+    outs, names = [], []
+    for i in range(2):
+        net = W.build_fp32_net(model, 2, reproducible=True)
+        static_names = [net.op_name(k) for k in range(net.num_ops())]
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+        net.autotune(iters=7)
+        assert [net.op_name(k) for k in range(net.num_ops())] == static_names      # nothing moved
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+        outs.append({n: _h(net.tensor(n)).copy() for n in ("fc1000", "prob", "pool1")})
+        names.append(static_names)
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+    ref = NO.run_fp32(model, x)
+    got = outs[0]["fc1000"]
+    want = ref["fc1000"].reshape(got.shape)
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
