@@ -185,7 +185,8 @@ def test_net_mi355x_resnet50_int8_batch8_prediction_through_the_plan(tmp_path):
     ms, ms_loop = float(t[t.index("ms_per_prediction") + 1]), float(t[t.index("ms_per_prediction_op_loop") + 1])
     print("Net<MI355X,INT8>::prediction batch 8: %.4f ms through the plan (%d launches, %s), %.4f ms through the operator loop"
           % (ms, plan["launches"], "hipGraph" if plan["graph"] else "eager", ms_loop))
-    assert ms * 2 < ms_loop
+    # (round 6: lazy event records took the operator loop from 0.80 - 0.95 ms to ~0.45 ms - profiles/r06/op_loop.txt; the plan stays ~2 x ahead)
+    assert ms * 1.5 < ms_loop and ms_loop < 0.70
 
 
 def _run_mode(tmp_path, name, batch, x, mode_args, env_extra=None, precision="fp32", scales=None):
