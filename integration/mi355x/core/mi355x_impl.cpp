@@ -286,6 +286,12 @@ void MI355X_API::async_memcpy_p2p(void* dst, size_t dst_offset, int dst_id, cons
 // ---- Device<MI355X>: properties from hipGetDeviceProperties; max_stream data + compute streams (non-blocking) ----
 template <>
 void Device<MI355X>::create_stream() {
+    // Context<MI355X>(dev, ..) creates a device's streams lazily from whichever thread first asks (context.h:45-48) - e.g. the
+    // `Context ctx(0, 0, 0)` of net.cpp:446 / worker.cpp:117 from a thread that serves ANOTHER device: the streams must belong to
+    // THIS device (recorded by get_info while Env::env_init had it current), not to the caller's
+    int caller = 0;
+    MI355X_CHECK(hipGetDevice(&caller));
+    if (caller != _info._idx) MI355X_CHECK(hipSetDevice(_info._idx));
     _data_stream.clear();
     _compute_stream.clear();
     for (int i = 0; i < _max_stream; ++i) {
@@ -295,6 +301,7 @@ void Device<MI355X>::create_stream() {
         _data_stream.push_back(sd);
         _compute_stream.push_back(sc);
     }
+    if (caller != _info._idx) MI355X_CHECK(hipSetDevice(caller));
 }
 template <>
 void Device<MI355X>::get_info() {

@@ -33,6 +33,7 @@
 #include "anakin_config.h"
 
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -498,6 +499,107 @@ static int run_calibrate(const std::string& model_path, const std::vector<float>
     return 0;
 }
 
+// ---- `devices <n>`: one std::thread per device id, each TargetWrapper<MI355X>::set_device(d) and then its own Graph + Net<MI355X> +
+// captured plan (what a multi-GPU serving process does: one Net <-> one device, the batch sharded by the caller - SURVEY 8e; the
+// reference's Net takes the calling thread's CURRENT device, net.cpp:340) plus one Gemm<MI355X> call (the C ABI's per-thread plan cache
+// is keyed by device). Runs on the multi-device mock runtime (MOCK_HIP_DEVICES=8, integration/mock_hip) in the CPU test tier and on
+// however many GPUs a box has. Checks, per device: the Net's input / output tensors and EVERY tensor of the plan's arena live on that
+// device; nothing was launched or copied on another device's stream or memory (the mock counts those); every device received the same
+// number of allocations, bytes and launches (nothing silently landed on device 0). -> devices.txt
+template <Precision P>
+static int run_devices(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int ndev) {
+    typedef int (*device_of_t)(const void*);
+    typedef void (*stats_t)(long long*);
+    device_of_t device_of = (device_of_t)dlsym(RTLD_DEFAULT, "mock_hip_device_of");
+    stats_t stats = (stats_t)dlsym(RTLD_DEFAULT, "mock_hip_stats");
+    auto where = [&](const void* p) -> int {
+        if (device_of) return device_of(p);
+        hipPointerAttribute_t a;
+        return hipPointerGetAttributes(&a, p) == hipSuccess ? a.device : -1;
+    };
+    int count = 0;
+    TargetWrapper<MI355X>::get_device_count(count);
+    if (count < ndev) { fprintf(stderr, "devices: %d asked, %d present\n", ndev, count); return 2; }
+    long long before[80] = {0};
+    if (stats) stats(before);
+    std::atomic<int> bad{0};
+    std::vector<std::string> notes(ndev);
+    std::mutex build_mu;      // (the reference's graph / operator registries are not re-entrant while Nets are BUILT: Worker serialises this too, worker.cpp:13-39)
+    std::vector<std::thread> pool;
+    for (int d = 0; d < ndev; ++d)
+        pool.emplace_back([&, d]() {
+            TargetWrapper<MI355X>::set_device(d);
+            std::unique_ptr<Graph<MI355X, P> > g(new Graph<MI355X, P>());
+            std::unique_ptr<Net<MI355X, P> > net;
+            {
+                std::lock_guard<std::mutex> lk(build_mu);
+                if (!g->load(model_path)) { ++bad; return; }
+                g->Optimize();
+                net.reset(new Net<MI355X, P>(true));
+                net->init(*g, P == Precision::INT8);
+            }
+            auto in = net->get_in(g->get_ins()[0]);
+            auto out = net->get_out(g->get_outs()[0]);
+            Tensor4d<X86> hin(in->valid_shape(), AK_FLOAT), hout(out->valid_shape(), AK_FLOAT);
+            memcpy(hin.mutable_data(), input.data(), input.size() * sizeof(float));
+            for (int it = 0; it < 3; ++it) { in->copy_from(hin); net->prediction(); hout.copy_from(*out); }
+            int wrong = 0, seen = 0;
+            if (TargetWrapper<MI355X>::get_device_id() != d) ++wrong;
+            if (where(in->data()) != d) ++wrong;
+            if (where(out->data()) != d) ++wrong;
+            MI355XNetPlan& plan = net->mi355x_plan();
+            if (plan.net) {
+                for (int t = 0; t < saber_hip_net_num_tensors(plan.net); ++t) {
+                    void* p = saber_hip_net_tensor_ptr(plan.net, t);
+                    if (p && saber_hip_net_tensor_bytes(plan.net, t)) { ++seen; if (where(p) != d) ++wrong; }
+                }
+            } else ++wrong;
+            for (auto& ex : net->_exec_funcs) {
+                if (ex.ctx_p && ex.ctx_p->get_device_id() != d) ++wrong;
+                for (auto* t : ex.outs) if (t->valid_size() && t->data() && where(t->data()) != d) ++wrong;
+            }
+            // Gemm<MI355X, float, float> (saber_hip_gemm_f32): its per-thread plan (weight planes, scratch) must be built on this device
+            {
+                void *a = nullptr, *b = nullptr, *c = nullptr;
+                MI355X_CHECK(hipMalloc(&a, 256 * 256 * 4)); MI355X_CHECK(hipMalloc(&b, 256 * 256 * 4)); MI355X_CHECK(hipMalloc(&c, 256 * 256 * 4));
+                const int rc = saber_hip_gemm_f32(0, 0, 256, 256, 256, 1.f, (const float*)a, (const float*)b, 0.f, (float*)c,
+                                                  (saber_hip_stream_t)net->_exec_funcs[0].ctx_p->get_compute_stream());
+                if (rc != SABER_HIP_OK) ++wrong;
+                TargetWrapper<MI355X>::device_sync();
+                saber_hip_gemm_f32_release_plans();
+                (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+            }
+            bad += wrong;
+            char buf[256];
+            snprintf(buf, sizeof buf, "device %d: plan %d launches %d plan tensors checked %d wrong %d", d, plan.net ? 1 : 0, plan.launches, seen, wrong);
+            notes[d] = buf;
+            std::lock_guard<std::mutex> lk(build_mu);      // (tear the Net down under the same lock)
+            net.reset();
+            g.reset();
+        });
+    for (auto& th : pool) th.join();
+    FILE* f = fopen((outdir + "/devices.txt").c_str(), "w");
+    for (auto& n : notes) fprintf(f, "%s\n", n.c_str());
+    long long after[80] = {0};
+    int uneven = 0;
+    if (stats) {
+        stats(after);
+        for (int d = 0; d < ndev; ++d)
+            fprintf(f, "mock device %d: allocations %lld bytes %lld launches %lld streams %lld\n", d, after[16 + d] - before[16 + d], after[d] - before[d],
+                    after[32 + d] - before[32 + d], after[48 + d] - before[48 + d]);
+        for (int d = 1; d < ndev; ++d)      // every device did the same work (device 0 additionally holds what main() made before the threads)
+            if (after[32 + d] - before[32 + d] != after[32 + 1] - before[32 + 1] || after[16 + d] - before[16 + d] != after[16 + 1] - before[16 + 1] ||
+                after[d] - before[d] != after[1] - before[1]) ++uneven;
+        if (ndev > 1 && (after[32] - before[32] != after[33] - before[33] || after[0] - before[0] != after[1] - before[1])) ++uneven;
+        fprintf(f, "wrong_device_launch %lld wrong_device_copy %lld wrong_device_event %lld uneven %d\n", after[64], after[65], after[66], uneven);
+        bad += (int)(after[64] + after[65] + after[66]) + uneven;
+    }
+    fprintf(f, "devices %d bad %d mock %d\n", ndev, bad.load(), stats ? 1 : 0);
+    fclose(f);
+    printf("devices %s: %d devices, %d violations\n", bad.load() ? "FAILED" : "ok", ndev, bad.load());
+    return bad.load() ? 3 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) {
         fprintf(stderr, "usage: %s model.txt weights.bin input.bin outdir [timing iters]\n", argv[0]);
@@ -543,6 +645,11 @@ int main(int argc, char** argv) {
         const int th = atoi(argv[6]), rq = argc > 7 ? atoi(argv[7]) : 64;
         if (precision == "int8") return run_threads<Precision::INT8>(argv[1], input, argv[4], th, rq);
         return run_threads<Precision::FP32>(argv[1], input, argv[4], th, rq);
+    }
+    if (argc > 6 && std::string(argv[5]) == "devices") {
+        Env<MI355X>::env_init();
+        if (precision == "int8") return run_devices<Precision::INT8>(argv[1], input, argv[4], atoi(argv[6]));
+        return run_devices<Precision::FP32>(argv[1], input, argv[4], atoi(argv[6]));
     }
     if (argc > 6 && std::string(argv[5]) == "calibrate") {
         Env<MI355X>::env_init();

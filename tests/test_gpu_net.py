@@ -13,6 +13,7 @@ import os
 import subprocess
 
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -236,6 +237,19 @@ def test_worker_mi355x_fp32_reproducible_mode_answers_bit_identically(tmp_path):
     prob = np.fromfile(os.path.join(d, "out_worker.bin"), np.float32)
     ref = NO.run_fp32(W.framework_model(model, "fp32"), x)
     _fp32_check(prob, ref["prob"], "prob (Worker<MI355X>::sync_prediction, reproducible FP32)")
+
+
+def test_devices_mode_on_the_real_device(tmp_path):
+    """the per-device checks of tests/test_net_oplist.py::test_eight_devices_on_the_mock_runtime... on real hardware, for as many
+    GPUs as the box has (one on the test pool: hipPointerGetAttributes says where every tensor of the Net and of its plan lives)"""
+    batch = 2
+    x = W.make_input(batch)
+    model = W.build_model("resnet50")
+    scales = W.calibrate(model, x)
+    n = torch.cuda.device_count()
+    model, d, r = _run_mode(tmp_path, "resnet50", batch, x, ["devices", str(n)], precision="int8", scales=scales)
+    txt = open(os.path.join(d, "devices.txt")).read()
+    assert "devices ok" in r.stdout and txt.strip().split("\n")[-1] == "devices %d bad 0 mock 0" % n, txt
 
 
 def test_worker_mi355x_int8_serves_the_headline_model(tmp_path):
