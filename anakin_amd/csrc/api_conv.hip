@@ -153,7 +153,8 @@ void name_algo(saber_hip_conv* op) {
     int bmk = 0, bnp = 0;
     tile_dims(op->tile, &bmk, &bnp);
     char buf[96];
-    if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
+    if (op->stem32) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_f32_bf16x3_nchw_in");
+    else if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
     else if (op->pw > 1) {
@@ -320,6 +321,26 @@ int saber_hip_conv2d_set_pooling(saber_hip_conv_t* op, int pool_type, int kh, in
         name_algo(op);
         return SABER_HIP_OK;
     }
+    // FP32 stem: NCHW f32 image -> 7x7 / 2 / pad 3 conv (3 -> 64) + relu -> 3x3 / 2 max pooling -> NHWC f32 as ONE launch (conv_stem_f32.hip)
+    if (!op->is_i8 && op->algo == ALGO_IGEMM_F32 && op->pre_transpose && d.in_dtype == SABER_HIP_F32 && d.out_dtype == SABER_HIP_F32 &&
+        d.out_layout == SABER_HIP_NHWC && d.c == 3 && d.k == 64 && d.kh == 7 && d.kw == 7 && d.stride_h == 2 && d.stride_w == 2 && d.pad_h == 3 &&
+        d.pad_w == 3 && d.dil_h == 1 && d.dil_w == 1 && d.group == 1 && d.res_mode == SABER_HIP_RES_NONE && d.act == SABER_HIP_ACT_RELU &&
+        d.act_negative_slope == 0.f && !op->pair_k2 && pool_type == SABER_HIP_POOL_MAX && kh == 3 && kw == 3 && stride_h == 2 && stride_w == 2 &&
+        pad_h == 0 && pad_w == 0 && op->weights_set && op->w_stem_host.size() == (size_t)64 * 3 * 49 && !getenv("SABER_HIP_NO_STEM_F32")) {
+        const int poh = saber_hip_pool_out_dim(op->oh, pad_h, kh, stride_h, floor_mode), pow_ = saber_hip_pool_out_dim(op->ow, pad_w, kw, stride_w, floor_mode);
+        if ((poh - 1) * 2 < op->oh && (pow_ - 1) * 2 < op->ow) {      // every window starts inside the conv image (ceil and floor shapes)
+            std::vector<uint8_t> fr;
+            stem_f32_pack(op->w_stem_host.data(), fr);
+            HIP_TRY(op->d_wstem32.upload(fr));
+            op->pool_oh = poh;
+            op->pool_ow = pow_;
+            op->pool_fused = 1;
+            op->stem32 = 1;
+            op->ws_bytes = 0;      // (no NHWC4 copy of the image any more)
+            name_algo(op);
+            return SABER_HIP_OK;
+        }
+    }
     const bool fusable = stem_ok(op) && pool_type == SABER_HIP_POOL_MAX && kh == 3 && kw == 3 && stride_h == 2 &&
                          stride_w == 2 && pad_h == 0 && pad_w == 0 && d.res_mode == SABER_HIP_RES_NONE &&
                          (d.out_dtype == SABER_HIP_S8 || d.out_dtype == SABER_HIP_U8);
@@ -349,6 +370,11 @@ int saber_hip_conv2d_set_tile(saber_hip_conv_t* op, int tile) {
     // tile id in the low byte, optional stage depth (k-steps per stage: 1, 2, 4) in bits 8..15,
     // optional staging variant in bits 16..23 (1 = register-staged, 2 = LDS-DMA ring, 3 / 4 = LDS-DMA ring
     // with 2 / 4 wave groups: needs stage depth 4 and a 32x32, 64x32 or 64x64 tile)
+    if (op->stem32) {      // FP32 stem launch: variant 15, low byte 0 = tile by launch size, 1 = 8 x 8 pooled pixels per workgroup, 2 = 4 x 8, 3 = 4 x 4
+        if (((tile >> 16) & 0xff) != 15 || (tile & 0xff) > 3) return fail(SABER_HIP_INVALID_VALUE, "FP32 stem launch: (15 << 16) | 0..3");
+        op->stem32 = 1 + (tile & 0xff);
+        return SABER_HIP_OK;
+    }
     if (op->pool_fused) return fail(SABER_HIP_INVALID_VALUE, "fused conv+pooling has a single kernel");
     const int ks = (tile >> 8) & 0xff;
     const int var = (tile >> 16) & 0xff;
@@ -546,6 +572,7 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
         if (w_dtype != SABER_HIP_F32) return fail(SABER_HIP_INVALID_VALUE, "FP32 conv needs f32 weights");
         const float* wf = (const float*)w;
         std::vector<float> wr;
+        if (d.group == 1 && Cg == 3 && kh == 7 && kw == 7 && K == 64) op->w_stem_host.assign(wf, wf + (size_t)K * inner);      // (the FP32 stem launch packs its own planes: set_pooling)
         if (op->algo == ALGO_IGEMM_F32) {
             wr.assign((size_t)K_pad * op->Kg_pad, 0.f);
             const int Ce = op->c_eff;
@@ -782,6 +809,11 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
     const void* xin = x;
     if (op->gpool) return fail(SABER_HIP_INVALID_VALUE, "conv + fused global pooling: use saber_hip_conv2d_run_gpool");
     if (op->img1) return img_conv_run(op, x, y, res, nullptr, s);
+    if (op->stem32) {
+        HIP_TRY(launch_conv_stem_f32_pool_raw((const float*)x, op->d_wstem32.p, op->has_bias ? op->d_bias.p : nullptr, (float*)y, d.n, d.h, d.w, op->oh,
+                                              op->ow, op->pool_oh, op->pool_ow, op->stem32 - 1, s));
+        return SABER_HIP_OK;
+    }
     if (op->pool_fused) {
         ConvKArgs a;
         const int rc = stem_pool_args(op, x, y, workspace, s, &a);

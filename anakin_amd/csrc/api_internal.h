@@ -99,6 +99,10 @@ struct saber_hip_conv {
     int stem = 0;            // 1: LDS-patch stem kernel (conv_stem.h) instead of the NHWC4 implicit GEMM
     int pool_fused = 0, pool_oh = 0, pool_ow = 0;   // SaberConv2DPooling: fused stem conv + 3x3/2 max pooling
     int pool2 = 0;           // SaberConv2DPooling, FP32: relu'd implicit-GEMM conv + 2x2/2 max pooling in the epilogue
+    int stem32 = 0;          // SaberConv2DPooling, FP32 stem (with pool_fused): NCHW image -> 7x7/2 conv + relu + 3x3/2 max pooling in ONE launch
+                             // (conv_stem_f32.hip); d_wstem32 = its weight planes in MFMA fragment order, packed by set_pooling from w_stem_host
+    DevBuf<uint8_t> d_wstem32;
+    std::vector<float> w_stem_host;   // the OIHW f32 weights of a 3 -> 64 7x7 FP32 conv as handed to set_weights (9.4 K floats)
     int halo = 0;            // 4 / 8: LDS-halo 3x3 kernel with that many tile rows (conv3x3_halo.h); 0: not used
     int fc_small = 0;        // 1: small-batch fc kernel (fc_small.hip) instead of the implicit-GEMM conv kernel
     int b3h = 0;             // FP32 3x3: 1..5 = LDS-halo bf16-plane kernel variant (conv3x3_b3h.hip), 0: not used

@@ -341,4 +341,9 @@ hipError_t launch_xcd_map_probe(unsigned* out, int blocks, hipStream_t s);   // 
 hipError_t launch_gemm_f32(int ta, int tb, int m, int n, int k, float alpha, const float* a, const float* b,
                            float beta, float* c, hipStream_t s);
 
+// FP32 stem: NCHW f32 image -> conv 7x7 / 2 / pad 3 (3 -> 64) + bias + relu -> max pooling 3x3 / 2 -> NHWC f32, one launch (conv_stem_f32.hip)
+struct StemF32Args;
+void stem_f32_pack(const float* w_oihw, std::vector<uint8_t>& out);
+hipError_t launch_conv_stem_f32_pool_raw(const float* x, const void* w, const float* bias, float* y, int n, int h, int w_, int oh, int ow, int ph,
+                                         int pw, int variant, hipStream_t s);
 }  // namespace saber_mi355x

@@ -358,10 +358,11 @@ def build_int8_net(model, scales, batch, hw=224, fuse=True, chain=2, stage=True,
     return net
 
 
-def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False, reproducible=False):
+def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False, reproducible=False, fuse_stem=True):
     """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
     does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132).
     shared_device: see build_int8_net (here: no split-K through one XCD's L2).
+    fuse_stem: conv1 (NCHW image in) + relu + pool1 as one launch where the library has the kernel (ResNet's 7x7 / 2 stem, round 6).
     reproducible: saber_hip_net_optimize flag SABER_HIP_NET_REPRODUCIBLE_FP32 - FP32 ops keep their static kernel selection whatever
     autotune / set_choices say, so that two nets of one model answer bit-identically."""
     from . import lib as L
@@ -369,29 +370,51 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, sha
     net = S.Net()
     B = batch
     net.add_tensor("data", (B, 3, hw, hw), F32)
-    net.add_tensor("data_nhwc", (B, hw, hw, 4), F32)
-    net.add_transpose_in(B, 3, hw, hw, 4, "data", "data_nhwc")
-    shape = {"data_nhwc": (hw, 4)}
-    alias = {"data": "data_nhwc"}
+    spec = model["spec"]
+    shape, alias = {}, {}
+    fused_away = set()   # pooling ops emitted as part of a SaberConv2DPooling
+    done_convs = set()
+    produced = []   # (op index, logical edge name the op has just produced): lets a test check every edge right after its op,
+                    # before a later in-place residual sum overwrites the buffer
+    # the ResNet stem: conv1 reading the NCHW image + relu + pool1 as ONE launch where the library has the fused kernel (round 6,
+    # conv_stem_f32.hip: SaberConv2DPooling<AK_FLOAT> on 7x7 / 2, 3 -> 64 + 3x3 / 2 max pooling) - no NHWC copy of the image, no conv1 edge
+    l0, l1 = spec[0], (spec[1] if len(spec) > 1 else None)
+    if fuse_stem and l0["kind"] == "conv" and l0["src"] == "data" and l1 is not None and l1["kind"] == "pool" and l1["src"] == l0["name"] \
+            and l1["type"] == 0 and l0["relu"] and sum(1 for e in spec for k in ("src", "a", "b") if e.get(k) == l0["name"]) == 1:
+        w0, b0 = model["params"][l0["name"]]
+        p0 = S.ConvParam(w0, b0, 1, (l0["pad"],) * 2, (l0["stride"],) * 2, (1, 1), True)
+        cp0 = S.SaberConv2DPooling(int8=False).init((B, 3, hw, hw), p0, l1["type"], (l1["win"],) * 2, (l1["stride"],) * 2, (l1["pad"],) * 2,
+                                                     F32, F32, floor_mode=l1.get("floor", False), in_layout=L.NCHW)
+        if cp0.fused and cp0.algo().startswith("stem7x7s2_maxpool3x3s2_f32"):
+            po = cp0.out_hw[0]
+            net.add_tensor(l1["name"], (B, po, po, l0["cout"]), F32)
+            shape[l1["name"]] = (po, l0["cout"])
+            net.add_conv(cp0.conv, "data", l1["name"])
+            net.keep.append(cp0)
+            produced.append((net.num_ops() - 1, l1["name"]))
+            fused_away.add(l1["name"])
+            done_convs.add(l0["name"])
+    if not done_convs:
+        net.add_tensor("data_nhwc", (B, hw, hw, 4), F32)
+        net.add_transpose_in(B, 3, hw, hw, 4, "data", "data_nhwc")
+        shape["data_nhwc"] = (hw, 4)
+        alias["data"] = "data_nhwc"
 
     def T(n):
         return alias.get(n, n)
-    spec = model["spec"]
     sib = {}
-    fused_away = set()   # pooling ops emitted as part of a SaberConv2DPooling
     consumers = {}
     for e in spec:
         for key in ("src", "a", "b"):
             if key in e:
                 consumers[e[key]] = consumers.get(e[key], 0) + 1
-    produced = []   # (op index, logical edge name the op has just produced): lets a test check every edge right after its op,
-                    # before a later in-place residual sum overwrites the buffer
-
     def mark(*names):
         for n_ in names:
             produced.append((net.num_ops() - 1, n_))
     for li, l in enumerate(spec):
         kd, nm = l["kind"], l["name"]
+        if kd == "conv" and nm in done_convs:
+            continue
         if kd == "conv":
             hin, cin = shape[T(l["src"])]
             ho = _out_hw(hin, l["k"], l["stride"], l["pad"])

@@ -94,6 +94,19 @@ PY
   ls $O ;;
 stage_b1)   # the XCD-resident res5 stage launch against the ops one by one at batch 1 / 2 / 8 (round-5 verdict item 3: re-measure at batch 1)
   for n in 1 2 8; do python scripts/probe/stage_time.py $n; done > $O/stage_time.txt 2>&1; cat $O/stage_time.txt ;;
+fp32)       # ResNet50 FP32 b8 / b1 (+ VGG16) bench lines with the per-op table
+  python bench.py --precision fp32 --batch 8 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b8.json 2> $O/fp32_b8_per_op.txt
+  python bench.py --precision fp32 --batch 1 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b1.json 2> $O/fp32_b1_per_op.txt
+  SABER_HIP_STEM_F32_TILE=1 python bench.py --precision fp32 --batch 8 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b8_t1.json 2> $O/fp32_b8_t1_per_op.txt
+  SABER_HIP_STEM_F32_TILE=2 python bench.py --precision fp32 --batch 8 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b8_t2.json 2> $O/fp32_b8_t2_per_op.txt
+  SABER_HIP_STEM_F32_TILE=3 python bench.py --precision fp32 --batch 8 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b8_t3.json 2> $O/fp32_b8_t3_per_op.txt
+  SABER_HIP_STEM_F32_TILE=2 python bench.py --precision fp32 --batch 1 --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/fp32_b1_t2.json 2> $O/fp32_b1_t2_per_op.txt
+  python - <<'PY'
+import json
+for f in ("fp32_b8","fp32_b1","fp32_b8_t1","fp32_b8_t2","fp32_b8_t3","fp32_b1_t2"):
+    d=json.load(open("gpurun_out/r06_fp32/%s.json"%f)); print(f, d["value"], d["ms_per_step"], d["latency_ms"]["p50"], d["config"]["launches"])
+PY
+  for f in fp32_b8 fp32_b1 fp32_b8_t1 fp32_b8_t2 fp32_b8_t3 fp32_b1_t2; do echo $f; grep -h "^ *0 " $O/${f}_per_op.txt; done ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;

@@ -1539,6 +1539,50 @@ def test_fc_i8_softmax_in_one_launch(M, K, N):
             assert np.allclose(got_p.sum(1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 224, 224), (1, 96, 96), (3, 70, 70), (1, 61, 47), (2, 33, 40), (9, 64, 64)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_stem_f32_one_launch_vs_oracle_and_the_three_ops(case, variant):
+    """conv_stem_f32.hip (round 6): NCHW f32 image -> conv 7x7 / 2 / pad 3 (3 -> 64) + bias + relu -> max pooling 3x3 / 2 (ceil shapes) ->
+    NHWC f32 in ONE launch, both tile forms, ragged pooled sizes and windows clipped at the conv image's edge - against the oracle's
+    conv -> pooling (naive order; 1e-4 on both FP32 criteria) and against the library's own three launches (transpose, implicit-GEMM conv on
+    the f32 MFMA, pooling) within 2e-5; the same bits on repeated launches; floor-mode pooling too."""
+    N, H, W = case
+    rng = np.random.default_rng(900 + N + H + W)
+    x = rng.uniform(-1, 1, (N, 3, H, W)).astype(np.float32)
+    w = (rng.standard_normal((64, 3, 7, 7)) * np.sqrt(2.0 / 147)).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.2).astype(np.float32)
+    for floor in (False, True):
+        conv_ref = O.conv_f32_nchw(x, w, b, True, (3, 3), (2, 2))
+        want = O.pool_f32_nchw(conv_ref, (3, 3), (2, 2), (0, 0), 0, floor_mode=floor).transpose(0, 2, 3, 1)
+        stem = S.SaberConv2DPooling(int8=False).init((N, 3, H, W), S.ConvParam(w, b, 1, (3, 3), (2, 2), (1, 1), True), L.POOL_MAX, (3, 3),
+                                                      (2, 2), (0, 0), L.F32, L.F32, floor_mode=floor, in_layout=L.NCHW)
+        assert stem.fused and stem.algo() == "stem7x7s2_maxpool3x3s2_f32_bf16x3_nchw_in", stem.algo()
+        stem.conv.set_tile((15 << 16) | variant)
+        y = stem.new_output()
+        assert tuple(y.shape) == want.shape, (y.shape, want.shape)
+        y.fill_(-7.0)
+        stem.dispatch(dev(x), y)
+        got = host(y)
+        a = np.abs(got - want).max() / np.abs(want).max()
+        e = (np.abs(got - want) / (np.abs(want) + np.abs(want).mean())).max()
+        assert a <= FP32_RTOL and e <= FP32_RTOL, (case, variant, floor, a, e)
+        y2 = stem.new_output()
+        stem.dispatch(dev(x), y2)
+        assert np.array_equal(host(y2), got)
+        # the three separate launches of rounds 1 - 5 (SABER_HIP_NO_STEM_F32 is read per set_pooling call)
+        import os
+        os.environ["SABER_HIP_NO_STEM_F32"] = "1"
+        try:
+            three = S.SaberConv2DPooling(int8=False).init((N, 3, H, W), S.ConvParam(w, b, 1, (3, 3), (2, 2), (1, 1), True), L.POOL_MAX, (3, 3),
+                                                           (2, 2), (0, 0), L.F32, L.F32, floor_mode=floor, in_layout=L.NCHW)
+        finally:
+            del os.environ["SABER_HIP_NO_STEM_F32"]
+        assert not three.fused
+        y3 = three.new_output()
+        three.dispatch(dev(x), y3)
+        assert np.abs(host(y3) - got).max() <= 2e-5 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("fenced", [False, True], ids=["write_through", "fenced"])
 def test_fc_i8_softmax_hand_off_under_concurrent_load(fenced):
     """(round-5 advisor) the fc + softmax launch hands its logits to the last-arriving workgroup through memory across XCDs with
