@@ -156,7 +156,7 @@ void name_algo(saber_hip_conv* op) {
     if (op->stem32) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_f32_bf16x3_nchw_in");
     else if (op->pool_fused) snprintf(buf, sizeof buf, "stem7x7s2_maxpool3x3s2_i8_4x8%s", op->pre_quant ? "_fusedquant" : "");
     else if (op->stem) snprintf(buf, sizeof buf, "stem7x7s2_i8_8x16%s", op->pre_quant ? "_fusedquant" : "");
-    else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? "fc_f32_small_16xk4" : "fc_i8_small_16xk4");
+    else if (op->fc_small) snprintf(buf, sizeof buf, op->algo == ALGO_IGEMM_F32 ? ((op->d_fcpart.p && !op->d_wfc.p) ? "fc_f32_splitk_16xk4" : "fc_f32_small_16xk4") : "fc_i8_small_16xk4");
     else if (op->pw > 1) {
         int ptm = 0, pp = 0, pd = 0, pmb = 0;
         (void)conv1x1_pwk_variant(op->pw - 1, &ptm, &pp, &pd, &pmb);
@@ -592,6 +592,19 @@ int saber_hip_conv2d_set_weights(saber_hip_conv_t* op, const void* w, int w_dtyp
         }
         std::vector<uint8_t> raw((const uint8_t*)wr.data(), (const uint8_t*)wr.data() + wr.size() * sizeof(float));
         HIP_TRY(op->d_w.upload(raw));
+        // an fc with few output tiles: scratch of the split-K kernel (fc_f32_splitk.hip) - OPT-IN (SABER_HIP_FC_F32_SPLITK=1): measured no
+        // faster than the one-workgroup-per-tile fc + the softmax launch (18.3 vs 16.7 us at batch 8, 12.6 vs 13.2 at batch 1,
+        // profiles/r06/fc_tail.txt): the split adds two round trips through the device's coherence point to a tail that is a latency chain
+        {
+            const char* e = getenv("SABER_HIP_FC_F32_SPLITK");
+            if (op->algo == ALGO_IGEMM_F32 && d.h == 1 && d.w == 1 && kh == 1 && kw == 1 && d.group == 1 && op->epi == EPI_F32 && !op->pre_transpose &&
+                d.out_layout == SABER_HIP_NHWC && d.res_mode == SABER_HIP_RES_NONE && e && e[0] == '1' &&
+                fc_f32_splitk_ok(d.n, op->c_eff, op->Kg_pad, K, false)) {
+                HIP_TRY(op->d_fcpart.alloc_zero(fc_f32_splitk_part_floats(op->c_eff, K)));
+                HIP_TRY(op->d_fcctr.alloc_zero(fc_f32_splitk_counters(K)));
+                if (op->fc_small) name_algo(op);
+            }
+        }
         // an fc at <= 16 batch rows is ONE pass over its weights. SABER_HIP_FC_F32_PACKED=1 (A/B): the same matrix once more
         // fragment-major, so that every load instruction of the streaming kernel reads 1 KB contiguous ([16-output tile][16-float step]
         // [lane][4]; fc_small.hip) - superseded by the kernel that reads the row-major weights in contiguous runs and transposes in LDS.
@@ -865,6 +878,10 @@ int saber_hip_conv2d_run(saber_hip_conv_t* op, const void* x, void* y, const voi
         break;
     case ALGO_IGEMM_F32:
         if (op->fc_small) {
+            if (op->d_fcpart.p && !op->d_wfc.p) {      // few output tiles: the reduction split over workgroups (fc_f32_splitk.hip)
+                HIP_TRY(launch_fc_f32_splitk(a, op->d_fcpart.p, op->d_fcctr.p, nullptr, s));
+                break;
+            }
             if (op->d_wfc.p) a.w = op->d_wfc.p;
             HIP_TRY(launch_fc_f32_small(a, op->d_wfc.p != nullptr, s));
             break;

@@ -110,6 +110,8 @@ struct saber_hip_conv {
     int pw = 0;              // FP32 1x1 / stride 1: 1 = persistent register-weights kernel (C = 64 / 128, conv1x1_pw.hip), 2 .. 5 = the
                              // reduction-split kernel's variants 1 .. 4 (C = 128 .. 2048, conv1x1_pwk.hip), 0: not used
     DevBuf<uint8_t> d_wpw;   // its weight planes in that kernel's fragment order
+    DevBuf<float> d_fcpart;  // FP32 fc at <= 16 rows and <= 2048 outputs: the split-K kernel's partial sums + arrival counters (fc_f32_splitk.hip;
+    DevBuf<unsigned> d_fcctr; // allocated by set_weights when the shape is eligible AND SABER_HIP_FC_F32_SPLITK=1: opt-in, measured no faster - profiles/r06/fc_tail.txt)
     DevBuf<float> d_wfc;     // FP32 fc at <= 16 rows: the weights fragment-major for the streaming kernel (fc_small.hip: fc_f32_stream_kernel PACKED)
     int img1 = 0;            // INT8: 1 = image-resident kernel (stage_xcd.hip: img_conv_kernel): workgroup = one image x 16 NT channels
     int gpool = 0;           // ... with the global average pooling of its output fused (saber_hip_net_optimize flag 128): img1 only

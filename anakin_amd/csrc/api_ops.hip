@@ -128,12 +128,15 @@ int saber_hip_fc_run_q(saber_hip_fc_t* fc, const int8_t* xq, float* y, saber_hip
 bool fc_softmax_ok(const saber_hip_fc* fc, bool quantised_input) {
     if (!fc || !fc->conv || (fc->pre_quant && !quantised_input)) return false;
     const saber_hip_conv* c = fc->conv;
+    if (c->fc_small && c->algo == ALGO_IGEMM_F32)      // FP32: the split-K kernel's last tile normalises the rows (fc_f32_splitk.hip)
+        return c->d_fcpart.p && !c->d_wfc.p && fc_f32_splitk_ok(c->d.n, c->c_eff, c->Kg_pad, c->d.k, true);
     const int ksw = (c->c_eff + 255) / 256;
     return c->fc_small && c->algo == ALGO_IGEMM_I8 && (ksw == 2 || ksw == 4 || ksw == 8 || ksw == 16) &&
            fc_i8_small_softmax_ok(c->d.n, c->c_eff, c->Kg_pad, c->d.k);
 }
 int fc_softmax_prepare(saber_hip_fc* fc) {
     if (!fc || !fc->conv) return fail(SABER_HIP_INVALID_VALUE, "null argument");
+    if (fc->conv->algo == ALGO_IGEMM_F32) return SABER_HIP_OK;      // (the FP32 kernel's counters come with its partial-sum scratch: set_weights)
     if (!fc->conv->d_sm_ctr.p) HIP_TRY(fc->conv->d_sm_ctr.alloc_zero(32));
     return SABER_HIP_OK;
 }
@@ -144,6 +147,14 @@ int fc_run_softmax(saber_hip_fc* fc, const void* x, float* y, float* prob, void*
         // first use outside a net: the counter (nothing may be allocated under stream capture)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)fc_softmax_prepare(fc);
+    }
+    if (!g_capture && fc->conv->algo == ALGO_IGEMM_F32 && fc_softmax_ok(fc, quantised_input)) {
+        saber_hip_conv* op = fc->conv;
+        if (!op->weights_set) return fail(SABER_HIP_INVALID_VALUE, "set_weights not called");
+        ConvKArgs a;
+        conv_fill_args(op, a, x, y, nullptr);
+        HIP_TRY(launch_fc_f32_splitk(a, op->d_fcpart.p, op->d_fcctr.p, prob, s));
+        return SABER_HIP_OK;
     }
     if (!g_capture && fc_softmax_ok(fc, quantised_input) && fc->conv->d_sm_ctr.p) {
         saber_hip_conv* op = fc->conv;

@@ -293,6 +293,11 @@ int fc_f32_packed_steps(int c);
 bool fc_f32_small_ok(int m, int c, int kg_pad);
 bool fc_i8_small_softmax_ok(int m, int c, int kg_pad, int k);
 hipError_t launch_fc_i8_small_softmax(const ConvKArgs& a, float* prob, unsigned* ctr, hipStream_t s);
+// FP32 fc at <= 16 rows with the reduction split over workgroups (+ the Softmax over its output in the same launch when prob != null)
+bool fc_f32_splitk_ok(int m, int c, int kg_pad, int k, bool softmax);
+size_t fc_f32_splitk_part_floats(int c, int k);
+size_t fc_f32_splitk_counters(int k);
+hipError_t launch_fc_f32_splitk(const ConvKArgs& a, float* part, unsigned* ctr, float* prob, hipStream_t s);
 bool gemm_f32_rows_ok(int m, int k);
 hipError_t launch_gemm_f32_rows(int m, int n, int k, float alpha, const float* A, const float* B, float beta, float* C, const void* zero,
                                 hipStream_t s);

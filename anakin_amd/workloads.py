@@ -358,7 +358,8 @@ def build_int8_net(model, scales, batch, hw=224, fuse=True, chain=2, stage=True,
     return net
 
 
-def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False, reproducible=False, fuse_stem=True):
+def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, shared_device=False, reproducible=False, fuse_stem=True,
+                   fc_softmax=True):
     """FP32 op list: NHWC f32 on the device, conv+eltwise fused in place as the reference's FP32 graph
     does (ConvEltwise writes onto the residual's buffer, conv_elewise_fusion_scheduler.cpp:113-132).
     shared_device: see build_int8_net (here: no split-K through one XCD's L2).
@@ -506,6 +507,8 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, sha
         net.optimize(2048)
     if reproducible:
         net.optimize(8192)
+    # the fc and the Softmax over its output as one launch where the library's small-batch FP32 fc can normalise its own rows (flag 4096)
+    net.fc_softmaxed = net.optimize(4096) if fc_softmax else 0
     net.finalize()
     return net
 

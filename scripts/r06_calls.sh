@@ -107,6 +107,12 @@ for f in ("fp32_b8","fp32_b1","fp32_b8_t1","fp32_b8_t2","fp32_b8_t3","fp32_b1_t2
     d=json.load(open("gpurun_out/r06_fp32/%s.json"%f)); print(f, d["value"], d["ms_per_step"], d["latency_ms"]["p50"], d["config"]["launches"])
 PY
   for f in fp32_b8 fp32_b1 fp32_b8_t1 fp32_b8_t2 fp32_b8_t3 fp32_b1_t2; do echo $f; grep -h "^ *0 " $O/${f}_per_op.txt; done ;;
+fctail)     # the FP32 classifier tail: split-K fc (+ softmax in the launch) against the one-workgroup-per-tile fc + the softmax launch
+  for b in 8 1; do
+    python bench.py --precision fp32 --batch $b --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/split_b$b.json 2> $O/split_b${b}_per_op.txt
+    SABER_HIP_FC_F32_SPLITK=0 python bench.py --precision fp32 --batch $b --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/plain_b$b.json 2> $O/plain_b${b}_per_op.txt
+  done
+  for f in split_b8 plain_b8 split_b1 plain_b1; do echo $f; python -c "import json;d=json.load(open('$O/$f.json'));print(d['value'],d['ms_per_step'],d['config']['launches'])"; tail -n 4 $O/${f}_per_op.txt; done ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;

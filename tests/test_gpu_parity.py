@@ -1583,6 +1583,67 @@ def test_stem_f32_one_launch_vs_oracle_and_the_three_ops(case, variant):
         assert np.abs(host(y3) - got).max() <= 2e-5 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("shape", [(1, 2048, 1000), (8, 2048, 1000), (16, 4096, 1000), (3, 512, 40), (8, 1024, 2048), (5, 2048, 1001)])
+def test_fc_f32_split_k_and_softmax_in_one_launch(shape):
+    """fc_f32_splitk.hip (round 6): the FP32 fc at <= 16 rows with few output tiles runs with its reduction split over workgroups
+    (deterministic second step: the tile's last arriver adds the partials in split order) - the logits within 1e-4 of the oracle on both
+    FP32 criteria and of the default one-workgroup-per-tile kernel, the SAME BITS over 20 launches on changing
+    buffers; saber_hip_fc_run_softmax = the Softmax operator over those logits in the same launch (<= 1024 outputs), 30 launches in a
+    row while two other streams keep the memory system busy: every row sums to 1 and equals softmax of the logits the same launch wrote."""
+    M, K, N = shape
+    rng = np.random.default_rng(77 + M + K + N)
+    w = (rng.standard_normal((N, K)) * np.sqrt(1.0 / K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    import os
+    os.environ["SABER_HIP_FC_F32_SPLITK"] = "1"      # opt-in (read by set_weights): measured no faster than the two launches, profiles/r06/fc_tail.txt
+    try:
+        fc = S.SaberFc(False).init(M, N, K, w, b, L.F32)
+    finally:
+        del os.environ["SABER_HIP_FC_F32_SPLITK"]
+    assert fc.algo() == "fc_f32_splitk_16xk4", fc.algo()
+    want = O.fc_f32(x, w, b)
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    xd = dev(x)
+    first = None
+    for it in range(20):
+        y.fill_(float(it))
+        fc.dispatch(xd, y)
+        got = host(y)
+        if first is None:
+            first = got
+            a = np.abs(got - want).max() / np.abs(want).max()
+            e = (np.abs(got - want) / (np.abs(want) + np.abs(want).mean())).max()
+            assert a <= FP32_RTOL and e <= FP32_RTOL, (shape, a, e)
+        assert np.array_equal(got, first), (shape, it)
+    fc1 = S.SaberFc(False).init(M, N, K, w, b, L.F32)
+    assert fc1.algo() == "fc_f32_small_16xk4"
+    y1 = torch.empty_like(y)
+    fc1.dispatch(xd, y1)
+    assert np.abs(host(y1) - first).max() <= 2e-5 * np.abs(want).max()
+    if N > 1024:
+        return
+    big_a = torch.randn(32 << 20, device="cuda")
+    big_b = torch.empty_like(big_a)
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    p = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    xs = [dev(rng.standard_normal((M, K)).astype(np.float32)) for _ in range(4)]
+    for it in range(30):
+        for st in side:
+            with torch.cuda.stream(st):
+                big_b.copy_(big_a)
+        y.fill_(1e30)
+        p.fill_(-1.0)
+        fc.dispatch_softmax(xs[it % 4], y, p)
+        torch.cuda.current_stream().synchronize()
+        sm = torch.softmax(y, 1)
+        assert torch.allclose(p.sum(1), torch.ones(M, device="cuda"), atol=1e-5) and (p - sm).abs().max() <= 1e-4 * sm.max(), (shape, it)
+    torch.cuda.synchronize()
+    wantp = O.softmax_f32(O.fc_f32(host(xs[1]), w, b))
+    fc.dispatch_softmax(xs[1], y, p)
+    assert np.abs(host(p) - wantp).max() <= FP32_RTOL * wantp.max()
+
+
 @pytest.mark.parametrize("fenced", [False, True], ids=["write_through", "fenced"])
 def test_fc_i8_softmax_hand_off_under_concurrent_load(fenced):
     """(round-5 advisor) the fc + softmax launch hands its logits to the last-arriving workgroup through memory across XCDs with
