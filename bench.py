@@ -435,11 +435,11 @@ def main():
         else:
             roof = dict(bound="mfma", achieved=round(dom["mfma_frac"] * dom["mfma_peak"], 2), peak=dom["mfma_peak"], unit="TFLOP/s",
                         frac=dom["mfma_frac"], traffic=None)
-        # HBM traffic of that kernel from the committed PMC passes (profiles/r05/traffic.json: per launch, FETCH_SIZE doubled per
+        # HBM traffic of that kernel from the committed PMC passes (profiles/r06/traffic.json: per launch, FETCH_SIZE doubled per
         # the gfx950 correction) - only while the sources it was measured on are unchanged (src_sha): a stale counter is worse than none
         try:
             tr = None
-            for rd in ("r05", "r04", "r03"):      # the newest profile round whose sources still match
+            for rd in ("r06", "r05", "r04", "r03"):      # the newest profile round whose sources still match
                 tp = os.path.join(ROOT, "profiles", rd, "traffic.json")
                 if os.path.exists(tp):
                     tr = json.load(open(tp))

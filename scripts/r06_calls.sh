@@ -113,6 +113,17 @@ fctail)     # the FP32 classifier tail: split-K fc (+ softmax in the launch) aga
     SABER_HIP_FC_F32_SPLITK=0 python bench.py --precision fp32 --batch $b --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/plain_b$b.json 2> $O/plain_b${b}_per_op.txt
   done
   for f in split_b8 plain_b8 split_b1 plain_b1; do echo $f; python -c "import json;d=json.load(open('$O/$f.json'));print(d['value'],d['ms_per_step'],d['config']['launches'])"; tail -n 4 $O/${f}_per_op.txt; done ;;
+final)      # the round's evidence run, one box: GPU test suite, the INT8 profile (tune cache, traces, PMC), every BASELINE configuration, the other models' profiles
+  mkdir -p gpurun_out/final
+  (timeout 1200 python -m pytest tests -m gpu -q --maxfail=20 -p no:cacheprovider 2>&1 | tail -15) > gpurun_out/final/pytest.txt
+  bash scripts/profile_r06.sh r06 > gpurun_out/final/profile_r06.log 2>&1
+  cp gpurun_out/r06/tune.json profiles/tune.json      # the remaining runs of this script apply this selection
+  bash scripts/run_all_configs.sh > gpurun_out/final/configs_summary.txt 2>&1
+  cp gpurun_out/configs.jsonl gpurun_out/r06/configs.jsonl
+  bash scripts/profile_model.sh r06_resnet101_int8 --model resnet101 > gpurun_out/final/p101.log 2>&1
+  bash scripts/profile_model.sh r06_resnet50_fp32 --precision fp32 > gpurun_out/final/pfp32.log 2>&1
+  bash scripts/profile_model.sh r06_vgg16_fp32 --model vgg16 --precision fp32 > gpurun_out/final/pvgg.log 2>&1
+  tail -4 gpurun_out/final/pytest.txt; tail -12 gpurun_out/final/configs_summary.txt ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;
