@@ -124,6 +124,15 @@ final)      # the round's evidence run, one box: GPU test suite, the INT8 profil
   bash scripts/profile_model.sh r06_resnet50_fp32 --precision fp32 > gpurun_out/final/pfp32.log 2>&1
   bash scripts/profile_model.sh r06_vgg16_fp32 --model vgg16 --precision fp32 > gpurun_out/final/pvgg.log 2>&1
   tail -4 gpurun_out/final/pytest.txt; tail -12 gpurun_out/final/configs_summary.txt ;;
+driver)     # what the driver runs at round end: smoke(), then the bench with its exact flags
+  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -3 $O/smoke.txt
+  ( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err ) 2> $O/time.txt; grep real $O/time.txt
+  python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r06_driver/bench_driver.json"))
+print(d["metric"], d["value"], d["value_p50"], d["ms_per_step"], d["config"]["kernel_selection"], d["config"]["launches"], d["roofline"]["traffic"], d["roofline"].get("traffic_src_sha"), d["cpu_baseline"]["value"], d["batch1"]["p50_ms"])
+PY
+  ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;
