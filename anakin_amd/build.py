@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsaber_mi355x.so")
 SOURCES = ["conv_igemm.hip", "elementwise.hip", "fc_small.hip", "conv1x1_chain.hip", "conv_chain_coop.hip", "conv_stage_coop.hip", "stage_xcd.hip", "conv3x3_b3h.hip", "conv1x1_pw.hip", "conv1x1_pwk.hip", "conv_stem_f32.hip", "fc_f32_splitk.hip"] + \
-    ["api_%s.hip" % n for n in ("conv", "autotune", "ops", "chain", "stage", "net", "net_optimize", "net_autotune", "capture", "gemm")] + \
+    ["api_%s.hip" % n for n in ("conv", "autotune", "ops", "chain", "stage", "net", "net_optimize", "net_autotune", "capture", "gemm", "streams")] + \
     ["igemm_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1), (1, 2), (1, 3), (2, 3), (3, 3)]] + \
     ["igemm_dma_m%d_e%d.hip" % me for me in [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 3)]] + \
     ["halo_e%d.hip" % e for e in range(4)] + ["img_e%d.hip" % e for e in (0, 1, 3)] + ["stem_e%d.hip" % e for e in range(4)] + ["stem_pool.hip"]

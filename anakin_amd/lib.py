@@ -50,7 +50,7 @@ SYMBOLS = [
     "saber_hip_net_autotune", "saber_hip_net_destroy",
     "saber_hip_net_add_relu_f32", "saber_hip_net_add_activation_f32", "saber_hip_net_bind_tensor", "saber_hip_net_num_tensors", "saber_hip_net_tensor_bytes",
     "saber_hip_capture_begin", "saber_hip_capture_end", "saber_hip_capture_active", "saber_hip_net_tensor_of_ptr",
-    "saber_hip_net_compact_arena", "saber_hip_net_arena_compacted",
+    "saber_hip_net_compact_arena", "saber_hip_net_arena_compacted", "saber_hip_serving_streams",
 ]
 
 
@@ -237,6 +237,7 @@ def load():
     lib.saber_hip_capture_end.argtypes = [C.POINTER(P)]
     lib.saber_hip_capture_active.argtypes = []
     lib.saber_hip_net_tensor_of_ptr.argtypes = [P, P]
+    lib.saber_hip_serving_streams.argtypes = [I, C.POINTER(P), C.POINTER(I)]
     _lib = lib
     return lib
 

@@ -504,14 +504,19 @@ def main():
         # ---------------- serving throughput: several independent batches in flight (extra, NOT `value`) ----------
         # The forward pass is a chain of 35 dependent launches that leaves most CUs idle most of the time; a server with
         # more than one request queue (the reference's Worker runs one Net per thread, framework/core/worker.h) fills them
-        # with another batch. Two / three op lists with the same kernel selection, each a hipGraph on its own stream.
+        # with another batch. Two / three / four op lists with the same kernel selection, each a hipGraph on its own stream.
         multi = None
         if not args.no_b1 and world == 1 and args.precision == "int8":
             try:
                 multi = {}
                 extra, streams = [], []
-                for i in range(3):
-                    st = torch.cuda.Stream()
+                # streams that do not share a hardware queue (saber_hip_serving_streams: the runtime serves every stream of the process from
+                # four queues assigned by creation order - rounds 4 / 5 measured streams_3 BELOW streams_2 because the third stream of this
+                # process happened to share the first one's queue; profiles/r06/multi_stream_curve.txt)
+                from anakin_amd.streams import serving_streams
+                picked, distinct_queues = serving_streams(4)
+                for i in range(4):
+                    st = picked[i]
                     with torch.cuda.stream(st):
                         # every net of this leg runs BESIDE the others: built with SABER_HIP_NET_SHARED_DEVICE (no persistent stage launch,
                         # no cooperating-workgroup chains, no split-K through an XCD's L2 - selected out, not found out by a time-out)
@@ -541,7 +546,7 @@ def main():
                                 n_.run()
                                 n_.capture()
                         torch.cuda.synchronize()
-                    for k in (2, 3):
+                    for k in (2, 3, 4):
                         group = list(zip(extra[:k], streams[:k]))
 
                         def round_():
@@ -562,6 +567,7 @@ def main():
                 arena_now = extra[0].arena_bytes()
                 multi["coop_fallbacks"] = sum(n_.coop_fallbacks() for n_ in extra)
                 multi["launches_per_net"] = extra[0].num_launches()
+                multi["distinct_hardware_queues"] = distinct_queues
                 multi["arena_mb_per_net"] = round(arena_now / 2**20, 1)
                 multi["arena_mb_per_net_every_edge"] = round(arena_full / 2**20, 1)
                 multi["note"] = "independent batch-%d forward passes in flight on separate streams; each batch's latency is ms_per_round" % B

@@ -576,6 +576,16 @@ int saber_hip_capture_active(void);
 /* captured lists: id of the NEWEST tensor the pass saw at `ptr` (for an output address: the tensor the last writer produced), -1: none */
 int saber_hip_net_tensor_of_ptr(const saber_hip_net_t* net, const void* ptr);
 
+/* ---- serving: streams that do not share a hardware queue --------------------------------------------------------------------
+ * Replaces, for a server that keeps several Nets in flight on one device, the streams Env<T> hands every Context<T>
+ * (saber/core/context.h:38-77, saber/core/env.h; one Net per Worker pool thread: framework/core/worker.h). The HIP runtime serves all
+ * streams of a process from GPU_MAX_HW_QUEUES (default 4) hardware queues assigned by creation order; two Nets whose streams share a
+ * queue run one after the other. Fills out[0 .. n) with non-blocking streams of the CURRENT device taken round-robin from a per-device
+ * set of up to FOUR streams no two of which share a queue (found once per device by overlapping spin kernels, ~3 ms, on an otherwise
+ * idle device: call it before the serving threads start); *distinct (may be null) = the size of that set. Streams with the same index
+ * modulo *distinct are the same stream: passes enqueued on it run in order. The library owns the streams (never destroy them). */
+int saber_hip_serving_streams(int n, saber_hip_stream_t* out, int* distinct);
+
 #ifdef __cplusplus
 }
 #endif

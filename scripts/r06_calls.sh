@@ -133,6 +133,39 @@ d=json.load(open("gpurun_out/r06_driver/bench_driver.json"))
 print(d["metric"], d["value"], d["value_p50"], d["ms_per_step"], d["config"]["kernel_selection"], d["config"]["launches"], d["roofline"]["traffic"], d["roofline"].get("traffic_src_sha"), d["cpu_baseline"]["value"], d["batch1"]["p50_ms"])
 PY
   ;;
+worker_streams)  # Worker<MI355X, INT8> with the plans' streams from saber_hip_serving_streams (distinct hardware queues) against a fresh stream per plan
+  python - <<'PY'
+import os, subprocess, tempfile, sys
+sys.path.insert(0, os.getcwd())
+from anakin_amd import workloads as W
+from integration import net_model as NM
+exe = os.path.join("integration", "_build", "test_net_mi355x.bin")
+model = W.framework_model(W.build_model("resnet50"), "int8")
+scales = W.calibrate(model, W.make_input(2))
+out = []
+with tempfile.TemporaryDirectory() as td:
+    base = W.build_model("resnet50")
+    mt, wb = NM.write_model(base, dict(scales), 8, td, "int8", calibrator_config=True)
+    W.make_input(8).tofile(os.path.join(td, "input.bin"))
+    for rep in range(2):
+        for serving in ("0", "1"):
+            env = dict(os.environ, SABER_MI355X_NET_PLAN_SERVING_STREAMS=serving)
+            for threads in (2, 3, 4, 6, 8):
+                r = subprocess.run([os.path.abspath(exe), mt, wb, os.path.join(td, "input.bin"), td, "worker", str(threads), "900"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", cwd=td, env=env, timeout=600)
+                wt = open(os.path.join(td, "worker.txt")).read().split()
+                f = {wt[i]: wt[i + 1] for i in range(0, len(wt) - 1, 2)}
+                out.append("rep %d serving_streams %s worker threads %d: %s images/s median %s ms max %s ms mismatches %s" % (rep, serving, threads, f["images_per_s"], f["median_ms"], f["max_ms"], f["mismatches"]))
+                print(out[-1], flush=True)
+open("gpurun_out/r06_worker_streams/worker_serving_streams_ab.txt", "w").write("\n".join(out) + "\n")
+PY
+  ;;
+streams)    # images/s against the number of independent passes in flight
+  python scripts/probe/multi_stream_curve.py > $O/multi_stream_curve.txt 2>&1; grep "^batch" $O/multi_stream_curve.txt
+  python scripts/probe/multi_stream_curve.py --pick > $O/multi_stream_curve_pick.txt 2>&1; echo "picked, default queues"; grep "^batch" $O/multi_stream_curve_pick.txt
+  GPU_MAX_HW_QUEUES=8 python scripts/probe/multi_stream_curve.py --pick > $O/multi_stream_curve_pick_q8.txt 2>&1; echo "picked, GPU_MAX_HW_QUEUES=8"; grep "^batch" $O/multi_stream_curve_pick_q8.txt
+  if [ -n "${STREAMS_ALL:-}" ]; then for q in 2 8 16; do   # is the step down past three (batch 8) / four (batch 4) passes the runtime's four hardware queues?
+    GPU_MAX_HW_QUEUES=$q python scripts/probe/multi_stream_curve.py > $O/multi_stream_curve_q$q.txt 2>&1; echo "GPU_MAX_HW_QUEUES=$q"; grep "^batch" $O/multi_stream_curve_q$q.txt
+  done; fi ;;
 pytest)     # a subset of the GPU tests: bash scripts/r06_calls.sh pytest <pytest args...>
   python -m pytest -x -q "$@" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt ;;
 *) echo "unknown step $STEP"; exit 2 ;;
