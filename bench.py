@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet101", "vgg16"])
     ap.add_argument("--precision", default="int8", choices=["int8", "fp32"])
+    ap.add_argument("--model-file", default=None,
+                    help="an `.anakin.bin` (the reference's model format: protobuf wire format, read by anakin_amd/anakin_bin.py) holding the --model "
+                         "network as original operators with raw BatchNorm / Scale blobs; replaces the seeded synthetic weights (the default, and what "
+                         "the driver times: there is no model file on the GPU box). `--write-model-file PATH` writes the synthetic model out first.")
+    ap.add_argument("--write-model-file", default=None, help="write the synthetic --model network as an `.anakin.bin` to this path, then use it as --model-file")
     ap.add_argument("--graph", default="framework", choices=["framework", "caffe"],
                     help="INT8: 'framework' = the op list the reference's own optimiser + edge rules emit (workloads.framework_spec: "
                          "stride-up, conv1 -> s8, INT8 tail; what Net<MI355X> runs), 'caffe' = the round-1/2 list (plain Caffe topology)")
@@ -258,6 +263,17 @@ def main():
 
     B = args.batch
     model = W.build_model(args.model)
+    if args.write_model_file:
+        from anakin_amd import anakin_bin
+        if rank == 0:
+            anakin_bin.write_model(model, args.write_model_file, batch=B)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        args.model_file = args.write_model_file
+    if args.model_file:
+        from anakin_amd import anakin_bin
+        model = dict(anakin_bin.load_model(args.model_file), name=args.model)
     if args.precision == "int8" and args.graph == "framework":
         model = W.framework_model(model, "int8")
     x = W.make_input(B, seed=1234 + rank)

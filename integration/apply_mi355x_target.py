@@ -83,7 +83,11 @@ def patch_framework(ref, dst):
     shutil.copy(os.path.join(HERE, "mi355x", "framework", "mi355x_pblock.h"), os.path.join(F, "core"))
     shutil.copy(os.path.join(HERE, "mi355x", "framework", "text_model_parser.cpp"),
                 os.path.join(F, "model_parser", "parser", "parser.cpp"))
-    os.remove(os.path.join(F, "model_parser", "parser", "model_io.cpp"))
+    # model_io.cpp (NodeIO over protoc-generated classes) gives way to the wire-format reader / writer: `.anakin.bin` without libprotobuf
+    shutil.copy(os.path.join(HERE, "mi355x", "framework", "anakin_bin_parser.cpp"),
+                os.path.join(F, "model_parser", "parser", "model_io.cpp"))
+    shutil.copy(os.path.join(HERE, "mi355x", "framework", "anakin_bin_model.h"),
+                os.path.join(F, "model_parser", "parser", "anakin_bin_model.h"))
     insert(os.path.join(F, "core", "parameter.h"), "#endif",
            "#ifdef USE_MI355X_PLACE\n#include \"framework/core/mi355x_pblock.h\"\n#endif\n\n", after=False, count=-1)
     insert(os.path.join(F, "core", "data_types.h"), "\tANAKIN_PBLOCK_TO_TYPE_ID(X86, anakin_block)\n#endif\n",

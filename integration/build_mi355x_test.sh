@@ -38,7 +38,7 @@ FW="$F/graph/graph.cpp $F/graph/node.cpp $F/graph/llvm/scheduler.cpp $F/graph/ll
     $F/graph/llvm/optimizer/parall_scheduler.cpp $F/core/functor.cpp $F/core/singleton.cpp $F/core/net/net.cpp
     $F/core/net/operator_func.cpp $F/core/net/calibrator_parse.cpp $F/core/net/calibrator_factory.cpp
     $F/core/net/auto_layout_config.cpp $F/core/net/worker.cpp $F/core/net/entropy_calibrator.cpp $F/core/net/batch_stream.cpp $F/core/operator/operator.cpp $F/core/operator/operator_attr.cpp
-    $F/core/operator/operator_help.cpp $F/model_parser/parser/parser.cpp $F/utils/parameter_fusion.cpp $F/utils/data_common.cpp"
+    $F/core/operator/operator_help.cpp $F/model_parser/parser/parser.cpp $F/model_parser/parser/model_io.cpp $F/utils/parameter_fusion.cpp $F/utils/data_common.cpp"
 OPS=$(python - <<PY
 import sys
 sys.path.insert(0, "$HERE")

@@ -21,7 +21,8 @@
 //     calibrator <net_config.txt> <calibrator.txt>     (Graph::load_calibrator_config, graph.cpp:555-571, instead of prec / scale)
 // The graph is built with the reference's own public construction API (Graph::AddOp / AddOpAttr / Freeze, graph.h:97-139 - the
 // route of test/framework/net/net_subgraph_test.cpp); weight blocks come from GraphGlobalMem::new_block as in the protobuf parser
-// (parser.cpp / model_io.cpp). save() and the in-memory-buffer load() are not provided (Status failure).
+// (parser.cpp / model_io.cpp). Every other file is taken for an `.anakin.bin`: load / save / load(buffer) / InspectAnakin at the end of this
+// file hand it to anakin_bin_parser.cpp (the protobuf wire format without a protobuf library).
 // Reference-side glue of the MI355X target's TEST BUILD (integration/), not part of the product library.
 #include "framework/model_parser/parser/parser.h"
 
@@ -33,13 +34,14 @@
 
 #include "framework/graph/graph.h"
 #include "framework/graph/graph_global_mem.h"
+#include "framework/model_parser/parser/anakin_bin_model.h"
 
 namespace anakin {
 namespace parser {
 
 using namespace anakin::saber;
 
-static Status unsupported() { return Status::ANAKINFAIL("text model parser: only load(path) is provided (no protobuf in this build)"); }
+static Status unsupported() { return Status::ANAKINFAIL("text model parser: a text model is loaded from its path only"); }
 
 template <typename Ttype, Precision Ptype>
 Status load_text_model(graph::Graph<Ttype, Ptype>* graph, const std::string& path) {
@@ -210,23 +212,65 @@ Status load_text_model(graph::Graph<Ttype, Ptype>* graph, const std::string& pat
     return Status::OK();
 }
 
+// ---- the interface of parser.h: a file that starts with the text form's `precision` record goes to the loader above, anything else is an
+// `.anakin.bin` (protobuf wire format; anakin_bin_parser.cpp, in model_io.cpp's place) ---------------------------------------------------
 template <typename Ttype, Precision Ptype>
-Status load(graph::Graph<Ttype, Ptype>* graph, std::string& model_path) { return load_text_model(graph, model_path); }
+Status load_anakin_bin(graph::Graph<Ttype, Ptype>* graph, const char* data, size_t len);
 template <typename Ttype, Precision Ptype>
-Status load(graph::Graph<Ttype, Ptype>* graph, const char* model_path) { return load_text_model(graph, std::string(model_path)); }
+Status save_anakin_bin(graph::Graph<Ttype, Ptype>* graph, const char* path);
+
+static bool is_text_model(const char* data, size_t len) {
+    size_t i = 0;
+    while (i < len && (data[i] == ' ' || data[i] == '\n' || data[i] == '\t' || data[i] == '\r')) ++i;
+    if (i < len && data[i] == '#') return true;
+    return len - i >= 9 && std::memcmp(data + i, "precision", 9) == 0;
+}
+static bool read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) return false;
+    out.resize((size_t)f.tellg());
+    f.seekg(0);
+    f.read(&out[0], (std::streamsize)out.size());
+    return f.good() || out.empty();
+}
+
 template <typename Ttype, Precision Ptype>
-Status load(graph::Graph<Ttype, Ptype>*, const char*, size_t) { return unsupported(); }
+Status load(graph::Graph<Ttype, Ptype>* graph, const char* model_path) {
+    std::string head;
+    {
+        std::ifstream f(model_path, std::ios::binary);
+        if (!f) return Status::ANAKINFAIL((std::string("model parser: cannot open ") + model_path).c_str());
+        head.resize(64);
+        f.read(&head[0], 64);
+        head.resize((size_t)f.gcount());
+    }
+    if (is_text_model(head.data(), head.size())) return load_text_model(graph, std::string(model_path));
+    std::string bytes;
+    if (!read_file(model_path, bytes)) return Status::ANAKINFAIL((std::string("model parser: cannot read ") + model_path).c_str());
+    return load_anakin_bin(graph, bytes.data(), bytes.size());
+}
 template <typename Ttype, Precision Ptype>
-Status save(graph::Graph<Ttype, Ptype>*, std::string&) { return unsupported(); }
+Status load(graph::Graph<Ttype, Ptype>* graph, std::string& model_path) { return load(graph, model_path.c_str()); }
 template <typename Ttype, Precision Ptype>
-Status save(graph::Graph<Ttype, Ptype>*, const char*) { return unsupported(); }
+Status load(graph::Graph<Ttype, Ptype>* graph, const char* buffer, size_t len) {      // an `.anakin.bin` in memory (parser.cpp:244-249)
+    if (is_text_model(buffer, len)) return unsupported();
+    return load_anakin_bin(graph, buffer, len);
+}
+template <typename Ttype, Precision Ptype>
+Status save(graph::Graph<Ttype, Ptype>* graph, const char* model_path) { return save_anakin_bin(graph, model_path); }
+template <typename Ttype, Precision Ptype>
+Status save(graph::Graph<Ttype, Ptype>* graph, std::string& model_path) { return save_anakin_bin(graph, model_path.c_str()); }
 
 bool InspectAnakin(const std::string& path) {
-    std::ifstream f(path);
-    std::string tok;
-    return f.is_open() && (f >> tok) && tok == "precision";
+    std::string bytes;
+    if (!read_file(path, bytes)) return false;
+    return InspectAnakin(bytes.data(), bytes.size());
 }
-bool InspectAnakin(const char*, size_t) { return false; }
+bool InspectAnakin(const char* buffer, size_t len) {
+    if (is_text_model(buffer, len)) return true;
+    ::anakin_bin::Graph g;
+    return ::anakin_bin::decode((const uint8_t*)buffer, len, g) && !g.nodes.empty();
+}
 
 #define MI355X_PARSER_INSTANCE(T, P)                                              \
     template Status load<T, P>(graph::Graph<T, P>*, std::string&);                \

@@ -56,6 +56,7 @@
 #include "saber/core/tensor.h"
 #include "saber/funcs/timer.h"
 #include "framework/graph/graph.h"
+#include "framework/model_parser/parser/anakin_bin_model.h"
 #include "framework/core/operator/operator.h"
 #include "framework/core/net/calibrator_parse.h"
 #define private public
@@ -76,6 +77,27 @@ static const char* dtype_name(DataType t) {
 }
 static const char* layout_name(LayoutType l) { return l == Layout_NHWC ? "nhwc" : (l == Layout_NCHW ? "nchw" : "other"); }
 
+// SABER_TEST_CALIBRATOR="<net_config.txt> <calibrator.txt>": Graph::load_calibrator_config after the load (graph.cpp:555-571) - what the
+// text form's `calibrator` record does, for an `.anakin.bin`, which has no place for the two paths
+template <typename G>
+static void apply_calibrator_env(G& graph) {
+    const char* e = getenv("SABER_TEST_CALIBRATOR");
+    if (!e) return;
+    std::istringstream is(e);
+    std::string cfg, table;
+    if (is >> cfg >> table) graph.load_calibrator_config(cfg, table);
+}
+
+template <Precision P>
+static int run_savebin(const std::string& model_path, const std::string& out_path) {
+    Graph<MI355X, P> graph;
+    Status st = graph.load(model_path);
+    if (!st) { fprintf(stderr, "Graph::load(%s) failed: %s\n", model_path.c_str(), st.info()); return 2; }
+    st = graph.save(out_path);
+    if (!st) { fprintf(stderr, "Graph::save(%s) failed: %s\n", out_path.c_str(), st.info()); return 2; }
+    return 0;
+}
+
 template <Precision P>
 static int run(const std::string& model_path, const std::vector<float>& input, const std::string& outdir, int iters) {
     typedef Graph<MI355X, P> graph_t;
@@ -85,6 +107,7 @@ static int run(const std::string& model_path, const std::vector<float>& input, c
     // GraphGlobalMem, Freeze, then SetOpPrec / SetVarScale or Graph::load_calibrator_config as the model says
     Status st = graph->load(model_path);
     if (!st) { fprintf(stderr, "Graph::load(%s) failed: %s\n", model_path.c_str(), st.info()); return 2; }
+    apply_calibrator_env(*graph);
     const std::string in_name = graph->get_ins()[0];
 
     graph->Optimize();      // the reference's fusion pass + stride-up + schedulers + memory planner
@@ -618,12 +641,33 @@ int main(int argc, char** argv) {
         (void)hipSetDeviceFlags(m == "blocking" ? hipDeviceScheduleBlockingSync : (m == "yield" ? hipDeviceScheduleYield : hipDeviceScheduleSpin));
     }
     if (!worker_mode || getenv("SABER_TEST_LOGFILES")) logger::init(argv[0]);
-    std::ifstream fm(argv[1]);
+    // the model: the text form (its `precision` record says what to instantiate) or an `.anakin.bin` (protobuf wire format; the nodes'
+    // bit_type says it - any INT8 node: Net<MI355X, INT8> - unless SABER_TEST_PRECISION does)
     std::string line, precision = "int8";
-    while (std::getline(fm, line)) {
-        std::istringstream is(line);
-        std::string k, v;
-        if ((is >> k >> v) && k == "precision") precision = v;
+    {
+        std::ifstream fb(argv[1], std::ios::binary | std::ios::ate);
+        if (!fb) { fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
+        std::string bytes((size_t)fb.tellg(), '\0');
+        fb.seekg(0);
+        fb.read(&bytes[0], (std::streamsize)bytes.size());
+        size_t i0 = 0;
+        while (i0 < bytes.size() && isspace((unsigned char)bytes[i0])) ++i0;
+        const bool text = i0 < bytes.size() && (bytes[i0] == '#' || bytes.compare(i0, 9, "precision") == 0);
+        if (text) {
+            std::istringstream fm(bytes);
+            while (std::getline(fm, line)) {
+                std::istringstream is(line);
+                std::string k, v;
+                if ((is >> k >> v) && k == "precision") precision = v;
+            }
+        } else {
+            anakin_bin::Graph g;
+            if (!anakin_bin::decode((const uint8_t*)bytes.data(), bytes.size(), g)) { fprintf(stderr, "%s: not a text model and not a GraphProto\n", argv[1]); return 2; }
+            precision = "fp32";
+            for (auto& n : g.nodes)
+                if (n.bit_type == anakin_bin::DT_INT8) precision = "int8";
+        }
+        if (const char* e = getenv("SABER_TEST_PRECISION")) precision = e;
     }
     auto slurp = [](const char* path) {
         std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -654,6 +698,12 @@ int main(int argc, char** argv) {
     if (argc > 6 && std::string(argv[5]) == "calibrate") {
         Env<MI355X>::env_init();
         return run_calibrate(argv[1], input, argv[4], atoi(argv[6]));
+    }
+    if (argc > 6 && std::string(argv[5]) == "savebin") {
+        // Graph::load(model) -> Graph::save(argv[6]): the frozen graph (precisions and edge scales set, NOT optimised) as an `.anakin.bin`
+        Env<MI355X>::env_init();
+        if (precision == "int8") return run_savebin<Precision::INT8>(argv[1], argv[6]);
+        return run_savebin<Precision::FP32>(argv[1], argv[6]);
     }
     const int iters = argc > 5 ? (std::string(argv[5]) == "dry" ? -1 : atoi(argv[5])) : 0;
     Env<MI355X>::env_init();

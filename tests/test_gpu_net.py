@@ -332,3 +332,91 @@ def test_entropy_calibrator_mi355x_writes_the_calibration_table(tmp_path):
         assert abs(float(val) - want[layer]) <= 2e-4 * want[layer] + 1e-6, (edge, float(val), want[layer])   # ("%f" in the file)
         checked += 1
     assert checked >= 60, checked
+
+
+@pytest.mark.parametrize("precision,route", [("int8", "calibrator_files"), ("int8", "scales_in_file"), ("fp32", "-")])
+def test_net_mi355x_from_an_anakin_bin(tmp_path, precision, route):
+    """The north star's "same .anakin.bin model": ResNet50 as an `.anakin.bin` (the reference's model format: original operators, raw BatchNorm /
+    Scale blobs; written by anakin_amd/anakin_bin.py, a well-formed GraphProto by the official protobuf runtime - tests/test_anakin_bin.py)
+    through Graph<MI355X>::load (the wire-format reader in model_io.cpp's place: integration/mi355x/framework/anakin_bin_parser.cpp) ->
+    Optimize -> Net::init -> prediction. INT8: every edge and the logits are the oracle's bits, with the precisions / scales either in the file
+    (bit_type + per-edge scale) or in the two calibrator text files next to it; FP32: every edge within 1e-4."""
+    from anakin_amd import anakin_bin as AB
+    assert os.path.exists(BIN), "integration/_build/test_net_mi355x.bin is missing: run __graft_entry__.build()"
+    batch = 2
+    model = W.build_model("resnet50")
+    x = W.make_input(batch)
+    scales = W.calibrate(model, x) if precision == "int8" else {}
+    d = str(tmp_path)
+    path = os.path.join(d, "resnet50.anakin.bin")
+    cal = route == "calibrator_files"
+    AB.write_model(model, path, batch=batch, precision=precision, scales=None if cal else scales)
+    x.tofile(os.path.join(d, "input.bin"))
+    env = dict(os.environ, SABER_TEST_PRECISION=precision)
+    env.pop("LD_PRELOAD", None)
+    if cal:
+        cfg, tab = NM.calibrator_files([dict(l, _bn=l["name"] in model["raw"]) for l in model["spec"]], scales, d)
+        env["SABER_TEST_CALIBRATOR"] = "%s %s" % (cfg, tab)
+    r = subprocess.run([BIN, path, "-", os.path.join(d, "input.bin"), d, "20"], env=env, capture_output=True, text=True, timeout=900, cwd=d)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "net ok" in r.stdout
+    ops = NM.parse_oplist(os.path.join(d, "oplist.txt"))
+    fm = W.framework_model(model, precision)
+    checked = 0
+    if precision == "int8":
+        ref = NO.run_int8(fm, dict(scales), x)
+        for o in ops:
+            if o["type"] in ("Input", "Output", "Split"):
+                continue
+            got, want = load(d, o, 0, o["outs"][0]), ref[o["name"]]
+            if o["type"] == "Softmax":
+                assert np.abs(got.reshape(batch, -1) - want.reshape(batch, -1)).max() <= 1e-4 * want.max()
+            else:
+                assert got.dtype == want.dtype and np.array_equal(got.reshape(want.shape), want), o["name"]
+            checked += 1
+        assert checked == 76
+        last = [o for o in ops if o["type"] == "Softmax"][0]
+        want = load(d, last, 0, last["outs"][0]).ravel()
+        assert np.array_equal(np.fromfile(os.path.join(d, "out_prob_out.bin"), np.float32), want)
+    else:
+        ref = NO.run_fp32(fm, x)
+        spec = {l["name"]: l for l in fm["spec"]}
+        for o in ops:
+            if o["type"] in ("Input", "Output", "Split", "Gather"):
+                continue
+            nm = spec[o["name"]]["eltwise"] if o["type"] == "ConvEltwise" else o["name"]
+            _fp32_check(load(d, o, 0, o["outs"][0]), ref[nm], nm)
+            checked += 1
+        assert checked >= 56
+        _fp32_check(np.fromfile(os.path.join(d, "out_prob_out.bin"), np.float32), ref["prob"], "prob")
+    plan = read_plan(d)
+    assert plan["plan"] == 1 and plan["captured_ops"] == (76 if precision == "int8" else 60), plan
+
+
+def test_ctypes_route_from_an_anakin_bin_answers_with_the_oracles_bits(tmp_path):
+    """anakin_bin.load_model(file) -> workloads.build_int8_net (the C ABI from Python; what `bench.py --model-file` does): ResNet50 INT8 batch 2
+    from the file's operators, weights folded by fold_bn, scales from the file's edges - every edge the oracle's bits on the in-memory model."""
+    from anakin_amd import anakin_bin as AB
+    model = W.build_model("resnet50")
+    x = W.make_input(2)
+    scales = W.calibrate(model, x)
+    path = str(tmp_path / "resnet50.anakin.bin")
+    AB.write_model(model, path, batch=2, precision="int8", scales=scales)
+    loaded = AB.load_model(path)
+    fm = W.framework_model(dict(loaded, name="resnet50"), "int8")
+    ref = NO.run_int8(W.framework_model(model, "int8"), dict(scales), x)
+    # the file carries the scales as 9-digit decimals' floats (the text route's records): calibrate() values rounded the same way
+    f9 = lambda v: float(np.float32(float("%.9g" % v)))      # noqa: E731
+    assert all(loaded["scales"][k] == f9(v) for k, v in scales.items())
+    net = W.build_int8_net(fm, dict(scales), 2)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    net.run()
+    torch.cuda.synchronize()
+    checked = 0
+    for nm in net.tensors:
+        if nm == "data" or nm not in ref or net.unwritten(nm) or nm == "prob":
+            continue
+        got = net.tensor(nm).cpu().numpy()
+        assert np.array_equal(got, ref[nm].reshape(got.shape)), nm
+        checked += 1
+    assert checked > 20
