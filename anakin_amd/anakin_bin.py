@@ -312,12 +312,14 @@ def _val(x):
 
 
 # ------------------------------------------------------------------------------------------------ workloads model <-> file
-def write_model(model, path, batch=1, hw=224, precision="fp32", scales=None, rename=None):
+def write_model(model, path, batch=1, hw=224, precision="fp32", scales=None, rename=None, calibration_in_file=True):
     """The network of a workloads model dict as the `.anakin.bin` the converter writes: ORIGINAL operators (Convolution / BatchNorm / Scale /
     ReLU / Pooling / Eltwise / Dense / Softmax) with raw, unfolded blobs, frozen (Input / Split / Output nodes named as Graph::Freeze names
     them, graph.cpp:237-296: `<var>split`, the output after its variable) - node for node the graph the text model of
     integration/net_model.py builds. precision "int8" + scales: nodes carry bit_type INT8 and the edges their activation scale (what
-    Graph::SetOpPrec / SetVarScale leave in the graph: graph.cpp:108-180); without scales an INT8 deployment adds the calibrator files."""
+    Graph::SetOpPrec / SetVarScale leave in the graph: graph.cpp:108-180); calibration_in_file=False leaves both out - the deployment then
+    hands the two calibrator text files to Graph::load_calibrator_config - but the INT8 Eltwise's coefficients still carry 1 / its output
+    scale (the INT8 eltwise ignores its output scale, saber_eltwise.cpp:85: the requantisation rides in the coefficients)."""
     R = rename or (lambda n: n)
     spec, params, raw = model["spec"], model["params"], model.get("raw", {})
     V = lambda n: n if n == "data" else R(n) + "_out"                                        # noqa: E731 - a layer's output variable
@@ -328,7 +330,7 @@ def write_model(model, path, batch=1, hw=224, precision="fp32", scales=None, ren
     def node(name, op, ins, outs, attrs, prec_of=None):
         # Graph::SetOpPrec is called for the node that carries the layer's name (and the Split behind it) - the BatchNorm / Scale / ReLU
         # nodes of a conv keep the default and take the conv's precision when Graph::Optimize fuses them (integration/net_model.py: `prec`)
-        bt = INT8 if int8 and op in ("Convolution", "Pooling", "Eltwise", "Dense") else FLOAT
+        bt = INT8 if int8 and calibration_in_file and op in ("Convolution", "Pooling", "Eltwise", "Dense") else FLOAT
         n = {"name": name, "Op": {"name": op}, "attr": {k: _val(v) for k, v in attrs.items()}, "bit_type": bt, "_ins": list(ins), "_outs": list(outs)}
         nodes.append(n)
         return n
@@ -388,7 +390,7 @@ def write_model(model, path, batch=1, hw=224, precision="fp32", scales=None, ren
             writer[v] = n["name"]
     layer_of_var = {V(l["name"]): l["name"] for l in spec}
     layer_of_var["data"] = "data"
-    var_scale = {v: f9(scales[layer_of_var[v]]) for v in layer_of_var if int8 and scales and layer_of_var[v] in scales}
+    var_scale = {v: f9(scales[layer_of_var[v]]) for v in layer_of_var if int8 and scales and calibration_in_file and layer_of_var[v] in scales}
     edges, outs = [], []           # (bottom node, top node, scale or None)
     for v, w in list(writer.items()):
         rd = readers.get(v, [])
@@ -401,7 +403,7 @@ def write_model(model, path, batch=1, hw=224, precision="fp32", scales=None, ren
             edges.append((w, rd[0], s))
         else:
             sp = v + "split"
-            prec = INT8 if int8 else FLOAT
+            prec = INT8 if int8 and calibration_in_file else FLOAT
             nodes.append({"name": sp, "Op": {"name": "Split"}, "attr": {"split_num": _val(len(rd))}, "bit_type": prec, "_ins": [v], "_outs": []})
             edges.append((w, sp, s))
             edges += [(sp, r, s) for r in rd]

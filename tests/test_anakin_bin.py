@@ -321,7 +321,7 @@ def test_reference_graph_load_reads_a_python_written_anakin_bin(M, tmp_path, pre
     r = _dry([mt, wb, os.path.join(dt, "input.bin"), dt, "dry"], dt)
     assert r.returncode == 0, r.stderr[-2000:]
     path = os.path.join(db, "model.anakin.bin")
-    AB.write_model(model, path, batch=1, precision=precision, scales=None if cal else scales)
+    AB.write_model(model, path, batch=1, precision=precision, scales=scales, calibration_in_file=not cal)
     extra = {"SABER_TEST_PRECISION": precision}
     if cal:
         extra["SABER_TEST_CALIBRATOR"] = "%s %s" % (os.path.join(dt, "net_config.txt"), os.path.join(dt, "calibrator.txt"))

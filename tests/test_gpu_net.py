@@ -350,7 +350,7 @@ def test_net_mi355x_from_an_anakin_bin(tmp_path, precision, route):
     d = str(tmp_path)
     path = os.path.join(d, "resnet50.anakin.bin")
     cal = route == "calibrator_files"
-    AB.write_model(model, path, batch=batch, precision=precision, scales=None if cal else scales)
+    AB.write_model(model, path, batch=batch, precision=precision, scales=scales, calibration_in_file=not cal)
     x.tofile(os.path.join(d, "input.bin"))
     env = dict(os.environ, SABER_TEST_PRECISION=precision)
     env.pop("LD_PRELOAD", None)
