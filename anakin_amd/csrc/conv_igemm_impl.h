@@ -99,6 +99,15 @@ __device__ __forceinline__ v4f mma_step3(const v4i (&a)[3], const v4i (&b)[3], v
 // two f32 -> packed (hi, mid, lo) bf16 pairs; every subtraction is exact, the conversions round to nearest even
 // (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef SABER_PROBE_NOSPLIT
+    // PROBE BUILD ONLY (scripts/probe/build_nosplit.py -> anakin_amd/build_probe/: never the product library; results are WRONG): the three
+    // planes cost one instruction - what every FP32 consumer would pay if its producer had written the edge as bf16 planes (round-5 verdict
+    // item 2(i)), with the edge still read as 4 bytes per value (planes would be 6): an upper bound of what plane edges can gain
+    h = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    m = h;
+    l = h;
+    return;
+#endif
     const v2f x = {x0, x1};
     const v2bf hb = __builtin_convertvector(x, v2bf);
     const v2f r1 = x - __builtin_convertvector(hb, v2f);

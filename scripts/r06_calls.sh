@@ -107,6 +107,21 @@ for f in ("fp32_b8","fp32_b1","fp32_b8_t1","fp32_b8_t2","fp32_b8_t3","fp32_b1_t2
     d=json.load(open("gpurun_out/r06_fp32/%s.json"%f)); print(f, d["value"], d["ms_per_step"], d["latency_ms"]["p50"], d["config"]["launches"])
 PY
   for f in fp32_b8 fp32_b1 fp32_b8_t1 fp32_b8_t2 fp32_b8_t3 fp32_b1_t2; do echo $f; grep -h "^ *0 " $O/${f}_per_op.txt; done ;;
+nosplit)    # what bf16-plane FP32 edges could gain AT MOST: the product library against the probe build whose plane split costs one instruction (wrong results, timing only)
+  for b in 8 1; do
+    python bench.py --precision fp32 --batch $b --steps 200 --no-b1 --no-cpu-baseline --per-op --retune > $O/fp32_b${b}_product.json 2> $O/fp32_b${b}_product_per_op.txt
+    SABER_MI355X_LIB=$PWD/anakin_amd/build_probe/libsaber_mi355x_nosplit.so python bench.py --precision fp32 --batch $b --steps 200 --no-b1 --no-cpu-baseline --per-op --retune > $O/fp32_b${b}_nosplit.json 2> $O/fp32_b${b}_nosplit_per_op.txt
+  done
+  SABER_MI355X_LIB=$PWD/anakin_amd/build_probe/libsaber_mi355x_nosplit.so python bench.py --model vgg16 --precision fp32 --batch 8 --steps 100 --no-b1 --no-cpu-baseline --retune > $O/vgg16_nosplit.json 2> $O/vgg16_nosplit.err
+  python bench.py --model vgg16 --precision fp32 --batch 8 --steps 100 --no-b1 --no-cpu-baseline --retune > $O/vgg16_product.json 2> $O/vgg16_product.err
+  python - <<'PY'
+import json
+for f in ("fp32_b8_product","fp32_b8_nosplit","fp32_b1_product","fp32_b1_nosplit","vgg16_product","vgg16_nosplit"):
+    try:
+        d=json.load(open("gpurun_out/r06_nosplit/%s.json"%f)); print(f, d["value"], d["ms_per_step"], d["config"]["launches"], d["config"]["kernel_selection"])
+    except Exception as e: print(f, "ERR", e)
+PY
+  ;;
 fctail)     # the FP32 classifier tail: split-K fc (+ softmax in the launch) against the one-workgroup-per-tile fc + the softmax launch
   for b in 8 1; do
     python bench.py --precision fp32 --batch $b --steps 200 --no-b1 --no-cpu-baseline --per-op > $O/split_b$b.json 2> $O/split_b${b}_per_op.txt
