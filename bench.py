@@ -664,6 +664,9 @@ def main():
                                 "3 pool threads x (Graph::load + load_calibrator_config + Optimize + Net with its captured plan on its own stream, "
                                 "SABER_HIP_NET_SHARED_DEVICE), timed once every pool thread serves; median / max = submit -> answer with at most "
                                 "2 x threads requests outstanding" % B)
+                            # four pool threads = the hardware's four concurrently served queues: the best Worker shape measured
+                            # (50 - 52k images/s; profiles/r06/worker_serving_streams_ab.txt)
+                            ref_list["worker_4_threads"] = worker_run("worker", 4, 600)
                             ref_list["worker_6_threads"] = worker_run("worker", 6, 600)
                             # the SAME per-thread Graph + Net<MI355X> + request (host tensor -> input, prediction(), output -> host tensor) from
                             # plain std::threads, without the reference's Worker / ThreadPool shell around it
