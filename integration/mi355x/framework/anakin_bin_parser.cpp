@@ -258,7 +258,9 @@ Status save_anakin_bin(graph::Graph<Ttype, Ptype>* graph, const char* path) {
                     if (!sc.empty()) { v.tensor.scale.type = ab::DT_FLOAT; v.tensor.scale.size = (int64_t)sc.size(); }
                 }
             } else {
-                return "attribute " + key + " of " + n.name + ": type " + ty + " has no model-file form";
+                // (a string list arrives here: PTuple<std::string> has no ANAKIN_TO_TYPE_ID in framework/core/data_types.h, its any reports an
+                // empty type name - the reference's own save falls into its last branch for it as well, model_io.cpp:447-455)
+                return "attribute " + key + " of " + n.name + ": type '" + ty + "' has no model-file form";
             }
         }
         return std::string();
