@@ -371,8 +371,11 @@ static int run_worker(const std::string& model_path, const std::vector<float>& i
             if (out.size() != 1 || out[0].valid_size() != first[0].valid_size() ||
                 !same_answer((const float*)out[0].data(), (const float*)first[0].data(), first[0].valid_size(), exact)) ++bad;
         };
+        // SABER_TEST_WINDOW=<k>: k x threads requests outstanding instead of 2 x (the client waits for its OLDEST request before it submits the
+        // next: a narrow window lets one slow answer stall the submissions)
+        const int window = (getenv("SABER_TEST_WINDOW") ? std::max(1, atoi(getenv("SABER_TEST_WINDOW"))) : 2) * threads;
         for (int r = 0; r < requests; ++r) {
-            if ((int)fly.size() >= 2 * threads) reap();
+            if ((int)fly.size() >= window) reap();
             const auto ts = clk::now();
             fly.emplace_back(worker.sync_prediction(ins), ts);
         }

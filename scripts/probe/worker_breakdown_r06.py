@@ -9,7 +9,8 @@ with tempfile.TemporaryDirectory() as td:
     base = W.build_model("resnet50")
     mt, wb = NM.write_model(base, dict(scales), 8, td, "int8", calibrator_config=True)
     W.make_input(8).tofile(os.path.join(td, "input.bin"))
-    for mode, threads in (("worker", 4), ("worker_pinned", 4), ("worker", 3), ("threads", 4)):
-        r = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, mode, str(threads), "1200"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", cwd=td, timeout=600)
-        print("=====", mode, threads)
+    for mode, threads, window in (("worker", 4, 2), ("worker", 4, 4), ("worker", 4, 8), ("worker", 6, 4), ("worker", 8, 4), ("worker", 3, 4), ("worker_pinned", 4, 4), ("threads", 4, 2)):
+        r = subprocess.run([exe, mt, wb, os.path.join(td, "input.bin"), td, mode, str(threads), "1200"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, errors="replace", cwd=td, timeout=600,
+                           env=dict(os.environ, SABER_TEST_WINDOW=str(window)))
+        print("=====", mode, threads, "window %d x threads" % window)
         print("\n".join(l for l in r.stdout.split("\n") if "us" in l or "ok" in l or "per request" in l)[-3000:])
