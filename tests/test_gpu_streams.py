@@ -35,16 +35,16 @@ def test_serving_streams_overlap_pairwise_and_all_together():
     cyc = 100_000
     ms = min(_spin_ms([streams[0]], cyc) for _ in range(3))
     cyc = int(cyc * 0.3 / ms)
-    solo = min(_spin_ms([streams[0]], cyc) for _ in range(3))
+    solo = min(_spin_ms([streams[0]], cyc) for _ in range(5))
     for i in range(distinct):
         for j in range(i + 1, distinct):
             both = min(_spin_ms([streams[i], streams[j]], cyc) for _ in range(3))
-            assert both < 1.4 * solo, (i, j, solo, both)
+            assert both < 1.5 * solo, (i, j, solo, both)
     every = min(_spin_ms(streams[:distinct], cyc) for _ in range(3))
-    assert every < 1.5 * solo, (distinct, solo, every)
+    assert every < 1.6 * solo, (distinct, solo, every)
     # the same stream twice does serialise: what the probe tells apart
     twice = min(_spin_ms([streams[0], streams[distinct]], cyc) for _ in range(3))
-    assert twice > 1.7 * solo, (solo, twice)
+    assert twice > 1.6 * solo, (solo, twice)
 
 
 @pytest.mark.gpu
