@@ -91,3 +91,68 @@ def test_bench_gpus_2_spawns_its_own_ranks_and_the_gather_is_cheap():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline", "--no-b1"],
                          capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=600)
     assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE is 1" in (bad.stdout + bad.stderr)
+
+
+RCCL_ONE_RANK = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["REPO_ROOT"])
+from anakin_amd import shard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"], world_size=1, rank=0, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(5)
+steps = [torch.randn(8, 1000, generator=g).cuda() for _ in range(40)]
+# the blocking gather (world 1 goes through all_gather_into_tensor when asked to: call the collective itself)
+out = torch.empty_like(steps[0])
+dist.all_gather_into_tensor(out, steps[0])
+torch.cuda.synchronize()
+assert torch.equal(out, steps[0])
+# per-step asynchronous gather (double-buffered), on a side stream like bench.py's compute stream
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    ag = shard.AsyncLogitGather(steps[0], 1)
+    for i, x in enumerate(steps):
+        ag.step(x)
+        if i:
+            ag_prev = ag.latest()
+            assert ag_prev is not None
+    ag.flush()
+    st.synchronize()
+    assert torch.equal(ag.latest(), steps[-1])
+    # the amortised gather: one collective per 16 steps + the remainder ring (40 = 2 x 16 + 8)
+    bg = shard.BatchedLogitGather(steps[0], 1, every=16)
+    seen = []
+    for i, x in enumerate(steps):
+        bg.step(x)
+        if (i + 1) % 16 == 0:
+            bg.flush()
+            st.synchronize()
+            seen.append(bg.latest().clone())
+    bg.finish()
+    st.synchronize()
+    seen.append(bg.latest().clone())
+assert bg.gathers == 3 and [tuple(s.shape) for s in seen] == [(1, 16, 8, 1000), (1, 16, 8, 1000), (1, 8, 8, 1000)]
+flat = torch.cat([s[0] for s in seen], 0)
+assert torch.equal(flat, torch.stack(steps, 0))
+dist.barrier()
+dist.destroy_process_group()
+print("rccl one rank ok: backend nccl, %d gathers, every logit bit-identical" % bg.gathers)
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_paths_run_on_the_device_with_one_rank(tmp_path):
+    """No multi-GPU node has been available to this build, and two ranks cannot share a device under RCCL (the N > 1 dry runs above go through
+    gloo). What CAN run on one MI355X: an RCCL communicator of ONE rank - `ncclCommInitRank`, `ncclAllGather` on device tensors from a side
+    stream, asynchronous work handles - through exactly the code of anakin_amd/shard.py that `bench.py --gpus N` uses with the nccl backend
+    (the blocking gather, the per-step double-buffered gather, the amortised ring with its remainder): every gathered logit bit-identical."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(RCCL_ONE_RANK)
+    env = dict(os.environ, REPO_ROOT=ROOT, PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "rccl one rank ok" in p.stdout
