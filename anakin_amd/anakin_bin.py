@@ -76,11 +76,15 @@ def _signed(v, bits=64):
     return v
 
 
-def _decode(buf, msg):
+def _decode(buf, msg, depth=0):
+    if depth > 8:                                       # CacheDate lists nested deeper than any model holds: refused, not recursed into
+        raise FormatError("lists nested more than 8 deep")
     fields, out, pos = SCHEMA[msg], {}, 0
     while pos < len(buf):
         key, pos = _varint(buf, pos)
         num, wt = key >> 3, key & 7
+        if num == 0:
+            raise FormatError("field number 0")
         if wt == 0:
             raw, pos = _varint(buf, pos)
         elif wt == 1:
@@ -102,24 +106,28 @@ def _decode(buf, msg):
             continue                                    # unknown field: skipped
         name, kind, rep = fields[num]
         if isinstance(kind, tuple):                     # map entry {1: key, 2: value}
+            if wt != 2:
+                continue
             e = _decode_entry(raw, kind[1])
             out.setdefault(name, {})[e[0]] = e[1]
             continue
+        # a known field that arrives with a wire type its kind cannot have is an UNKNOWN field (skipped), as in every protobuf parser;
+        # repeated numeric scalars are accepted packed (2) or one by one
         if kind == "float":
-            if wt == 2:
+            if wt == 2 and rep:
                 if len(raw) % 4:
                     raise FormatError("packed floats: %d bytes" % len(raw))
                 val = np.frombuffer(bytes(raw), dtype="<f4")
             elif wt == 5:
                 val = np.frombuffer(bytes(raw), dtype="<f4")
             else:
-                raise FormatError("float with wire type %d" % wt)
+                continue
             if rep:
                 out[name] = np.concatenate([out[name], val]) if name in out else val
             else:
                 out[name] = float(val[0])
         elif kind in ("int", "bool"):
-            if wt == 2:                                 # packed
+            if wt == 2 and rep:                         # packed
                 vals, p = [], 0
                 while p < len(raw):
                     v, p = _varint(raw, p)
@@ -127,7 +135,7 @@ def _decode(buf, msg):
             elif wt == 0:
                 vals = [_signed(raw)]
             else:
-                raise FormatError("integer with wire type %d" % wt)
+                continue
             if kind == "bool":
                 vals = [bool(v) for v in vals]
             if rep:
@@ -136,7 +144,7 @@ def _decode(buf, msg):
                 out[name] = vals[-1]
         elif kind in ("string", "bytes"):
             if wt != 2:
-                raise FormatError("%s with wire type %d" % (kind, wt))
+                continue
             val = bytes(raw).decode("utf-8", "surrogateescape") if kind == "string" else bytes(raw)
             if rep:
                 out.setdefault(name, []).append(val)
@@ -144,8 +152,8 @@ def _decode(buf, msg):
                 out[name] = val
         else:
             if wt != 2:
-                raise FormatError("message %s with wire type %d" % (kind, wt))
-            val = _decode(raw, kind)
+                continue
+            val = _decode(raw, kind, depth + 1 if (msg == "CacheDate" and kind == "CacheDate") else depth)
             if rep:
                 out.setdefault(name, []).append(val)
             else:
@@ -157,8 +165,20 @@ def _decode_entry(buf, value_msg):
     key, val, pos = "", {}, 0
     while pos < len(buf):
         k, pos = _varint(buf, pos)
-        if k & 7 != 2:
-            raise FormatError("map entry with wire type %d" % (k & 7))
+        wt = k & 7
+        if k >> 3 == 0:
+            raise FormatError("field number 0")
+        if wt == 0:
+            _, pos = _varint(buf, pos)
+            continue
+        if wt in (1, 5):
+            n = 8 if wt == 1 else 4
+            if pos + n > len(buf):
+                raise FormatError("truncated fixed field in a map entry")
+            pos += n
+            continue
+        if wt != 2:
+            raise FormatError("wire type %d" % wt)
         n, pos = _varint(buf, pos)
         raw, pos = buf[pos:pos + n], pos + n
         if len(raw) != n:

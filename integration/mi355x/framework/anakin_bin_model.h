@@ -116,7 +116,8 @@ public:
         const uint64_t k = varint();
         *field = (int)(k >> 3);
         *wt = (int)(k & 7);
-        return ok_ && *field > 0;
+        if (ok_ && *field <= 0) fail();      // field number 0 does not exist: a corrupted key, not the end of the message
+        return ok_;
     }
     uint32_t fixed32() {
         if (end_ - p_ < 4) return (uint32_t)fail();
@@ -155,12 +156,12 @@ public:
     void ints(int wt, std::vector<int32_t>& out) {
         if (wt == 2) { Reader r = sub(); while (!r.done()) out.push_back((int32_t)r.varint()); if (!r.ok()) fail(); }
         else if (wt == 0) out.push_back((int32_t)varint());
-        else fail();
+        else skip(wt);               // (a wire type the field cannot have: an unknown field, as in every protobuf parser)
     }
     void bools(int wt, std::vector<uint8_t>& out) {
         if (wt == 2) { Reader r = sub(); while (!r.done()) out.push_back(r.varint() != 0); if (!r.ok()) fail(); }
         else if (wt == 0) out.push_back(varint() != 0);
-        else fail();
+        else skip(wt);
     }
     void floats(int wt, std::vector<float>& out) {
         if (wt == 2) {
@@ -171,7 +172,7 @@ public:
             out.resize(at + n / 4);
             if (n) std::memcpy(out.data() + at, r.p_, n);     // (little-endian host: the wire order)
         } else if (wt == 5) out.push_back(f32());
-        else fail();
+        else skip(wt);
     }
     void mark_bad() { fail(); }
 private:
@@ -190,11 +191,12 @@ inline void read_cache(Reader r, Cache& c, Reader& parent, int depth = 0) {
         case 3: r.floats(wt, c.f); break;
         case 4: r.bools(wt, c.b); break;
         case 5:
-            if (wt == 2 && depth < 8) { c.l.emplace_back(); read_cache(r.sub(), c.l.back(), r, depth + 1); }
-            else r.mark_bad();
+            if (wt != 2) r.skip(wt);
+            else if (depth < 8) { c.l.emplace_back(); read_cache(r.sub(), c.l.back(), r, depth + 1); }
+            else r.mark_bad();       // lists nested deeper than any model holds (the format has lists of lists): refused, not recursed into
             break;
-        case 6: c.type = (int)(int32_t)r.varint(); break;
-        case 7: c.size = (int64_t)r.varint(); break;
+        case 6: if (wt == 0) c.type = (int)(int32_t)r.varint(); else r.skip(wt); break;
+        case 7: if (wt == 0) c.size = (int64_t)r.varint(); else r.skip(wt); break;
         case 8: if (wt == 2) c.c = r.str(); else r.skip(wt); break;
         default: r.skip(wt);
         }
