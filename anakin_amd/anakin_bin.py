@@ -454,6 +454,15 @@ def write_model(model, path, batch=1, hw=224, precision="fp32", scales=None, ren
 
 
 def load_model(path_or_bytes):
+    """A graph that is a well-formed GraphProto but not a usable network (an operator without its weights, an edge to a node that does not
+    exist ...) raises FormatError naming what is missing, like a malformed file."""
+    try:
+        return _load_model(path_or_bytes)
+    except (KeyError, IndexError) as e:
+        raise FormatError("the graph lacks %s %r" % ("an attribute / node" if isinstance(e, KeyError) else "an element", e.args[0] if e.args else e)) from e
+
+
+def _load_model(path_or_bytes):
     """An `.anakin.bin` of the ResNet / VGG operator family as a workloads model dict: `spec` (conv / pool / gpool / eltwise / fc / softmax
     with BatchNorm + Scale + ReLU folded into their conv entry the way Graph::Optimize's fusion does, graph.cpp:375-436), `params` (weights
     with BatchNorm + Scale folded by workloads.fold_bn = WeightsFusion::update_weights), `raw` (the unfolded blobs), plus "input_shape",

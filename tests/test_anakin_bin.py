@@ -275,9 +275,20 @@ def test_int8_scales_and_precisions_travel_in_the_file(tmp_path):
 
 def test_operators_outside_the_path_are_refused():
     model = W.build_model("resnet50")
-    g = AB.read_graph(AB.write_model(model, None))
+    wire = AB.write_model(model, None)
+    g = AB.read_graph(wire)
     g["nodes"][5]["Op"]["name"] = "Deconvolution"
     with pytest.raises(AB.FormatError, match="outside the path"):
+        AB.load_model(AB.write_graph(g))
+    # well-formed GraphProtos that are not usable networks: a conv without its weights, an edge from a node that does not exist
+    g = AB.read_graph(wire)
+    conv = next(n for n in g["nodes"] if n["Op"]["name"] == "Convolution")
+    del conv["attr"]["weight_1"]
+    with pytest.raises(AB.FormatError, match="weight_1"):
+        AB.load_model(AB.write_graph(g))
+    g = AB.read_graph(wire)
+    g["edges_in"]["conv1"]["target"][0]["node"] = "nowhere"
+    with pytest.raises(AB.FormatError):
         AB.load_model(AB.write_graph(g))
 
 
