@@ -143,6 +143,15 @@ Status load_anakin_bin(graph::Graph<Ttype, Ptype>* graph, const char* data, size
         graph->add_vertex(node_p->name(), node_p);
     }
 
+    // an edge whose ends are not nodes of the file would trip a CHECK deep inside GraphBase (an abort): refused here with its name
+    for (int dir = 0; dir < 2; ++dir)
+        for (const auto& kv : (dir == 0 ? g.edges_in : g.edges_out)) {
+            if (!by_name.count(kv.first)) return bad(std::string(dir == 0 ? "edges_in" : "edges_out") + " of an unknown node " + kv.first);
+            for (const ab::Target& tg : kv.second.target)
+                if (!by_name.count(tg.node)) return bad("edge " + (dir == 0 ? tg.node + "_" + kv.first : kv.first + "_" + tg.node) + ": unknown node " + tg.node);
+            for (const std::string& other : kv.second.val)
+                if (!by_name.count(other)) return bad("edge " + (dir == 0 ? other + "_" + kv.first : kv.first + "_" + other) + ": unknown node " + other);
+        }
     auto finish = [&](graph::Edge<Ttype>& e) {
         auto it = g.edges_info.find(e.name());
         if (it != g.edges_info.end()) {

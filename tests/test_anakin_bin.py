@@ -461,6 +461,12 @@ def test_reference_graph_load_and_save_carry_every_attribute_kind(M, tmp_path):
     open(src, "wb").write(g.SerializeToString())
     r = _dry([src, "-", os.path.join(d, "input.bin"), d, "savebin", dst], d, {"SABER_TEST_PRECISION": "fp32"})
     assert r.returncode == 2 and "weight_q" in r.stderr and "only float blocks" in r.stderr, r.stderr[-1500:]
+    # an edge to a node the file does not hold is refused by name (the reference would abort in a CHECK inside GraphBase)
+    t = g.edges_in["b"].target.add(); t.node = "ghost"
+    open(src, "wb").write(g.SerializeToString())
+    r = _dry([src, "-", os.path.join(d, "input.bin"), d, "savebin", dst], d, {"SABER_TEST_PRECISION": "fp32"})
+    assert r.returncode == 2 and "unknown node ghost" in r.stderr, r.stderr[-1500:]
+    del g.edges_in["b"].target[-1]
     # a weight whose payload is shorter than its shape is refused at load with the node's name
     del g.nodes[1].attr["weight_q"]
     g.nodes[1].attr["weight_1"].tensor.data.size = 20
