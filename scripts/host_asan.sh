@@ -10,10 +10,17 @@
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/saber_asan/report.txt}
-D=/tmp/saber_asan
+SAN=${2:-address}      # address | undefined (UndefinedBehaviorSanitizer: host code only, the device compilation ignores the option)
+D=/tmp/saber_${SAN}
 mkdir -p $D/obj
-RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1)
-FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -fsanitize=address -fno-gpu-sanitize -shared-libsan"
+if [ $SAN = address ]; then
+  RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1)
+  SF="-fsanitize=address -fno-gpu-sanitize -shared-libsan"
+else
+  RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.ubsan_standalone-x86_64.so" | head -1)
+  SF="-fsanitize=undefined -fno-sanitize-recover=undefined -shared-libsan -Wno-option-ignored"
+fi
+FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form $SF"
 pids=()
 for f in $ROOT/anakin_amd/csrc/api_*.hip; do
   o=$D/obj/$(basename ${f%.hip}).o
@@ -21,10 +28,10 @@ for f in $ROOT/anakin_amd/csrc/api_*.hip; do
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
 OBJS=$(ls $ROOT/anakin_amd/build/*.o | grep -v "/api_")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fsanitize=address -shared-libsan -o $D/libsaber_mi355x.so $D/obj/api_*.o $OBJS || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared $SF -o $D/libsaber_mi355x.so $D/obj/api_*.o $OBJS || exit 1
 cd $ROOT
 : > $OUT
-echo "# host side of libsaber_mi355x.so (api_*.hip) under AddressSanitizer on the mock HIP runtime; $(date -u +%F)" >> $OUT
+echo "# host side of libsaber_mi355x.so (api_*.hip) under -fsanitize=$SAN on the mock HIP runtime; $(date -u +%F)" >> $OUT
 SABER_ASAN_LIBDIR=$D SABER_ASAN_RT=$RT python - >> $OUT 2>&1 <<'PY'
 import os, subprocess, sys, tempfile
 sys.path.insert(0, os.getcwd())
@@ -33,7 +40,7 @@ from integration import net_model as NM
 BIN = os.path.abspath("integration/_build/test_net_mi355x.bin")
 MOCK = os.path.abspath("integration/_build/libmock_hip.so")
 env = dict(os.environ, LD_PRELOAD=os.environ["SABER_ASAN_RT"] + " " + MOCK, LD_LIBRARY_PATH=os.environ["SABER_ASAN_LIBDIR"] + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
-           ASAN_OPTIONS="detect_leaks=0:exitcode=97:abort_on_error=0:detect_odr_violation=0:replace_str=0:intercept_memcmp=0:intercept_strlen=0:intercept_strchr=0:intercept_strstr=0:intercept_strcmp=0", SABER_MI355X_NET_PLAN_TUNE="0")
+           UBSAN_OPTIONS="halt_on_error=1:exitcode=98:print_stacktrace=1", ASAN_OPTIONS="detect_leaks=0:exitcode=97:abort_on_error=0:detect_odr_violation=0:replace_str=0:intercept_memcmp=0:intercept_strlen=0:intercept_strchr=0:intercept_strstr=0:intercept_strcmp=0", SABER_MI355X_NET_PLAN_TUNE="0")
 bad = 0
 def run(tag, name, precision, batch, mode, cal=False, rename=None, extra_env=None):
     global bad
@@ -46,8 +53,8 @@ def run(tag, name, precision, batch, mode, cal=False, rename=None, extra_env=Non
         e = dict(env); e.update(extra_env or {})
         r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d] + mode, env=e, capture_output=True, text=True, errors="replace", cwd=d, timeout=1800)
         loaded = "saber_asan" in open("/proc/self/maps").read() if False else None
-        san = "AddressSanitizer" in r.stderr or "AddressSanitizer" in r.stdout
-        print("%-44s rc %d %s" % (tag, r.returncode, "ASAN REPORT" if san else "clean"), flush=True)
+        san = any(k in r.stderr or k in r.stdout for k in ("AddressSanitizer", "runtime error:"))
+        print("%-44s rc %d %s" % (tag, r.returncode, "SANITIZER REPORT" if san else "clean"), flush=True)
         if san or r.returncode != 0:
             bad += 1
             print((r.stderr[-4000:]))
@@ -64,6 +71,6 @@ PY
 rc=$?
 # proof that the instrumented library is the one that ran
 LD_LIBRARY_PATH=$D ldd $ROOT/integration/_build/test_net_mi355x.bin | grep saber_mi355x >> $OUT
-nm -D $D/libsaber_mi355x.so | grep -c "__asan" | sed 's/^/__asan symbols referenced by the library: /' >> $OUT
+nm -D $D/libsaber_mi355x.so | grep -c "__asan\|__ubsan" | sed 's/^/sanitizer symbols referenced by the library: /' >> $OUT
 tail -12 $OUT
 exit $rc
