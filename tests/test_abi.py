@@ -95,3 +95,17 @@ def test_algorithm_selection_is_host_side(built):
     assert algo(64, 64, 3, 0, L.F32, L.F32, in_layout=L.NCHW, out_layout=L.NCHW).startswith("igemm_f32_")
     assert algo(32, 32, 3, 1, L.U8, L.U8, group=4) == "direct_i8"
     assert algo(20, 24, 5, 1, L.S8, L.F32) == "direct_i8"
+
+
+def test_descriptors_and_selection_codes_fuzzed_without_gpu(built):
+    """tests/fuzz_desc.py in a subprocess (a crash would take pytest with it): 800 random convolution / fc descriptors (edge values in every field:
+    negative, zero, 2^31 - 1, NaN / inf coefficients), pooling shape queries with zero strides, then 2 000 plausible convolutions with twelve random
+    kernel-selection codes each through saber_hip_conv2d_set_tile - every call returns a status (the reference's contract: SaberInvalidValue /
+    SaberUnImplError, saber_types.h:223-233), none crashes, hangs or aborts."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_desc.py"), "7", "800"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "plausible convs: created" in r.stdout
+    created = int(r.stdout.split("plausible convs: created")[1].split(",")[0])
+    assert created > 500, r.stdout[-500:]
