@@ -2272,3 +2272,122 @@ def test_strided_conv3x3_conv1x1_chain_with_subsampled_shortcut(case):
     plain = S.SaberConv2D(int8=True).init((N, Cc, Ho, Wo), pb, mdt, O.S8, s_in, s_mid)
     with pytest.raises(L.SaberHipError):
         S.SaberConvChain(plain, None, conv3x3=c0)
+
+
+def _random_conv_geometry(rng, int8):
+    k = int(rng.choice([1, 1, 3, 3, 3, 5, 7]))
+    stride = int(rng.choice([1, 1, 1, 2]))
+    dil = int(rng.choice([1, 1, 1, 2])) if k > 1 else 1
+    pad = int(rng.choice([0, (dil * (k - 1)) // 2, (dil * (k - 1)) // 2, 1]))
+    C = int(rng.choice([3, 4, 16, 32, 48, 64, 96, 128, 256, 512]) if int8 else rng.choice([3, 4, 8, 16, 32, 64, 96, 128, 256]))
+    K = int(rng.choice([8, 10, 16, 24, 34, 40, 64, 72, 128, 200, 256]))
+    N = int(rng.choice([1, 1, 2, 3, 8]))
+    lo = dil * (k - 1) + 1 - 2 * pad
+    H = int(rng.integers(max(lo, 1), 30))
+    Wd = int(rng.integers(max(lo, 1), 34))
+    if C >= 256 and k >= 5:
+        k, pad, dil = 3, 1, 1
+    return N, H, Wd, C, K, k, pad, stride, dil
+
+
+# every kernel-selection code the library might accept for a conv: (tile | stage depth << 8 | variant << 16); refused ones are skipped
+_I8_CODES = [t | (ks << 8) | (v << 16) for v in (1, 2, 3, 4) for t in range(6) for ks in (1, 2, 4)] + \
+            [t | (ks << 8) | (v << 16) for v in (5, 6) for t in range(3) for ks in (1, 2, 4)] + [7 << 16, 8 << 16, 12 << 16] + \
+            [rb | ((ib | nw) << 8) | (9 << 16) for rb in (1, 2, 4, 7) for ib in (1, 2) for nw in (0, 0x80)]
+_F32_CODES = [t | ((ks | (sh << 4)) << 8) | (11 << 16) for t in range(10) for ks in (1, 2) for sh in (0, 1, 2, 3)] + \
+             [v | (13 << 16) for v in range(1, 9)] + [v | (14 << 16) for v in range(0, 5)] + \
+             [t | (ks << 8) | (v << 16) for v in (1, 2) for t in range(6) for ks in (1, 2, 4)]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_conv_i8_random_geometry_every_accepted_selection_is_bit_exact(seed):
+    """Property: for a random INT8 convolution (kernel 1 .. 7, stride, dilation, padding, ragged sizes, C from 3 to 512, any K, all input / output
+    dtype combinations, relu or not) the static selection AND every kernel-selection code saber_hip_conv2d_set_tile accepts for it give the
+    oracle's bytes. Shapes nobody picked by hand; 100 codes tried per case (implicit GEMM register / LDS-DMA forms, halo, image-resident, stem)."""
+    rng = np.random.default_rng(9000 + seed)
+    N, H, Wd, C, K, k, pad, stride, dil = _random_conv_geometry(rng, True)
+    idt = int(rng.choice([O.S8, O.U8]))
+    odt = int(rng.choice([O.S8, O.U8, O.F32]))
+    relu = int(rng.integers(0, 2)) if odt != O.U8 else 1
+    x = (rng.integers(0, 256, (N, H, Wd, C)).astype(np.uint8) if idt == O.U8 else rng.integers(-128, 128, (N, H, Wd, C)).astype(np.int8))
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    in_scale, out_scale = float(rng.choice([0.017, 0.0039, 0.11])), float(rng.choice([0.041, 0.009, 0.3]))
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, odt)
+    want = O.conv_i8(x, wq, bp, sc, odt, relu, (pad, pad), (stride, stride), (dil, dil))
+    p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (dil, dil), bool(relu), None)
+    conv = S.SaberConv2D(int8=True).init((N, C, H, Wd), p, idt, odt, in_scale, out_scale)
+    xin = dev(x)
+
+    def run():
+        y = conv.new_output()
+        conv.dispatch(xin, y)
+        return host(y)
+    got = run()
+    assert got.dtype == want.dtype and np.array_equal(got, want), ("static", conv.algo(), (N, H, Wd, C, K, k, pad, stride, dil))
+    tried = set()
+    for code in _I8_CODES:
+        try:
+            conv.set_tile(code)
+        except L.SaberHipError:
+            continue
+        if conv.algo() in tried:
+            continue
+        tried.add(conv.algo())
+        assert np.array_equal(run(), want), (conv.algo(), hex(code), (N, H, Wd, C, K, k, pad, stride, dil), idt, odt, relu)
+    assert tried
+    print("seed %d %s: %d kernel forms bit-exact" % (seed, (N, H, Wd, C, K, k, pad, stride, dil), len(tried)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_conv_f32_random_geometry_every_accepted_selection_within_tolerance(seed):
+    """The FP32 twin: random geometry, optional in-place residual sum + relu, NHWC; the static selection and every accepted selection code (f32
+    MFMA, bf16-plane implicit GEMM with its tiles / 8-wave forms / split-K, the halo and pointwise kernels) within 1e-4 of the oracle on both
+    criteria, and the same bits on a second launch."""
+    rng = np.random.default_rng(7000 + seed)
+    N, H, Wd, C, K, k, pad, stride, dil = _random_conv_geometry(rng, False)
+    elt = bool(rng.integers(0, 2))
+    x = (rng.random((N, C, H, Wd)) * 3.0 - 1.0).astype(np.float32)
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    want = O.conv_f32_nchw(x, w, b, not elt, (pad, pad), (stride, stride), (dil, dil))
+    res = (rng.random(want.shape) * 2.0).astype(np.float32)
+    if elt:
+        want = np.maximum(want + res, 0.0)
+    p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (dil, dil), not elt)
+    if elt:
+        p.res_mode, p.res_relu, p.sum_scale = L.RES_SUM_INPLACE, True, 1.0
+    conv = S.SaberConv2D(int8=False).init((N, C, H, Wd), p, L.F32, L.F32, in_layout=L.NHWC, out_layout=L.NHWC)
+    xin = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rin = np.ascontiguousarray(res.transpose(0, 2, 3, 1))
+
+    def run():
+        y = conv.new_output()
+        if elt:
+            y.copy_(dev(rin))
+        conv.dispatch(xin, y)
+        return host(y).transpose(0, 3, 1, 2)
+
+    def check(what):
+        got = run()
+        d = np.abs(got - want)
+        scale = max(float(np.abs(want).max()), 1e-6)
+        e_max = float(d.max() / scale)
+        e_el = float((d / (np.abs(want) + np.abs(want).mean() + 1e-12)).max())
+        assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (what, conv.algo(), (N, H, Wd, C, K, k, pad, stride, dil), elt, e_max, e_el)
+        assert np.array_equal(run(), got), ("not deterministic", conv.algo())
+    check("static")
+    tried = set()
+    for code in _F32_CODES:
+        try:
+            conv.set_tile(code)
+        except L.SaberHipError:
+            continue
+        if conv.algo() in tried:
+            continue
+        tried.add(conv.algo())
+        check(hex(code))
+    assert tried
+    print("seed %d %s%s: %d kernel forms within 1e-4" % (seed, (N, H, Wd, C, K, k, pad, stride, dil), " + sum" if elt else "", len(tried)))
