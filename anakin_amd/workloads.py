@@ -336,8 +336,9 @@ def build_int8_net(model, scales, batch, hw=224, fuse=True, chain=2, stage=True,
             net.add_tensor(nm, (B, l["cout"]), F32)
             net.add_fc(fc, l["src"], nm)
         elif kd == "softmax":
-            net.add_tensor(nm, (B, 1000), F32)
-            net.add_softmax(B, 1000, l["src"], nm)
+            classes = next(e["cout"] for e in model["spec"] if e["name"] == l["src"])      # (the fc in front of it: 1000 for the BASELINE models)
+            net.add_tensor(nm, (B, classes), F32)
+            net.add_softmax(B, classes, l["src"], nm)
     net.unfused_ops = net.num_ops()
     if shared_device:
         net.optimize(2048)           # (sticks to the net: every later optimize / autotune / set_choices call honours it)
@@ -498,8 +499,9 @@ def build_fp32_net(model, batch, hw=224, pair_siblings=True, fuse_pool=True, sha
                 net.add_eltwise_f32(B * l["cout"], 0.5, 0.5, True, nm, nm, nm)
             mark(nm)
         elif kd == "softmax":
-            net.add_tensor(nm, (B, 1000), F32)
-            net.add_softmax(B, 1000, T(l["src"]), nm)
+            classes = next(e["cout"] for e in spec if e["name"] == l["src"])
+            net.add_tensor(nm, (B, classes), F32)
+            net.add_softmax(B, classes, T(l["src"]), nm)
             mark(nm)
     net.alias = alias
     net.produced = produced

@@ -590,3 +590,109 @@ def test_reproducible_fp32_flag_two_autotuned_nets_same_bits():
     got = outs[0]["fc1000"]
     want = ref["fc1000"].reshape(got.shape)
     assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def _random_resnet_like(rng):
+    """A ResNet-shaped network with widths / depths / input size nobody tuned for: stem conv (3x3 or 7x7, stride 2) [+ max pooling], 2 - 3 stages of
+    1 - 3 bottleneck blocks (mid channels 16 .. 256, x4 expansion, Caffe's stride placement), global pooling, fc, softmax - the operator patterns
+    saber_hip_net_optimize looks for (sibling pairs, 3x3-led chains, strided heads, stage runs, eltwise epilogues, pooling absorption), at sizes
+    where some of its kernels apply and some do not."""
+    stem_c = int(rng.choice([16, 32, 64]))
+    stem_k = int(rng.choice([3, 7]))
+    options = [[16, 32], [32, 64], [64, 128], [64, 128, 256], [32, 64, 128], [64, 256], [128, 256]]
+    mids = options[int(rng.integers(0, len(options)))]
+    nblk = [int(rng.integers(1, 4)) for _ in mids]
+    hw = int(rng.choice([32, 40, 56, 64, 72, 96]))
+    pool = bool(rng.integers(0, 2))
+    classes = int(rng.choice([10, 100, 1000]))
+    L = [dict(kind="conv", name="conv1", src="data", cin=3, cout=stem_c, k=stem_k, stride=2, pad=stem_k // 2, relu=True)]
+    prev, cin = "conv1", stem_c
+    if pool:
+        L.append(dict(kind="pool", name="pool1", src="conv1", win=3, stride=2, pad=0, type=0))
+        prev = "pool1"
+    for si, (mid, nb) in enumerate(zip(mids, nblk)):
+        cout = mid * 4
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and si > 0) else 1
+            tag = "res%d%s" % (si + 2, chr(ord("a") + bi))
+            if bi == 0:
+                L.append(dict(kind="conv", name=tag + "_branch1", src=prev, cin=cin, cout=cout, k=1, stride=stride, pad=0, relu=False))
+                shortcut = tag + "_branch1"
+            else:
+                shortcut = prev
+            L.append(dict(kind="conv", name=tag + "_branch2a", src=prev, cin=cin, cout=mid, k=1, stride=stride, pad=0, relu=True))
+            L.append(dict(kind="conv", name=tag + "_branch2b", src=tag + "_branch2a", cin=mid, cout=mid, k=3, stride=1, pad=1, relu=True))
+            L.append(dict(kind="conv", name=tag + "_branch2c", src=tag + "_branch2b", cin=mid, cout=cout, k=1, stride=1, pad=0, relu=False, eltwise=tag))
+            L.append(dict(kind="eltwise", name=tag, a=tag + "_branch2c", b=shortcut, relu=True))
+            prev, cin = tag, cout
+    L.append(dict(kind="gpool", name="pool5", src=prev))
+    L.append(dict(kind="fc", name="fc", src="pool5", cin=cin, cout=classes))
+    L.append(dict(kind="softmax", name="prob", src="fc"))
+    params, raw = {}, {}
+    for idx, l in enumerate(L):
+        if l["kind"] == "conv":
+            c, k, ks = l["cin"], l["cout"], l["k"]
+            w = (rng.standard_normal((k, c, ks, ks)) * np.sqrt(2.0 / (c * ks * ks))).astype(np.float32)
+            gamma, beta = rng.uniform(0.5, 1.5, k).astype(np.float32), rng.uniform(-0.1, 0.1, k).astype(np.float32)
+            mean, var = rng.uniform(-0.1, 0.1, k).astype(np.float32), rng.uniform(0.5, 1.5, k).astype(np.float32)
+            params[l["name"]] = W.fold_bn(w, None, 1.0, 1e-5, mean, var, gamma, beta)
+            raw[l["name"]] = dict(w=w, mean=mean, var=var, gamma=gamma, beta=beta)
+        elif l["kind"] == "fc":
+            params[l["name"]] = ((rng.standard_normal((l["cout"], l["cin"])) * np.sqrt(1.0 / l["cin"])).astype(np.float32),
+                                 rng.uniform(-0.1, 0.1, l["cout"]).astype(np.float32))
+    return dict(name="random_resnet", spec=L, params=params, raw=raw), hw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_resnet_like_int8_networks_every_edge_bit_exact(seed):
+    """Property test of the executor-level fuser: a random ResNet-shaped INT8 network (widths, depths, stem, input size, batch drawn at random)
+    through workloads.framework_spec (the reference's stride-up rule) and saber_hip_net_optimize with every fusion on - whatever it decides to
+    fuse, pair, chain or run as a stage at these sizes, every written edge is the oracle's bytes on the unfused list; eagerly, after an
+    autotune, and replayed as a hipGraph; and the same network with no executor-level fusion at all."""
+    L.require_device()
+    rng = np.random.default_rng(4200 + seed)
+    model, hw = _random_resnet_like(rng)
+    batch = int(rng.choice([1, 2, 3, 8]))
+    fm = W.framework_model(model, "int8")
+    x = rng.uniform(-1.0, 1.0, (batch, 3, hw, hw)).astype(np.float32)
+    scales = W.calibrate(fm, x)
+    ref = NO.run_int8(fm, dict(scales), x)
+
+    def check(net, what):
+        n = 0
+        for nm in net.tensors:
+            if nm == "data" or nm not in ref or net.unwritten(nm):
+                continue
+            got = _h(net.tensor(nm))
+            if nm == "prob":
+                assert np.abs(got.reshape(batch, -1) - ref[nm].reshape(batch, -1)).max() <= 1e-4 * ref[nm].max(), (what, nm)
+            else:
+                assert np.array_equal(got, ref[nm].reshape(got.shape)), (what, nm, seed, hw, batch)
+            n += 1
+        assert n >= 3
+        return n
+
+    for fuse in (True, False):
+        net = W.build_int8_net(fm, dict(scales), batch, hw=hw, fuse=fuse)
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+        n_edges = check(net, "eager fuse=%s" % fuse)
+        if fuse:
+            net.autotune(iters=2)
+            for nm in net.tensors:
+                if nm != "data" and not net.unwritten(nm):
+                    net.tensor(nm).zero_()
+            net.tensor("data").copy_(torch.from_numpy(x).cuda())
+            net.run()
+            check(net, "autotuned")
+            net.capture()
+            for nm in net.tensors:
+                if nm != "data" and not net.unwritten(nm):
+                    net.tensor(nm).zero_()
+            net.tensor("data").copy_(torch.from_numpy(x).cuda())
+            net.replay()
+            check(net, "hipGraph")
+            print("seed %d: %dx%d batch %d, %d layers -> %d ops in %d launches, %d edges checked, stages %s" % (
+                seed, hw, hw, batch, len(fm["spec"]), net.num_ops(), net.num_launches(), n_edges, net.stages()))
+        assert net.coop_fallbacks() == 0
