@@ -696,3 +696,86 @@ def test_random_resnet_like_int8_networks_every_edge_bit_exact(seed):
             print("seed %d: %dx%d batch %d, %d layers -> %d ops in %d launches, %d edges checked, stages %s" % (
                 seed, hw, hw, batch, len(fm["spec"]), net.num_ops(), net.num_launches(), n_edges, net.stages()))
         assert net.coop_fallbacks() == 0
+
+
+def _fp32_edges_of(model, x, hw, autotune=False):
+    """every logical edge of an FP32 op list against the oracle right after the op that produces it (the criteria of _fp32_every_edge)"""
+    ref = NO.run_fp32(model, x)
+    net = W.build_fp32_net(model, x.shape[0], hw=hw)
+    net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    if autotune:
+        net.run()
+        net.autotune(iters=2)
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+    done, checked = -1, 0
+    for idx, name in net.produced:
+        while done < idx:
+            done += 1
+            net.run_op(done)
+        got = _h(net.tensor(net.alias.get(name, name)))
+        want = ref[name]
+        got = got.transpose(0, 3, 1, 2) if got.ndim == 4 else got.reshape(want.reshape(got.shape[0], -1).shape)
+        want = want.reshape(got.shape)
+        d = np.abs(got - want)
+        e_max = float(d.max() / max(np.abs(want).max(), 1e-12))
+        e_el = float((d / (np.abs(want) + np.abs(want).mean() + 1e-12)).max())
+        assert e_max <= FP32_RTOL and e_el <= FP32_RTOL, (name, net.op_name(idx), e_max, e_el)
+        checked += 1
+    assert done == net.num_ops() - 1
+    return checked, net
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_resnet_like_fp32_networks_every_edge_within_tolerance(seed):
+    """The FP32 side of the property test: the same random ResNet-shaped networks through workloads.build_fp32_net (fused stem where it applies,
+    sibling pairs, in-place residual sums, whatever FP32 kernel the static choice - and then the autotuner - picks at these sizes): every
+    edge within 1e-4 of the oracle on both criteria."""
+    L.require_device()
+    rng = np.random.default_rng(4200 + seed)
+    model, hw = _random_resnet_like(rng)
+    batch = int(rng.choice([1, 2, 3, 8]))
+    x = rng.uniform(-1.0, 1.0, (batch, 3, hw, hw)).astype(np.float32)
+    n0, net = _fp32_edges_of(model, x, hw)
+    n1, net = _fp32_edges_of(model, x, hw, autotune=True)
+    assert n0 == n1 and n0 >= 5
+    print("seed %d: %dx%d batch %d, %d layers -> %d ops, %d edges checked twice" % (seed, hw, hw, batch, len(model["spec"]), net.num_ops(), n0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_random_vgg_like_fp32_networks_every_edge_within_tolerance(seed):
+    """A VGG-shaped FP32 network at random widths / depths / input sizes (odd sizes too: the fused conv + relu + 2x2 pooling launch needs even
+    conv outputs, elsewhere the two ops stay apart), conv + bias + relu, max pooling in ceil mode, fc + relu over the NCHW flatten, softmax."""
+    L.require_device()
+    rng = np.random.default_rng(5100 + seed)
+    hw = int(rng.choice([24, 30, 33, 40, 56]))
+    nstage = int(rng.integers(2, 4))
+    Lspec, prev, cin, i, size = [], "data", 3, 0, hw
+    for s in range(nstage):
+        width = int(rng.choice([16, 32, 64, 96]))
+        for _ in range(int(rng.integers(1, 3))):
+            i += 1
+            Lspec.append(dict(kind="conv", name="conv%d" % i, src=prev, cin=cin, cout=width, k=3, stride=1, pad=1, relu=True))
+            prev, cin = "conv%d" % i, width
+        Lspec.append(dict(kind="pool", name="pool%d" % (s + 1), src=prev, win=2, stride=2, pad=0, type=0))
+        prev, size = "pool%d" % (s + 1), -(-size // 2)
+    hidden, classes = int(rng.choice([64, 128])), int(rng.choice([10, 100]))
+    Lspec.append(dict(kind="fc", name="fc6", src=prev, cin=cin * size * size, cout=hidden, relu=True, flatten_chw=(cin, size, size)))
+    Lspec.append(dict(kind="fc", name="fc7", src="fc6", cin=hidden, cout=classes))
+    Lspec.append(dict(kind="softmax", name="prob", src="fc7"))
+    params = {}
+    for l in Lspec:
+        if l["kind"] == "conv":
+            params[l["name"]] = ((rng.standard_normal((l["cout"], l["cin"], 3, 3)) * np.sqrt(2.0 / (l["cin"] * 9))).astype(np.float32),
+                                 rng.uniform(-0.1, 0.1, l["cout"]).astype(np.float32))
+        elif l["kind"] == "fc":
+            params[l["name"]] = ((rng.standard_normal((l["cout"], l["cin"])) * np.sqrt(1.0 / l["cin"])).astype(np.float32),
+                                 rng.uniform(-0.1, 0.1, l["cout"]).astype(np.float32))
+    model = dict(name="random_vgg", spec=Lspec, params=params, raw={})
+    batch = int(rng.choice([1, 2, 5]))
+    x = rng.uniform(-1.0, 1.0, (batch, 3, hw, hw)).astype(np.float32)
+    n0, net = _fp32_edges_of(model, x, hw)
+    n1, net = _fp32_edges_of(model, x, hw, autotune=True)
+    assert n0 == n1 and n0 >= 4
+    print("seed %d: %dx%d batch %d, %d layers -> %d ops, %d edges checked twice" % (seed, hw, hw, batch, len(Lspec), net.num_ops(), n0))
