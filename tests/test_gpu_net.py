@@ -420,3 +420,49 @@ def test_ctypes_route_from_an_anakin_bin_answers_with_the_oracles_bits(tmp_path)
         assert np.array_equal(got, ref[nm].reshape(got.shape)), nm
         checked += 1
     assert checked > 20
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_net_mi355x_random_resnet_like_int8_every_edge_bit_exact(tmp_path, seed):
+    """The property test of tests/test_gpu_resnet.py through the REFERENCE's framework: a random ResNet-shaped INT8 network (widths, depths, stem,
+    input size, batch drawn at random) as original operators with raw BatchNorm blobs -> Graph::load -> the reference's Optimize (fusion,
+    stride-up, schedulers, memory planner) -> Net<MI355X>::init -> prediction through the captured plan: every edge and the logits are the
+    oracle's bytes on workloads.framework_spec, prediction() == the op-by-op pass == the operator loop."""
+    import importlib
+    G = importlib.import_module("tests.test_gpu_resnet")
+    assert os.path.exists(BIN), "integration/_build/test_net_mi355x.bin is missing: run __graft_entry__.build()"
+    rng = np.random.default_rng(4200 + seed)
+    model, hw = G._random_resnet_like(rng)
+    batch = int(rng.choice([1, 2, 3, 8]))
+    x = rng.uniform(-1.0, 1.0, (batch, 3, hw, hw)).astype(np.float32)
+    fm = W.framework_model(model, "int8")
+    scales = W.calibrate(fm, x)
+    d = str(tmp_path)
+    mt, wb = NM.write_model(model, scales, batch, d, "int8", hw=hw, calibrator_config=True)
+    x.tofile(os.path.join(d, "input.bin"))
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([BIN, mt, wb, os.path.join(d, "input.bin"), d, "10"], env=env, capture_output=True, text=True, timeout=900, cwd=d)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ops = NM.parse_oplist(os.path.join(d, "oplist.txt"))
+    ref = NO.run_int8(fm, dict(scales), x)
+    checked = 0
+    for o in ops:
+        if o["type"] in ("Input", "Output", "Split"):
+            continue
+        got, want = load(d, o, 0, o["outs"][0]), ref[o["name"]]
+        if o["type"] == "Softmax":
+            assert np.abs(got.reshape(batch, -1) - want.reshape(batch, -1)).max() <= 1e-4 * want.max()
+        else:
+            assert got.dtype == want.dtype and np.array_equal(got.reshape(want.shape), want), (o["name"], seed, hw, batch)
+        checked += 1
+    assert checked == len(fm["spec"])
+    last = [o for o in ops if o["type"] == "Softmax"][0]
+    want = load(d, last, 0, last["outs"][0]).ravel()
+    # (probabilities: the plan may run the fc and the Softmax as one launch - another order of the row sum - so 1e-4, the Softmax contract;
+    # the operator loop runs the operators the op-by-op pass ran: the same bits)
+    assert np.abs(np.fromfile(os.path.join(d, "out_prob_out.bin"), np.float32) - want).max() <= 1e-4 * want.max()
+    assert np.array_equal(np.fromfile(os.path.join(d, "out_prob_out_oploop.bin"), np.float32), want)
+    plan = read_plan(d)
+    assert plan["plan"] == 1 and plan["captured_ops"] == checked, plan
+    print("seed %d: %dx%d batch %d, %d operators after the reference's optimiser -> %d launches behind prediction()" % (seed, hw, hw, batch, checked, plan["launches"]))
