@@ -2391,3 +2391,64 @@ def test_conv_f32_random_geometry_every_accepted_selection_within_tolerance(seed
         check(hex(code))
     assert tried
     print("seed %d %s%s: %d kernel forms within 1e-4" % (seed, (N, H, Wd, C, K, k, pad, stride, dil), " + sum" if elt else "", len(tried)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_pooling_eltwise_fc_random_shapes_vs_oracle(seed):
+    """The streaming operators on shapes drawn at random: 8-bit and FP32 pooling (window 1 .. 5, stride 1 .. 3, padding, ceil and floor output
+    rule, max / the two averages, ragged sizes, channel counts that are not multiples of the vector width), INT8 and FP32 eltwise sums with
+    arbitrary coefficients / scales / lengths, INT8 (s8 / u8 / quantise-on-entry) and FP32 fully connected layers with ragged M, N, K - the
+    oracle's bytes where the path is integer or a fixed-order f32 reduction, 1e-4 for the FP32 fc."""
+    rng = np.random.default_rng(8800 + seed)
+    # ---- pooling -----------------------------------------------------------------------------------------------------------------
+    for _ in range(4):
+        win = int(rng.integers(1, 6))
+        st = int(rng.integers(1, 4))
+        pad = int(rng.integers(0, (win + 1) // 2 + 0)) if win > 1 else 0
+        pad = min(pad, win - 1)
+        N, H, Wd, Cc = int(rng.integers(1, 4)), int(rng.integers(win, 40)), int(rng.integers(win, 40)), int(rng.choice([1, 3, 6, 10, 16, 24, 64, 100, 256]))
+        pt = int(rng.integers(0, 3))
+        floor = bool(rng.integers(0, 2))
+        dt = int(rng.choice([O.S8, O.U8]))
+        x = (rng.integers(0, 256, (N, H, Wd, Cc)).astype(np.uint8) if dt == O.U8 else rng.integers(-128, 128, (N, H, Wd, Cc)).astype(np.int8))
+        want = O.pool_i8_nhwc(x, (win, win), (st, st), (pad, pad), pt, floor_mode=floor)
+        got = host(S.pooling_i8(dev(x), (win, win), (st, st), (pad, pad), pt, floor_mode=floor))
+        assert got.shape == want.shape and np.array_equal(got, want), ("pool i8", (N, H, Wd, Cc), win, st, pad, pt, floor, dt)
+        xf = rng.standard_normal((N, Cc, H, Wd)).astype(np.float32)
+        wantf = O.pool_f32_nchw(xf, (win, win), (st, st), (pad, pad), pt, floor_mode=floor)
+        gotf = host(S.pooling_f32(dev(xf), (win, win), (st, st), (pad, pad), pt, floor_mode=floor))
+        assert np.array_equal(gotf, wantf), ("pool f32 nchw", (N, Cc, H, Wd), win, st, pad, pt, floor)
+        xh = np.ascontiguousarray(xf.transpose(0, 2, 3, 1))
+        goth = host(S.pooling_f32(dev(xh), (win, win), (st, st), (pad, pad), pt, layout=L.NHWC, floor_mode=floor))
+        assert np.array_equal(goth, wantf.transpose(0, 2, 3, 1)), ("pool f32 nhwc", (N, Cc, H, Wd), win, st, pad, pt, floor)
+    # ---- eltwise -----------------------------------------------------------------------------------------------------------------
+    for _ in range(4):
+        n = int(rng.choice([1, 15, 16, 17, 1003, 4096, 65537]))
+        a, b = rng.integers(-128, 128, n).astype(np.int8), rng.integers(-128, 128, n).astype(np.int8)
+        sa, sb = float(rng.uniform(0.01, 0.5)), float(rng.uniform(0.01, 0.5))
+        c0, c1 = float(np.float32(rng.uniform(0.5, 20.0))), float(np.float32(rng.uniform(0.5, 20.0)))
+        relu = bool(rng.integers(0, 2))
+        assert np.array_equal(host(S.eltwise_sum(dev(a), dev(b), (c0, c1), relu, sa, sb)), O.eltwise_i8(a, b, sa, sb, c0, c1, relu)), ("eltwise i8", n, relu)
+        fa, fb = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        assert np.array_equal(host(S.eltwise_sum(dev(fa), dev(fb), (c0, c1), relu)), O.eltwise_f32(fa, fb, c0, c1, relu)), ("eltwise f32", n, relu)
+    # ---- fully connected ---------------------------------------------------------------------------------------------------------
+    for _ in range(3):
+        M, N, K = int(rng.integers(1, 20)), int(rng.choice([1, 7, 10, 33, 64, 100, 1000])), int(rng.choice([16, 48, 100, 256, 528, 1000, 2048, 4112]))
+        w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        xf = rng.standard_normal((M, K)).astype(np.float32)
+        want = O.fc_f32(xf, w, b)
+        fc = S.SaberFc(False).init(M, N, K, w, b, L.F32)
+        assert np.abs(host(fc.dispatch(dev(xf), y)) - want).max() <= FP32_RTOL * max(np.abs(want).max(), 1e-6), ("fc f32", M, N, K, fc.algo())
+        if K % 16 == 0:
+            ws = O.weight_scales(w)
+            wq = O.quant_weights(w, ws)
+            for dt in (L.S8, L.U8):
+                xs = (rng.integers(0, 256, (M, K)).astype(np.uint8) if dt == L.U8 else rng.integers(-128, 128, (M, K)).astype(np.int8))
+                fc = S.SaberFc(True).init(M, N, K, wq, b, dt, 0.031, 0.5 if dt == L.U8 else 1.0, w_scale=ws)
+                wanti = O.fc_i8(xs, wq, ws, 0.031, b, 0.5) if dt == L.U8 else O.fc_i8(xs, wq, ws, 0.031, b)
+                assert np.array_equal(host(fc.dispatch(dev(xs), y)), wanti), ("fc i8", M, N, K, dt, fc.algo())
+            in_scale = float(np.abs(xf).max() / 127)
+            fc = S.SaberFc(True).init(M, N, K, w, b, L.F32, in_scale)
+            assert np.array_equal(host(fc.dispatch(dev(xf), y)), O.fc_i8(O.quant_flat_s8(xf, in_scale), wq, ws, in_scale, b)), ("fc i8 f32-in", M, N, K, fc.algo())
