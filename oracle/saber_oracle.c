@@ -453,11 +453,18 @@ int orc_pool_f32_nchw(int N, int C, int H, int W, int OH, int OW, int kh, int kw
                     if (he > H) he = H;
                     if (we > W) we = W;
                     const float* xp = x + ((size_t)n * C + c) * H * W;
-                    float r = type == 0 ? xp[hs * W + ws] : 0.f;
+                    /* saber_pooling.cpp:437-462: result = 0, the FIRST element of the window is assigned, the others are maxed / added - an EMPTY
+                     * window (ceil-mode output whose window starts past the image: stride > window) therefore yields 0 for max pooling and 0 / 0 or
+                     * 0 / negative for the averages. (Through round 5 the maximum started from xp[hs * W + ws] before the loop: the same for every
+                     * non-empty window, the next row's first element - or a read past the tensor - for an empty one; found by the round-6 random
+                     * sweep, where the GPU kernel answered 0 like the reference.) */
+                    float r = 0.f;
+                    int first = 1;
                     for (int ih = hs; ih < he; ++ih)
                         for (int iw = ws; iw < we; ++iw) {
                             const float v = xp[ih * W + iw];
-                            if (type == 0) r = r >= v ? r : v;
+                            if (first) { r = v; first = 0; }
+                            else if (type == 0) r = r >= v ? r : v;
                             else r += v;
                         }
                     if (type == 1) { /* divisor clipped at in+pad on the far edge, saber_pooling.cpp:466-480 */
