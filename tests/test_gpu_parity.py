@@ -2453,3 +2453,45 @@ def test_pooling_eltwise_fc_random_shapes_vs_oracle(seed):
             in_scale = float(np.abs(xf).max() / 127)
             fc = S.SaberFc(True).init(M, N, K, w, b, L.F32, in_scale)
             assert np.array_equal(host(fc.dispatch(dev(xf), y)), O.fc_i8(O.quant_flat_s8(xf, in_scale), wq, ws, in_scale, b)), ("fc i8 f32-in", M, N, K, fc.algo())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_layout_quant_softmax_gemm_random_shapes_vs_oracle(seed):
+    """The remaining operators of the path on shapes drawn at random: quantise f32 NCHW -> s8 / u8 NHWC (ties, saturation, channel padding),
+    dequantise back, the two f32 transposes, flat quantisation, softmax over ragged row lengths (large logits included), Gemm with both
+    transposes / alpha / beta on ragged M, N, K - bytes where the path is a rounding or a copy, 1e-4 for softmax and the GEMM."""
+    rng = np.random.default_rng(6600 + seed)
+    for _ in range(3):
+        n, c, h, w = int(rng.integers(1, 4)), int(rng.choice([1, 3, 4, 5, 16, 17, 64, 100])), int(rng.integers(1, 30)), int(rng.integers(1, 30))
+        x = (rng.standard_normal((n, c, h, w)) * 40.0).astype(np.float32)
+        x.reshape(-1)[:: max(1, x.size // 50)] = np.float32(0.5) * np.round(x.reshape(-1)[:: max(1, x.size // 50)] * 2)      # exact .5 ties
+        scale = float(rng.choice([0.25, 0.5, 1.0, 0.37]))
+        for odt in (O.S8, O.U8):
+            want = O.quant_nchw_to_nhwc(x, scale, odt)
+            got = host(S.quantize_nchw_to_nhwc(dev(x), scale, odt))
+            assert np.array_equal(got, want), ("quantise", (n, c, h, w), scale, odt)
+            back = host(S.dequantize_nhwc_to_nchw(dev(want), scale))
+            assert np.array_equal(back, O.dequant_nhwc_to_nchw(want, scale)), ("dequantise", (n, c, h, w), scale, odt)
+        c_pad = c + int(rng.integers(0, 4))
+        t = host(S.transpose_nchw_to_nhwc(dev(x), c_pad))
+        assert np.array_equal(t[..., :c], x.transpose(0, 2, 3, 1)) and not t[..., c:].any(), ("nchw->nhwc", (n, c, h, w), c_pad)
+        assert np.array_equal(host(S.transpose_nhwc_to_nchw(dev(t), c)), x), ("nhwc->nchw", (n, c, h, w), c_pad)
+        flat = (rng.standard_normal(int(rng.choice([1, 63, 64, 1000, 4097]))) * 30).astype(np.float32)
+        assert np.array_equal(host(S.quantize_flat_s8(dev(flat), scale)), O.quant_flat_s8(flat, scale)), ("flat quantise", flat.size)
+    for _ in range(3):
+        rows, cols = int(rng.integers(1, 20)), int(rng.choice([1, 2, 10, 63, 64, 65, 1000, 1001, 4096]))
+        z = (rng.standard_normal((rows, cols)) * float(rng.choice([1.0, 10.0, 60.0]))).astype(np.float32)
+        want = O.softmax_f32(z)
+        got = host(S.softmax(dev(z)))
+        assert np.abs(got - want).max() <= FP32_RTOL * want.max() and np.allclose(got.sum(1), 1.0, atol=1e-5), ("softmax", rows, cols)
+    for _ in range(3):
+        M, N, K = int(rng.choice([1, 3, 8, 17, 64, 100])), int(rng.choice([1, 10, 64, 100, 1000])), int(rng.choice([1, 7, 64, 100, 513, 2048]))
+        ta, tb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        alpha, beta = float(rng.choice([1.0, 0.5, -2.0])), float(rng.choice([0.0, 1.0, 0.25]))
+        A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+        Bm = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+        C0 = rng.standard_normal((M, N)).astype(np.float32)
+        want = O.gemm_f32(A, Bm, M, N, K, ta, tb, alpha, beta, C0)
+        cd = dev(C0.copy())
+        got = host(S.gemm(ta, tb, M, N, K, alpha, dev(A), dev(Bm), beta, cd))
+        assert np.abs(got - want).max() <= FP32_RTOL * max(np.abs(want).max(), 1e-6), ("gemm", M, N, K, ta, tb, alpha, beta)
