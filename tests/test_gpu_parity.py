@@ -2495,3 +2495,49 @@ def test_layout_quant_softmax_gemm_random_shapes_vs_oracle(seed):
         cd = dev(C0.copy())
         got = host(S.gemm(ta, tb, M, N, K, alpha, dev(A), dev(Bm), beta, cd))
         assert np.abs(got - want).max() <= FP32_RTOL * max(np.abs(want).max(), 1e-6), ("gemm", M, N, K, ta, tb, alpha, beta)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_conv_i8_fused_eltwise_random_geometry_every_accepted_selection(seed):
+    """The executor's fused epilogue (conv -> s8, + residual x its scale, coefficients, optional relu, requantise: RES_ELTWISE) on random
+    geometry: the oracle's conv followed by its SaberEltwise<AK_INT8>, byte for byte, under the static selection and every selection code
+    set_tile accepts; and the in-place JIT sum (RES_JIT_SUM: conv accumulating onto the bytes already in the output) likewise."""
+    rng = np.random.default_rng(9900 + seed)
+    N, H, Wd, C, K, k, pad, stride, dil = _random_conv_geometry(rng, True)
+    if C < 16:
+        C = 16
+    K = int(rng.choice([16, 32, 64, 128, 256]))
+    idt = int(rng.choice([O.S8, O.U8]))
+    relu = bool(rng.integers(0, 2))
+    x = (rng.integers(0, 256, (N, H, Wd, C)).astype(np.uint8) if idt == O.U8 else rng.integers(-128, 128, (N, H, Wd, C)).astype(np.int8))
+    w = (rng.standard_normal((K, C, k, k)) * np.sqrt(2.0 / (C * k * k))).astype(np.float32)
+    b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    in_scale, out_scale, s_res, s_out = 0.02, 0.05, float(rng.choice([0.043, 0.11])), float(rng.choice([0.06, 0.2]))
+    c = float(np.float32(1.0 / s_out))
+    ws = O.weight_scales(w)
+    wq = O.quant_weights(w, ws)
+    bp, sc = O.conv_i8_prepare(ws, b, in_scale, out_scale, idt, O.S8)
+    y1 = O.conv_i8(x, wq, bp, sc, O.S8, 0, (pad, pad), (stride, stride), (dil, dil))
+    res = rng.integers(-128, 128, y1.shape).astype(np.int8)
+    want = O.eltwise_i8(y1, res, out_scale, s_res, c, c, relu)
+    p = S.ConvParam(w, b, 1, (pad, pad), (stride, stride), (dil, dil), False, None)
+    p.res_mode, p.res_relu, p.sum_scale, p.coeff, p.scale_res = L.RES_ELTWISE, relu, 1.0, (c, c), s_res
+    conv = S.SaberConv2D(int8=True).init((N, C, H, Wd), p, idt, O.S8, in_scale, out_scale)
+    xin, rd = dev(x), dev(res)
+
+    def run():
+        y = conv.new_output()
+        conv.dispatch(xin, y, rd)
+        return host(y)
+    assert np.array_equal(run(), want), ("static", conv.algo(), (N, H, Wd, C, K, k, pad, stride, dil), idt, relu)
+    tried = set()
+    for code in _I8_CODES:
+        try:
+            conv.set_tile(code)
+        except L.SaberHipError:
+            continue
+        if conv.algo() in tried:
+            continue
+        tried.add(conv.algo())
+        assert np.array_equal(run(), want), (conv.algo(), hex(code), (N, H, Wd, C, K, k, pad, stride, dil), idt, relu)
+    assert tried
