@@ -266,3 +266,49 @@ def test_shared_device_nets_never_select_placement_dependent_variants():
     got = _h(fnet.tensor("fc1000"))
     want = fref["fc1000"].reshape(got.shape)
     assert np.abs(got - want).max() <= FP32_RTOL * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [8, 1])
+def test_resnet50_int8_soak_every_pass_gives_the_same_bits(batch):
+    """A soak of exactly what the driver times (the committed kernel selection: the persistent res4 stage launch with its cross-workgroup flags
+    and edge counters, the cooperating chains, fc + softmax through its arrival counter): 20 000 forward passes back to back, eager and as hipGraph
+    replays, fresh images every 500 passes - after EVERY pass the logits, the probabilities and three edges behind the hand-off protocols (the
+    stage's last block, res5c, pool5) are compared on the device with the first pass of their image: one stale flag, one early read or one lost
+    arrival in 20 000 passes would show as a changed byte. The first pass of every image is checked against the oracle's bits."""
+    L.require_device()
+    model = W.framework_model(W.build_model("resnet50"), "int8")
+    scales = W.calibrate(model, W.make_input(2))
+    net = W.build_int8_net(model, dict(scales), batch)
+    net.tensor("data").copy_(torch.from_numpy(W.make_input(batch)).cuda())
+    net.run()
+    _apply_committed_selection(net, "resnet50", batch)
+    net.run()
+    net.capture()
+    assert net.stages(), "the configuration the driver times runs res4 as one persistent launch"
+    watch = [nm for nm in ("res4f", "res5c", "pool5", "fc1000", "prob") if nm in net.tensors and not net.unwritten(nm)]
+    assert "fc1000" in watch and "prob" in watch and len(watch) >= 4, watch
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    passes = 0
+    for img in range(40):
+        x = W.make_input(batch, seed=500 + img)
+        net.tensor("data").copy_(torch.from_numpy(x).cuda())
+        net.run()
+        first = {nm: net.tensor(nm).clone() for nm in watch}
+        if img % 10 == 0:           # the oracle needs seconds per batch-8 pass: every tenth image
+            ref = NO.run_int8(model, dict(scales), x)
+            for nm in watch:
+                if nm != "prob":
+                    got = _h(first[nm])
+                    assert np.array_equal(got, ref[nm].reshape(got.shape)), (img, nm)
+        for it in range(500):
+            if it % 2:
+                net.replay()
+            else:
+                net.run()
+            for nm in watch:
+                bad += (net.tensor(nm) != first[nm]).any().to(torch.int64)
+            passes += 1
+    torch.cuda.synchronize()
+    assert passes == 20000 and int(bad.item()) == 0, (passes, int(bad.item()))
+    assert net.coop_fallbacks() == 0

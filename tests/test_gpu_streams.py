@@ -86,3 +86,41 @@ def test_nets_in_flight_on_serving_streams_answer_with_the_oracles_bits():
             assert np.array_equal(got, ref[nm].reshape(got.shape)), (i, nm)
             checked += 1
         assert checked > 20 and n.coop_fallbacks() == 0
+
+
+@pytest.mark.gpu
+def test_four_passes_in_flight_soak_every_net_keeps_its_bits():
+    """Four shared-device ResNet50 INT8 batch-8 nets (compacted arenas: edges of disjoint lifetimes share memory) replayed together on the four
+    serving streams 3 000 rounds: after every pass each net's logits and pool5 are compared on its own stream with its first pass - a pass in
+    flight beside three others never sees another net's bytes or a recycled slot too early."""
+    from anakin_amd import lib as L
+    from anakin_amd import workloads as W
+    from anakin_amd.streams import serving_streams
+    L.require_device()
+    model = W.framework_model(W.build_model("resnet50"), "int8")
+    scales = W.calibrate(model, W.make_input(2))
+    streams, distinct = serving_streams(4)
+    nets, firsts, bads = [], [], []
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            n = W.build_int8_net(model, dict(scales), 8, shared_device=True)
+            n.tensor("data").copy_(torch.from_numpy(W.make_input(8, seed=71 + i)).cuda())
+            n.run()
+            n.compact()
+            n.run()
+            n.capture()
+            n.replay()
+            firsts.append({nm: n.tensor(nm).clone() for nm in ("fc1000", "pool5")})
+            bads.append(torch.zeros((), dtype=torch.int64, device="cuda"))
+        nets.append(n)
+    torch.cuda.synchronize()
+    assert not torch.equal(firsts[0]["fc1000"], firsts[1]["fc1000"])          # different images: different answers
+    for _ in range(3000):
+        for n, st, f, b in zip(nets, streams, firsts, bads):
+            with torch.cuda.stream(st):
+                n.replay()
+                for nm in f:
+                    b += (n.tensor(nm) != f[nm]).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert [int(b.item()) for b in bads] == [0, 0, 0, 0]
+    assert all(n.coop_fallbacks() == 0 for n in nets)
