@@ -779,3 +779,44 @@ def test_random_vgg_like_fp32_networks_every_edge_within_tolerance(seed):
     n1, net = _fp32_edges_of(model, x, hw, autotune=True)
     assert n0 == n1 and n0 >= 4
     print("seed %d: %dx%d batch %d, %d layers -> %d ops, %d edges checked twice" % (seed, hw, hw, batch, len(Lspec), net.num_ops(), n0))
+
+
+@pytest.mark.gpu
+def test_resnet50_fp32_soak_split_k_hand_off_every_pass_gives_the_same_bits():
+    """ResNet50 FP32 batch 8 with an autotuned selection (the few-pixel layers then run split-K: partial sums handed between workgroups through one
+    XCD's L2, summed in split order by the last arrival; the in-place residual sums; the pointwise kernels' reduction split over waves): 4 000
+    passes, eager and hipGraph replays alternating, two images - the logits and res4f / res5c after every pass are the bits of the first pass
+    (the hand-off's result does not depend on who arrives last), never a NaN (the placement guard's poison), and within 1e-4 of the oracle."""
+    L.require_device()
+    model = W.build_model("resnet50")
+    batch = 8
+    net = W.build_fp32_net(model, batch)
+    x0 = W.make_input(batch)
+    net.tensor("data").copy_(torch.from_numpy(x0).cuda())
+    net.run()
+    net.autotune(iters=3)
+    names = [net.op_name(i) for i in range(net.num_ops())]
+    assert any("_split" in n for n in names), names
+    net.tensor("data").copy_(torch.from_numpy(x0).cuda())
+    net.run()
+    net.capture()
+    ref = NO.run_fp32(model, x0[:2])
+    got = _h(net.tensor(net.alias.get("fc1000", "fc1000")))[:2]
+    assert np.abs(got - ref["fc1000"].reshape(got.shape)).max() <= FP32_RTOL * np.abs(ref["fc1000"]).max()
+    watch = [net.alias.get(nm, nm) for nm in ("res4f", "res5c", "fc1000")]
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    nan = torch.zeros((), dtype=torch.int64, device="cuda")
+    for img in range(2):
+        net.tensor("data").copy_(torch.from_numpy(W.make_input(batch, seed=900 + img)).cuda())
+        net.run()
+        first = {nm: net.tensor(nm).clone() for nm in watch}
+        for it in range(2000):
+            if it % 2:
+                net.replay()
+            else:
+                net.run()
+            for nm in watch:
+                bad += (net.tensor(nm) != first[nm]).any().to(torch.int64)
+            nan += torch.isnan(net.tensor(watch[-1])).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0 and int(nan.item()) == 0, (int(bad.item()), int(nan.item()))
