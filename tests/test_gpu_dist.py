@@ -150,7 +150,11 @@ def test_rccl_all_gather_paths_run_on_the_device_with_one_rank(tmp_path):
     (the blocking gather, the per-step double-buffered gather, the amortised ring with its remainder): every gathered logit bit-identical."""
     script = tmp_path / "rccl_one_rank.py"
     script.write_text(RCCL_ONE_RANK)
-    env = dict(os.environ, REPO_ROOT=ROOT, PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as so:          # a port nobody holds (two suites on one host must not meet on a fixed one)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, REPO_ROOT=ROOT, PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
