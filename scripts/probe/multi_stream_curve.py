@@ -14,7 +14,8 @@ PICK = "--pick" in sys.argv      # the first four streams from saber_hip_serving
 
 model = W.framework_model(W.build_model("resnet50"), "int8")
 scales = W.calibrate(model, W.make_input(2))
-for B in (8, 4):
+BATCHES = tuple(int(a) for a in sys.argv[1:] if a.isdigit()) or (8, 4)
+for B in BATCHES:
     nets, streams = [], []
     picked = []
     if PICK:

@@ -174,6 +174,15 @@ with tempfile.TemporaryDirectory() as td:
 open("gpurun_out/r06_worker_streams/worker_serving_streams_ab.txt", "w").write("\n".join(out) + "\n")
 PY
   ;;
+streams_trace)   # what every kernel of the pass costs with 0 / 3 other passes in flight: kernel traces of 1 and 4 nets on the serving streams
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  for k in 1 4; do
+    rocprofv3 --kernel-trace --stats -d $O/trace$k -o t -- python scripts/probe/multi_stream_profile_target.py $k > $O/target$k.log 2>&1
+    N=$(grep "launches per net" $O/target$k.log | awk '{print $4}')
+    python scripts/rocprof_summary.py $(find $O/trace$k -name '*_results.db' | head -1) 40 $((N*k*100)) > $O/kernel_trace_summary_${k}_in_flight.txt
+    rm -rf $O/trace$k
+  done
+  head -12 $O/kernel_trace_summary_1_in_flight.txt; head -12 $O/kernel_trace_summary_4_in_flight.txt ;;
 streams)    # images/s against the number of independent passes in flight
   python scripts/probe/multi_stream_curve.py > $O/multi_stream_curve.txt 2>&1; grep "^batch" $O/multi_stream_curve.txt
   python scripts/probe/multi_stream_curve.py --pick > $O/multi_stream_curve_pick.txt 2>&1; echo "picked, default queues"; grep "^batch" $O/multi_stream_curve_pick.txt
